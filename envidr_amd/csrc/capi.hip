@@ -1,0 +1,19 @@
+// Library-level C-ABI pieces: error text and ABI version.
+#include "common.hip.h"
+
+#include <stdarg.h>
+
+namespace envidr {
+static thread_local char g_error[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+}  // namespace envidr
+
+extern "C" {
+const char* envidr_last_error(void) { return envidr::g_error; }
+int envidr_abi_version(void) { return 1; }
+}

@@ -1,0 +1,152 @@
+// Occupancy-grid ray marcher core, shared by the standalone operators (raymarching.hip) and the
+// fused persistent render kernel (fused_render.hip).
+//
+// Semantics follow the reference's inference / training marchers
+// (raymarching/src/raymarching.cu:839-944 and :340-508): per step clamp the position to the
+// scene cube, pick the cascade level, truncate to a voxel, test one bit of the Morton-ordered
+// bitfield, then either emit a sample and advance by dt or hop to the voxel's exit face.
+//
+// Bit-exactness contract (tests/test_raymarching_gpu.py): every float op below is a single IEEE
+// fp32 (or, where the reference's expression promotes, fp64) operation in the reference's order;
+// this TU is built with -ffp-contract=off and HIP's correctly rounded fp32 division.
+#pragma once
+#include "common.hip.h"
+
+namespace envidr {
+
+struct MarchConsts {
+    float bound;
+    float dt_gamma;
+    float dt_min;      // 2*sqrt(3)/max_steps
+    float dt_max;      // 2*sqrt(3)*2^(C-1)/H
+    float cascades;    // C as float (the reference passes it through float parameters)
+    float Hf;          // H as float
+    float rH;          // 1/H
+    float H3;          // H*H*H evaluated in uint32 then converted, like the reference's `H * H * H`
+    uint32_t H;
+    const uint8_t* __restrict__ grid;
+};
+
+__host__ __device__ inline MarchConsts make_march_consts(float bound, float dt_gamma, uint32_t max_steps,
+                                                        uint32_t C, uint32_t H, const uint8_t* grid) {
+    MarchConsts k;
+    const float two_sqrt3 = 2 * 1.7320508075688772f;
+    k.bound = bound;
+    k.dt_gamma = dt_gamma;
+    k.dt_min = two_sqrt3 / max_steps;
+    k.dt_max = two_sqrt3 * (1 << (C - 1)) / H;
+    k.cascades = (float)C;
+    k.Hf = (float)H;
+    k.rH = 1 / (float)H;
+    k.H3 = (float)(H * H * H);
+    k.H = H;
+    k.grid = grid;
+    return k;
+}
+
+struct RayGeom {
+    float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
+};
+
+__device__ __forceinline__ RayGeom load_ray(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                            uint32_t id) {
+    RayGeom r;
+    const float* o = rays_o + (size_t)id * 3;
+    const float* d = rays_d + (size_t)id * 3;
+    r.ox = o[0]; r.oy = o[1]; r.oz = o[2];
+    r.dx = d[0]; r.dy = d[1]; r.dz = d[2];
+    r.rdx = 1 / r.dx; r.rdy = 1 / r.dy; r.rdz = 1 / r.dz;
+    return r;
+}
+
+__device__ __forceinline__ float step_size(const MarchConsts& k, float t) {
+    return clampf(t * k.dt_gamma, k.dt_min, k.dt_max);
+}
+
+// frexp exponent clamped to [0, C-1]; the reference routes this through float min/max.
+__device__ __forceinline__ int clamp_level(const MarchConsts& k, float mag) {
+    int e;
+    frexpf(mag, &e);
+    return (int)fminf(k.cascades - 1, fmaxf(0, (float)e));
+}
+
+// voxel coordinate along one axis: the reference evaluates 0.5 * (p * rbound + 1) * H in double
+// (the literal 0.5 promotes), narrows to float for the clamp, then truncates to int.
+__device__ __forceinline__ int voxel_coord(const MarchConsts& k, float p, float mip_rbound) {
+    const float inner = p * mip_rbound + 1;
+    const float scaled = (float)(0.5 * (double)inner * (double)k.H);
+    return (int)clampf(scaled, 0.0f, (float)(k.H - 1));
+}
+
+// distance (in t) to the exit face of voxel coordinate n along one axis
+__device__ __forceinline__ float exit_time(const MarchConsts& k, int n, float d, float rd, float p, float mip_bound) {
+    return (((n + 0.5f + 0.5f * copysignf(1.0f, d)) * k.rH * 2 - 1) * mip_bound - p) * rd;
+}
+
+// Advance `t` to the next occupied sample strictly before `far`.
+// On success: (x,y,z) is the clamped sample position, dt the step used for alpha, and `t` has
+// already been advanced past the sample (t_after = t_sample + dt).  Returns false when the ray
+// leaves [.., far) without another occupied sample.
+__device__ __forceinline__ bool march_next(const MarchConsts& k, const RayGeom& r, float far, float& t,
+                                           float& x, float& y, float& z, float& dt) {
+    while (t < far) {
+        x = clampf(r.ox + t * r.dx, -k.bound, k.bound);
+        y = clampf(r.oy + t * r.dy, -k.bound, k.bound);
+        z = clampf(r.oz + t * r.dz, -k.bound, k.bound);
+        dt = step_size(k, t);
+
+        const int lvl_pos = clamp_level(k, fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))));
+        const int lvl_dt = clamp_level(k, (float)((double)(dt * k.Hf) * 0.5));
+        const int level = max(lvl_pos, lvl_dt);
+
+        const float mip_bound = fminf(scalbnf(1.0f, level), k.bound);
+        const float mip_rbound = 1 / mip_bound;
+
+        const int nx = voxel_coord(k, x, mip_rbound);
+        const int ny = voxel_coord(k, y, mip_rbound);
+        const int nz = voxel_coord(k, z, mip_rbound);
+
+        // level * H3 + morton is a float expression in the reference (H3 is float)
+        const uint32_t bit = (uint32_t)((float)level * k.H3 + (float)morton_encode(nx, ny, nz));
+        const bool occupied = k.grid[bit >> 3] & (1u << (bit & 7));
+
+        if (occupied) {
+            t += dt;
+            return true;
+        }
+        const float tx = exit_time(k, nx, r.dx, r.rdx, x, mip_bound);
+        const float ty = exit_time(k, ny, r.dy, r.rdy, y, mip_bound);
+        const float tz = exit_time(k, nz, r.dz, r.rdz, z, mip_bound);
+        const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+        do {
+            t += step_size(k, t);
+        } while (t < tt);
+    }
+    return false;
+}
+
+// One compositing update (reference raymarching.cu:996-1030, inference form: transmittance is
+// re-derived from the running weight sum, termination is tested with the pre-update T).
+struct Accum {
+    float ws, depth, r, g, b, t;
+};
+
+__device__ __forceinline__ float alpha_from_sigma(float sigma, float delta, uint32_t input_alpha) {
+    return input_alpha ? 0.0f + sigma : 1.0f - __expf(-sigma * delta);
+}
+
+// returns true when the ray must terminate AFTER this sample (T < T_thresh)
+__device__ __forceinline__ bool composite_sample(Accum& a, float alpha, float delta_depth, float cr, float cg,
+                                                 float cb, float T_thresh, uint32_t accum_deltas) {
+    const float T = 1 - a.ws;
+    const float w = alpha * T;
+    a.ws += w;
+    a.t = accum_deltas ? a.t + delta_depth : delta_depth;
+    a.depth += w * a.t;
+    a.r += w * cr;
+    a.g += w * cg;
+    a.b += w * cb;
+    return T < T_thresh;
+}
+
+}  // namespace envidr

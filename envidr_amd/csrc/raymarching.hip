@@ -1,0 +1,533 @@
+// raymarching operators for gfx950 -- C-ABI launchers + kernels.
+//
+// Replaces the reference extension raymarching/src/raymarching.cu (host functions :148-1054,
+// declarations raymarching.h:7-18).  One lane per ray, 256-thread workgroups (one wave64 per
+// SIMD); the marcher/compositor bodies live in march_core.hip.h so the fused render kernel
+// runs the very same code.
+#include "march_core.hip.h"
+
+#include <float.h>
+
+using namespace envidr;
+
+// ---------------------------------------------------------------------------------------------
+// near/far from aabb (reference kernel_near_far_from_aabb, raymarching.cu:91-145)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void order2(float& a, float& b) {
+    if (a > b) { const float c = a; a = b; b = c; }
+}
+
+__global__ void __launch_bounds__(kBlock) k_near_far_from_aabb(const float* __restrict__ rays_o,
+                                                               const float* __restrict__ rays_d,
+                                                               const float* __restrict__ aabb, uint32_t N,
+                                                               float min_near, float* __restrict__ nears,
+                                                               float* __restrict__ fars) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const RayGeom r = load_ray(rays_o, rays_d, n);
+
+    float near = (aabb[0] - r.ox) * r.rdx, far = (aabb[3] - r.ox) * r.rdx;
+    order2(near, far);
+    float ny = (aabb[1] - r.oy) * r.rdy, fy = (aabb[4] - r.oy) * r.rdy;
+    order2(ny, fy);
+    bool miss = near > fy || ny > far;
+    if (!miss) {
+        if (ny > near) near = ny;
+        if (fy < far) far = fy;
+        float nz = (aabb[2] - r.oz) * r.rdz, fz = (aabb[5] - r.oz) * r.rdz;
+        order2(nz, fz);
+        miss = near > fz || nz > far;
+        if (!miss) {
+            if (nz > near) near = nz;
+            if (fz < far) far = fz;
+            if (near < min_near) near = min_near;
+        }
+    }
+    nears[n] = miss ? FLT_MAX : near;
+    fars[n] = miss ? FLT_MAX : far;
+}
+
+// ---------------------------------------------------------------------------------------------
+// background-sphere coordinates (reference kernel_sph_from_ray, raymarching.cu:162-198)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_sph_from_ray(const float* __restrict__ rays_o,
+                                                         const float* __restrict__ rays_d, float radius,
+                                                         uint32_t N, float* __restrict__ coords) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const RayGeom r = load_ray(rays_o, rays_d, n);
+    const float inv_pi = 0.3183098861837907f;
+
+    // ||o + t d|| = radius, larger root (origin assumed inside the sphere)
+    const float A = r.dx * r.dx + r.dy * r.dy + r.dz * r.dz;
+    const float Bh = r.ox * r.dx + r.oy * r.dy + r.oz * r.dz;
+    const float Cc = r.ox * r.ox + r.oy * r.oy + r.oz * r.oz - radius * radius;
+    const float t = (-Bh + sqrtf(Bh * Bh - A * Cc)) / A;
+
+    const float x = r.ox + t * r.dx, y = r.oy + t * r.dy, z = r.oz + t * r.dz;
+    // the reference calls the double overload of atan2 on float arguments
+    const float theta = (float)atan2((double)sqrtf(x * x + z * z), (double)y);
+    const float phi = (float)atan2((double)z, (double)x);
+    coords[2 * (size_t)n] = 2 * theta * inv_pi - 1;
+    coords[2 * (size_t)n + 1] = phi * inv_pi;
+}
+
+// ---------------------------------------------------------------------------------------------
+// morton / packbits / scatter index (raymarching.cu:214-330)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_morton3D(const int32_t* __restrict__ coords, uint32_t N,
+                                                     int32_t* __restrict__ indices) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int32_t* c = coords + (size_t)n * 3;
+    indices[n] = (int32_t)morton_encode((uint32_t)c[0], (uint32_t)c[1], (uint32_t)c[2]);
+}
+
+__global__ void __launch_bounds__(kBlock) k_morton3D_invert(const int32_t* __restrict__ indices, uint32_t N,
+                                                            int32_t* __restrict__ coords) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int32_t code = indices[n];   // arithmetic shifts of the signed value, like the reference
+    int32_t* c = coords + (size_t)n * 3;
+    c[0] = (int32_t)compact3((uint32_t)(code >> 0));
+    c[1] = (int32_t)compact3((uint32_t)(code >> 1));
+    c[2] = (int32_t)compact3((uint32_t)(code >> 2));
+}
+
+// One lane packs one output byte from 8 consecutive floats = two 16-byte loads per lane.
+__global__ void __launch_bounds__(kBlock) k_packbits(const float* __restrict__ grid, uint32_t N, float thresh,
+                                                     uint8_t* __restrict__ bitfield) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float4* g = reinterpret_cast<const float4*>(grid + (size_t)n * 8);
+    const float4 a = g[0], b = g[1];
+    uint32_t bits = 0;
+    bits |= (a.x > thresh) << 0; bits |= (a.y > thresh) << 1; bits |= (a.z > thresh) << 2; bits |= (a.w > thresh) << 3;
+    bits |= (b.x > thresh) << 4; bits |= (b.y > thresh) << 5; bits |= (b.z > thresh) << 6; bits |= (b.w > thresh) << 7;
+    bitfield[n] = (uint8_t)bits;
+}
+
+__global__ void __launch_bounds__(kBlock) k_get_scatter_idx(const int32_t* __restrict__ rays, uint32_t N,
+                                                            int32_t* __restrict__ idx_map) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t id = rays[3 * (size_t)n], off = rays[3 * (size_t)n + 1], cnt = rays[3 * (size_t)n + 2];
+    for (uint32_t s = 0; s < cnt; ++s) idx_map[off + s] = (int32_t)id;
+}
+
+// ---------------------------------------------------------------------------------------------
+// inference marcher (reference kernel_march_rays, raymarching.cu:839-944)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_march_rays(uint32_t n_alive, uint32_t n_step,
+                                                       const int32_t* __restrict__ rays_alive,
+                                                       const float* __restrict__ rays_t,
+                                                       const float* __restrict__ rays_o,
+                                                       const float* __restrict__ rays_d, MarchConsts k,
+                                                       const float* __restrict__ fars, float* __restrict__ xyzs,
+                                                       float* __restrict__ dirs, float* __restrict__ deltas,
+                                                       const float* __restrict__ noises) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const uint32_t id = (uint32_t)rays_alive[n];
+    const RayGeom r = load_ray(rays_o, rays_d, id);
+    const float far = fars[id];
+
+    float t = rays_t[id];
+    float last_t = t;
+    t += step_size(k, t) * noises[n];
+
+    const size_t base = (size_t)n * n_step;
+    float* px = xyzs + base * 3;
+    float* pd = dirs + base * 3;
+    float* pl = deltas + base * 2;
+    for (uint32_t s = 0; s < n_step; ++s) {
+        float x, y, z, dt;
+        if (!march_next(k, r, far, t, x, y, z, dt)) break;
+        px[0] = x; px[1] = y; px[2] = z;
+        pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
+        pl[0] = dt;
+        pl[1] = t - last_t;
+        last_t = t;
+        px += 3; pd += 3; pl += 2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// inference compositor (reference kernel_composite_rays, raymarching.cu:957-1046)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh,
+                                                           uint32_t accum_deltas, uint32_t input_alpha,
+                                                           int32_t* __restrict__ rays_alive,
+                                                           float* __restrict__ rays_t,
+                                                           const float* __restrict__ sigmas,
+                                                           const float* __restrict__ rgbs,
+                                                           const float* __restrict__ deltas,
+                                                           float* __restrict__ weights_sum,
+                                                           float* __restrict__ depth, float* __restrict__ image) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_alive) return;
+    const uint32_t id = (uint32_t)rays_alive[n];
+    const size_t base = (size_t)n * n_step;
+    const float* ps = sigmas + base;
+    const float* pc = rgbs + base * 3;
+    const float* pl = deltas + base * 2;
+
+    Accum a;
+    a.t = rays_t[id];
+    a.ws = weights_sum[id];
+    a.depth = depth[id];
+    a.r = image[3 * (size_t)id]; a.g = image[3 * (size_t)id + 1]; a.b = image[3 * (size_t)id + 2];
+
+    uint32_t s = 0;
+    for (; s < n_step; ++s) {
+        const float d0 = pl[2 * s];
+        if (d0 == 0) break;   // padded / exhausted sample
+        const float alpha = alpha_from_sigma(ps[s], d0, input_alpha);
+        if (composite_sample(a, alpha, pl[2 * s + 1], pc[3 * s], pc[3 * s + 1], pc[3 * s + 2], T_thresh,
+                             accum_deltas))
+            break;
+    }
+    if (s < n_step) rays_alive[n] = -1;
+    else rays_t[id] = a.t;
+
+    weights_sum[id] = a.ws;
+    depth[id] = a.depth;
+    image[3 * (size_t)id] = a.r; image[3 * (size_t)id + 1] = a.g; image[3 * (size_t)id + 2] = a.b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave-level order-preserving compaction of the live ray ids (new; replaces the host-syncing
+// boolean-mask gather of nerf/render_func/cuda_ray.py:345).
+// Each 256-thread workgroup counts its survivors with wave ballots, reserves a contiguous output
+// range in workgroup order through a decoupled look-back on per-block prefix slots, and scatters.
+// Order preservation keeps results identical to the reference's rays_alive ordering.
+// ---------------------------------------------------------------------------------------------
+struct alignas(8) BlockPrefix { int32_t flag; int32_t value; };   // flag: 0 empty, 1 aggregate, 2 inclusive
+
+__global__ void __launch_bounds__(kBlock) k_compact_alive(uint32_t n_alive, const int32_t* __restrict__ in_alive,
+                                                          int32_t* __restrict__ out_alive,
+                                                          int32_t* __restrict__ out_count,
+                                                          unsigned long long* __restrict__ prefix_slots,
+                                                          int32_t* __restrict__ ticket) {
+    __shared__ int32_t s_wave_count[kBlock / 64];
+    __shared__ int32_t s_block_base;
+    __shared__ uint32_t s_block_id;
+
+    // dynamic block id: dispatch order is not guaranteed, a ticket makes look-back deadlock free
+    if (threadIdx.x == 0) s_block_id = (uint32_t)atomicAdd(ticket, 1);
+    __syncthreads();
+    const uint32_t bid = s_block_id;
+    const uint32_t n = bid * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    const int32_t id = n < n_alive ? in_alive[n] : -1;
+    const bool keep = id >= 0;
+    const unsigned long long mask = __ballot(keep);
+    const int32_t rank_in_wave = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave_count[wave] = __popcll(mask);
+    __syncthreads();
+
+    int32_t wave_base = 0, block_total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kBlock / 64; ++w) {
+        const int32_t c = s_wave_count[w];
+        if (w < wave) wave_base += c;
+        block_total += c;
+    }
+
+    if (threadIdx.x == 0) {
+        // publish aggregate, then look back over predecessors (single-word {flag,value} granules)
+        auto pack = [](int32_t flag, int32_t value) {
+            return ((unsigned long long)(uint32_t)flag << 32) | (uint32_t)value;
+        };
+        if (bid == 0) {
+            __hip_atomic_store(&prefix_slots[0], pack(2, block_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_block_base = 0;
+        } else {
+            __hip_atomic_store(&prefix_slots[bid], pack(1, block_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int32_t running = 0;
+            int32_t look = (int32_t)bid - 1;
+            while (true) {
+                const unsigned long long v =
+                    __hip_atomic_load(&prefix_slots[look], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int32_t flag = (int32_t)(v >> 32);
+                if (flag == 0) { __builtin_amdgcn_s_sleep(1); continue; }
+                running += (int32_t)(uint32_t)v;
+                if (flag == 2) break;
+                --look;
+            }
+            __hip_atomic_store(&prefix_slots[bid], pack(2, running + block_total), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            s_block_base = running;
+        }
+        if ((bid + 1) * blockDim.x >= n_alive) *out_count = s_block_base + block_total;
+    }
+    __syncthreads();
+    if (keep) out_alive[s_block_base + wave_base + rank_in_wave] = id;
+}
+
+// ---------------------------------------------------------------------------------------------
+// training marcher (reference kernel_march_rays_train, raymarching.cu:340-508)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_march_rays_train(const float* __restrict__ rays_o,
+                                                             const float* __restrict__ rays_d, MarchConsts k,
+                                                             uint32_t early_stop_steps, uint32_t N, uint32_t M,
+                                                             const float* __restrict__ nears,
+                                                             const float* __restrict__ fars,
+                                                             float* __restrict__ xyzs, float* __restrict__ dirs,
+                                                             float* __restrict__ deltas, int32_t* __restrict__ rays,
+                                                             int32_t* __restrict__ counter,
+                                                             const float* __restrict__ noises) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const RayGeom r = load_ray(rays_o, rays_d, n);
+    const float near = nears[n], far = fars[n];
+
+    float t0 = near;
+    t0 += step_size(k, t0) * noises[n];
+
+    // pass 1: count occupied steps
+    float t = t0, x, y, z, dt;
+    uint32_t num_steps = 0;
+    while (num_steps < early_stop_steps && march_next(k, r, far, t, x, y, z, dt)) ++num_steps;
+
+    // reserve output ranges (the compiler folds these into one atomic per wave)
+    const uint32_t point_index = (uint32_t)atomicAdd(counter, (int32_t)num_steps);
+    const uint32_t ray_index = (uint32_t)atomicAdd(counter + 1, 1);
+    rays[3 * (size_t)ray_index] = (int32_t)n;
+    rays[3 * (size_t)ray_index + 1] = (int32_t)point_index;
+    rays[3 * (size_t)ray_index + 2] = (int32_t)num_steps;
+    if (num_steps == 0 || point_index + num_steps > M) return;
+
+    // pass 2: re-march and write
+    float* px = xyzs + (size_t)point_index * 3;
+    float* pd = dirs + (size_t)point_index * 3;
+    float* pl = deltas + (size_t)point_index * 2;
+    t = t0;
+    float last_t = near;
+    for (uint32_t s = 0; s < num_steps; ++s) {
+        if (!march_next(k, r, far, t, x, y, z, dt)) break;
+        px[0] = x; px[1] = y; px[2] = z;
+        pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
+        pl[0] = dt;
+        pl[1] = t - last_t;
+        last_t = t;
+        px += 3; pd += 3; pl += 2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// training compositor forward / backward (raymarching.cu:529-832)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_composite_train_fwd(const float* __restrict__ sigmas,
+                                                                const float* __restrict__ rgbs,
+                                                                const float* __restrict__ deltas,
+                                                                const int32_t* __restrict__ rays, uint32_t M,
+                                                                uint32_t N, float T_thresh, uint32_t accum_deltas,
+                                                                uint32_t input_alpha, float* __restrict__ weights_sum,
+                                                                float* __restrict__ depth, float* __restrict__ image,
+                                                                float* __restrict__ weights) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t id = rays[3 * (size_t)n], off = rays[3 * (size_t)n + 1], cnt = rays[3 * (size_t)n + 2];
+
+    float r = 0, g = 0, b = 0, ws = 0, t = 0, d = 0;
+    if (cnt != 0 && off + cnt <= M) {
+        float T = 1.0f;
+        for (uint32_t s = 0; s < cnt; ++s) {
+            const size_t m = (size_t)off + s;
+            const float alpha = alpha_from_sigma(sigmas[m], deltas[2 * m], input_alpha);
+            const float w = alpha * T;
+            if (weights) weights[m] = w;
+            r += w * rgbs[3 * m]; g += w * rgbs[3 * m + 1]; b += w * rgbs[3 * m + 2];
+            t = accum_deltas ? t + deltas[2 * m + 1] : deltas[2 * m + 1];
+            d += w * t;
+            ws += w;
+            T *= 1.0f - alpha;
+            if (T < T_thresh) break;
+        }
+    }
+    weights_sum[id] = ws;
+    depth[id] = d;
+    image[3 * (size_t)id] = r; image[3 * (size_t)id + 1] = g; image[3 * (size_t)id + 2] = b;
+}
+
+__global__ void __launch_bounds__(kBlock) k_composite_train_bwd(
+    const float* __restrict__ grad_weights_sum, const float* __restrict__ grad_image,
+    const float* __restrict__ grad_depth, const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+    const float* __restrict__ deltas, const int32_t* __restrict__ rays, const float* __restrict__ weights_sum,
+    const float* __restrict__ image, const float* __restrict__ depth, uint32_t M, uint32_t N, float T_thresh,
+    float* __restrict__ grad_sigmas, float* __restrict__ grad_rgbs, uint32_t accum_deltas, uint32_t input_alpha) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t id = rays[3 * (size_t)n], off = rays[3 * (size_t)n + 1], cnt = rays[3 * (size_t)n + 2];
+    if (cnt == 0 || off + cnt > M) return;
+
+    const float gr = grad_image[3 * (size_t)id], gg = grad_image[3 * (size_t)id + 1], gb = grad_image[3 * (size_t)id + 2];
+    const float gws = grad_weights_sum[id];
+    const float r_final = image[3 * (size_t)id], g_final = image[3 * (size_t)id + 1], b_final = image[3 * (size_t)id + 2];
+    const float ws_final = weights_sum[id];
+    // Reference quirk kept on purpose (raymarching.cu:771,797): the depth terms read element 0 of
+    // `depth` / `grad_depth`, not the ray's own element -- those two pointers are never offset.
+    const float d_final = depth[0], gd = grad_depth[0];
+
+    float T = 1.0f, r = 0, g = 0, b = 0, t = 0, d = 0;
+    for (uint32_t s = 0; s < cnt; ++s) {
+        const size_t m = (size_t)off + s;
+        const float alpha = alpha_from_sigma(sigmas[m], deltas[2 * m], input_alpha);
+        const float w = alpha * T;
+        const float grad_scale = input_alpha ? (1.0f / (1.0f - alpha + 1e-4f)) : deltas[2 * m];
+        const float cr = rgbs[3 * m], cg = rgbs[3 * m + 1], cb = rgbs[3 * m + 2];
+        r += w * cr; g += w * cg; b += w * cb;
+        t = accum_deltas ? t + deltas[2 * m + 1] : deltas[2 * m + 1];
+        d += w * t;
+        T *= 1.0f - alpha;
+
+        grad_rgbs[3 * m] = gr * w; grad_rgbs[3 * m + 1] = gg * w; grad_rgbs[3 * m + 2] = gb * w;
+        grad_sigmas[m] = grad_scale * (gr * (T * cr - (r_final - r)) + gg * (T * cg - (g_final - g)) +
+                                       gb * (T * cb - (b_final - b)) + gd * (T * t - (d_final - d)) +
+                                       gws * (1 - ws_final));
+        if (T < T_thresh) break;
+    }
+}
+
+// =============================================================================================
+// C-ABI launchers
+// =============================================================================================
+#define LAUNCH_1D(kernel, count, stream, ...)                                                            \
+    do {                                                                                                 \
+        if ((count) == 0) return ENVIDR_OK;                                                              \
+        hipLaunchKernelGGL(kernel, dim3(ceil_div((count), kBlock)), dim3(kBlock), 0, as_stream(stream),  \
+                           __VA_ARGS__);                                                                 \
+        return check_launch(#kernel);                                                                    \
+    } while (0)
+
+extern "C" {
+
+int envidr_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N,
+                              float min_near, float* nears, float* fars, envidr_stream_t stream) {
+    ENVIDR_REQUIRE(N == 0 || (rays_o && rays_d && aabb && nears && fars), "near_far_from_aabb: null pointer");
+    LAUNCH_1D(k_near_far_from_aabb, N, stream, rays_o, rays_d, aabb, N, min_near, nears, fars);
+}
+
+int envidr_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords,
+                        envidr_stream_t stream) {
+    ENVIDR_REQUIRE(N == 0 || (rays_o && rays_d && coords), "sph_from_ray: null pointer");
+    LAUNCH_1D(k_sph_from_ray, N, stream, rays_o, rays_d, radius, N, coords);
+}
+
+int envidr_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, envidr_stream_t stream) {
+    ENVIDR_REQUIRE(N == 0 || (coords && indices), "morton3D: null pointer");
+    LAUNCH_1D(k_morton3D, N, stream, coords, N, indices);
+}
+
+int envidr_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, envidr_stream_t stream) {
+    ENVIDR_REQUIRE(N == 0 || (coords && indices), "morton3D_invert: null pointer");
+    LAUNCH_1D(k_morton3D_invert, N, stream, indices, N, coords);
+}
+
+int envidr_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield,
+                    envidr_stream_t stream) {
+    ENVIDR_REQUIRE(N == 0 || (grid && bitfield), "packbits: null pointer");
+    ENVIDR_REQUIRE((reinterpret_cast<uintptr_t>(grid) & 15) == 0, "packbits: grid must be 16-byte aligned");
+    LAUNCH_1D(k_packbits, N, stream, grid, N, density_thresh, bitfield);
+}
+
+int envidr_get_scatter_idx(const int32_t* rays, uint32_t N, int32_t* idx_map, envidr_stream_t stream) {
+    ENVIDR_REQUIRE(N == 0 || (rays && idx_map), "get_scatter_idx: null pointer");
+    LAUNCH_1D(k_get_scatter_idx, N, stream, rays, N, idx_map);
+}
+
+int envidr_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                      const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                      uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
+                      float* xyzs, float* dirs, float* deltas, const float* noises, envidr_stream_t stream) {
+    (void)nears;   // the reference kernel loads nears[index] but never uses it
+    ENVIDR_REQUIRE(n_alive == 0 || (rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs &&
+                                    deltas && noises),
+                   "march_rays: null pointer");
+    ENVIDR_REQUIRE(C >= 1 && H >= 1 && max_steps >= 1, "march_rays: C, H, max_steps must be >= 1");
+    const MarchConsts k = make_march_consts(bound, dt_gamma, max_steps, C, H, grid);
+    LAUNCH_1D(k_march_rays, n_alive, stream, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, k, fars, xyzs,
+              dirs, deltas, noises);
+}
+
+int envidr_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, uint32_t accum_deltas,
+                          uint32_t input_alpha, int32_t* rays_alive, float* rays_t, const float* sigmas,
+                          const float* rgbs, const float* deltas, float* weights_sum, float* depth, float* image,
+                          envidr_stream_t stream) {
+    ENVIDR_REQUIRE(n_alive == 0 || (rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image),
+                   "composite_rays: null pointer");
+    LAUNCH_1D(k_composite_rays, n_alive, stream, n_alive, n_step, T_thresh, accum_deltas, input_alpha, rays_alive,
+              rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+}
+
+int envidr_compact_alive(uint32_t n_alive, const int32_t* rays_alive, int32_t* out_alive, int32_t* out_count,
+                         envidr_stream_t stream) {
+    ENVIDR_REQUIRE(out_count != nullptr, "compact_alive: out_count is null");
+    hipStream_t s = as_stream(stream);
+    if (n_alive == 0) {
+        if (hipMemsetAsync(out_count, 0, sizeof(int32_t), s) != hipSuccess) return check_launch("compact_alive memset");
+        return ENVIDR_OK;
+    }
+    ENVIDR_REQUIRE(rays_alive && out_alive, "compact_alive: null pointer");
+    // look-back scratch: one 8-byte slot per workgroup + a ticket, kept in a per-library buffer
+    // that grows monotonically (allocation only on growth, never in steady state).
+    static void* scratch = nullptr;
+    static size_t scratch_bytes = 0;
+    const uint32_t blocks = ceil_div(n_alive, kBlock);
+    const size_t need = (size_t)blocks * sizeof(unsigned long long) + 16;
+    if (need > scratch_bytes) {
+        if (scratch) (void)hipFree(scratch);
+        scratch_bytes = need * 2;
+        if (hipMalloc(&scratch, scratch_bytes) != hipSuccess) {
+            scratch = nullptr; scratch_bytes = 0;
+            return check_launch("compact_alive scratch alloc");
+        }
+    }
+    if (hipMemsetAsync(scratch, 0, need, s) != hipSuccess) return check_launch("compact_alive memset");
+    int32_t* ticket = reinterpret_cast<int32_t*>(scratch);
+    unsigned long long* slots = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(scratch) + 16);
+    hipLaunchKernelGGL(k_compact_alive, dim3(blocks), dim3(kBlock), 0, s, n_alive, rays_alive, out_alive, out_count,
+                       slots, ticket);
+    return check_launch("k_compact_alive");
+}
+
+int envidr_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
+                            float dt_gamma, uint32_t max_steps, uint32_t early_stop_steps, uint32_t N, uint32_t C,
+                            uint32_t H, uint32_t M, const float* nears, const float* fars, float* xyzs, float* dirs,
+                            float* deltas, int32_t* rays, int32_t* counter, const float* noises,
+                            envidr_stream_t stream) {
+    ENVIDR_REQUIRE(N == 0 || (rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && rays && counter &&
+                              noises),
+                   "march_rays_train: null pointer");
+    ENVIDR_REQUIRE(C >= 1 && H >= 1 && max_steps >= 1, "march_rays_train: C, H, max_steps must be >= 1");
+    const MarchConsts k = make_march_consts(bound, dt_gamma, max_steps, C, H, grid);
+    LAUNCH_1D(k_march_rays_train, N, stream, rays_o, rays_d, k, early_stop_steps, N, M, nears, fars, xyzs, dirs,
+              deltas, rays, counter, noises);
+}
+
+int envidr_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas,
+                                        const int32_t* rays, uint32_t M, uint32_t N, float T_thresh,
+                                        uint32_t accum_deltas, uint32_t input_alpha, float* weights_sum,
+                                        float* depth, float* image, float* weights, envidr_stream_t stream) {
+    ENVIDR_REQUIRE(N == 0 || (rays && weights_sum && depth && image), "composite_rays_train_forward: null pointer");
+    ENVIDR_REQUIRE(N == 0 || M == 0 || (sigmas && rgbs && deltas), "composite_rays_train_forward: null sample array");
+    LAUNCH_1D(k_composite_train_fwd, N, stream, sigmas, rgbs, deltas, rays, M, N, T_thresh, accum_deltas,
+              input_alpha, weights_sum, depth, image, weights);
+}
+
+int envidr_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image,
+                                         const float* grad_depth, const float* sigmas, const float* rgbs,
+                                         const float* deltas, const int32_t* rays, const float* weights_sum,
+                                         const float* image, const float* depth, uint32_t M, uint32_t N,
+                                         float T_thresh, float* grad_sigmas, float* grad_rgbs, uint32_t accum_deltas,
+                                         uint32_t input_alpha, envidr_stream_t stream) {
+    ENVIDR_REQUIRE(N == 0 || (grad_weights_sum && grad_image && grad_depth && sigmas && rgbs && deltas && rays &&
+                              weights_sum && image && depth && grad_sigmas && grad_rgbs),
+                   "composite_rays_train_backward: null pointer");
+    LAUNCH_1D(k_composite_train_bwd, N, stream, grad_weights_sum, grad_image, grad_depth, sigmas, rgbs, deltas, rays,
+              weights_sum, image, depth, M, N, T_thresh, grad_sigmas, grad_rgbs, accum_deltas, input_alpha);
+}
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+"""TEST INFRASTRUCTURE: ctypes access to
+    * oracle/_build/libenvidr_oracle.so -- our plain-C restatement (oracle/c/envidr_oracle.c), prefix `oracle_`
+    * oracle/_ref/libenvidr_ref.so      -- the reference's own kernel bodies on the CPU (oracle/ref), prefix `ref_`
+Both expose the C-ABI of include/envidr_amd.h minus the stream argument, on host pointers, so the
+same argument tuples drive the oracle, the reference bodies and (via envidr_amd._lib) the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+from envidr_amd._lib import SIGNATURES, argtypes  # the signature table only; no GPU needed
+
+HERE = Path(__file__).resolve().parent
+ORACLE_LIB = HERE / "_build" / "libenvidr_oracle.so"
+REF_LIB = HERE / "_ref" / "libenvidr_ref.so"
+
+
+def build_oracle(verbose: bool = False) -> Path:
+    src = HERE / "c" / "envidr_oracle.c"
+    if not ORACLE_LIB.exists() or ORACLE_LIB.stat().st_mtime < src.stat().st_mtime:
+        r = subprocess.run(["make", "-C", str(HERE / "c")], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("oracle build failed:\n" + r.stdout + r.stderr)
+        if verbose:
+            print(f"[oracle] built {ORACLE_LIB}")
+    return ORACLE_LIB
+
+
+class HostLib:
+    """Calls `<prefix><name>(...)` with numpy arrays (passed by address), numbers and None."""
+
+    def __init__(self, path: Path, prefix: str):
+        self.path, self.prefix = path, prefix
+        self.lib = ctypes.CDLL(str(path))
+        for name, sig in SIGNATURES.items():
+            fn = getattr(self.lib, prefix + name, None)
+            if fn is not None:
+                fn.argtypes = argtypes(sig, with_stream=False)
+                fn.restype = ctypes.c_int
+
+    def has(self, name: str) -> bool:
+        return hasattr(self.lib, self.prefix + name)
+
+    def call(self, name: str, *args) -> None:
+        sig = SIGNATURES[name]
+        assert len(args) == len(sig), f"{name}: expected {len(sig)} args, got {len(args)}"
+        conv = []
+        for kind, a in zip(sig, args):
+            if kind == "p":
+                if a is None:
+                    conv.append(None)
+                else:
+                    assert isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"], f"{name}: need contiguous ndarray"
+                    conv.append(a.ctypes.data)
+            elif kind == "f":
+                conv.append(float(a))
+            else:
+                conv.append(int(a))
+        rc = getattr(self.lib, self.prefix + name)(*conv)
+        if rc != 0:
+            raise RuntimeError(f"{self.prefix}{name} returned {rc}")
+
+
+_oracle: HostLib | None = None
+_ref: HostLib | None = None
+
+
+def oracle() -> HostLib:
+    global _oracle
+    if _oracle is None:
+        _oracle = HostLib(build_oracle(), "oracle_")
+    return _oracle
+
+
+def ref_available() -> bool:
+    return REF_LIB.exists()
+
+
+def ref() -> HostLib:
+    """The reference's kernel bodies (prebuilt in the container that has /root/reference)."""
+    global _ref
+    if _ref is None:
+        if not REF_LIB.exists():
+            raise FileNotFoundError(f"{REF_LIB} not built; run `python oracle/ref/build_ref.py` where /root/reference exists")
+        _ref = HostLib(REF_LIB, "ref_")
+    return _ref

@@ -1,0 +1,64 @@
+/*
+ * TEST INFRASTRUCTURE -- never linked into, imported by, or shipped with the product path.
+ *
+ * Keyword/intrinsic definitions that let the *bodies* of the reference's device kernels
+ * (/root/reference/<ext>/src/<ext>.cu, read where they lie, never copied into this repo) be
+ * compiled by g++ as ordinary host C++ and driven one emulated thread at a time.
+ *
+ * This is NOT a build of the reference's CUDA extension: that needs nvcc, the CUDA runtime
+ * headers and a CUDA device, none of which exist in this image (DESIGN.md "Oracle pinning"
+ * says so plainly).  What it gives us is the reference authors' own arithmetic -- the same
+ * expressions, in the same order, with the same float/double/int mixing -- executed on the
+ * CPU, which is what SURVEY.md section 8(c) prescribes as the level-0 oracle.
+ *
+ * Known, documented deviations from a real CUDA run:
+ *   - __expf/__sinf map to libm expf/sinf (device fast-math differs by a few ulp anyway);
+ *   - no FMA contraction (g++ -ffp-contract=off); nvcc would contract a*b+c;
+ *   - atomics are serial, therefore deterministic.
+ */
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <limits>
+#include <stdexcept>
+#include <type_traits>
+
+#define __global__
+#define __device__
+#define __host__
+#define __restrict__
+
+struct EmuDim3 { uint32_t x = 0, y = 0, z = 0; };
+static thread_local EmuDim3 threadIdx, blockIdx, blockDim;
+
+using std::max;
+using std::min;
+
+/* serial stand-ins for the device atomics the kernels use */
+template <typename T> static inline T atomicAdd(T* addr, T v) { T old = *addr; *addr = old + v; return old; }
+static inline uint32_t atomicAdd(int* addr, uint32_t v) { int old = *addr; *addr = old + (int)v; return (uint32_t)old; }
+
+/* half types are only ever *named* by the float instantiations we run */
+struct __half { float v; __half() = default; __half(float f) : v(f) {} operator float() const { return v; } };
+struct __half2 { __half x, y; };
+static inline void atomicAdd(__half2* a, __half2 v) { a->x = (float)a->x + (float)v.x; a->y = (float)a->y + (float)v.y; }
+namespace at { struct Half { float v; Half() = default; Half(float f) : v(f) {} operator float() const { return v; } }; }
+static inline at::Half atomicAdd(__half* a, at::Half v) { at::Half old(a->v); a->v += v.v; return old; }
+
+#define __sinf sinf
+#define __expf expf
+
+/* Run `body()` once per emulated thread of a 1-D or (x, y) grid. */
+template <typename F>
+static inline void emu_launch(uint32_t grid_x, uint32_t grid_y, uint32_t block_x, F body) {
+    blockDim.x = block_x; blockDim.y = 1; blockDim.z = 1;
+    for (uint32_t by = 0; by < grid_y; ++by)
+        for (uint32_t bx = 0; bx < grid_x; ++bx)
+            for (uint32_t tx = 0; tx < block_x; ++tx) {
+                blockIdx.x = bx; blockIdx.y = by; threadIdx.x = tx;
+                body();
+            }
+}
+static inline uint32_t emu_blocks(uint32_t n, uint32_t block) { return (n + block - 1) / block; }

@@ -1,0 +1,303 @@
+"""Seeded operator test cases shared by the CPU pinning tests (oracle vs reference kernel bodies),
+the golden-vector generator and the GPU parity tests (HIP vs oracle).
+
+Each case is (case_id, op_name, args, tol) where args are numpy arrays / numbers in C-ABI order
+(include/envidr_amd.h) and tol is None for "every output must be bit-identical" or a float
+relative-L2 bound for outputs that go through libm-vs-device transcendental functions.
+Sizes are small enough that the serial reference emulation finishes in seconds.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from envidr_amd import scenes
+
+F = np.float32
+
+
+def _camera_case(H=48, W=48, bound=1.0, **kw):
+    ro, rd = scenes.camera_rays(H, W, **kw)
+    aabb = np.array([-bound, -bound, -bound, bound, bound, bound], F)
+    return ro, rd, aabb
+
+
+def _special_rays(rng, n=256):
+    """random rays plus the awkward ones: axis-parallel (zero components -> inf reciprocals),
+    origins inside the box, rays that miss."""
+    ro = rng.uniform(-3, 3, size=(n, 3)).astype(F)
+    rd = rng.normal(size=(n, 3)).astype(F)
+    rd[:16, 0] = 0
+    rd[8:24, 1] = 0
+    rd[24:32] = np.array([0, 0, 1], F)
+    ro[32:64] = rng.uniform(-0.9, 0.9, size=(32, 3)).astype(F)
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    return ro, rd.astype(F)
+
+
+def near_far_cases():
+    rng = np.random.default_rng(10)
+    out = []
+    ro, rd, aabb = _camera_case()
+    N = ro.shape[0]
+    out.append(("camera", "near_far_from_aabb", (ro, rd, aabb, N, 0.2, np.zeros(N, F), np.zeros(N, F)), None))
+    ro, rd = _special_rays(rng)
+    N = ro.shape[0]
+    aabb2 = np.array([-1, -0.5, -0.25, 0.75, 1, 1], F)
+    out.append(("special", "near_far_from_aabb", (ro, rd, aabb2, N, 0.05, np.zeros(N, F), np.zeros(N, F)), None))
+    out.append(("empty", "near_far_from_aabb", (ro[:0], rd[:0], aabb2, 0, 0.05, np.zeros(0, F), np.zeros(0, F)), None))
+    return out
+
+
+def misc_cases():
+    rng = np.random.default_rng(11)
+    out = []
+    ro, rd = _special_rays(rng, 300)
+    ro *= 0.2
+    out.append(("sph", "sph_from_ray", (ro, rd, 1.7, 300, np.zeros((300, 2), F)), 1e-6))
+    c = rng.integers(0, 1024, size=(1000, 3)).astype(np.int32)
+    out.append(("morton", "morton3D", (c, 1000, np.zeros(1000, np.int32)), None))
+    idx = rng.integers(0, 2 ** 30, size=1000).astype(np.int32)
+    out.append(("morton_inv", "morton3D_invert", (idx, 1000, np.zeros((1000, 3), np.int32)), None))
+    g = rng.normal(size=(4096 * 8,)).astype(F)
+    g[::7] = 0.01
+    out.append(("packbits", "packbits", (g, 4096, 0.01, np.zeros(4096, np.uint8)), None))
+    rays = np.array([[5, 0, 3], [2, 3, 0], [9, 3, 4], [1, 7, 1]], np.int32)
+    out.append(("scatter", "get_scatter_idx", (rays, 4, np.full(8, -1, np.int32)), None))
+    return out
+
+
+def _march_inputs(H=40, W=40, bound=1.0, cascades=1, shape=None, min_near=0.2):
+    from oracle import clib
+    ro, rd, aabb = _camera_case(H, W, bound)
+    N = ro.shape[0]
+    nears, fars = np.zeros(N, F), np.zeros(N, F)
+    clib.oracle().call("near_far_from_aabb", ro, rd, aabb, N, min_near, nears, fars)
+    bitfield = scenes.occupancy_bitfield(shape or scenes.shell(), bound=bound, cascades=cascades)
+    return ro, rd, nears, fars, bitfield
+
+
+def march_cases():
+    rng = np.random.default_rng(12)
+    out = []
+    for cid, kw in [
+        ("c1_step1", dict(n_step=1, dt_gamma=0.0)),
+        ("c1_step8", dict(n_step=8, dt_gamma=0.0)),
+        ("c1_cone_noise", dict(n_step=4, dt_gamma=1 / 128, noise=True)),
+        ("c2_bound2", dict(n_step=8, dt_gamma=0.0, bound=2.0, cascades=2, shape=scenes.ball(1.3))),
+        ("c1_torus_subset", dict(n_step=3, dt_gamma=0.0, shape=scenes.torus(), subset=True, max_steps=512)),
+    ]:
+        bound, cascades = kw.get("bound", 1.0), kw.get("cascades", 1)
+        ro, rd, nears, fars, bitfield = _march_inputs(bound=bound, cascades=cascades, shape=kw.get("shape"))
+        N = ro.shape[0]
+        alive = np.arange(N, dtype=np.int32)
+        if kw.get("subset"):
+            alive = rng.permutation(N)[: N // 3].astype(np.int32)
+        n_alive, n_step = alive.shape[0], kw["n_step"]
+        rays_t = nears.copy()
+        if kw.get("subset"):  # resume mid-ray
+            rays_t = np.where(nears < 1e30, nears + rng.uniform(0, 0.5, N).astype(F), nears).astype(F)
+        noises = rng.uniform(0, 1, n_alive).astype(F) if kw.get("noise") else np.zeros(n_alive, F)
+        M = n_alive * n_step
+        M += 128 - (M % 128)
+        args = (n_alive, n_step, alive, rays_t, ro, rd, bound, kw["dt_gamma"], kw.get("max_steps", 1024), cascades, 128,
+                bitfield, nears, fars, np.zeros((M, 3), F), np.zeros((M, 3), F), np.zeros((M, 2), F), noises)
+        out.append((cid, "march_rays", args, None))
+    return out
+
+
+def composite_cases():
+    from oracle import clib
+    rng = np.random.default_rng(13)
+    out = []
+    for cid, n_step, accum, ia in [("rgb", 4, 1, 0), ("roughness_as_depth", 8, 0, 0), ("alpha_in", 2, 1, 1)]:
+        ro, rd, nears, fars, bitfield = _march_inputs(H=32, W=32)
+        N = ro.shape[0]
+        alive = np.arange(N, dtype=np.int32)
+        M = N * n_step + 128
+        xyzs, dirs, deltas = np.zeros((M, 3), F), np.zeros((M, 3), F), np.zeros((M, 2), F)
+        clib.oracle().call("march_rays", N, n_step, alive, nears.copy(), ro, rd, 1.0, 0.0, 1024, 1, 128, bitfield, nears, fars,
+                           xyzs, dirs, deltas, np.zeros(N, F))
+        sig = rng.uniform(0, 400, M).astype(F) if not ia else rng.uniform(0, 0.9, M).astype(F)
+        rgb = rng.uniform(0, 1, (M, 3)).astype(F)
+        ws = rng.uniform(0, 0.3, N).astype(F)
+        args = (N, n_step, 1e-4, accum, ia, alive.copy(), nears.copy(), sig, rgb, deltas, ws, rng.uniform(0, 1, N).astype(F),
+                rng.uniform(0, 1, (N, 3)).astype(F))
+        out.append((cid, "composite_rays", args, 1e-6))
+    return out
+
+
+def train_cases():
+    from oracle import clib
+    rng = np.random.default_rng(14)
+    out = []
+    ro, rd, nears, fars, bitfield = _march_inputs(H=24, W=24)
+    N = ro.shape[0]
+    M = 40000
+    march_args = (ro, rd, bitfield, 1.0, 0.0, 1024, 1024, N, 1, 128, M, nears, fars, np.zeros((M, 3), F), np.zeros((M, 3), F),
+                  np.zeros((M, 2), F), np.zeros((N, 3), np.int32), np.zeros(2, np.int32), np.zeros(N, F))
+    out.append(("march_train", "march_rays_train", march_args, None))
+    out.append(("march_train_earlystop", "march_rays_train", march_args[:6] + (16,) + march_args[7:], None))
+    res = [np.copy(a) if isinstance(a, np.ndarray) else a for a in march_args]
+    clib.oracle().call("march_rays_train", *res)
+    deltas, rays, counter = res[15], res[16], res[17]
+    Mused = int(counter[0])
+    sig = rng.uniform(0, 300, M).astype(F)
+    rgb = rng.uniform(0, 1, (M, 3)).astype(F)
+    for cid, wts in [("fwd", None), ("fwd_weights", np.zeros(M, F))]:
+        out.append((f"composite_train_{cid}", "composite_rays_train_forward",
+                    (sig, rgb, deltas, rays, M, N, 1e-4, 1, 0, np.zeros(N, F), np.zeros(N, F), np.zeros((N, 3), F), wts), 1e-6))
+    fw = [sig, rgb, deltas, rays, M, N, 1e-4, 1, 0, np.zeros(N, F), np.zeros(N, F), np.zeros((N, 3), F), None]
+    clib.oracle().call("composite_rays_train_forward", *fw)
+    ws, depth, image = fw[9], fw[10], fw[11]
+    out.append(("composite_train_bwd", "composite_rays_train_backward",
+                (rng.normal(size=N).astype(F), rng.normal(size=(N, 3)).astype(F), rng.normal(size=N).astype(F), sig, rgb, deltas,
+                 rays, ws, image, depth, M, N, 1e-4, np.zeros(M, F), np.zeros((M, 3), F), 1, 0), 1e-5))
+    assert Mused > 0
+    return out
+
+
+def _points(rng, B, D):
+    x = rng.uniform(0, 1, size=(B, D)).astype(F)
+    x[0] = 0.0
+    x[1] = 1.0
+    x[2, 0] = -0.01          # out of range -> zero features
+    x[3, D - 1] = 1.0001
+    x[4] = 0.5
+    return x
+
+
+def hash_cases():
+    rng = np.random.default_rng(15)
+    out = []
+    for D, C, L, log2T, base, desired in [(3, 2, 16, 19, 16, 2048), (3, 4, 6, 12, 4, 64), (2, 1, 5, 10, 8, 256),
+                                           (2, 8, 4, 9, 4, 40), (3, 1, 4, 14, 8, 48), (3, 8, 3, 11, 4, 24), (2, 2, 8, 15, 16, 1024),
+                                           (2, 4, 4, 8, 2, 19)]:
+        offsets, pls = scenes.hash_level_offsets(D, L, base, log2T, desired)
+        S = float(np.log2(pls))
+        B = 700 if L == 16 else 300
+        x = _points(rng, B, D)
+        table = rng.uniform(-1, 1, size=(int(offsets[-1]), C)).astype(F)
+        cid = f"D{D}C{C}L{L}"
+        fwd = (x, table, offsets, np.zeros((L, B, C), F), B, D, C, L, S, base, 1, np.zeros((B, L * D * C), F))
+        out.append((cid + "_fwd_grad", "hash_encode_forward", fwd, None))
+        out.append((cid + "_fwd", "hash_encode_forward", fwd[:10] + (0, None), None))
+    return out
+
+
+def hash_backward_cases():
+    from oracle import clib
+    rng = np.random.default_rng(16)
+    out = []
+    for D, C, L, log2T, base, desired in [(3, 2, 8, 12, 8, 128), (2, 4, 4, 9, 4, 40), (3, 1, 3, 10, 4, 20)]:
+        offsets, pls = scenes.hash_level_offsets(D, L, base, log2T, desired)
+        S = float(np.log2(pls))
+        B = 200
+        x = _points(rng, B, D)
+        table = rng.uniform(-1, 1, size=(int(offsets[-1]), C)).astype(F)
+        dy_dx = np.zeros((B, L * D * C), F)
+        clib.oracle().call("hash_encode_forward", x, table, offsets, np.zeros((L, B, C), F), B, D, C, L, S, base, 1, dy_dx)
+        grad = rng.normal(size=(L, B, C)).astype(F)
+        cid = f"D{D}C{C}L{L}"
+        # scatter order differs between serial CPU and GPU atomics -> tolerance on the table gradient
+        out.append((cid + "_bwd", "hash_encode_backward",
+                    (grad, x, table, offsets, np.zeros_like(table), B, D, C, L, S, base, 1, dy_dx, np.zeros((B, D), F)), 1e-5))
+        out.append((cid + "_bwd_inputs_only", "hash_encode_backward",
+                    (grad, x, table, offsets, None, B, D, C, L, S, base, 1, dy_dx, np.zeros((B, D), F)), None))
+        if C != 1:
+            out.append((cid + "_bwd2", "hash_encode_second_backward",
+                        (grad, x, table, offsets, B, D, C, L, S, base, 1, dy_dx, rng.normal(size=(B, D)).astype(F),
+                         np.zeros((L, B, C), F), np.zeros_like(table)), 1e-5))
+    return out
+
+
+def grid_cases():
+    rng = np.random.default_rng(17)
+    out = []
+    for D, C, L, log2T, base, desired, gridtype, align in [(3, 2, 16, 19, 16, 2048, 0, 0), (2, 2, 4, 19, 16, 2048, 0, 0),
+                                                            (3, 4, 5, 10, 4, 50, 1, 0), (1, 1, 4, 8, 4, 64, 0, 1),
+                                                            (4, 2, 3, 10, 2, 8, 0, 0), (5, 8, 2, 9, 2, 4, 1, 1), (2, 8, 6, 12, 8, 300, 0, 1)]:
+        offsets, pls = scenes.grid_level_offsets(D, L, base, log2T, desired, bool(align))
+        S = float(np.log2(pls))
+        B = 400 if L == 16 else 200
+        x = _points(rng, B, D)
+        table = rng.uniform(-1, 1, size=(int(offsets[-1]), C)).astype(F)
+        cid = f"D{D}C{C}L{L}g{gridtype}a{align}"
+        out.append((cid + "_fwd_grad", "grid_encode_forward",
+                    (x, table, offsets, np.zeros((L, B, C), F), B, D, C, L, S, base, np.zeros((B, L * D * C), F), gridtype, align), None))
+        out.append((cid + "_fwd", "grid_encode_forward",
+                    (x, table, offsets, np.zeros((L, B, C), F), B, D, C, L, S, base, None, gridtype, align), None))
+    return out
+
+
+def grid_backward_cases():
+    from oracle import clib
+    rng = np.random.default_rng(18)
+    out = []
+    for D, C, L, log2T, base, desired, gridtype, align in [(3, 2, 6, 12, 8, 100, 0, 0), (2, 4, 4, 9, 4, 40, 1, 1)]:
+        offsets, pls = scenes.grid_level_offsets(D, L, base, log2T, desired, bool(align))
+        S = float(np.log2(pls))
+        B = 200
+        x = _points(rng, B, D)
+        table = rng.uniform(-1, 1, size=(int(offsets[-1]), C)).astype(F)
+        dy_dx = np.zeros((B, L * D * C), F)
+        clib.oracle().call("grid_encode_forward", x, table, offsets, np.zeros((L, B, C), F), B, D, C, L, S, base, dy_dx, gridtype, align)
+        grad = rng.normal(size=(L, B, C)).astype(F)
+        out.append((f"D{D}C{C}_bwd", "grid_encode_backward",
+                    (grad, x, table, offsets, np.zeros_like(table), B, D, C, L, S, base, dy_dx, np.zeros((B, D), F), gridtype, align), 1e-5))
+        out.append((f"D{D}C{C}_bwd_noinput", "grid_encode_backward",
+                    (grad, x, table, offsets, np.zeros_like(table), B, D, C, L, S, base, None, None, gridtype, align), 1e-5))
+    return out
+
+
+def _unit_dirs(rng, B):
+    d = rng.normal(size=(B, 3)).astype(F)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = d.astype(F)
+    d[0] = (0, 0, 1)
+    d[1] = (0, 0, -1)
+    d[2] = (1, 0, 0)
+    d[3] = (0, -1, 0)
+    return d
+
+
+def freq_sh_cases():
+    rng = np.random.default_rng(19)
+    out = []
+    for D, deg in [(3, 4), (3, 10), (2, 6), (1, 1)]:
+        B = 333
+        C = D + 2 * D * deg
+        x = rng.uniform(-1, 1, size=(B, D)).astype(F)
+        out.append((f"freq_D{D}deg{deg}", "freq_encode_forward", (x, B, D, deg, C, np.zeros((B, C), F)), 2e-6))
+        o = np.zeros((B, C), F)
+        from oracle import clib
+        clib.oracle().call("freq_encode_forward", x, B, D, deg, C, o)
+        out.append((f"freq_bwd_D{D}deg{deg}", "freq_encode_backward",
+                    (rng.normal(size=(B, C)).astype(F), o, B, D, deg, C, np.zeros((B, D), F)), 1e-5))
+    for degree in range(1, 9):
+        B = 257
+        d = _unit_dirs(rng, B)
+        out.append((f"sh_deg{degree}", "sh_encode_forward", (d, np.zeros((B, degree * degree), F), B, 3, degree, None), 2e-6))
+        out.append((f"sh_deg{degree}_grad", "sh_encode_forward",
+                    (d, np.zeros((B, degree * degree), F), B, 3, degree, np.zeros((B, 3 * degree * degree), F)), 2e-6))
+    B, degree = 100, 4
+    d = _unit_dirs(rng, B) * 1.3    # SH polynomials are also evaluated off the unit sphere
+    out.append(("sh_nonunit", "sh_encode_forward", (d.astype(F), np.zeros((B, 16), F), B, 3, degree, np.zeros((B, 48), F)), 2e-6))
+    from oracle import clib
+    dy = np.zeros((B, 48), F)
+    clib.oracle().call("sh_encode_forward", d.astype(F), np.zeros((B, 16), F), B, 3, degree, dy)
+    out.append(("sh_bwd", "sh_encode_backward",
+                (rng.normal(size=(B, 16)).astype(F), d.astype(F), B, 3, degree, dy, rng.normal(size=(B, 3)).astype(F)), 1e-5))
+    return out
+
+
+ALL_GROUPS = {
+    "near_far": near_far_cases, "misc": misc_cases, "march": march_cases, "composite": composite_cases,
+    "train": train_cases, "hash": hash_cases, "hash_bwd": hash_backward_cases, "grid": grid_cases,
+    "grid_bwd": grid_backward_cases, "freq_sh": freq_sh_cases,
+}
+
+
+def all_cases():
+    for gname, fn in ALL_GROUPS.items():
+        for cid, op, args, tol in fn():
+            yield f"{gname}/{cid}", op, args, tol

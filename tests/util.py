@@ -1,0 +1,43 @@
+"""Test helpers: run one C-ABI operator on any of the three implementations with numpy in/out.
+
+backend = "oracle" (oracle/c restatement), "ref" (reference kernel bodies on CPU) or "hip"
+(libenvidr_amd.so on cuda:0, through envidr_amd._lib -- i.e. through the C ABI).
+Pointer arguments are numpy arrays (or None); they are copied, the call mutates the copies, and the
+(possibly mutated) copies are returned in argument order so in-place outputs can be compared.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from envidr_amd._lib import SIGNATURES
+
+
+def run_op(backend: str, name: str, *args):
+    sig = SIGNATURES[name]
+    assert len(sig) == len(args), (name, len(sig), len(args))
+    if backend in ("oracle", "ref"):
+        from oracle import clib
+        lib = clib.oracle() if backend == "oracle" else clib.ref()
+        work = [np.ascontiguousarray(a).copy() if (k == "p" and a is not None) else a for k, a in zip(sig, args)]
+        lib.call(name, *work)
+        return [w for k, w in zip(sig, work) if k == "p"]
+    assert backend == "hip"
+    import torch
+    from envidr_amd import _lib
+    dev = torch.device("cuda:0")
+    work = [torch.from_numpy(np.ascontiguousarray(a).copy()).to(dev) if (k == "p" and a is not None) else a
+            for k, a in zip(sig, args)]
+    _lib.call(name, *work)
+    torch.cuda.synchronize()
+    return [None if w is None else w.cpu().numpy() for k, w in zip(sig, work) if k == "p"]
+
+
+def rel_l2(a: np.ndarray, b: np.ndarray) -> float:
+    a = a.astype(np.float64).ravel(); b = b.astype(np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def bits_equal(a: np.ndarray, b: np.ndarray) -> bool:
+    """bitwise equality for float arrays (distinguishes -0/+0, matches NaN payloads)."""
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    return a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes()
