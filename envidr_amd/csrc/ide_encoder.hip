@@ -1,0 +1,37 @@
+// Integrated directional encoding as a HIP operator -- the reference implements it in PyTorch
+// (ide_encoder/ide_encoder.py:98-130: complex pow + a [.,17]x[17,36] matmul + exp).  One lane per
+// direction, output row [Re(all terms) | Im(all terms)].
+#include "sh_core.hip.h"
+
+using namespace envidr;
+
+template <int DEG_VIEW>
+__global__ void __launch_bounds__(kBlock) k_ide_forward(const float* __restrict__ dirs,
+                                                        const float* __restrict__ roughness, float roughness_scalar,
+                                                        uint32_t B, float* __restrict__ outputs) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    constexpr int N = ide_terms(DEG_VIEW);
+    const float kinv = roughness ? roughness[b] : roughness_scalar;
+    float* o = outputs + (size_t)b * 2 * N;
+    ide_eval<DEG_VIEW>(dirs[3 * (size_t)b], dirs[3 * (size_t)b + 1], dirs[3 * (size_t)b + 2], kinv,
+                       [&](int j, float re, float im) { o[j] = re; o[N + j] = im; });
+}
+
+extern "C" int envidr_ide_encode_forward(const float* dirs, const float* roughness_ptr, float roughness_scalar, uint32_t B,
+                                         uint32_t deg_view, float* outputs, envidr_stream_t stream) {
+    ENVIDR_REQUIRE(deg_view >= 1 && deg_view <= 5,
+                   "ide_encode_forward: deg_view must be in [1, 5] (the reference raises ValueError above 5)");
+    if (B == 0) return ENVIDR_OK;
+    ENVIDR_REQUIRE(dirs && outputs, "ide_encode_forward: null pointer");
+    const dim3 grid(ceil_div(B, kBlock)), block(kBlock);
+    hipStream_t s = as_stream(stream);
+    switch (deg_view) {
+        case 1: hipLaunchKernelGGL(k_ide_forward<1>, grid, block, 0, s, dirs, roughness_ptr, roughness_scalar, B, outputs); break;
+        case 2: hipLaunchKernelGGL(k_ide_forward<2>, grid, block, 0, s, dirs, roughness_ptr, roughness_scalar, B, outputs); break;
+        case 3: hipLaunchKernelGGL(k_ide_forward<3>, grid, block, 0, s, dirs, roughness_ptr, roughness_scalar, B, outputs); break;
+        case 4: hipLaunchKernelGGL(k_ide_forward<4>, grid, block, 0, s, dirs, roughness_ptr, roughness_scalar, B, outputs); break;
+        case 5: hipLaunchKernelGGL(k_ide_forward<5>, grid, block, 0, s, dirs, roughness_ptr, roughness_scalar, B, outputs); break;
+    }
+    return check_launch("k_ide_forward");
+}

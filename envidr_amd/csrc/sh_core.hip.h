@@ -1,0 +1,88 @@
+// Real spherical harmonics up to degree 8 and the integrated directional encoding (IDE), shared by
+// the standalone encoders and the fused render kernel.  Coefficients come from
+// sh_ide_tables.inc (generated from the closed forms by tools/gen_tables.py).
+#pragma once
+#include "common.hip.h"
+#include "sh_ide_tables.inc"
+
+namespace envidr {
+
+// (x + i y)^m for m = 0..M-1 by repeated complex multiplication
+template <int M, typename T>
+__device__ __forceinline__ void complex_powers(T x, T y, T (&re)[M], T (&im)[M]) {
+    re[0] = 1; im[0] = 0;
+#pragma unroll
+    for (int m = 1; m < M; ++m) {
+        re[m] = re[m - 1] * x - im[m - 1] * y;
+        im[m] = re[m - 1] * y + im[m - 1] * x;
+    }
+}
+
+// Y[l*l + l + m] = N Q_l^|m|(z) * (m >= 0 ? Re : Im)((x+iy)^|m|); optional gradient rows dx, dy, dz.
+// DEG is the reference's "degree" C (1..8): DEG*DEG outputs.
+template <int DEG, bool GRAD>
+__device__ __forceinline__ void sh_eval(float x, float y, float z, float* __restrict__ out, float* __restrict__ gx,
+                                        float* __restrict__ gy, float* __restrict__ gz) {
+    float re[DEG], im[DEG];
+    complex_powers<DEG, float>(x, y, re, im);
+#pragma unroll
+    for (int l = 0; l < DEG; ++l) {
+#pragma unroll
+        for (int m = 0; m <= l; ++m) {
+            // Horner on the (l - m + 1) coefficients; the table is constexpr so they become immediates
+            float q = 0, dq = 0;
+#pragma unroll
+            for (int k = l - m; k >= 0; --k) q = q * z + kShPoly[l][m][k];
+            if constexpr (GRAD) {
+#pragma unroll
+                for (int k = l - m; k >= 1; --k) dq = dq * z + kShPoly[l][m][k] * (float)k;
+            }
+            const int ip = l * l + l + m, in = l * l + l - m;
+            out[ip] = q * re[m];
+            if (m) out[in] = q * im[m];
+            if constexpr (GRAD) {
+                const float mre = m ? (float)m * re[m ? m - 1 : 0] : 0.0f;   // d/dx Re = m Re^(m-1); d/dy Im = m Re^(m-1)
+                const float mim = m ? (float)m * im[m ? m - 1 : 0] : 0.0f;   // d/dx Im = m Im^(m-1); d/dy Re = -m Im^(m-1)
+                gx[ip] = q * mre;  gy[ip] = q * -mim;  gz[ip] = dq * re[m];
+                if (m) { gx[in] = q * mim;  gy[in] = q * mre;  gz[in] = dq * im[m]; }
+            }
+        }
+    }
+}
+
+// IDE (ide_encoder/ide_encoder.py:98-130): for i < DEG_VIEW, l = 2^i, m = 0..l:
+//   (x+iy)^m * P(z) * exp(-l(l+1)/2 * kappa_inv),   P(z) = sum_k mat[k,(l,m)] z^k
+// The reference evaluates P in fp32 where the l = 16 coefficients reach 9e4 and cancel: its own
+// result carries up to ~1e-2 of rounding noise near |z| = 1 (DESIGN.md "IDE numerics").  We evaluate
+// the SAME fp32-rounded coefficient table in fp64 Horner (in z^2, the polynomials have parity), which
+// costs ~120 DFMA per call and is exact to fp32 rounding.
+// emit(j, re_part, im_part) receives term j = 0 .. n_terms-1 in the reference's (l, m) order.
+template <int DEG_VIEW, typename Emit>
+__device__ __forceinline__ void ide_eval(float xf, float yf, float zf, float kappa_inv, Emit&& emit) {
+    constexpr int LMAX = 1 << (DEG_VIEW - 1);
+    double x = xf, y = yf;
+    const double z = zf;
+    if (xf == 0.0f && yf == 0.0f) y += 1.0;   // reference: y = y + (x == 0 & y == 0)
+    double re[LMAX + 1], im[LMAX + 1];
+    complex_powers<LMAX + 1, double>(x, y, re, im);
+    const double z2 = z * z;
+    int j = 0;
+#pragma unroll
+    for (int i = 0; i < DEG_VIEW; ++i) {
+        const int l = 1 << i;
+        const float att = expf(-(0.5f * (float)(l * (l + 1))) * kappa_inv);
+#pragma unroll
+        for (int m = 0; m <= l; ++m, ++j) {
+            const int start = kIdeStart[j], cnt = kIdeCount[j];
+            double p = kIdeCoef[start];
+#pragma unroll
+            for (int k = 1; k < cnt; ++k) p = p * z2 + kIdeCoef[start + k];
+            if ((l - m) & 1) p *= z;
+            emit(j, (float)(re[m] * p) * att, (float)(im[m] * p) * att);
+        }
+    }
+}
+
+__host__ __device__ constexpr int ide_terms(int deg_view) { return (1 << deg_view) - 1 + deg_view; }
+
+}  // namespace envidr

@@ -1,0 +1,73 @@
+// shencoder operators for gfx950 -- replaces shencoder/src/shencoder.cu (sh_encode_forward :404,
+// sh_encode_backward :421; declarations shencoder.h:9-10).  One lane per direction; the basis is
+// evaluated from generated coefficient tables (sh_core.hip.h) rather than a hard-coded expression
+// list, in per-lane registers, then written as contiguous rows.
+#include "sh_core.hip.h"
+
+using namespace envidr;
+
+template <int DEG, bool GRAD>
+__global__ void __launch_bounds__(kBlock) k_sh_forward(const float* __restrict__ inputs, float* __restrict__ outputs,
+                                                       uint32_t B, float* __restrict__ dy_dx) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    constexpr int C2 = DEG * DEG;
+    const float x = inputs[3 * (size_t)b], y = inputs[3 * (size_t)b + 1], z = inputs[3 * (size_t)b + 2];
+    float o[C2], gx[GRAD ? C2 : 1], gy[GRAD ? C2 : 1], gz[GRAD ? C2 : 1];
+    sh_eval<DEG, GRAD>(x, y, z, o, gx, gy, gz);
+    float* po = outputs + (size_t)b * C2;
+#pragma unroll
+    for (int i = 0; i < C2; ++i) po[i] = o[i];
+    if constexpr (GRAD) {
+        float* pg = dy_dx + (size_t)b * 3 * C2;
+#pragma unroll
+        for (int i = 0; i < C2; ++i) { pg[i] = gx[i]; pg[C2 + i] = gy[i]; pg[2 * C2 + i] = gz[i]; }
+    }
+}
+
+// grad_inputs[b,d] += sum_ch grad[b,ch] * dy_dx[b,d,ch]   (accumulates, like the reference)
+__global__ void __launch_bounds__(kBlock) k_sh_backward(const float* __restrict__ grad, uint32_t B, uint32_t D, uint32_t C2,
+                                                        const float* __restrict__ dy_dx, float* __restrict__ grad_inputs) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * D) return;
+    const uint32_t b = t / D, d = t - b * D;
+    const float* g = grad + (size_t)b * C2;
+    const float* j = dy_dx + ((size_t)b * D + d) * C2;
+    float acc = grad_inputs[t];
+    for (uint32_t ch = 0; ch < C2; ++ch) acc += g[ch] * j[ch];
+    grad_inputs[t] = acc;
+}
+
+extern "C" {
+
+int envidr_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t C, float* dy_dx,
+                             envidr_stream_t stream) {
+    ENVIDR_REQUIRE(D == 3, "sh_encode_forward: input dim must be 3 (got %u)", D);
+    ENVIDR_REQUIRE(C >= 1 && C <= 8, "sh_encode_forward: degree must be in [1, 8] (got %u)", C);
+    if (B == 0) return ENVIDR_OK;
+    ENVIDR_REQUIRE(inputs && outputs, "sh_encode_forward: null pointer");
+    const dim3 grid(ceil_div(B, kBlock)), block(kBlock);
+    hipStream_t s = as_stream(stream);
+#define ENVIDR_SH(DEG)                                                                                         \
+    case DEG:                                                                                                  \
+        if (dy_dx) hipLaunchKernelGGL((k_sh_forward<DEG, true>), grid, block, 0, s, inputs, outputs, B, dy_dx); \
+        else hipLaunchKernelGGL((k_sh_forward<DEG, false>), grid, block, 0, s, inputs, outputs, B, dy_dx);      \
+        break;
+    switch (C) { ENVIDR_SH(1) ENVIDR_SH(2) ENVIDR_SH(3) ENVIDR_SH(4) ENVIDR_SH(5) ENVIDR_SH(6) ENVIDR_SH(7) ENVIDR_SH(8) }
+#undef ENVIDR_SH
+    return check_launch("k_sh_forward");
+}
+
+int envidr_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t C,
+                              const float* dy_dx, float* grad_inputs, envidr_stream_t stream) {
+    (void)inputs;
+    ENVIDR_REQUIRE(D == 3, "sh_encode_backward: input dim must be 3 (got %u)", D);
+    ENVIDR_REQUIRE(C >= 1 && C <= 8, "sh_encode_backward: degree must be in [1, 8] (got %u)", C);
+    if (B == 0) return ENVIDR_OK;
+    ENVIDR_REQUIRE(grad && dy_dx && grad_inputs, "sh_encode_backward: null pointer");
+    hipLaunchKernelGGL(k_sh_backward, dim3(ceil_div(B * D, kBlock)), dim3(kBlock), 0, as_stream(stream), grad, B, D, C * C,
+                       dy_dx, grad_inputs);
+    return check_launch("k_sh_backward");
+}
+
+}  // extern "C"

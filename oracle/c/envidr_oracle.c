@@ -721,8 +721,10 @@ API int oracle_sh_encode_backward(const float* grad, const float* inputs, uint32
 
 /* ============================ integrated directional encoding ============================ */
 /* ide_encoder/ide_encoder.py:5-55 (coefficient tables) and :98-130 (forward).  Evaluated in double
- * from the closed forms, rounded once; this is the high-precision anchor.  The fp32 behaviour of the
- * reference's torch implementation is pinned separately by golden vectors (tests/golden). */
+ * from the closed forms on the reference's fp32-rounded coefficient table, rounded once: this is the
+ * reference's polynomial evaluated WITHOUT its fp32 cancellation noise (up to ~1e-2 for l = 16 near
+ * |z| = 1, DESIGN.md "IDE numerics").  The reference's actual fp32 outputs are pinned by golden
+ * vectors generated from the imported module (tests/golden/make_golden.py). */
 static double gen_binom(double a, int k) { double p = 1; for (int i = 0; i < k; ++i) p *= (a - i); return p / factorial(k); }
 static double ide_coeff(int l, int m, int k) {   /* sph_harm_coeff(l, m, k) */
     const double al = (m % 2 ? -1.0 : 1.0) * pow(2.0, l) * factorial(l) / factorial(k) / factorial(l - k - m) *
@@ -737,7 +739,8 @@ API int oracle_ide_encode_forward(const float* dirs, const float* roughness_ptr,
     const int lmax = 1 << (deg_view - 1);
     double* mat = (double*)calloc((size_t)(lmax + 1) * n, sizeof(double));
     for (int i = 0; i < n; ++i)
-        for (int k = 0; k <= ml_l[i] - ml_m[i]; ++k) mat[(size_t)k * n + i] = ide_coeff(ml_l[i], ml_m[i], k);
+        for (int k = 0; k <= ml_l[i] - ml_m[i]; ++k)
+            mat[(size_t)k * n + i] = (double)(float)ide_coeff(ml_l[i], ml_m[i], k);   /* torch.Tensor(mat): fp32 table */
 #pragma omp parallel for schedule(static)
     for (int64_t b = 0; b < (int64_t)B; ++b) {
         const double x = dirs[3 * b], z = dirs[3 * b + 2];
@@ -753,9 +756,9 @@ API int oracle_ide_encode_forward(const float* dirs, const float* roughness_ptr,
         for (int i = 0; i < n; ++i) {
             double zc = 0;
             for (int k = 0; k <= lmax; ++k) zc += zp[k] * mat[(size_t)k * n + i];
-            const double att = exp(-0.5 * ml_l[i] * (ml_l[i] + 1) * kinv);
-            outputs[(size_t)b * 2 * n + i] = (float)(re[ml_m[i]] * zc * att);
-            outputs[(size_t)b * 2 * n + n + i] = (float)(im[ml_m[i]] * zc * att);
+            const float att = expf(-(0.5f * (float)(ml_l[i] * (ml_l[i] + 1))) * (float)kinv);   /* fp32 exp like torch */
+            outputs[(size_t)b * 2 * n + i] = (float)(re[ml_m[i]] * zc) * att;
+            outputs[(size_t)b * 2 * n + n + i] = (float)(im[ml_m[i]] * zc) * att;
         }
     }
     free(mat);

@@ -290,10 +290,24 @@ def freq_sh_cases():
     return out
 
 
+def ide_cases():
+    rng = np.random.default_rng(20)
+    out = []
+    for deg in range(1, 6):
+        B = 300
+        d = _unit_dirs(rng, B)
+        n = (2 ** deg - 1 + deg) * 2
+        out.append((f"ide_deg{deg}_scalar", "ide_encode_forward", (d, None, 0.64, B, deg, np.zeros((B, n), F)), 2e-6))
+        rough = rng.uniform(0, 0.3, B).astype(F)
+        rough[:8] = 0
+        out.append((f"ide_deg{deg}_rough", "ide_encode_forward", (d, rough, 0.0, B, deg, np.zeros((B, n), F)), 2e-6))
+    return out
+
+
 ALL_GROUPS = {
     "near_far": near_far_cases, "misc": misc_cases, "march": march_cases, "composite": composite_cases,
     "train": train_cases, "hash": hash_cases, "hash_bwd": hash_backward_cases, "grid": grid_cases,
-    "grid_bwd": grid_backward_cases, "freq_sh": freq_sh_cases,
+    "grid_bwd": grid_backward_cases, "freq_sh": freq_sh_cases, "ide": ide_cases,
 }
 
 
