@@ -1,0 +1,285 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY (never imported by envidr_amd/).
+
+CPU restatement of the reference's per-sample shading chain and of its inference render loop:
+
+  shade_samples   = NeRFNetwork.forward_sigma + NeRFRenderer.get_color_mlp_extra_params +
+                    NeRFNetwork.forward_color for the toaster.ini configuration
+                    (nerf/network.py:381-698, nerf/renderer.py:20-39,147-198), torch fp32 on CPU,
+                    normals through torch autograd exactly like the reference;
+  render_rays     = the `else:` (inference) branch of run_cuda
+                    (nerf/render_func/cuda_ray.py:238-359): march -> shade -> composite ->
+                    compact, same n_step policy, same padding rule, up to four composites.
+
+Native pieces (march / composite / hash lookup / IDE) come from the C oracle (oracle/c), which is
+pinned bit-exactly to the reference's kernel bodies; the MLPs are torch.nn.functional.linear on CPU
+like the reference's nn.Linear.  Pinned end-to-end against frames rendered by the imported
+reference itself (tests/golden/make_golden.py -> tests/golden/frame_*.npz).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+import torch.nn.functional as Fn
+
+from oracle import clib
+
+F32 = np.float32
+
+
+@dataclass
+class RenderOptions:
+    """The reference flags that shape the inference path (defaults = toaster.ini + options.py)."""
+    bound: float = 1.0
+    cascades: int = 1
+    grid_size: int = 128
+    min_near: float = 0.2
+    max_steps: int = 1024
+    dt_gamma: float = 0.0
+    T_thresh: float = 1e-4
+    density_scale: float = 1.0
+    base_resolution: int = 16
+    num_levels: int = 16
+    level_dim: int = 2
+    enabled_levels: int = -1
+    ide_deg: int = 5
+    roughness_bias: float = -1.0
+    roughness_act_scale: float = 0.2
+    roughness_scale: float = 1.0
+    diffuse_kappa_inv: float = 0.64
+    light_intensity_scale: float = 1.0
+    intensity_scale: float = 1.0
+    beta_min: float = 0.0005
+    beta_max: float = 1.0
+    bg_color: float = 1.0
+    visual_items: tuple = ("specular", "roughness", "diffuse")
+    get_normal_image: bool = True
+    ide_mode: str = "torch"      # "torch": the reference's fp32 complex-pow formulation; "exact": C oracle (fp64 Horner)
+
+
+# ------------------------------------------------------------------------------------------------
+# hash encoding as an autograd function (hashencoder/hashgrid.py:17-107 semantics, first order)
+# ------------------------------------------------------------------------------------------------
+class _HashEncode(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x01, table, offsets, S, H):
+        B, D = x01.shape
+        L, C = offsets.shape[0] - 1, table.shape[1]
+        out = np.empty((L, B, C), F32)
+        dy_dx = np.empty((B, L * D * C), F32)
+        clib.oracle().call("hash_encode_forward", np.ascontiguousarray(x01.detach().numpy()), table.detach().numpy(),
+                           offsets.numpy(), out, B, D, C, L, S, H, 1, dy_dx)
+        ctx.meta = (B, D, C, L, S, H)
+        ctx.save_for_backward(x01, table, offsets, torch.from_numpy(dy_dx))
+        return torch.from_numpy(out).permute(1, 0, 2).reshape(B, L * C)
+
+    @staticmethod
+    def backward(ctx, grad):
+        x01, table, offsets, dy_dx = ctx.saved_tensors
+        B, D, C, L, S, H = ctx.meta
+        g = np.ascontiguousarray(grad.view(B, L, C).permute(1, 0, 2).contiguous().numpy())
+        gin = np.zeros((B, D), F32)
+        clib.oracle().call("hash_encode_backward", g, np.ascontiguousarray(x01.detach().numpy()), table.detach().numpy(),
+                           offsets.numpy(), None, B, D, C, L, S, H, 1, dy_dx.numpy(), gin)
+        return torch.from_numpy(gin), None, None, None, None
+
+
+def hash_encode(xyz: torch.Tensor, scene, opt: RenderOptions) -> torch.Tensor:
+    x01 = (xyz + opt.bound) / (2 * opt.bound)           # hashgrid.py:161
+    S = float(np.log2(scene.per_level_scale))
+    return _HashEncode.apply(x01, torch.from_numpy(scene.table), torch.from_numpy(scene.offsets), S, opt.base_resolution)
+
+
+# ------------------------------------------------------------------------------------------------
+# integrated directional encoding, the reference's fp32 torch formulation (ide_encoder.py:57-130)
+# ------------------------------------------------------------------------------------------------
+_IDE_CACHE: dict = {}
+
+
+def _ide_tables(deg: int):
+    if deg not in _IDE_CACHE:
+        ml = [(m, 2 ** i) for i in range(deg) for m in range(2 ** i + 1)]
+        lmax = 2 ** (deg - 1)
+        mat = np.zeros((lmax + 1, len(ml)))
+        for i, (m, l) in enumerate(ml):
+            for k in range(l - m + 1):
+                gb = np.prod(0.5 * (l + k + m - 1.0) - np.arange(l)) / math.factorial(l)
+                al = (-1) ** m * 2 ** l * math.factorial(l) / math.factorial(k) / math.factorial(l - k - m) * gb
+                mat[k, i] = np.sqrt((2.0 * l + 1.0) * math.factorial(l - m) / (4.0 * np.pi * math.factorial(l + m))) * al
+        ml_arr = np.array(ml).T
+        sigma = 0.5 * ml_arr[1] * (ml_arr[1] + 1)
+        _IDE_CACHE[deg] = (torch.Tensor(mat), torch.Tensor(ml_arr[0].astype(np.float64)), torch.arange(lmax + 1),
+                           torch.Tensor(sigma))
+    return _IDE_CACHE[deg]
+
+
+def ide_torch(dirs: torch.Tensor, kappa_inv, deg: int) -> torch.Tensor:
+    mat, m_arr, pow_level, sigma = _ide_tables(deg)
+    x, y, z = dirs[..., 0:1], dirs[..., 1:2], dirs[..., 2:3]
+    y = y + torch.logical_and(x == 0, y == 0)
+    vmz = z ** pow_level
+    vmxy = (x + 1j * y) ** m_arr
+    ide = vmxy * torch.matmul(vmz, mat) * torch.exp(-sigma * kappa_inv)
+    return torch.cat([torch.real(ide), torch.imag(ide)], dim=-1)
+
+
+def ide_exact(dirs: torch.Tensor, kappa_inv, deg: int) -> torch.Tensor:
+    d = np.ascontiguousarray(dirs.detach().numpy().astype(F32))
+    B = d.shape[0]
+    n = (2 ** deg - 1 + deg) * 2
+    out = np.empty((B, n), F32)
+    if isinstance(kappa_inv, torch.Tensor):
+        clib.oracle().call("ide_encode_forward", d, np.ascontiguousarray(kappa_inv.detach().numpy().reshape(-1).astype(F32)), 0.0,
+                           B, deg, out)
+    else:
+        clib.oracle().call("ide_encode_forward", d, None, float(kappa_inv), B, deg, out)
+    return torch.from_numpy(out)
+
+
+# ------------------------------------------------------------------------------------------------
+# per-sample shading
+# ------------------------------------------------------------------------------------------------
+def _mlp(layers, h):
+    for i, (W, b) in enumerate(layers):
+        h = Fn.linear(h, torch.from_numpy(W), torch.from_numpy(b))
+        if i != len(layers) - 1:
+            h = Fn.relu(h)
+    return h
+
+
+def laplace_density(sdf: torch.Tensor, beta: float, opt: RenderOptions) -> torch.Tensor:
+    b = min(max(beta, opt.beta_min), opt.beta_max)      # network.py:39-44 (value of the clamp trick)
+    b = torch.tensor(b, dtype=torch.float32)
+    alpha = 1 / b
+    return alpha * (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / b))
+
+
+def shade_samples(scene, xyzs: np.ndarray, dirs: np.ndarray, opt: RenderOptions, env_rot_radian: float | None = None,
+                  geometry_only: bool = False) -> dict:
+    """all per-sample quantities the render loop composites; numpy in, dict of numpy out."""
+    ide = ide_torch if opt.ide_mode == "torch" else ide_exact
+    xyz = torch.from_numpy(np.ascontiguousarray(xyzs, F32)).requires_grad_(True)
+    d = torch.from_numpy(np.ascontiguousarray(dirs, F32))
+
+    feat = hash_encode(xyz, scene, opt)
+    if opt.enabled_levels > 0:                           # network.py:390-393
+        mask = torch.zeros(opt.num_levels, opt.level_dim)
+        mask[:opt.enabled_levels] += 1
+        feat = feat * mask.reshape(-1)
+    h = _mlp(scene.mlps["sdf"], feat)
+    sdf = h[..., 0]
+    geo_feat = Fn.normalize(h[..., 1:13], dim=-1)
+    roughness = opt.roughness_act_scale * Fn.softplus(h[..., 13:14] + opt.roughness_bias) * opt.roughness_scale
+    blend = torch.sigmoid(h[..., 14:15])
+
+    grad = torch.autograd.grad(sdf, xyz, torch.ones_like(sdf), retain_graph=False, create_graph=False)[0]
+    normals = Fn.normalize(grad, dim=-1, eps=1e-10)     # renderer.py:186-192
+    sigma = laplace_density(sdf, scene.beta, opt) * opt.density_scale
+
+    out = {"sdf": sdf, "sigma": sigma, "normal": normals, "geo_feat": geo_feat, "roughness": roughness, "blend": blend}
+    if not geometry_only:
+        with torch.no_grad():
+            gf, n, rough = geo_feat.detach(), normals.detach(), roughness.detach()
+            w_o = -d
+            w_r = 2 * torch.sum(w_o * n, dim=-1, keepdim=True) * n - w_o          # renderer.py:38
+            n_env = n
+            if env_rot_radian is not None:                                       # renderer.py:160-161,171-172
+                c, s = math.cos(env_rot_radian), math.sin(env_rot_radian)
+                R = torch.tensor([[c, 0, -s], [0, 1, 0], [s, 0, c]], dtype=torch.float64).float()
+                w_r = w_r @ R
+                n_env = n @ R
+            w_r_enc = ide(w_r, rough, opt.ide_deg) * opt.light_intensity_scale
+            n_dot = torch.sum(n * w_o, dim=-1, keepdim=True)
+            n_env_enc = ide(n_env, opt.diffuse_kappa_inv, opt.ide_deg) * opt.light_intensity_scale
+
+            e_n = Fn.normalize(_mlp(scene.mlps["env"], n_env_enc), dim=-1)
+            c_diffuse = torch.sigmoid(_mlp(scene.mlps["diffuse"], torch.cat([gf, e_n], -1))) * 1.0   # metallic = 1
+            e_r = Fn.normalize(_mlp(scene.mlps["env"], w_r_enc), dim=-1)
+            h_c = torch.cat([gf, n, e_r, n_dot], -1)
+            c_specular = torch.sigmoid(_mlp(scene.mlps["specular"], h_c))
+            rgb = (c_diffuse + c_specular) * opt.intensity_scale
+        out.update({"c_diffuse": c_diffuse, "c_specular": c_specular, "rgb": rgb, "w_r_enc": w_r_enc, "n_env_enc": n_env_enc})
+    return {k: v.detach().numpy() for k, v in out.items()}
+
+
+# ------------------------------------------------------------------------------------------------
+# inference render loop
+# ------------------------------------------------------------------------------------------------
+def render_rays(scene, rays_o: np.ndarray, rays_d: np.ndarray, opt: RenderOptions, env_rot_radian: float | None = None,
+                trace: list | None = None) -> dict:
+    o = clib.oracle()
+    N = rays_o.shape[0]
+    rays_o = np.ascontiguousarray(rays_o, F32)
+    rays_d = np.ascontiguousarray(rays_d, F32)
+    aabb = np.array([-opt.bound] * 3 + [opt.bound] * 3, F32)
+    nears, fars = np.empty(N, F32), np.empty(N, F32)
+    o.call("near_far_from_aabb", rays_o, rays_d, aabb, N, opt.min_near, nears, fars)
+
+    def state():
+        return dict(ws=np.zeros(N, F32), depth=np.zeros(N, F32), image=np.zeros((N, 3), F32),
+                    alive=np.arange(N, dtype=np.int32), t=nears.copy())
+
+    main = state()
+    extra = {}
+    if opt.get_normal_image:
+        extra["normal"] = state()
+    if "diffuse" in opt.visual_items:
+        extra["diffuse"] = state()
+    if "specular" in opt.visual_items:
+        extra["specular"] = state()
+
+    def composite(st, n_alive, n_step, sig, rgb, deltas, accum=1):
+        o.call("composite_rays", n_alive, n_step, opt.T_thresh, accum, 0, st["alive"], st["t"], sig,
+               np.ascontiguousarray(rgb, F32), deltas, st["ws"], st["depth"], st["image"])
+
+    step = 0
+    n_samples = 0
+    while step < opt.max_steps:
+        n_alive = main["alive"].shape[0]
+        if n_alive <= 0:
+            break
+        n_step = max(min(N // n_alive, 8), 1)
+        M = n_alive * n_step
+        M += 128 - (M % 128)                          # raymarching.py:350-351 (adds a full 128 when aligned)
+        xyzs, dirs, deltas = np.zeros((M, 3), F32), np.zeros((M, 3), F32), np.zeros((M, 2), F32)
+        o.call("march_rays", n_alive, n_step, main["alive"], main["t"], rays_o, rays_d, opt.bound, opt.dt_gamma, opt.max_steps,
+               opt.cascades, opt.grid_size, scene.bitfield, nears, fars, xyzs, dirs, deltas, np.zeros(n_alive, F32))
+        n_samples += int((deltas[:, 0] > 0).sum())
+        if trace is not None:
+            trace.append((n_alive, n_step, M))
+        s = shade_samples(scene, xyzs, dirs, opt, env_rot_radian)
+        sig = np.ascontiguousarray(s["sigma"], F32)
+        composite(main, n_alive, n_step, sig, s["rgb"], deltas)
+        if "diffuse" in extra:
+            composite(extra["diffuse"], n_alive, n_step, sig, s["c_diffuse"], deltas)
+            extra["diffuse"]["alive"] = extra["diffuse"]["alive"][extra["diffuse"]["alive"] >= 0]
+        if "specular" in extra:
+            deltas[:, 1:] = s["roughness"]             # cuda_ray.py:329-333: roughness rides in the depth slot
+            composite(extra["specular"], n_alive, n_step, sig, s["c_specular"], deltas, accum=0)
+            extra["specular"]["alive"] = extra["specular"]["alive"][extra["specular"]["alive"] >= 0]
+        if "normal" in extra:
+            composite(extra["normal"], n_alive, n_step, sig, s["normal"], deltas)
+            extra["normal"]["alive"] = extra["normal"]["alive"][extra["normal"]["alive"] >= 0]
+        main["alive"] = main["alive"][main["alive"] >= 0]
+        step += n_step
+
+    res = {"image": main["image"] + (1 - main["ws"])[:, None] * opt.bg_color, "depth": main["depth"], "weights_sum": main["ws"],
+           "n_samples": n_samples}
+    if "normal" in extra:
+        n = extra["normal"]["image"]
+        n = n / np.maximum(np.linalg.norm(n, axis=-1, keepdims=True), 1e-10).astype(F32)
+        # NeRFRenderer.render's final blend (renderer.py:529-530)
+        res["normal_image"] = n * main["ws"][:, None] + (1 - main["ws"][:, None])
+    if "diffuse" in extra:
+        res["diffuse_image"] = extra["diffuse"]["image"]
+    if "specular" in extra:
+        res["specular_image"] = extra["specular"]["image"]
+        res["roughness_image"] = extra["specular"]["depth"][:, None]
+    return res
+
+
+def psnr(pred: np.ndarray, truth: np.ndarray) -> float:
+    """-10 log10(mean((p - t)^2))   (nerf/utils.py:296-303)"""
+    return float(-10 * np.log10(np.mean((pred.astype(np.float64) - truth.astype(np.float64)) ** 2)))

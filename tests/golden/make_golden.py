@@ -1,0 +1,305 @@
+"""Generate the committed golden vectors from the REFERENCE ITSELF, run on the CPU in the build
+container (the only place /root/reference exists).  Never runs on the GPU box.
+
+    python tests/golden/make_golden.py
+
+What runs (SURVEY.md 8c levels 1 and 2):
+  * the reference's own Python -- `nerf.options.config_parser()` on configs/scenes/toaster.ini,
+    `NeRFNetwork(...)`, `forward_sigma` / `get_color_mlp_extra_params` / `forward_color`,
+    `IntegratedDirEncoder`, and `model.render(...)` -> `run_cuda` inference loop -- imported
+    unmodified from /root/reference;
+  * with its extension modules (`raymarching._ext._raymarching`, `hashencoder._ext._hashencoder`,
+    ...) played by oracle/_ref: the reference's kernel bodies executed on the CPU.
+
+Harness-side adaptations only (no reference file is touched): third-party packages that are not
+installed and not on the path (trimesh, cv2, ...) are stubbed in sys.modules, `np.math` is restored
+(numpy 2 dropped it), `Tensor.cuda()` is the identity, and a small argparse-based stand-in plays
+`configargparse`.
+
+Model parameters are NOT stored: both this script and the tests regenerate them from
+`envidr_amd.scenes.toaster_scene(seed)` (numpy PCG64, platform independent) and this script
+injects them into the reference model.  The fixtures hold inputs + the reference's outputs.
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import sys
+import types
+from pathlib import Path
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+REFERENCE = Path("/root/reference")
+OUT = Path(__file__).resolve().parent
+
+from envidr_amd import scenes  # noqa: E402
+from oracle import clib  # noqa: E402
+
+F = np.float32
+
+
+# ------------------------------------------------------------------------------------------------
+# harness: make the reference importable and runnable on the CPU
+# ------------------------------------------------------------------------------------------------
+class _IniArgumentParser(argparse.ArgumentParser):
+    """argparse + `--config file.ini` (key = value | [a, b] | True) expanded into argv."""
+
+    def add_argument(self, *a, **kw):
+        kw.pop("is_config_file", None)
+        return super().add_argument(*a, **kw)
+
+    def parse_args(self, args=None, namespace=None):
+        argv = list(sys.argv[1:] if args is None else args)
+        out = []
+        i = 0
+        while i < len(argv):
+            if argv[i] == "--config":
+                out += self._expand(argv[i + 1])
+                i += 2
+            else:
+                out.append(argv[i])
+                i += 1
+        # command line wins over the file: file args first
+        cfg = [a for a in out if isinstance(a, tuple)]
+        cli = [a for a in out if not isinstance(a, tuple)]
+        flat = [x for t in cfg for x in t] + cli
+        return super().parse_args(flat, namespace)
+
+    @staticmethod
+    def _expand(path):
+        res = []
+        for raw in Path(path).read_text().splitlines():
+            line = raw.split("#")[0].split(";")[0].strip()
+            if not line or "=" not in line:
+                continue
+            key, val = (s.strip() for s in line.split("=", 1))
+            if val == "True":
+                res.append((f"--{key}",))
+            elif val in ("False", ""):
+                continue
+            elif val.startswith("["):
+                items = [v.strip() for v in val.strip("[]").split(",") if v.strip()]
+                res.append((f"--{key}", *items))
+            else:
+                res.append((f"--{key}", val))
+        return res
+
+
+class _RefBackend:
+    """Plays a pybind extension module: same function names / argument orders as the reference's
+    bindings, taking CPU torch tensors, forwarding to oracle/_ref through the shared C signature."""
+
+    def __init__(self, names):
+        self._ref = clib.ref()
+        for n in names:
+            setattr(self, n, self._make(n))
+
+    def _make(self, name):
+        from envidr_amd._lib import SIGNATURES
+        sig = SIGNATURES[name]
+
+        def fn(*args):
+            conv = []
+            for kind, a in zip(sig, args):
+                if kind == "p":
+                    if a is None:
+                        conv.append(None)
+                    else:
+                        assert a.is_contiguous(), name
+                        conv.append(a.detach().numpy())
+                else:
+                    conv.append(a)
+            self._ref.call(name, *conv)
+        return fn
+
+
+def install_reference():
+    np.math = math
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    for mod in ["trimesh", "cv2", "tensorboardX", "mcubes", "torch_ema", "lpips", "imageio", "cachetools", "open3d",
+                "open3d.visualization", "open3d.visualization.rendering", "torchvision", "torchvision.transforms",
+                "dearpygui", "dearpygui.dearpygui", "IPython", "matplotlib", "matplotlib.pyplot", "packaging"]:
+        if mod not in sys.modules:
+            try:
+                __import__(mod)
+            except Exception:
+                sys.modules[mod] = MagicMock()
+    cap = types.ModuleType("configargparse")
+    cap.ArgumentParser = _IniArgumentParser
+    sys.modules["configargparse"] = cap
+
+    rm = _RefBackend(["near_far_from_aabb", "sph_from_ray", "morton3D", "morton3D_invert", "packbits", "get_scatter_idx",
+                      "march_rays_train", "composite_rays_train_forward", "composite_rays_train_backward", "march_rays",
+                      "composite_rays"])
+    he = _RefBackend(["hash_encode_forward", "hash_encode_backward", "hash_encode_second_backward"])
+    for pkg, name, backend in [("raymarching", "_raymarching", rm), ("hashencoder", "_hashencoder", he)]:
+        ext = types.ModuleType(f"{pkg}._ext")
+        setattr(ext, name, backend)
+        sys.modules[f"{pkg}._ext"] = ext
+        sys.modules[f"{pkg}._ext.{name}"] = backend
+    sys.path.insert(0, str(REFERENCE))
+
+
+def build_reference_model(scene: scenes.SceneParams, extra_argv=()):
+    """the reference's own option parser + constructor (main_nerf.py:16,59-78), then our seeded weights."""
+    from nerf.options import config_parser
+    from nerf.network import NeRFNetwork
+    old = sys.argv
+    sys.argv = ["main_nerf.py", "--config", str(REFERENCE / "configs/scenes/toaster.ini"), "--test", *extra_argv]
+    try:
+        opt = config_parser()
+    finally:
+        sys.argv = old
+    model = NeRFNetwork(encoding="hashgrid", encoding_dir=opt.encoding_dir, bound=opt.bound, cuda_ray=opt.cuda_ray,
+                        density_scale=1, min_near=opt.min_near, density_thresh=opt.density_thresh, bg_radius=opt.bg_radius,
+                        use_sdf=opt.use_sdf, hidden_dim=opt.hidden_dim, num_layers=opt.num_layers,
+                        num_layers_color=opt.num_layers_color, hidden_dim_color=opt.hidden_dim_color,
+                        num_layers_bg=opt.num_layers_bg, num_levels=opt.num_levels, geo_feat_dim=opt.geo_feat_dim,
+                        opt=opt, env_opt=None)
+    model.eval()
+    with torch.no_grad():
+        assert tuple(model.encoder.embeddings.shape) == scene.table.shape
+        assert np.array_equal(model.encoder.offsets.numpy(), scene.offsets)
+        model.encoder.embeddings.data = torch.from_numpy(scene.table.copy())
+        for name, attr in [("sdf", "sdf_net"), ("env", "env_net"), ("diffuse", "diffuse_net"), ("specular", "color_net"),
+                           ("renv", "renv_net")]:
+            net = getattr(model, attr)
+            assert len(net) == len(scene.mlps[name]), name
+            for lin, (W, b) in zip(net, scene.mlps[name]):
+                assert tuple(lin.weight.shape) == W.shape, (name, lin.weight.shape, W.shape)
+                lin.weight.data = torch.from_numpy(W.copy())
+                lin.bias.data = torch.from_numpy(b.copy())
+        model.sdf_density.beta.data = torch.tensor(scene.beta)
+        model.density_bitfield.data = torch.from_numpy(scene.bitfield.copy())
+    return model, opt
+
+
+# ------------------------------------------------------------------------------------------------
+# fixtures
+# ------------------------------------------------------------------------------------------------
+def sample_points(rng, n):
+    """points around the r = 0.5 shell with unit view directions, plus the degenerate ones"""
+    p = rng.normal(size=(n, 3))
+    p = p / np.linalg.norm(p, axis=1, keepdims=True) * rng.uniform(0.44, 0.56, size=(n, 1))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    p[0] = 0.0          # the padded-sample position the reference also shades
+    p[1] = (1.0, -1.0, 1.0)
+    return p.astype(F), d.astype(F)
+
+
+def golden_shading(model, opt, tag, env_rot=None, n=1536, seed=5):
+    rng = np.random.default_rng(seed)
+    xyz, dirs = sample_points(rng, n)
+    x = torch.from_numpy(xyz).requires_grad_(True)
+    d = torch.from_numpy(dirs)
+    sdfs, sigmas, geo, normals, _ = model.forward_sigma(x, use_sdf_sigma_grad=True, dirs=d, dists=None)
+    rough = model.roughness
+    blend = model.blend_weight
+    n_enc, w_r_enc, n_dot, n_env_enc = model.get_color_mlp_extra_params(normals, d, rough, env_rot)
+    rgb = model.forward_color(geo, d, n_enc, w_r_enc, n_dot, True, n_env_enc=n_env_enc, r_images=None, roughness=rough)
+    g = lambda t: t.detach().numpy().astype(F)
+    np.savez_compressed(OUT / f"shading_{tag}.npz", xyz=xyz, dirs=dirs, env_rot=np.array(np.nan if env_rot is None else env_rot),
+                        sdf=g(sdfs), sigma=g(sigmas), geo_feat=g(geo), normal=g(normals), roughness=g(rough), blend=g(blend),
+                        w_r_enc=g(w_r_enc), n_env_enc=g(n_env_enc), n_dot=g(n_dot), c_diffuse=g(model.c_diffuse),
+                        c_specular=g(model.c_specular), rgb=g(rgb))
+    print(f"[golden] shading_{tag}: {n} samples, mean sigma {float(sigmas.mean()):.2f}, mean roughness {float(rough.mean()):.4f}")
+
+
+def golden_frame(model, opt, tag, H, W, env_rot=None, theta=30.0, phi=-20.0):
+    import nerf.render_func.cuda_ray as cuda_ray
+    ro, rd = scenes.camera_rays(H, W, theta=theta, phi=phi)
+    trace = []
+    orig = cuda_ray.raymarching.march_rays
+
+    def traced(n_alive, n_step, *a, **k):   # record the (n_alive, n_step) schedule the reference ran
+        out = orig(n_alive, n_step, *a, **k)
+        trace.append((int(n_alive), int(n_step), int(out[0].shape[0]), int((out[2][:, 0] > 0).sum())))
+        return out
+
+    cuda_ray.raymarching.march_rays = traced
+    try:
+        res = model.render(torch.from_numpy(ro)[None], torch.from_numpy(rd)[None], staged=True, bg_color=1, perturb=False,
+                           get_normal_image=True, env_rot_radian=env_rot, **vars(opt))
+    finally:
+        cuda_ray.raymarching.march_rays = orig
+    g = lambda t: t.detach().numpy().astype(F).reshape(H * W, -1).squeeze(-1) if t.numel() == H * W else t.detach().numpy().astype(F).reshape(H * W, -1)
+    np.savez_compressed(OUT / f"frame_{tag}.npz", H=H, W=W, theta=theta, phi=phi,
+                        env_rot=np.array(np.nan if env_rot is None else env_rot),
+                        image=g(res["image"]), depth=g(res["depth"]), weights_sum=g(res["weights_sum"]),
+                        normal_image=g(res["normal_image"]), diffuse_image=g(res["diffuse_image"]),
+                        specular_image=g(res["specular_image"]), roughness_image=g(res["roughness_image"]),
+                        trace=np.array(trace, np.int32))
+    print(f"[golden] frame_{tag}: {H}x{W}, {len(trace)} loop iterations, {sum(t[3] for t in trace)} samples, "
+          f"hit fraction {float((res['weights_sum'] > 0).float().mean()):.3f}, mean rgb {res['image'].mean(dim=(0, 1)).tolist()}")
+
+
+def golden_ide():
+    from ide_encoder.ide_encoder import IntegratedDirEncoder
+    rng = np.random.default_rng(7)
+    out = {}
+    for deg in (4, 5):
+        enc = IntegratedDirEncoder(3, deg)
+        d = rng.normal(size=(2000, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        d = d.astype(F)
+        d[0] = (0, 0, 1)
+        d[1] = (0, 0, -1)
+        rough = rng.uniform(0.0, 0.2, size=(2000, 1)).astype(F)
+        rough[:50] = 0
+        out[f"dirs{deg}"] = d
+        out[f"rough{deg}"] = rough
+        out[f"ide{deg}_rough"] = enc(torch.from_numpy(d), torch.from_numpy(rough)).numpy()
+        out[f"ide{deg}_k064"] = enc(torch.from_numpy(d), 0.64).numpy()
+        out[f"mat{deg}"] = enc.mat.numpy()
+    np.savez_compressed(OUT / "ide.npz", **out)
+    print("[golden] ide: deg 4 and 5, per-sample and scalar roughness")
+
+
+def golden_ops():
+    """outputs of the reference kernel bodies on a few operator cases, so the GPU box (which has
+    neither /root/reference nor necessarily oracle/_ref) can still check against reference data."""
+    from tests import cases
+    from tests.util import bits_equal, run_op
+    from envidr_amd._lib import SIGNATURES
+    keep = {"march/c1_step8", "march/c2_bound2", "march/c1_cone_noise", "composite/rgb", "hash/D3C2L16_fwd_grad",
+            "hash/D2C1L5_fwd_grad", "grid/D3C2L16g0a0_fwd_grad", "near_far/special", "misc/packbits", "misc/morton",
+            "freq_sh/sh_deg4_grad", "freq_sh/freq_D3deg4", "train/composite_train_bwd", "hash_bwd/D3C2L8_bwd2"}
+    out = {}
+    for cid, op, args, tol in cases.all_cases():
+        if cid not in keep:
+            continue
+        res = run_op("ref", op, *args)
+        ptr_args = [a for kind, a in zip(SIGNATURES[op], args) if kind == "p"]
+        for k, (r, a) in enumerate(zip(res, ptr_args)):
+            # keep only what the call produced (arrays it changed), not the inputs it was given
+            if r is not None and r.size and not bits_equal(r, np.ascontiguousarray(a)):
+                out[f"{cid.replace('/', '.')}|{k}"] = r
+    np.savez_compressed(OUT / "ops_ref.npz", **out)
+    print(f"[golden] ops_ref: {len(out)} arrays from {len(keep)} cases")
+
+
+def main():
+    if not REFERENCE.exists():
+        raise SystemExit("/root/reference is not present: golden vectors can only be regenerated in the build container")
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    install_reference()
+    golden_ops()
+    golden_ide()
+    scene = scenes.toaster_scene()
+    model, opt = build_reference_model(scene)
+    print("[golden] reference model built:", type(model).__name__, "visual_items", opt.visual_items, "indir_ref", opt.indir_ref)
+    golden_shading(model, opt, "toaster")
+    golden_shading(model, opt, "toaster_rot", env_rot=0.7)
+    golden_frame(model, opt, "toaster_48", 48, 48)
+    golden_frame(model, opt, "toaster_rot_40", 40, 40, env_rot=2.1, theta=200.0, phi=-35.0)
+
+
+if __name__ == "__main__":
+    main()
