@@ -1,0 +1,545 @@
+// Fused persistent-wave inference renderer for gfx950 (include/envidr_render.h).
+//
+// One launch renders a whole ray batch.  Every wave64 is a persistent worker that owns 64 ray
+// slots (one per lane) and loops:
+//
+//   refill   lanes without a ray pull the next ray id from a global queue head (one aggregated
+//            atomic per wave), intersect it with the scene box and start marching;
+//   march    each lane advances its ray to the next OCCUPIED sample (march_core.hip.h -- the very
+//            code of the standalone march_rays operator, bit-exact with the reference);
+//   shade    the wave shades its 64 samples: per-lane hash-grid gathers with analytic Jacobian,
+//            then the MLPs on the matrix cores with activations kept in registers
+//            (mlp_mfma.hip.h): SDF forward + input-gradient (normals), 2 x IDE, 2 x environment
+//            MLP, diffuse and specular heads;
+//   blend    each lane composites its sample into its ray's accumulators; finished rays are
+//            written out and the lane becomes free again.
+//
+// What this removes relative to the reference loop (nerf/render_func/cuda_ray.py:277-346): every
+// per-iteration allocation / memset, the [M,*] sample tensors round-tripping HBM, ~40 small kernel
+// launches + 16 cuBLAS GEMMs per iteration, the autograd graph (incl. a 48.8 MB table-gradient
+// memset + scatter per iteration), the boolean-mask compaction and its host sync, and all shading
+// of padded / already-terminated samples: a lane only ever shades a sample its ray will composite.
+//
+// Equivalence to the reference: a ray's samples, step sizes and occupancy decisions are those of
+// the reference marcher resumed from the composited ray time after every sample, i.e. the
+// reference loop with n_step = 1; its per-ray compositing recurrence is the reference's.  The
+// reference's larger n_step only changes where the fp32 ray time is re-derived from the summed
+// deltas (ulp-level), see DESIGN.md.
+#include "grid_core.hip.h"
+#include "march_core.hip.h"
+#include "mlp_mfma.hip.h"
+#include "sh_core.hip.h"
+
+#include "../../include/envidr_render.h"
+
+#include <float.h>
+#include <vector>
+
+using namespace envidr;
+
+namespace {
+
+constexpr int kLevels = ENVIDR_MAX_LEVELS;
+
+struct HashLevelK {
+    uint32_t row0, size, stride1, stride2;
+    float scale;
+    uint32_t hashed, pow2, enabled;
+};
+
+struct RenderArgs {
+    const float* rays_o;
+    const float* rays_d;
+    uint32_t N;
+    MarchConsts mk;
+    float min_near, T_thresh, density_scale, bg;
+    uint32_t max_samples;
+    // hash grid
+    const float* table;
+    HashLevelK lv[kLevels];
+    uint32_t num_levels;
+    float bound2;                 // 2 * bound
+    // sdf net
+    const float* sdf_w[3];
+    const float* sdf_b[3];
+    const float* sdf_w2t;
+    const float* sdf_w1t;
+    const float* sdf_w3r0;
+    float inv_beta, beta;
+    float rough_bias, rough_act_scale, rough_scale;
+    // env / heads
+    const float* env_w[4];
+    const float* env_b[4];
+    const float* dif_w[2];
+    const float* dif_b[2];
+    const float* spc_w[3];
+    const float* spc_b[3];
+    float kappa_diffuse, light_scale, intensity_scale;
+    int has_rot;
+    float rot[9];
+    // outputs
+    float* image; float* depth; float* ws; float* normal; float* diffuse; float* specular; float* roughness;
+    unsigned long long* stats;
+    uint32_t* ray_counter;
+};
+
+// slab test, identical arithmetic to k_near_far_from_aabb (raymarching.hip)
+__device__ __forceinline__ void near_far(const RayGeom& r, float bound, float min_near, float& near, float& far) {
+    near = (-bound - r.ox) * r.rdx; far = (bound - r.ox) * r.rdx;
+    if (near > far) { const float c = near; near = far; far = c; }
+    float ny = (-bound - r.oy) * r.rdy, fy = (bound - r.oy) * r.rdy;
+    if (ny > fy) { const float c = ny; ny = fy; fy = c; }
+    bool miss = near > fy || ny > far;
+    if (!miss) {
+        if (ny > near) near = ny;
+        if (fy < far) far = fy;
+        float nz = (-bound - r.oz) * r.rdz, fz = (bound - r.oz) * r.rdz;
+        if (nz > fz) { const float c = nz; nz = fz; fz = c; }
+        miss = near > fz || nz > far;
+        if (!miss) {
+            if (nz > near) near = nz;
+            if (fz < far) far = fz;
+            if (near < min_near) near = min_near;
+        }
+    }
+    if (miss) near = far = FLT_MAX;
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float softplusf(float x) { return x > 20.0f ? x : log1pf(expf(x)); }   // torch: beta 1, threshold 20
+
+template <int N>
+__device__ __forceinline__ void normalize_n(float (&v)[N], float eps) {
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) s += v[i] * v[i];
+    const float inv = 1.0f / fmaxf(sqrtf(s), eps);    // F.normalize: v / max(||v||, eps)
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = v[i] * inv;
+}
+
+template <int IDE_DEG, int ENV_T>
+__global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a) {
+    constexpr int TERMS = ide_terms(IDE_DEG);      // IDE_DIM = 2 * TERMS input features, TERMS lane-order steps
+    const uint32_t lane = lane_id();
+
+    // ---- per-lane ray slot ---------------------------------------------------------------------
+    int ray = -1;
+    bool drained = false;          // this lane saw the queue run dry
+    uint32_t n_taken = 0;          // samples composited for the current ray
+    RayGeom rg = {};
+    float far = 0, t_ray = 0;
+    Accum acc = {};
+    float an[3] = {0, 0, 0}, ad[3] = {0, 0, 0}, as[3] = {0, 0, 0}, arough = 0;
+    unsigned long long n_samples = 0, n_rounds = 0, n_rays = 0;
+
+    auto finish_ray = [&]() {
+        const size_t id = (size_t)ray;
+        const float rest = 1 - acc.ws;
+        a.image[3 * id] = acc.r + rest * a.bg; a.image[3 * id + 1] = acc.g + rest * a.bg; a.image[3 * id + 2] = acc.b + rest * a.bg;
+        a.depth[id] = acc.depth;
+        a.ws[id] = acc.ws;
+        if (a.normal) {
+            float v[3] = {an[0], an[1], an[2]};
+            const float inv = 1.0f / fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-10f);
+            a.normal[3 * id] = v[0] * inv; a.normal[3 * id + 1] = v[1] * inv; a.normal[3 * id + 2] = v[2] * inv;
+        }
+        if (a.diffuse) { a.diffuse[3 * id] = ad[0]; a.diffuse[3 * id + 1] = ad[1]; a.diffuse[3 * id + 2] = ad[2]; }
+        if (a.specular) { a.specular[3 * id] = as[0]; a.specular[3 * id + 1] = as[1]; a.specular[3 * id + 2] = as[2]; }
+        if (a.roughness) a.roughness[id] = arough;
+        ray = -1;
+    };
+
+    for (;;) {
+        // ================= refill + march: every lane ends with a sample or idle =================
+        bool have = false;
+        float px = 0, py = 0, pz = 0, dt = 0, delta_depth = 0, t_next = 0;
+        for (;;) {
+            if (ray < 0 && !drained) {
+                const uint32_t id = atomicAdd(a.ray_counter, 1u);       // aggregated to one atomic per wave
+                if (id < a.N) {
+                    ray = (int)id;
+                    rg = load_ray(a.rays_o, a.rays_d, id);
+                    float near;
+                    near_far(rg, a.mk.bound, a.min_near, near, far);
+                    t_ray = near;
+                    n_taken = 0;
+                    acc.ws = acc.depth = acc.r = acc.g = acc.b = 0; acc.t = near;
+                    an[0] = an[1] = an[2] = ad[0] = ad[1] = ad[2] = as[0] = as[1] = as[2] = arough = 0;
+                    ++n_rays;
+                } else {
+                    drained = true;
+                }
+            }
+            if (ray >= 0 && !have) {
+                float t = t_ray;
+                const float last_t = t;
+                if (n_taken < a.max_samples && march_next(a.mk, rg, far, t, px, py, pz, dt)) {
+                    have = true;
+                    delta_depth = t - last_t;
+                    t_next = t;
+                } else {
+                    finish_ray();
+                }
+            }
+            const bool again = !have && ray < 0 && !drained;
+            if (!__any(again)) break;
+        }
+        if (!__any(have)) break;
+        n_samples += have ? 1 : 0;
+        n_rounds += 1;
+        if (!have) { px = py = pz = 0; }
+
+        // ================= hash grid: features + Jacobian (per lane) ============================
+        float feat[2 * kLevels];
+        float jac[kLevels][3][2];
+        {
+            // (xyz + bound) / (2 bound)  -- hashencoder/hashgrid.py:161
+            const float x01[3] = {(px + a.mk.bound) / a.bound2, (py + a.mk.bound) / a.bound2, (pz + a.mk.bound) / a.bound2};
+            const bool inside = x01[0] >= 0 && x01[0] <= 1 && x01[1] >= 0 && x01[1] <= 1 && x01[2] >= 0 && x01[2] <= 1;
+#pragma unroll
+            for (int l = 0; l < kLevels; ++l) {
+                float o[2] = {0, 0}, g[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+                if (l < (int)a.num_levels && inside) {
+                    LevelGeom<3> geo;
+                    geo.stride[0] = 1; geo.stride[1] = a.lv[l].stride1; geo.stride[2] = a.lv[l].stride2;
+                    geo.size = a.lv[l].size; geo.hashed = a.lv[l].hashed != 0; geo.pow2 = a.lv[l].pow2 != 0;
+                    eval_level<3, 2, true, true>(x01, a.table + (size_t)a.lv[l].row0 * 2, geo, a.lv[l].scale, 0.0f, o, g);
+                }
+                const float m = a.lv[l].enabled ? 1.0f : 0.0f;     // network.py:390-393 level mask
+                feat[2 * l] = o[0] * m; feat[2 * l + 1] = o[1] * m;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { jac[l][d][0] = g[d][0] * m; jac[l][d][1] = g[d][1] * m; }
+            }
+        }
+
+        // ================= SDF network forward + input gradient (matrix cores) ===================
+        float h3[32];      // raw outputs of the last SDF layer for this lane's sample (rows 0..14 used)
+        float gfeat[32];   // d sdf / d feat
+        {
+            float inA[kLevels], inB[kLevels];
+#pragma unroll
+            for (int s = 0; s < kLevels; ++s) {
+                float e = feat[2 * s], o = feat[2 * s + 1];
+                pack_pair(e, o);
+                inA[s] = e; inB[s] = o;
+            }
+            f32x16 outA, outB, gfA, gfB;
+#pragma unroll 1
+            for (int grp = 0; grp < 2; ++grp) {
+                float in[kLevels];
+#pragma unroll
+                for (int s = 0; s < kLevels; ++s) in[s] = grp ? inB[s] : inA[s];
+                f32x16 h1[2], h2[2], o3[1];
+                layer_from_lanes<kLevels, 2>(a.sdf_w[0], a.sdf_b[0], lane, in, h1);
+                h1[0] = relu16(h1[0]); h1[1] = relu16(h1[1]);
+                layer_from_tiles<2, 2>(a.sdf_w[1], a.sdf_b[1], lane, h1, h2);
+                h2[0] = relu16(h2[0]); h2[1] = relu16(h2[1]);
+                layer_from_tiles<2, 1>(a.sdf_w[2], a.sdf_b[2], lane, h2, o3);
+                // backward of sdf = o3[row 0]:  g2 = W3[0,:] * [h2 > 0];  g1 = (W2^T g2) * [h1 > 0];  gfeat = W1^T g1
+                f32x16 g2[2], g1[2], gf[1];
+                const ParamBuf w3r0 = make_param_buf(a.sdf_w3r0, lane);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const f32x16 w = load_rowvec(w3r0, t);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) g2[t][r] = h2[t][r] > 0 ? w[r] : 0.0f;
+                }
+                layer_from_tiles<2, 2>(a.sdf_w2t, nullptr, lane, g2, g1);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) g1[t][r] = h1[t][r] > 0 ? g1[t][r] : 0.0f;
+                layer_from_tiles<2, 1>(a.sdf_w1t, nullptr, lane, g1, gf);
+                if (grp == 0) { outA = o3[0]; gfA = gf[0]; } else { outB = o3[0]; gfB = gf[0]; }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float u = outA[r], v = outB[r];
+                unpack_pair(u, v);
+                h3[tile_row(r, 0)] = u; h3[tile_row(r, 1)] = v;
+                float p = gfA[r], q = gfB[r];
+                unpack_pair(p, q);
+                gfeat[tile_row(r, 0)] = p; gfeat[tile_row(r, 1)] = q;
+            }
+        }
+
+        // ================= per-sample geometry terms =============================================
+        const float sdf = h3[0];
+        float geo[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) geo[i] = h3[1 + i];
+        normalize_n<12>(geo, 1e-12f);                                                   // network.py:434-435
+        const float rough = a.rough_act_scale * softplusf(h3[13] + a.rough_bias) * a.rough_scale;   // network.py:443-448
+        // kernel_input_backward order: levels outer, channels inner (hashencoder.cu:346-372)
+        float nrm[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float s = 0;
+#pragma unroll
+            for (int l = 0; l < kLevels; ++l) {
+                s += gfeat[2 * l] * jac[l][d][0];
+                s += gfeat[2 * l + 1] * jac[l][d][1];
+            }
+            nrm[d] = s / a.bound2;                                                      // d x01 / d xyz
+        }
+        normalize_n<3>(nrm, 1e-10f);                                                    // renderer.py:192
+        // Laplace density (network.py:32-37): (1/beta) (0.5 + 0.5 sign(s) expm1(-|s| / beta))
+        const float sgn = sdf > 0 ? 1.0f : (sdf < 0 ? -1.0f : 0.0f);
+        const float sigma = a.inv_beta * (0.5f + 0.5f * sgn * expm1f(-fabsf(sdf) / a.beta)) * a.density_scale;
+
+        // view-dependent inputs (renderer.py:147-180)
+        const float wo[3] = {-rg.dx, -rg.dy, -rg.dz};
+        const float ndot = nrm[0] * wo[0] + nrm[1] * wo[1] + nrm[2] * wo[2];
+        float wr[3], nenv[3] = {nrm[0], nrm[1], nrm[2]};
+        {
+            const float c = 2 * ndot;                                                   // reflect_dir, renderer.py:38
+#pragma unroll
+            for (int d = 0; d < 3; ++d) wr[d] = c * nrm[d] - wo[d];
+            if (a.has_rot) {
+                const float w0 = wr[0], w1 = wr[1], w2 = wr[2], n0 = nenv[0], n1 = nenv[1], n2 = nenv[2];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    wr[j] = w0 * a.rot[j] + w1 * a.rot[3 + j] + w2 * a.rot[6 + j];
+                    nenv[j] = n0 * a.rot[j] + n1 * a.rot[3 + j] + n2 * a.rot[6 + j];
+                }
+            }
+        }
+
+        // ================= environment MLP on IDE(normal) and IDE(reflection) =====================
+        float env_n[12], env_r[12];
+#pragma unroll 1
+        for (int enc = 0; enc < 2; ++enc) {
+            const float vx = enc ? wr[0] : nenv[0], vy = enc ? wr[1] : nenv[1], vz = enc ? wr[2] : nenv[2];
+            const float kinv = enc ? rough : a.kappa_diffuse;
+            float code[2 * TERMS];
+            ide_eval<IDE_DEG>(vx, vy, vz, kinv, [&](int j, float re, float im) {
+                code[j] = re * a.light_scale;
+                code[TERMS + j] = im * a.light_scale;
+            });
+#pragma unroll
+            for (int s = 0; s < TERMS; ++s) pack_pair(code[2 * s], code[2 * s + 1]);
+            f32x16 outA, outB;
+#pragma unroll 1
+            for (int grp = 0; grp < 2; ++grp) {
+                float in[TERMS];
+#pragma unroll
+                for (int s = 0; s < TERMS; ++s) in[s] = grp ? code[2 * s + 1] : code[2 * s];
+                f32x16 ha[ENV_T], hb[ENV_T], o[1];
+                layer_from_lanes<TERMS, ENV_T>(a.env_w[0], a.env_b[0], lane, in, ha);
+#pragma unroll
+                for (int t = 0; t < ENV_T; ++t) ha[t] = relu16(ha[t]);
+                layer_from_tiles<ENV_T, ENV_T>(a.env_w[1], a.env_b[1], lane, ha, hb);
+#pragma unroll
+                for (int t = 0; t < ENV_T; ++t) hb[t] = relu16(hb[t]);
+                layer_from_tiles<ENV_T, ENV_T>(a.env_w[2], a.env_b[2], lane, hb, ha);
+#pragma unroll
+                for (int t = 0; t < ENV_T; ++t) ha[t] = relu16(ha[t]);
+                layer_from_tiles<ENV_T, 1>(a.env_w[3], a.env_b[3], lane, ha, o);
+                if (grp == 0) outA = o[0]; else outB = o[0];
+            }
+            float e[16];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float u = outA[r], v = outB[r];
+                unpack_pair(u, v);
+                e[tile_row(r, 0)] = u; e[tile_row(r, 1)] = v;     // rows 0-3, 8-11 and 4-7, 12-15
+            }
+            float e12[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) e12[i] = e[i];
+            normalize_n<12>(e12, 1e-12f);                                               // network.py:541,600
+            if (enc == 0) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) env_n[i] = e12[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) env_r[i] = e12[i];
+            }
+        }
+
+        // ================= diffuse and specular heads ============================================
+        float cd[3], cs[3];
+        {
+            // diffuse input [geo_feat | env(normal)] (24), specular input [geo_feat | normal | env(refl) | n.v] (28)
+            float din[24], sin_[28];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { din[i] = geo[i]; din[12 + i] = env_n[i]; sin_[i] = geo[i]; sin_[15 + i] = env_r[i]; }
+            sin_[12] = nrm[0]; sin_[13] = nrm[1]; sin_[14] = nrm[2]; sin_[27] = ndot;
+#pragma unroll
+            for (int s = 0; s < 12; ++s) pack_pair(din[2 * s], din[2 * s + 1]);
+#pragma unroll
+            for (int s = 0; s < 14; ++s) pack_pair(sin_[2 * s], sin_[2 * s + 1]);
+            f32x16 dA, dB, sA, sB;
+#pragma unroll 1
+            for (int grp = 0; grp < 2; ++grp) {
+                float in_d[12], in_s[14];
+#pragma unroll
+                for (int s = 0; s < 12; ++s) in_d[s] = grp ? din[2 * s + 1] : din[2 * s];
+#pragma unroll
+                for (int s = 0; s < 14; ++s) in_s[s] = grp ? sin_[2 * s + 1] : sin_[2 * s];
+                f32x16 d1[1], d2[1], s1[2], s2[2], s3[1];
+                layer_from_lanes<12, 1>(a.dif_w[0], a.dif_b[0], lane, in_d, d1);
+                d1[0] = relu16(d1[0]);
+                layer_from_tiles<1, 1>(a.dif_w[1], a.dif_b[1], lane, d1, d2);
+                layer_from_lanes<14, 2>(a.spc_w[0], a.spc_b[0], lane, in_s, s1);
+                s1[0] = relu16(s1[0]); s1[1] = relu16(s1[1]);
+                layer_from_tiles<2, 2>(a.spc_w[1], a.spc_b[1], lane, s1, s2);
+                s2[0] = relu16(s2[0]); s2[1] = relu16(s2[1]);
+                layer_from_tiles<2, 1>(a.spc_w[2], a.spc_b[2], lane, s2, s3);
+                if (grp == 0) { dA = d2[0]; sA = s3[0]; } else { dB = d2[0]; sB = s3[0]; }
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {      // rows 0..2 live in registers 0..2 of lane half 0
+                float u = dA[r], v = dB[r];
+                unpack_pair(u, v);
+                cd[r] = sigmoidf(u);                                                    // color_act, metallic = 1
+                float p = sA[r], q = sB[r];
+                unpack_pair(p, q);
+                cs[r] = sigmoidf(p);
+            }
+        }
+
+        // ================= composite (raymarching.cu:996-1030 recurrence) =========================
+        if (have) {
+            const float alpha = 1.0f - expf(-sigma * dt);
+            const float T = 1 - acc.ws;
+            const float w = alpha * T;
+            acc.ws += w;
+            acc.t = acc.t + delta_depth;
+            acc.depth += w * acc.t;
+            const float cr = (cd[0] + cs[0]) * a.intensity_scale, cg = (cd[1] + cs[1]) * a.intensity_scale,
+                        cb = (cd[2] + cs[2]) * a.intensity_scale;
+            acc.r += w * cr; acc.g += w * cg; acc.b += w * cb;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { an[d] += w * nrm[d]; ad[d] += w * cd[d]; as[d] += w * cs[d]; }
+            arough += w * rough;
+            t_ray = acc.t;            // the reference resumes the marcher from the composited time
+            (void)t_next;
+            ++n_taken;
+            if (T < a.T_thresh) finish_ray();
+        }
+    }
+
+    if (a.stats) {
+        // wave-level reduction then one atomic per counter
+        for (int off = 32; off > 0; off >>= 1) {
+            n_samples += __shfl_down(n_samples, off);
+            n_rays += __shfl_down(n_rays, off);
+        }
+        if (lane == 0) {
+            atomicAdd(&a.stats[0], n_samples);
+            atomicAdd(&a.stats[1], n_rounds);
+            atomicAdd(&a.stats[2], n_rays);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+int device_cu_count() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t envidr_packed_weight_floats(int k_order, uint32_t k_in, uint32_t m_out) {
+    return packed_weight_floats(k_order ? kTileOrder : kLaneOrder, k_in, m_out);
+}
+uint32_t envidr_packed_rowvec_floats(uint32_t m_out) { return packed_bias_floats(m_out); }
+
+int envidr_pack_linear(const float* W_host, uint32_t m_out, uint32_t k_in, int transpose, int k_order, float* dst_host) {
+    ENVIDR_REQUIRE(W_host && dst_host && m_out && k_in, "pack_linear: null pointer or empty layer");
+    pack_linear(W_host, m_out, k_in, transpose != 0, k_order ? kTileOrder : kLaneOrder, dst_host);
+    return ENVIDR_OK;
+}
+int envidr_pack_rowvec(const float* v_host, uint32_t m_out, float* dst_host) {
+    ENVIDR_REQUIRE(v_host && dst_host && m_out, "pack_rowvec: null pointer or empty vector");
+    pack_rowvec(v_host, m_out, dst_host);
+    return ENVIDR_OK;
+}
+
+int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const float* rays_d, uint32_t N,
+                       const envidr_render_out* out, uint32_t* ray_counter, envidr_stream_t stream) {
+    ENVIDR_REQUIRE(d && out, "render_rays: null descriptor");
+    if (N == 0) return ENVIDR_OK;
+    ENVIDR_REQUIRE(rays_o && rays_d && ray_counter, "render_rays: null ray pointers / counter");
+    ENVIDR_REQUIRE(out->image && out->depth && out->weights_sum, "render_rays: image, depth and weights_sum are required");
+    ENVIDR_REQUIRE(d->density_bitfield && d->hash_table, "render_rays: null bitfield / hash table");
+    ENVIDR_REQUIRE(d->num_levels >= 1 && d->num_levels <= ENVIDR_MAX_LEVELS, "render_rays: num_levels %u not in [1,16]", d->num_levels);
+    ENVIDR_REQUIRE(d->cascades >= 1 && d->grid_size >= 1 && d->max_steps >= 1, "render_rays: bad grid parameters");
+    ENVIDR_REQUIRE(d->beta > 0, "render_rays: beta must be positive");
+    for (int i = 0; i < 3; ++i) ENVIDR_REQUIRE(d->sdf_w[i] && d->sdf_b[i] && d->specular_w[i] && d->specular_b[i], "render_rays: null sdf/specular weights");
+    for (int i = 0; i < 4; ++i) ENVIDR_REQUIRE(d->env_w[i] && d->env_b[i], "render_rays: null env weights");
+    for (int i = 0; i < 2; ++i) ENVIDR_REQUIRE(d->diffuse_w[i] && d->diffuse_b[i], "render_rays: null diffuse weights");
+    ENVIDR_REQUIRE(d->sdf_w2t && d->sdf_w1t && d->sdf_w3_row0, "render_rays: null sdf gradient weights");
+    ENVIDR_REQUIRE(d->num_levels == ENVIDR_MAX_LEVELS || d->num_levels * 2 <= 32, "render_rays: bad level count");
+
+    RenderArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rays_o = rays_o; a.rays_d = rays_d; a.N = N;
+    a.mk = make_march_consts(d->bound, d->dt_gamma, d->max_steps, d->cascades, d->grid_size, d->density_bitfield);
+    a.min_near = d->min_near; a.T_thresh = d->T_thresh; a.density_scale = d->density_scale; a.bg = d->bg_color;
+    a.max_samples = d->max_steps;
+    a.table = d->hash_table;
+    a.num_levels = d->num_levels;
+    a.bound2 = 2 * d->bound;
+    const LevelScale ls = make_level_scale(d->num_levels, d->log2_per_level_scale, d->base_resolution);
+    for (uint32_t l = 0; l < d->num_levels; ++l) {
+        const uint32_t size = (uint32_t)(d->hash_offsets[l + 1] - d->hash_offsets[l]);
+        const LevelGeom<3> g = make_level_geom<3>(size, ls.resolution[l], true);
+        a.lv[l].row0 = (uint32_t)d->hash_offsets[l];
+        a.lv[l].size = size;
+        a.lv[l].stride1 = g.stride[1]; a.lv[l].stride2 = g.stride[2];
+        a.lv[l].scale = ls.scale[l];
+        a.lv[l].hashed = g.hashed; a.lv[l].pow2 = g.pow2;
+        a.lv[l].enabled = (d->enabled_levels <= 0 || (int32_t)l < d->enabled_levels) ? 1u : 0u;
+        ENVIDR_REQUIRE(g.hashed || g.stride[0] == 1, "render_rays: unexpected dense stride");
+    }
+    for (int i = 0; i < 3; ++i) { a.sdf_w[i] = d->sdf_w[i]; a.sdf_b[i] = d->sdf_b[i]; a.spc_w[i] = d->specular_w[i]; a.spc_b[i] = d->specular_b[i]; }
+    for (int i = 0; i < 4; ++i) { a.env_w[i] = d->env_w[i]; a.env_b[i] = d->env_b[i]; }
+    for (int i = 0; i < 2; ++i) { a.dif_w[i] = d->diffuse_w[i]; a.dif_b[i] = d->diffuse_b[i]; }
+    a.sdf_w2t = d->sdf_w2t; a.sdf_w1t = d->sdf_w1t; a.sdf_w3r0 = d->sdf_w3_row0;
+    a.beta = d->beta; a.inv_beta = 1 / d->beta;
+    a.rough_bias = d->roughness_bias; a.rough_act_scale = d->roughness_act_scale; a.rough_scale = d->roughness_scale;
+    a.kappa_diffuse = d->diffuse_kappa_inv; a.light_scale = d->light_intensity_scale; a.intensity_scale = d->intensity_scale;
+    a.has_rot = d->has_env_rot;
+    for (int i = 0; i < 9; ++i) a.rot[i] = d->env_rot[i];
+    a.image = out->image; a.depth = out->depth; a.ws = out->weights_sum; a.normal = out->normal_image;
+    a.diffuse = out->diffuse_image; a.specular = out->specular_image; a.roughness = out->roughness_image;
+    a.stats = reinterpret_cast<unsigned long long*>(out->stats);
+    a.ray_counter = ray_counter;
+
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(ray_counter, 0, sizeof(uint32_t), s) != hipSuccess) return check_launch("render_rays memset");
+
+    // persistent grid: 4 single-wave workgroups per CU (one per SIMD; the kernel uses the full
+    // 512-register budget so exactly one wave fits a SIMD), fewer when the batch is small
+    const uint32_t max_waves = (uint32_t)device_cu_count() * 4;
+    const uint32_t waves = std::min(max_waves, ceil_div(N, 64));
+    const dim3 grid(waves), block(64);
+#define ENVIDR_LAUNCH(DEG, HT) hipLaunchKernelGGL((k_render_persistent<DEG, HT>), grid, block, 0, s, a)
+    if (d->ide_degree == 5 && d->env_hidden == 256) ENVIDR_LAUNCH(5, 8);
+    else if (d->ide_degree == 4 && d->env_hidden == 160) ENVIDR_LAUNCH(4, 5);
+    else if (d->ide_degree == 5 && d->env_hidden == 128) ENVIDR_LAUNCH(5, 4);
+    else if (d->ide_degree == 4 && d->env_hidden == 128) ENVIDR_LAUNCH(4, 4);
+    else {
+        set_error("render_rays: unsupported (ide_degree=%u, env_hidden=%u); built variants: (5,256) (4,160) (5,128) (4,128)",
+                  d->ide_degree, d->env_hidden);
+        return ENVIDR_EINVAL;
+    }
+#undef ENVIDR_LAUNCH
+    return check_launch("k_render_persistent");
+}
+
+}  // extern "C"

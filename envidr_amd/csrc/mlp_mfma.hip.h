@@ -1,0 +1,196 @@
+// Register-resident tiny-MLP evaluation on the gfx950 matrix cores (exact-fp32 MFMA).
+//
+// One wave64 pushes 32 samples ("a group") at a time through a chain of small dense layers.
+// The contraction is v_mfma_f32_32x32x2_f32:  D[32 x 32] += A[32 x 2] * B[2 x 32]  with
+//   A = a 32-output-feature tile of the layer's weights  (lane l holds W[m0 + (l & 31)][k(l >> 5)])
+//   B = activations, feature-major                        (lane l holds X[k(l >> 5)][sample l & 31])
+//   D = lane l, register r: feature m0 + (r & 3) + 8 (r >> 2) + 4 (l >> 5) of sample (l & 31).
+//
+// The trick that keeps a whole MLP in registers: a D tile has exactly the shape a B operand needs
+// (lanes <-> samples, the two lane halves hold two different features).  The reduction index k of the
+// next layer may be visited in ANY order as long as A and B agree, so step s = 16 T + r of the next
+// layer simply takes accumulator register r of tile T as its B operand -- no LDS, no shuffles, no
+// transposes between layers.  The weights are pre-permuted on the host (pack_linear below) so that the
+// A fragment of every (step, output tile) is one contiguous 256-byte row: one coalesced
+// global_load_dword per MFMA, streamed from L2 (all layers of the ENVIDR shading networks together
+// are < 1 MB, L2-resident on every XCD).
+//
+// Numerics: each output is an fp32 FMA chain over k in the packed order (MFMA f32 is bitwise an
+// fmaf chain, MI355X_MICROARCH.md), starting from the bias.  Parity against torch's fp32 GEMMs is
+// fp32-rounding-level (tests/test_fused_gpu.py).
+#pragma once
+#include "common.hip.h"
+
+namespace envidr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// feature index (inside a 32-feature tile) held by accumulator register r in lane half h
+__host__ __device__ constexpr int tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---- input orderings -----------------------------------------------------------------------
+// kLaneOrder : the layer input comes from per-lane feature registers packed with pack_pair();
+//              step s uses features (2s, 2s+1) in lane halves (0, 1).
+// kTileOrder : the layer input is the previous layer's accumulator tiles;
+//              step s = 16 T + r uses feature 32 T + tile_row(r, h).
+enum KOrder : int { kLaneOrder = 0, kTileOrder = 1 };
+
+__host__ __device__ constexpr int k_of_step(KOrder order, int s, int h) {
+    return order == kLaneOrder ? 2 * s + h : 32 * (s >> 4) + tile_row(s & 15, h);
+}
+constexpr uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+constexpr uint32_t steps_for(KOrder order, uint32_t k_in) { return order == kLaneOrder ? (k_in + 1) / 2 : round_up(k_in, 32) / 2; }
+constexpr uint32_t packed_weight_floats(KOrder order, uint32_t k_in, uint32_t m_out) {
+    return steps_for(order, k_in) * (round_up(m_out, 32) / 32) * 64;
+}
+constexpr uint32_t packed_bias_floats(uint32_t m_out) { return round_up(m_out, 32); }
+
+// Host-side packing.  W is row-major [m_out][k_in] (torch nn.Linear.weight); `transpose` packs W^T
+// instead (used for the input-gradient layers).  dst: [step][m_tile][64].
+inline void pack_linear(const float* W, uint32_t m_out, uint32_t k_in, bool transpose, KOrder order, float* dst) {
+    const uint32_t M = transpose ? k_in : m_out, K = transpose ? m_out : k_in;   // logical layer: K -> M
+    const uint32_t steps = steps_for(order, K), mt = round_up(M, 32) / 32;
+    for (uint32_t s = 0; s < steps; ++s)
+        for (uint32_t t = 0; t < mt; ++t)
+            for (uint32_t lane = 0; lane < 64; ++lane) {
+                const uint32_t h = lane >> 5, i = lane & 31;
+                const uint32_t m = 32 * t + i, k = (uint32_t)k_of_step(order, (int)s, (int)h);
+                float v = 0.0f;
+                if (m < M && k < K) v = transpose ? W[(size_t)k * k_in + m] : W[(size_t)m * k_in + k];
+                dst[((size_t)s * mt + t) * 64 + lane] = v;
+            }
+}
+// per-feature vector (bias, or a weight row) in accumulator layout: dst[tile][half][reg]
+inline void pack_rowvec(const float* v, uint32_t m_out, float* dst) {
+    const uint32_t mt = round_up(m_out, 32) / 32;
+    for (uint32_t t = 0; t < mt; ++t)
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t m = 32 * t + (uint32_t)tile_row(r, h);
+                dst[t * 32 + h * 16 + r] = m < m_out ? v[m] : 0.0f;
+            }
+}
+
+// ---- device side ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// Half exchange across the wave (v_permlane32_swap): afterwards
+//   a = [a.lower | b.lower],  b = [a.upper | b.upper]      (".lower" = lanes 0-31)
+__device__ __forceinline__ void swap_halves(float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+// per-lane features (even, odd) of the lane's own sample  ->  B operands of step s for group A
+// (samples of lanes 0-31, returned in `even`) and group B (samples of lanes 32-63, in `odd`).
+__device__ __forceinline__ void pack_pair(float& even, float& odd) { swap_halves(even, odd); }
+// accumulator register r of group A's tile and of group B's tile  ->  for every lane, its own
+// sample's features tile_row(r, 0) (returned in `a`) and tile_row(r, 1) (returned in `b`).
+__device__ __forceinline__ void unpack_pair(float& a, float& b) { swap_halves(a, b); }
+
+// ---- weight / bias fetch --------------------------------------------------------------------
+// All parameter reads go through a buffer resource (SGPR descriptor) with
+//   voffset = lane * 4 (one VGPR for the whole kernel), soffset = wave-uniform byte offset, imm offset.
+// Flat/global addressing would need a 64-bit per-lane VGPR address for every 4 KiB window of
+// weights; the compiler hoists those out of the persistent loop by the thousand and spills them.
+struct ParamBuf {
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t lane_off;    // lane * 4
+    uint32_t half16;      // (lane >> 5) * 64: byte offset of this lane half's 16 floats inside a packed row-vector tile
+};
+__device__ __forceinline__ ParamBuf make_param_buf(const float* base, uint32_t lane) {
+    ParamBuf p;
+    // wave-uniform pointer (kernel argument): descriptor lives in SGPRs; 0x00020000 = raw dword buffer
+    p.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+    p.lane_off = lane * 4u;
+    p.half16 = (lane >> 5) * 64u;
+    return p;
+}
+__device__ __forceinline__ float param_load(const ParamBuf& p, uint32_t byte_off_uniform) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(p.rsrc, p.lane_off, byte_off_uniform, 0));
+}
+
+// acc tile <- packed row vector (bias or a weight row), tile `tile`
+__device__ __forceinline__ f32x16 load_rowvec(const ParamBuf& p, int tile) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    f32x16 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(p.rsrc, p.half16, (uint32_t)(tile * 128 + q * 16), 0);
+        v[4 * q] = __uint_as_float(w[0]); v[4 * q + 1] = __uint_as_float(w[1]);
+        v[4 * q + 2] = __uint_as_float(w[2]); v[4 * q + 3] = __uint_as_float(w[3]);
+    }
+    return v;
+}
+
+__device__ __forceinline__ f32x16 relu16(f32x16 v) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
+    return v;
+}
+
+// One block of NSTEPS reduction steps into MT output tiles.
+//   byte0 : wave-uniform byte offset of this block's first step inside the layer's packed weights
+//   b(s)  : B operand (one float per lane) of local step s -- must be a compile-time-indexable register
+template <int NSTEPS, int MT, typename BOp>
+__device__ __forceinline__ void mfma_block(const ParamBuf& w, uint32_t byte0, f32x16 (&acc)[MT], BOp&& b) {
+#pragma unroll
+    for (int s = 0; s < NSTEPS; ++s) {
+        const float bv = b(s);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const float av = param_load(w, byte0 + (uint32_t)((s * MT + t) * 256));
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+        }
+    }
+}
+
+template <int MT>
+__device__ __forceinline__ void init_acc(const float* __restrict__ bias, uint32_t lane, f32x16 (&acc)[MT]) {
+    if (bias) {
+        const ParamBuf bb = make_param_buf(bias, lane);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t] = load_rowvec(bb, t);
+    } else {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    }
+}
+
+// Dense layer whose input is per-lane-packed registers in[STEPS] (kLaneOrder).  bias == nullptr: zero.
+template <int STEPS, int MT>
+__device__ __forceinline__ void layer_from_lanes(const float* __restrict__ w, const float* __restrict__ bias,
+                                                 uint32_t lane, const float (&in)[STEPS], f32x16 (&acc)[MT]) {
+    init_acc<MT>(bias, lane, acc);
+    const ParamBuf wb = make_param_buf(w, lane);
+    mfma_block<STEPS, MT>(wb, 0u, acc, [&](int s) { return in[s]; });
+}
+
+// Dense layer whose input is KT accumulator tiles of the previous layer (kTileOrder).  For wide
+// layers the loop over input tiles is a real (rolled) loop: each iteration selects the tile into
+// fixed registers (wave-uniform condition) so the 16 x MT MFMA body is emitted once.
+template <int KT, int MT>
+__device__ __forceinline__ void layer_from_tiles(const float* __restrict__ w, const float* __restrict__ bias,
+                                                 uint32_t lane, const f32x16 (&in)[KT], f32x16 (&acc)[MT]) {
+    init_acc<MT>(bias, lane, acc);
+    const ParamBuf wb = make_param_buf(w, lane);
+    constexpr uint32_t kTileBytes = 16u * MT * 256u;
+    if constexpr (KT <= 2) {
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+            mfma_block<16, MT>(wb, kt * kTileBytes, acc, [&](int s) { return in[kt][s]; });
+    } else {
+#pragma unroll 1
+        for (int kt = 0; kt < KT; ++kt) {
+            f32x16 cur = in[0];
+#pragma unroll
+            for (int j = 1; j < KT; ++j)
+                if (kt == j) cur = in[j];
+            mfma_block<16, MT>(wb, (uint32_t)kt * kTileBytes, acc, [&](int s) { return cur[s]; });
+        }
+    }
+}
+
+}  // namespace envidr

@@ -1,0 +1,253 @@
+"""Host side of the fused inference renderer (include/envidr_render.h).
+
+`FusedRenderer` owns the device-resident model state of one scene -- occupancy bitfield, hash
+table, and the MLP weights re-packed once into the MFMA tile layout -- and renders ray batches with
+a single persistent-kernel launch per call.  It is what `NeRFRenderer.render()` dispatches to for
+the inference branch of `run_cuda` (nerf/render_func/cuda_ray.py:238-359); the Python here only
+moves pointers.  No CPU fallback: without libenvidr_amd.so every call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+
+MAX_LEVELS = 16
+_FP = ctypes.c_void_p
+
+
+class RenderDesc(ctypes.Structure):
+    """mirror of `envidr_render_desc` (include/envidr_render.h) -- keep field order in sync"""
+    _fields_ = [
+        ("density_bitfield", _FP), ("bound", ctypes.c_float), ("cascades", ctypes.c_uint32), ("grid_size", ctypes.c_uint32),
+        ("min_near", ctypes.c_float), ("max_steps", ctypes.c_uint32), ("dt_gamma", ctypes.c_float), ("T_thresh", ctypes.c_float),
+        ("density_scale", ctypes.c_float), ("bg_color", ctypes.c_float),
+        ("hash_table", _FP), ("hash_offsets", ctypes.c_int32 * (MAX_LEVELS + 1)), ("num_levels", ctypes.c_uint32),
+        ("base_resolution", ctypes.c_uint32), ("log2_per_level_scale", ctypes.c_float), ("enabled_levels", ctypes.c_int32),
+        ("sdf_w", _FP * 3), ("sdf_b", _FP * 3), ("sdf_w2t", _FP), ("sdf_w1t", _FP), ("sdf_w3_row0", _FP),
+        ("beta", ctypes.c_float), ("roughness_bias", ctypes.c_float), ("roughness_act_scale", ctypes.c_float),
+        ("roughness_scale", ctypes.c_float),
+        ("ide_degree", ctypes.c_uint32), ("env_hidden", ctypes.c_uint32), ("env_w", _FP * 4), ("env_b", _FP * 4),
+        ("diffuse_kappa_inv", ctypes.c_float), ("light_intensity_scale", ctypes.c_float), ("intensity_scale", ctypes.c_float),
+        ("diffuse_w", _FP * 2), ("diffuse_b", _FP * 2), ("specular_w", _FP * 3), ("specular_b", _FP * 3),
+        ("has_env_rot", ctypes.c_int32), ("env_rot", ctypes.c_float * 9),
+    ]
+
+
+class RenderOut(ctypes.Structure):
+    """mirror of `envidr_render_out`"""
+    _fields_ = [("image", _FP), ("depth", _FP), ("weights_sum", _FP), ("normal_image", _FP), ("diffuse_image", _FP),
+                ("specular_image", _FP), ("roughness_image", _FP), ("stats", _FP)]
+
+
+@dataclass
+class FusedOptions:
+    """render knobs (defaults: configs/scenes/toaster.ini + nerf/options.py)"""
+    bound: float = 1.0
+    grid_size: int = 128
+    min_near: float = 0.2
+    max_steps: int = 1024
+    dt_gamma: float = 0.0
+    T_thresh: float = 1e-4
+    density_scale: float = 1.0
+    bg_color: float = 1.0
+    base_resolution: int = 16
+    enabled_levels: int = -1
+    beta_min: float = 0.0005
+    beta_max: float = 1.0
+    roughness_bias: float = -1.0
+    roughness_act_scale: float = 0.2
+    roughness_scale: float = 1.0
+    ide_degree: int = 5
+    diffuse_kappa_inv: float = 0.64
+    light_intensity_scale: float = 1.0
+    intensity_scale: float = 1.0
+
+
+def _bind_render(lib):
+    if getattr(lib, "_envidr_render_bound", False):
+        return
+    lib.envidr_packed_weight_floats.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
+    lib.envidr_packed_weight_floats.restype = ctypes.c_uint32
+    lib.envidr_packed_rowvec_floats.argtypes = [ctypes.c_uint32]
+    lib.envidr_packed_rowvec_floats.restype = ctypes.c_uint32
+    lib.envidr_pack_linear.argtypes = [_FP, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, _FP]
+    lib.envidr_pack_linear.restype = ctypes.c_int
+    lib.envidr_pack_rowvec.argtypes = [_FP, ctypes.c_uint32, _FP]
+    lib.envidr_pack_rowvec.restype = ctypes.c_int
+    lib.envidr_render_rays.argtypes = [ctypes.POINTER(RenderDesc), _FP, _FP, ctypes.c_uint32, ctypes.POINTER(RenderOut), _FP, _FP]
+    lib.envidr_render_rays.restype = ctypes.c_int
+    lib._envidr_render_bound = True
+
+
+def _np32(x) -> np.ndarray:
+    if isinstance(x, torch.Tensor):
+        x = x.detach().cpu().numpy()
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def pack_linear(W, k_order: int, transpose: bool = False) -> np.ndarray:
+    """torch-layout weight [out, in] -> MFMA tile layout (host)."""
+    lib = _lib.load()
+    _bind_render(lib)
+    W = _np32(W)
+    m_out, k_in = W.shape
+    M, K = (k_in, m_out) if transpose else (m_out, k_in)
+    dst = np.empty(lib.envidr_packed_weight_floats(k_order, K, M), np.float32)
+    rc = lib.envidr_pack_linear(W.ctypes.data, m_out, k_in, int(transpose), k_order, dst.ctypes.data)
+    if rc:
+        raise _lib.EnvidrError(lib.envidr_last_error().decode())
+    return dst
+
+
+def pack_rowvec(v) -> np.ndarray:
+    lib = _lib.load()
+    _bind_render(lib)
+    v = _np32(v).reshape(-1)
+    dst = np.empty(lib.envidr_packed_rowvec_floats(v.shape[0]), np.float32)
+    rc = lib.envidr_pack_rowvec(v.ctypes.data, v.shape[0], dst.ctypes.data)
+    if rc:
+        raise _lib.EnvidrError(lib.envidr_last_error().decode())
+    return dst
+
+
+class FusedRenderer:
+    """Device-resident scene + one-launch renderer.
+
+    mlps: dict with keys "sdf" (3 layers), "env" (4), "diffuse" (2), "specular" (3); each a list of
+    (weight [out,in], bias [out]) as numpy arrays or tensors (nn.Linear layout).
+    """
+
+    def __init__(self, bitfield, table, offsets, per_level_scale: float, mlps: dict, beta: float,
+                 opt: FusedOptions | None = None, device: str | torch.device = "cuda"):
+        self.lib = _lib.load()
+        _bind_render(self.lib)
+        self.opt = opt or FusedOptions()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.EnvidrError("FusedRenderer needs a GPU device; envidr_amd has no CPU path")
+        dev = self.device
+        self._keep: list[torch.Tensor] = []
+
+        def up(arr, dtype=torch.float32):
+            t = torch.as_tensor(np.ascontiguousarray(arr)).to(device=dev, dtype=dtype).contiguous()
+            self._keep.append(t)
+            return t
+
+        self.bitfield = up(bitfield, torch.uint8)
+        self.table = up(_np32(table))
+        offsets = np.asarray(offsets, dtype=np.int32)
+        self.num_levels = offsets.shape[0] - 1
+        if self.num_levels > MAX_LEVELS or self.table.shape[1] != 2:
+            raise _lib.EnvidrError("fused renderer supports hash grids with <= 16 levels of 2 features")
+        sdf, env, dif, spc = mlps["sdf"], mlps["env"], mlps["diffuse"], mlps["specular"]
+        if len(sdf) != 3 or len(env) != 4 or len(dif) != 2 or len(spc) != 3:
+            raise _lib.EnvidrError("fused renderer expects sdf/env/diffuse/specular MLPs of 3/4/2/3 layers")
+        feat = 2 * self.num_levels
+        if _np32(sdf[0][0]).shape != (64, feat) or _np32(sdf[1][0]).shape != (64, 64) or _np32(sdf[2][0]).shape[1] != 64:
+            raise _lib.EnvidrError("fused renderer expects the SDF network 2L -> 64 -> 64 -> 15")
+        env_hidden = _np32(env[0][0]).shape[0]
+        ide_dim = (2 ** self.opt.ide_degree - 1 + self.opt.ide_degree) * 2
+        if _np32(env[0][0]).shape[1] != ide_dim:
+            raise _lib.EnvidrError(f"env MLP input {_np32(env[0][0]).shape[1]} != IDE dim {ide_dim} of degree {self.opt.ide_degree}")
+
+        d = RenderDesc()
+        d.density_bitfield = self.bitfield.data_ptr()
+        d.bound = self.opt.bound
+        d.cascades = 1 + math.ceil(math.log2(self.opt.bound))
+        d.grid_size = self.opt.grid_size
+        d.min_near, d.max_steps, d.dt_gamma = self.opt.min_near, self.opt.max_steps, self.opt.dt_gamma
+        d.T_thresh, d.density_scale, d.bg_color = self.opt.T_thresh, self.opt.density_scale, self.opt.bg_color
+        d.hash_table = self.table.data_ptr()
+        for i, o in enumerate(offsets):
+            d.hash_offsets[i] = int(o)
+        d.num_levels = self.num_levels
+        d.base_resolution = self.opt.base_resolution
+        d.log2_per_level_scale = float(np.log2(per_level_scale))
+        d.enabled_levels = self.opt.enabled_levels
+
+        def layer(Wb, order, slot_w, slot_b, i):
+            slot_w[i] = up(pack_linear(Wb[0], order)).data_ptr()
+            slot_b[i] = up(pack_rowvec(Wb[1])).data_ptr()
+
+        layer(sdf[0], 0, d.sdf_w, d.sdf_b, 0)
+        layer(sdf[1], 1, d.sdf_w, d.sdf_b, 1)
+        layer(sdf[2], 1, d.sdf_w, d.sdf_b, 2)
+        d.sdf_w2t = up(pack_linear(sdf[1][0], 1, transpose=True)).data_ptr()
+        d.sdf_w1t = up(pack_linear(sdf[0][0], 1, transpose=True)).data_ptr()
+        d.sdf_w3_row0 = up(pack_rowvec(_np32(sdf[2][0])[0])).data_ptr()
+        d.beta = float(min(max(beta, self.opt.beta_min), self.opt.beta_max))     # LaplaceDensity.get_beta clamp
+        d.roughness_bias, d.roughness_act_scale = self.opt.roughness_bias, self.opt.roughness_act_scale
+        d.roughness_scale = self.opt.roughness_scale
+        d.ide_degree, d.env_hidden = self.opt.ide_degree, env_hidden
+        for i in range(4):
+            layer(env[i], 0 if i == 0 else 1, d.env_w, d.env_b, i)
+        d.diffuse_kappa_inv = self.opt.diffuse_kappa_inv
+        d.light_intensity_scale, d.intensity_scale = self.opt.light_intensity_scale, self.opt.intensity_scale
+        layer(dif[0], 0, d.diffuse_w, d.diffuse_b, 0)
+        layer(dif[1], 1, d.diffuse_w, d.diffuse_b, 1)
+        layer(spc[0], 0, d.specular_w, d.specular_b, 0)
+        layer(spc[1], 1, d.specular_w, d.specular_b, 1)
+        layer(spc[2], 1, d.specular_w, d.specular_b, 2)
+        d.has_env_rot = 0
+        self.desc = d
+        self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    @classmethod
+    def from_scene(cls, scene, opt: FusedOptions | None = None, device="cuda"):
+        """scene: envidr_amd.scenes.SceneParams"""
+        opt = opt or FusedOptions(bound=scene.bound, grid_size=scene.grid_size)
+        return cls(scene.bitfield, scene.table, scene.offsets, scene.per_level_scale, scene.mlps, scene.beta, opt, device)
+
+    def set_env_rotation(self, radian: float | None) -> None:
+        """w_r and the diffuse normal are multiplied by rot_theta(radian)[:3,:3] (renderer.py:160-172)."""
+        if radian is None:
+            self.desc.has_env_rot = 0
+            return
+        c, s = math.cos(radian), math.sin(radian)
+        R = np.array([[c, 0, -s], [0, 1, 0], [s, 0, c]], dtype=np.float64).astype(np.float32)
+        for i, v in enumerate(R.reshape(-1)):
+            self.desc.env_rot[i] = float(v)
+        self.desc.has_env_rot = 1
+
+    def render(self, rays_o: torch.Tensor, rays_d: torch.Tensor, env_rot_radian: float | None = None,
+               extras: bool = True, stats: bool = False, out: dict | None = None) -> dict:
+        """rays_o, rays_d: [N,3] fp32 on the GPU.  Returns image [N,3], depth [N], weights_sum [N]
+        (+ normal_image, diffuse_image, specular_image, roughness_image when `extras`)."""
+        if not (rays_o.is_cuda and rays_d.is_cuda):
+            raise _lib.EnvidrError("render: rays must live on the GPU")
+        rays_o = rays_o.contiguous().view(-1, 3).float()
+        rays_d = rays_d.contiguous().view(-1, 3).float()
+        N = rays_o.shape[0]
+        dev = rays_o.device
+        res = out if out is not None else {}
+
+        def buf(name, *shape):
+            if name not in res:
+                res[name] = torch.empty(*shape, dtype=torch.float32, device=dev)
+            return res[name]
+
+        o = RenderOut()
+        o.image = buf("image", N, 3).data_ptr()
+        o.depth = buf("depth", N).data_ptr()
+        o.weights_sum = buf("weights_sum", N).data_ptr()
+        if extras:
+            o.normal_image = buf("normal_image", N, 3).data_ptr()
+            o.diffuse_image = buf("diffuse_image", N, 3).data_ptr()
+            o.specular_image = buf("specular_image", N, 3).data_ptr()
+            o.roughness_image = buf("roughness_image", N).data_ptr()
+        if stats:
+            res["stats"] = torch.zeros(4, dtype=torch.int64, device=dev)
+            o.stats = res["stats"].data_ptr()
+        self.set_env_rotation(env_rot_radian)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = self.lib.envidr_render_rays(ctypes.byref(self.desc), rays_o.data_ptr(), rays_d.data_ptr(), N, ctypes.byref(o),
+                                         self.counter.data_ptr(), stream)
+        if rc:
+            raise _lib.EnvidrError(f"envidr_render_rays failed ({rc}): {self.lib.envidr_last_error().decode()}")
+        return res

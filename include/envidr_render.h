@@ -1,0 +1,121 @@
+/*
+ * envidr_render -- C-ABI of the fused inference render path.
+ *
+ * This entry point replaces, as ONE persistent-wave kernel launch, the whole host-driven
+ * march -> encode -> MLP -> composite -> compact loop of the reference's inference branch
+ *     nerf/render_func/cuda_ray.py:238-359   (run_cuda, `else:` branch)
+ * together with the per-sample model code it calls
+ *     nerf/network.py:381-522   forward_geometry / forward_sigma   (hash grid -> SDF MLP -> density)
+ *     nerf/renderer.py:182-198  compute_normal                      (analytic instead of autograd)
+ *     nerf/renderer.py:147-180  get_color_mlp_extra_params          (reflection, IDE x2, n.v)
+ *     nerf/network.py:524-698   forward_color                       (env MLP x2, diffuse, specular)
+ * for the network family of configs/scenes/toaster.ini / configs/neural_renderer.ini
+ * (hashgrid_diff position encoding, SDF + Laplace density, IDE-fed environment MLP, diffuse +
+ * specular heads, sigmoid colours, unit-norm feature activations).
+ *
+ * A renderer built on the reference would bind it in place of run_cuda's loop.
+ * Plain C: device pointers, host scalars, no torch / HIP types.
+ */
+#ifndef ENVIDR_RENDER_H
+#define ENVIDR_RENDER_H
+
+#include <stdint.h>
+#include "envidr_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ENVIDR_MAX_LEVELS 16
+
+/* ---- weight packing (host side, run once per model load) ------------------------------------
+ * The fused kernel streams each layer's weights in a layout pre-permuted for the MFMA tiles
+ * (envidr_amd/csrc/mlp_mfma.hip.h).  These helpers convert a torch-style row-major
+ * nn.Linear.weight [out, in] (HOST pointers) into that layout.
+ *   k_order: 0 = the layer's input is per-sample features written by scalar code ("lane order"),
+ *            1 = the layer's input is the previous layer's output tiles       ("tile order").
+ *   transpose != 0 packs W^T (the input-gradient layers of the SDF network). */
+uint32_t envidr_packed_weight_floats(int k_order, uint32_t k_in, uint32_t m_out);
+uint32_t envidr_packed_rowvec_floats(uint32_t m_out);
+int envidr_pack_linear(const float* W_host, uint32_t m_out, uint32_t k_in, int transpose, int k_order,
+                       float* dst_host);
+int envidr_pack_rowvec(const float* v_host, uint32_t m_out, float* dst_host);
+
+/* ---- scene / model description ---------------------------------------------------------------- */
+typedef struct envidr_render_desc {
+    /* occupancy grid marching (NeRFRenderer state + render kwargs) */
+    const uint8_t* density_bitfield; /* device, [cascades * grid_size^3 / 8], Morton order      */
+    float bound;                     /* scene half extent; aabb = [-bound, bound]^3              */
+    uint32_t cascades;               /* 1 + ceil(log2(bound))                                     */
+    uint32_t grid_size;              /* 128                                                       */
+    float min_near;                  /* 0.2                                                       */
+    uint32_t max_steps;              /* 1024: also the per-ray sample cap                         */
+    float dt_gamma;                  /* 0 = constant step                                         */
+    float T_thresh;                  /* 1e-4                                                      */
+    float density_scale;             /* 1                                                         */
+    float bg_color;                  /* scalar background blended with (1 - weights_sum)          */
+
+    /* hash grid (HashEncoder: D = 3, C = 2) */
+    const float* hash_table;         /* device, [offsets[L], 2]                                   */
+    int32_t hash_offsets[ENVIDR_MAX_LEVELS + 1]; /* HOST copy of the encoder's offsets buffer    */
+    uint32_t num_levels;             /* <= 16                                                     */
+    uint32_t base_resolution;        /* 16                                                        */
+    float log2_per_level_scale;      /* S                                                         */
+    int32_t enabled_levels;          /* <= 0: all levels; else features of levels >= this are 0   */
+
+    /* SDF network 2*L -> 64 -> 64 -> (1 + 12 + 1 + 1), packed (device pointers) */
+    const float* sdf_w[3];           /* w[0] lane order, w[1..2] tile order                       */
+    const float* sdf_b[3];           /* packed row vectors                                        */
+    const float* sdf_w2t;            /* W2^T, tile order                                          */
+    const float* sdf_w1t;            /* W1^T, tile order (64 -> 2*L)                              */
+    const float* sdf_w3_row0;        /* row 0 of W3 (d sdf / d h2) as a packed row vector         */
+    float beta;                      /* Laplace density beta (already clamped to [beta_min, max]) */
+    float roughness_bias;            /* -1                                                        */
+    float roughness_act_scale;       /* 0.2                                                       */
+    float roughness_scale;           /* 1                                                         */
+
+    /* environment MLP  ide_dim -> H -> H -> H -> 12 (evaluated twice per sample) */
+    uint32_t ide_degree;             /* 4 or 5                                                    */
+    uint32_t env_hidden;             /* 160 or 256 (multiple of 32)                               */
+    const float* env_w[4];
+    const float* env_b[4];
+    float diffuse_kappa_inv;         /* 0.64                                                      */
+    float light_intensity_scale;     /* 1                                                         */
+    float intensity_scale;           /* 1                                                         */
+
+    /* diffuse head 24 -> 32 -> 3 and specular head 28 -> 64 -> 64 -> 3 */
+    const float* diffuse_w[2];
+    const float* diffuse_b[2];
+    const float* specular_w[3];
+    const float* specular_b[3];
+
+    /* optional environment rotation: w_r and the diffuse normal are multiplied (row vector x
+     * matrix) by this row-major 3x3; has_env_rot = 0 skips it (renderer.py:160-161,171-172)      */
+    int32_t has_env_rot;
+    float env_rot[9];
+} envidr_render_desc;
+
+/* ---- per-call outputs (device pointers; any optional pointer may be NULL) --------------------- */
+typedef struct envidr_render_out {
+    float* image;           /* [N,3]  composited rgb + (1 - weights_sum) * bg_color                */
+    float* depth;           /* [N]                                                                 */
+    float* weights_sum;     /* [N]                                                                 */
+    float* normal_image;    /* [N,3]  optional: normalize(sum w n) (eps 1e-10), cuda_ray.py:357    */
+    float* diffuse_image;   /* [N,3]  optional                                                     */
+    float* specular_image;  /* [N,3]  optional                                                     */
+    float* roughness_image; /* [N]    optional: sum w roughness                                    */
+    uint64_t* stats;        /* [4]    optional: {samples shaded, wave rounds, rays, reserved}; caller zeroes */
+} envidr_render_out;
+
+/* Render N rays (rays_o, rays_d: device [N,3], unit directions).  `ray_counter` is a device uint32
+ * the kernel uses as its work queue head; the call zeroes it on `stream` before launching.
+ * Sample positions, occupancy decisions and step sizes equal the reference loop run with one sample
+ * per ray per iteration; colours agree with the reference's fp32 PyTorch path to fp32 rounding
+ * (DESIGN.md "parity"). */
+int envidr_render_rays(const envidr_render_desc* desc, const float* rays_o, const float* rays_d, uint32_t N,
+                       const envidr_render_out* out, uint32_t* ray_counter, envidr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ENVIDR_RENDER_H */

@@ -208,7 +208,9 @@ def shade_samples(scene, xyzs: np.ndarray, dirs: np.ndarray, opt: RenderOptions,
 # inference render loop
 # ------------------------------------------------------------------------------------------------
 def render_rays(scene, rays_o: np.ndarray, rays_d: np.ndarray, opt: RenderOptions, env_rot_radian: float | None = None,
-                trace: list | None = None) -> dict:
+                trace: list | None = None, force_n_step: int | None = None) -> dict:
+    """force_n_step=None follows the reference's schedule n_step = clamp(N // n_alive, 1, 8);
+    force_n_step=1 is the one-sample-per-iteration schedule the fused GPU kernel is equivalent to."""
     o = clib.oracle()
     N = rays_o.shape[0]
     rays_o = np.ascontiguousarray(rays_o, F32)
@@ -240,7 +242,7 @@ def render_rays(scene, rays_o: np.ndarray, rays_d: np.ndarray, opt: RenderOption
         n_alive = main["alive"].shape[0]
         if n_alive <= 0:
             break
-        n_step = max(min(N // n_alive, 8), 1)
+        n_step = max(min(N // n_alive, 8), 1) if force_n_step is None else force_n_step
         M = n_alive * n_step
         M += 128 - (M % 128)                          # raymarching.py:350-351 (adds a full 128 when aligned)
         xyzs, dirs, deltas = np.zeros((M, 3), F32), np.zeros((M, 3), F32), np.zeros((M, 2), F32)
