@@ -25,7 +25,7 @@ ARCH = "gfx950"
 #   written explicitly (fmaf / MFMA) where they are wanted.
 # -munsafe-fp-atomics: fp32 scatter-adds become one global_atomic_add_f32 instead of a CAS loop.
 HIPCC_FLAGS = [
-    f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+    f"--offload-arch={ARCH}", "-O3", "-std=c++20", "-fPIC", "-ffp-contract=off",
     "-munsafe-fp-atomics", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
 ]
 
@@ -83,4 +83,4 @@ def build(force: bool = False, verbose: bool = True, extra_flags: list[str] | No
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, extra_flags=[a for a in sys.argv[1:] if a.startswith("-D")])

@@ -132,6 +132,14 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
     Accum acc = {};
     float an[3] = {0, 0, 0}, ad[3] = {0, 0, 0}, as[3] = {0, 0, 0}, arough = 0;
     unsigned long long n_samples = 0, n_rounds = 0, n_rays = 0;
+#ifdef ENVIDR_SECTION_TIMERS
+    // per-wave cycle accounting (s_memtime), build with -DENVIDR_SECTION_TIMERS; stats[4..11]
+    unsigned long long tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tmark = __builtin_amdgcn_s_memtime();
+#define ENVIDR_TICK(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tsec[i] += now_ - tmark; tmark = now_; } while (0)
+#else
+#define ENVIDR_TICK(i) do {} while (0)
+#endif
 
     auto finish_ray = [&]() {
         const size_t id = (size_t)ray;
@@ -186,6 +194,7 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
             if (!__any(again)) break;
         }
         if (!__any(have)) break;
+        ENVIDR_TICK(0);   // refill + march
         n_samples += have ? 1 : 0;
         n_rounds += 1;
         if (!have) { px = py = pz = 0; }
@@ -213,6 +222,7 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
             }
         }
 
+        ENVIDR_TICK(1);   // hash grid
         // ================= SDF network forward + input gradient (matrix cores) ===================
         float h3[32];      // raw outputs of the last SDF layer for this lane's sample (rows 0..14 used)
         float gfeat[32];   // d sdf / d feat
@@ -238,7 +248,7 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
                 layer_from_tiles<2, 1>(a.sdf_w[2], a.sdf_b[2], lane, h2, o3);
                 // backward of sdf = o3[row 0]:  g2 = W3[0,:] * [h2 > 0];  g1 = (W2^T g2) * [h1 > 0];  gfeat = W1^T g1
                 f32x16 g2[2], g1[2], gf[1];
-                const ParamBuf w3r0 = make_param_buf(a.sdf_w3r0, lane);
+                const ParamBuf w3r0 = make_param_buf(a.sdf_w3r0, 2 * 128u, lane);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const f32x16 w = load_rowvec(w3r0, t);
@@ -264,6 +274,7 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
             }
         }
 
+        ENVIDR_TICK(2);   // sdf mlp fwd+bwd
         // ================= per-sample geometry terms =============================================
         const float sdf = h3[0];
         float geo[12];
@@ -306,6 +317,7 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
             }
         }
 
+        ENVIDR_TICK(3);   // geometry terms
         // ================= environment MLP on IDE(normal) and IDE(reflection) =====================
         float env_n[12], env_r[12];
 #pragma unroll 1
@@ -319,6 +331,7 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
             });
 #pragma unroll
             for (int s = 0; s < TERMS; ++s) pack_pair(code[2 * s], code[2 * s + 1]);
+            ENVIDR_TICK(4);   // IDE
             f32x16 outA, outB;
 #pragma unroll 1
             for (int grp = 0; grp < 2; ++grp) {
@@ -338,6 +351,7 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
                 layer_from_tiles<ENV_T, 1>(a.env_w[3], a.env_b[3], lane, ha, o);
                 if (grp == 0) outA = o[0]; else outB = o[0];
             }
+            ENVIDR_TICK(5);   // env mlp
             float e[16];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -400,6 +414,7 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
             }
         }
 
+        ENVIDR_TICK(6);   // heads (+ env unpack)
         // ================= composite (raymarching.cu:996-1030 recurrence) =========================
         if (have) {
             const float alpha = 1.0f - expf(-sigma * dt);
@@ -419,6 +434,7 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
             ++n_taken;
             if (T < a.T_thresh) finish_ray();
         }
+        ENVIDR_TICK(7);   // composite
     }
 
     if (a.stats) {
@@ -431,6 +447,9 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
             atomicAdd(&a.stats[0], n_samples);
             atomicAdd(&a.stats[1], n_rounds);
             atomicAdd(&a.stats[2], n_rays);
+#ifdef ENVIDR_SECTION_TIMERS
+            for (int i = 0; i < 8; ++i) atomicAdd(&a.stats[4 + i], tsec[i]);
+#endif
         }
     }
 }

@@ -20,6 +20,7 @@
 // fp32-rounding-level (tests/test_fused_gpu.py).
 #pragma once
 #include "common.hip.h"
+#include <utility>
 
 namespace envidr {
 
@@ -98,10 +99,12 @@ struct ParamBuf {
     uint32_t lane_off;    // lane * 4
     uint32_t half16;      // (lane >> 5) * 64: byte offset of this lane half's 16 floats inside a packed row-vector tile
 };
-__device__ __forceinline__ ParamBuf make_param_buf(const float* base, uint32_t lane) {
+// `bytes` is the exact size of the parameter array: buffer loads beyond it return 0 instead of
+// faulting, which lets the weight stream prefetch past the end of a layer.
+__device__ __forceinline__ ParamBuf make_param_buf(const float* base, uint32_t bytes, uint32_t lane) {
     ParamBuf p;
     // wave-uniform pointer (kernel argument): descriptor lives in SGPRs; 0x00020000 = raw dword buffer
-    p.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+    p.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
     p.lane_off = lane * 4u;
     p.half16 = (lane >> 5) * 64u;
     return p;
@@ -129,26 +132,47 @@ __device__ __forceinline__ f32x16 relu16(f32x16 v) {
     return v;
 }
 
-// One block of NSTEPS reduction steps into MT output tiles.
-//   byte0 : wave-uniform byte offset of this block's first step inside the layer's packed weights
-//   b(s)  : B operand (one float per lane) of local step s -- must be a compile-time-indexable register
-template <int NSTEPS, int MT, typename BOp>
-__device__ __forceinline__ void mfma_block(const ParamBuf& w, uint32_t byte0, f32x16 (&acc)[MT], BOp&& b) {
+// Software-pipelined stream of A fragments: a ring of PF registers holds fragments i .. i+PF-1 of the
+// layer's packed weights; taking fragment i immediately re-issues the load of fragment i+PF into the
+// freed register, so PF loads (PF * 256 B per wave) stay in flight under the MFMAs.  With one wave per
+// SIMD there is no other wave to hide the L2 round trip behind, this ring is what hides it.
+template <int PF>
+struct WeightStream {
+    ParamBuf w;
+    float ring[PF];
+    __device__ __forceinline__ void prime(const float* base, uint32_t bytes, uint32_t lane) {
+        w = make_param_buf(base, bytes, lane);
 #pragma unroll
-    for (int s = 0; s < NSTEPS; ++s) {
-        const float bv = b(s);
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            const float av = param_load(w, byte0 + (uint32_t)((s * MT + t) * 256));
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-        }
+        for (int i = 0; i < PF; ++i) ring[i] = param_load(w, (uint32_t)(i * 256));
+    }
+    // fragment at flat index block0 + I  (I compile-time, block0_bytes wave-uniform, (block0 % PF) == 0)
+    template <int I>
+    __device__ __forceinline__ float take(uint32_t block0_bytes) {
+        const float v = ring[I % PF];
+        ring[I % PF] = param_load(w, block0_bytes + (uint32_t)((I + PF) * 256));
+        return v;
+    }
+};
+
+template <int NSTEPS, int MT, int PF, int S = 0, typename BOp>
+__device__ __forceinline__ void mfma_steps(WeightStream<PF>& ws, uint32_t block0_bytes, f32x16 (&acc)[MT], BOp&& b) {
+    if constexpr (S < NSTEPS) {
+        const float bv = b(S);
+        // one step: MT output tiles share the B operand
+        [&]<int... T>(std::integer_sequence<int, T...>) {
+            ((acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.template take<S * MT + T>(block0_bytes), bv, acc[T], 0, 0, 0)), ...);
+        }(std::make_integer_sequence<int, MT>{});
+        // pin the software pipeline: without this the scheduler hoists every refill load of the layer
+        // to its top (they have no dependences), blows the register file and reloads them from scratch
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_steps<NSTEPS, MT, PF, S + 1>(ws, block0_bytes, acc, b);
     }
 }
 
 template <int MT>
 __device__ __forceinline__ void init_acc(const float* __restrict__ bias, uint32_t lane, f32x16 (&acc)[MT]) {
     if (bias) {
-        const ParamBuf bb = make_param_buf(bias, lane);
+        const ParamBuf bb = make_param_buf(bias, MT * 128u, lane);
 #pragma unroll
         for (int t = 0; t < MT; ++t) acc[t] = load_rowvec(bb, t);
     } else {
@@ -159,28 +183,36 @@ __device__ __forceinline__ void init_acc(const float* __restrict__ bias, uint32_
     }
 }
 
+constexpr int prefetch_depth(int mt) { return mt >= 8 ? 32 : 16; }   // must divide 16 * MT (tile-order blocks)
+
 // Dense layer whose input is per-lane-packed registers in[STEPS] (kLaneOrder).  bias == nullptr: zero.
 template <int STEPS, int MT>
 __device__ __forceinline__ void layer_from_lanes(const float* __restrict__ w, const float* __restrict__ bias,
                                                  uint32_t lane, const float (&in)[STEPS], f32x16 (&acc)[MT]) {
+    constexpr int PF = (STEPS * MT >= 32 && MT >= 8) ? 32 : 16;
+    WeightStream<PF> ws;
+    ws.prime(w, (uint32_t)(STEPS * MT * 256), lane);
     init_acc<MT>(bias, lane, acc);
-    const ParamBuf wb = make_param_buf(w, lane);
-    mfma_block<STEPS, MT>(wb, 0u, acc, [&](int s) { return in[s]; });
+    mfma_steps<STEPS, MT, PF>(ws, 0u, acc, [&](int s) { return in[s]; });
 }
 
 // Dense layer whose input is KT accumulator tiles of the previous layer (kTileOrder).  For wide
 // layers the loop over input tiles is a real (rolled) loop: each iteration selects the tile into
-// fixed registers (wave-uniform condition) so the 16 x MT MFMA body is emitted once.
+// fixed registers (wave-uniform condition) so the 16 x MT MFMA body is emitted once; the weight
+// ring carries across iterations.
 template <int KT, int MT>
 __device__ __forceinline__ void layer_from_tiles(const float* __restrict__ w, const float* __restrict__ bias,
                                                  uint32_t lane, const f32x16 (&in)[KT], f32x16 (&acc)[MT]) {
-    init_acc<MT>(bias, lane, acc);
-    const ParamBuf wb = make_param_buf(w, lane);
+    constexpr int PF = prefetch_depth(MT);
+    static_assert((16 * MT) % PF == 0, "ring position must be block-invariant");
     constexpr uint32_t kTileBytes = 16u * MT * 256u;
+    WeightStream<PF> ws;
+    ws.prime(w, KT * kTileBytes, lane);
+    init_acc<MT>(bias, lane, acc);
     if constexpr (KT <= 2) {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
-            mfma_block<16, MT>(wb, kt * kTileBytes, acc, [&](int s) { return in[kt][s]; });
+            mfma_steps<16, MT, PF>(ws, kt * kTileBytes, acc, [&](int s) { return in[kt][s]; });
     } else {
 #pragma unroll 1
         for (int kt = 0; kt < KT; ++kt) {
@@ -188,7 +220,7 @@ __device__ __forceinline__ void layer_from_tiles(const float* __restrict__ w, co
 #pragma unroll
             for (int j = 1; j < KT; ++j)
                 if (kt == j) cur = in[j];
-            mfma_block<16, MT>(wb, (uint32_t)kt * kTileBytes, acc, [&](int s) { return cur[s]; });
+            mfma_steps<16, MT, PF>(ws, (uint32_t)kt * kTileBytes, acc, [&](int s) { return cur[s]; });
         }
     }
 }

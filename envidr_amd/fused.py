@@ -242,7 +242,7 @@ class FusedRenderer:
             o.specular_image = buf("specular_image", N, 3).data_ptr()
             o.roughness_image = buf("roughness_image", N).data_ptr()
         if stats:
-            res["stats"] = torch.zeros(4, dtype=torch.int64, device=dev)
+            res["stats"] = torch.zeros(12, dtype=torch.int64, device=dev)
             o.stats = res["stats"].data_ptr()
         self.set_env_rotation(env_rot_radian)
         stream = torch.cuda.current_stream(dev).cuda_stream

@@ -104,7 +104,8 @@ typedef struct envidr_render_out {
     float* diffuse_image;   /* [N,3]  optional                                                     */
     float* specular_image;  /* [N,3]  optional                                                     */
     float* roughness_image; /* [N]    optional: sum w roughness                                    */
-    uint64_t* stats;        /* [4]    optional: {samples shaded, wave rounds, rays, reserved}; caller zeroes */
+    uint64_t* stats;        /* [12]   optional: {samples shaded, wave rounds, rays, reserved, 8 x section cycles
+                             *         (only when the library is built with -DENVIDR_SECTION_TIMERS)}; caller zeroes */
 } envidr_render_out;
 
 /* Render N rays (rays_o, rays_d: device [N,3], unit directions).  `ray_counter` is a device uint32
