@@ -1,0 +1,166 @@
+#!/usr/bin/env python
+"""Benchmark of the ENVIDR render hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Metric (BASELINE.json): rendered rays/s at 800x800, max 1024 samples/ray, plus PSNR of the GPU image
+against the CPU reference restatement on a sample of the same scene.
+
+One "step" = every rank renders ONE full 800x800 view (640 000 primary rays) of the synthetic
+toaster scene with the fused persistent kernel -- march + hash grid + SDF MLP + analytic normals +
+2x IDE + 2x environment MLP + diffuse/specular heads + compositing, all four auxiliary images on
+(normal / diffuse / specular / roughness, as the reference's toaster.ini renders them) -- and the
+finished RGB frame is gathered to rank 0 (RCCL gather over xGMI; no-op at N = 1).  Views are the
+env-rotation video frames of BASELINE config #5: view v = step * N + rank gets env rotation
+2 pi v / 200, so per-GPU work is fixed as N grows (weak scaling).  Inputs (rays, table, weights) are
+resident in HBM before the timed region.
+
+Printed by rank 0 as ONE JSON line; see DESIGN.md section "Measurement" for the roofline arithmetic.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H = W = 800
+FLOP_PER_SAMPLE = 650_880          # dense-layer FLOPs per shaded sample, toaster network
+HASH_BYTES_PER_SAMPLE = 1024       # 16 levels x 8 corners x 8 B gathered per sample
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+CPU_SAMPLE_RES = 112               # cpu_baseline renders a 112x112 frame of the same scene/camera
+
+
+def cpu_baseline(scene, env_rot: float) -> dict:
+    """the CPU restatement (oracle: C/OpenMP ops + torch CPU GEMMs, reference n_step schedule) timed
+    on the host cores on a bounded sample of the same workload"""
+    from envidr_amd import scenes
+    from oracle.py import render_oracle as ro
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    rays_o, rays_d = scenes.camera_rays(CPU_SAMPLE_RES, CPU_SAMPLE_RES)
+    opt = ro.RenderOptions(ide_mode="torch")
+    ro.render_rays(scene, rays_o[:256], rays_d[:256], opt, env_rot)          # warm-up (library loads, thread pools)
+    t0 = time.perf_counter()
+    res = ro.render_rays(scene, rays_o, rays_d, opt, env_rot)
+    dt = time.perf_counter() - t0
+    n = CPU_SAMPLE_RES * CPU_SAMPLE_RES
+    return {"value": n / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{CPU_SAMPLE_RES}x{CPU_SAMPLE_RES} frame of the same scene and camera ({n} rays, {res['n_samples']} samples, "
+                      f"{dt:.1f} s): oracle/ C+OpenMP ops + torch CPU fp32 GEMMs, reference n_step schedule",
+            "samples_per_s": res["n_samples"] / dt, "image": res["image"]}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (profiling runs)")
+    args = ap.parse_args()
+
+    from envidr_amd import parallel, scenes
+    from envidr_amd.fused import FusedRenderer
+    import torch.distributed as dist
+
+    rank, world, local = parallel.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    scene = scenes.toaster_scene()
+    renderer = FusedRenderer.from_scene(scene, device=dev)
+    rays_o, rays_d = (torch.from_numpy(a).to(dev) for a in scenes.camera_rays(H, W))
+    N = H * W
+    out: dict = {}
+    gather_list = [torch.empty(N, 3, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def env_rot(view: int) -> float:
+        return 2 * math.pi * (view % 200) / 200
+
+    def step(i: int) -> None:
+        res = renderer.render(rays_o, rays_d, env_rot(i * world + rank), extras=True, stats=True, out=out)
+        if world > 1:
+            dist.gather(res["image"], gather_list=gather_list, dst=0)
+
+    for i in range(args.warmup):
+        step(i)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    samples = 0
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()                      # same stream the kernel is launched on (torch's current stream)
+        res = renderer.render(rays_o, rays_d, env_rot((args.warmup + i) * world + rank), extras=True, stats=True, out=out)
+        ev[i][1].record()
+        if world > 1:
+            dist.gather(res["image"], gather_list=gather_list, dst=0)
+    fence()
+    dt = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    samples = int(out["stats"][0].item())      # samples shaded in the last frame
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        rays_per_s = world * N * args.steps / dt
+        flops = samples * FLOP_PER_SAMPLE / (kernel_ms * 1e-3) / 1e12
+        result = {
+            "metric": "rendered rays/s at 800x800, 1024 max samples/ray", "value": rays_per_s, "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]/[4] network (toaster.ini: hash L16xC2 + SDF 32-64-64-15 + IDE deg5 + env MLP "
+                                   "72-256-256-256-12 x2 + diffuse/specular heads) on a synthetic shell scene, 800x800 view per GPU per "
+                                   "step, env-rotation video frames sharded by view, normal/diffuse/specular/roughness images on",
+                       "rays_per_step_per_gpu": N, "samples_per_frame": samples, "samples_per_ray": samples / N,
+                       "max_steps": 1024, "T_thresh": 1e-4, "parallelism": f"views x{world} + RCCL image gather"},
+            "samples_per_s": world * samples * args.steps / dt,
+            "roofline": {"bound": "mfma", "achieved": flops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "k_render_persistent<5,8>", "kernel_ms": kernel_ms,
+                         "algorithmic_flop_per_sample": FLOP_PER_SAMPLE, "samples_per_launch": samples,
+                         "hbm_view": {"bound": "hbm", "achieved": samples * HASH_BYTES_PER_SAMPLE / (kernel_ms * 1e-3) / 1e9,
+                                      "peak": 8000.0, "unit": "GB/s"}},
+        }
+        prof = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(prof):
+            try:
+                result["roofline"]["traffic"] = json.load(open(prof)).get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(scene, env_rot(0))
+            # PSNR of the GPU render vs the CPU reference restatement on the same sample
+            so, sd = (torch.from_numpy(a).to(dev) for a in scenes.camera_rays(CPU_SAMPLE_RES, CPU_SAMPLE_RES))
+            g = renderer.render(so, sd, env_rot(0), extras=False)["image"].cpu().numpy()
+            ref = cpu.pop("image")
+            mse = float(np.mean((g.astype(np.float64) - ref) ** 2))
+            result["psnr_vs_cpu_reference_db"] = -10 * math.log10(max(mse, 1e-20))
+            result["rel_l2_vs_cpu_reference"] = float(np.linalg.norm(g.astype(np.float64) - ref) / np.linalg.norm(ref))
+            result["cpu_baseline"] = cpu
+            result["speedup_vs_cpu_baseline"] = rays_per_s / cpu["value"]
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,120 @@
+"""CPU-side checks of the C-ABI boundary: the shared library loads without a GPU, exports every entry
+point the headers declare, the host-side weight packing matches its specification, and the product
+package never touches the oracle."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _declared(header: str) -> set[str]:
+    text = (ROOT / "include" / header).read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(envidr_[a-zA-Z0-9_]+)\s*\(", text))
+
+
+def test_library_exports_every_declared_symbol():
+    from envidr_amd import _lib
+    lib = _lib.load()
+    declared = _declared("envidr_amd.h") | _declared("envidr_render.h")
+    assert len(declared) >= 28
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, f"declared in include/*.h but not exported: {missing}"
+    # and the Python binding table covers every operator of envidr_amd.h
+    ops = {"envidr_" + n for n in _lib.SIGNATURES}
+    assert ops <= declared
+    assert lib.envidr_abi_version() == 1
+
+
+def test_signature_table_matches_header_arity():
+    from envidr_amd import _lib
+    text = (ROOT / "include" / "envidr_amd.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for name, sig in _lib.SIGNATURES.items():
+        m = re.search(r"\benvidr_" + name + r"\s*\((.*?)\)\s*;", text, flags=re.S)
+        assert m, name
+        params = [p.strip() for p in m.group(1).split(",")]
+        assert params[-1].startswith("envidr_stream_t"), name
+        assert len(params) - 1 == len(sig), f"{name}: header has {len(params) - 1} args, table {len(sig)}"
+        for p, k in zip(params, sig):
+            is_ptr = "*" in p
+            assert is_ptr == (k == "p"), f"{name}: '{p}' vs kind {k}"
+            if not is_ptr:
+                want = {"uint32_t": "u", "float": "f", "int": "i"}[p.split()[0]]
+                assert want == k, f"{name}: '{p}' vs kind {k}"
+
+
+def test_errors_without_gpu_are_reported():
+    """argument validation happens before any launch, so it is testable on the CPU"""
+    from envidr_amd import _lib
+    lib = _lib.load()
+    lib.envidr_sh_encode_forward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                             ctypes.c_void_p, ctypes.c_void_p]
+    rc = lib.envidr_sh_encode_forward(None, None, 4, 3, 9, None, None)
+    assert rc == -1 and b"degree" in lib.envidr_last_error()
+    rc = lib.envidr_sh_encode_forward(None, None, 0, 3, 4, None, None)      # empty batch: successful no-op
+    assert rc == 0
+
+
+def _tile_row(r, h):
+    return (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+@pytest.mark.parametrize("m_out,k_in,order,transpose", [(64, 32, 0, False), (256, 72, 0, False), (256, 256, 1, False),
+                                                        (12, 256, 1, False), (15, 64, 1, False), (64, 64, 1, True),
+                                                        (64, 32, 1, True), (3, 32, 1, False), (160, 38, 0, False)])
+def test_pack_linear_layout(m_out, k_in, order, transpose):
+    """dst[(step * tiles + tile) * 64 + half * 32 + i] = W'[32 tile + i][k(step, half)] with zero padding"""
+    from envidr_amd.fused import pack_linear
+    rng = np.random.default_rng(0)
+    W = rng.normal(size=(m_out, k_in)).astype(np.float32)
+    got = pack_linear(W, order, transpose)
+    Wl = W.T if transpose else W                      # logical layer K -> M
+    M, K = Wl.shape
+    steps = (K + 1) // 2 if order == 0 else ((K + 31) // 32 * 32) // 2
+    tiles = (M + 31) // 32
+    assert got.shape == (steps * tiles * 64,)
+    for s in range(steps):
+        for h in range(2):
+            k = 2 * s + h if order == 0 else 32 * (s >> 4) + _tile_row(s & 15, h)
+            for t in range(tiles):
+                seg = got[(s * tiles + t) * 64 + h * 32:(s * tiles + t) * 64 + h * 32 + 32]
+                want = np.zeros(32, np.float32)
+                rows = np.arange(32 * t, min(32 * t + 32, M))
+                if k < K:
+                    want[: rows.size] = Wl[rows, k]
+                assert np.array_equal(seg, want)
+
+
+def test_pack_rowvec_layout():
+    from envidr_amd.fused import pack_rowvec
+    v = np.arange(40, dtype=np.float32) + 1
+    got = pack_rowvec(v)
+    assert got.shape == (64,)
+    for t in range(2):
+        for h in range(2):
+            for r in range(16):
+                m = 32 * t + _tile_row(r, h)
+                assert got[t * 32 + h * 16 + r] == (v[m] if m < 40 else 0)
+
+
+def test_product_never_imports_the_oracle():
+    """the shipped package must not route through oracle/ (or any CPU fallback)"""
+    for py in (ROOT / "envidr_amd").rglob("*.py"):
+        text = py.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f"{py} imports the oracle"
+    for src in (ROOT / "envidr_amd" / "csrc").glob("*.h*"):
+        text = src.read_text()
+        assert not re.search(r'#include\s*[<"][^>"]*oracle', text), f"{src} includes oracle code"
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from envidr_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "nope.so")
+    with pytest.raises(_lib.EnvidrError):
+        _lib.load()

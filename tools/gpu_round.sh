@@ -1,0 +1,45 @@
+#!/bin/bash
+# Round-end style GPU pass (run through gpurun): tests, smoke, bench, rocprof summaries.
+#   tools/gpu_round.sh <tag> [quick]
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+TAG=${1:-r01}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+if [ "$2" != "quick" ]; then
+  timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/smoke.log
+fi
+timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" >> $OUT/bench.err
+# kernel trace + stats of the same command (CPU leg skipped: it launches no kernels)
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/trace.log 2>&1 )
+# PMC passes, each on its own (no trace domains mixed in)
+for SET in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
+  N=$(echo $SET | tr ' ' '_' | cut -c1-30)
+  ( cd /tmp && rocprofv3 --pmc $SET --output-format csv -d $OUT/pmc_$N -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$N.log 2>&1 )
+done
+python - <<PY
+import csv, glob, json, collections, os
+out = "$OUT"
+summary = {}
+for f in glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    summary["kernel_stats"] = rows[:8]
+pmc = collections.defaultdict(list)
+for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        if "render_persistent" in row.get("Kernel_Name", ""):
+            pmc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+summary["pmc_per_launch_mean"] = {k: sum(v) / len(v) for k, v in pmc.items()}
+summary["pmc_launches"] = {k: len(v) for k, v in pmc.items()}
+p = summary["pmc_per_launch_mean"]
+if "FETCH_SIZE" in p and "WRITE_SIZE" in p:
+    # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE under-reports wide
+    # coalesced reads by 2x (MI355X_MICROARCH.md section HBM) -- the gathers here are 8-byte
+    # random reads, so both the raw and the doubled figure are kept.
+    summary["hbm_bytes_per_launch"] = (p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024
+    summary["hbm_bytes_per_launch_fetch_doubled"] = (2 * p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024
+json.dump(summary, open(out + "/summary.json", "w"), indent=1)
+print(json.dumps(summary, indent=1)[:3000])
+PY
+tail -3 $OUT/pytest_gpu.log $OUT/smoke.log 2>/dev/null; cat $OUT/bench.json | cut -c1-1500; tail -2 $OUT/bench.err
