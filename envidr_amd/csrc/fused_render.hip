@@ -80,7 +80,9 @@ struct RenderArgs {
     // outputs
     float* image; float* depth; float* ws; float* normal; float* diffuse; float* specular; float* roughness;
     unsigned long long* stats;
-    uint32_t* ray_counter;
+    uint32_t* ray_counter;      // [0] queue head, [1] number of hit rays (written by k_first_hit)
+    const uint32_t* hit_ids;    // [N] compacted ids of rays that have at least one sample
+    const float* hit_t;         // [N] per RAY: marcher time at its first sample
 };
 
 // slab test, identical arithmetic to k_near_far_from_aabb (raymarching.hip)
@@ -118,6 +120,40 @@ __device__ __forceinline__ void normalize_n(float (&v)[N], float eps) {
     for (int i = 0; i < N; ++i) v[i] = v[i] * inv;
 }
 
+// First-hit pre-pass: one lane per ray, full occupancy.  Empty-space skipping is cheap per ray but
+// long and divergent; inside the persistent kernel it would stall 63 shading lanes behind one
+// marching lane.  Rays with no occupied sample are finished here (background only); the others are
+// appended to a compact work list, wave by wave so neighbouring rays stay together.
+__global__ void __launch_bounds__(kBlock) k_first_hit(const RenderArgs a, uint32_t* __restrict__ hit_ids,
+                                                      float* __restrict__ hit_t, uint32_t* __restrict__ counters) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    bool hit = false;
+    if (id < a.N) {
+        const RayGeom rg = load_ray(a.rays_o, a.rays_d, id);
+        float near, far, x, y, z, dt, t_at = 0;
+        near_far(rg, a.mk.bound, a.min_near, near, far);
+        float t = near;
+        hit = march_next(a.mk, rg, far, t, x, y, z, dt, &t_at);
+        if (hit) {
+            hit_t[id] = t_at;
+        } else {
+            a.image[3 * (size_t)id] = a.bg; a.image[3 * (size_t)id + 1] = a.bg; a.image[3 * (size_t)id + 2] = a.bg;
+            a.depth[id] = 0;
+            a.ws[id] = 0;
+            if (a.normal) { a.normal[3 * (size_t)id] = 0; a.normal[3 * (size_t)id + 1] = 0; a.normal[3 * (size_t)id + 2] = 0; }
+            if (a.diffuse) { a.diffuse[3 * (size_t)id] = 0; a.diffuse[3 * (size_t)id + 1] = 0; a.diffuse[3 * (size_t)id + 2] = 0; }
+            if (a.specular) { a.specular[3 * (size_t)id] = 0; a.specular[3 * (size_t)id + 1] = 0; a.specular[3 * (size_t)id + 2] = 0; }
+            if (a.roughness) a.roughness[id] = 0;
+        }
+    }
+    const unsigned long long mask = __ballot(hit);
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == 0 && mask) base = atomicAdd(&counters[1], (uint32_t)__popcll(mask));
+    base = __shfl(base, 0);
+    if (hit) hit_ids[base + __popcll(mask & ((1ull << lane) - 1ull))] = id;
+}
+
 template <int IDE_DEG, int ENV_T>
 __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a) {
     constexpr int TERMS = ide_terms(IDE_DEG);      // IDE_DIM = 2 * TERMS input features, TERMS lane-order steps
@@ -128,7 +164,8 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
     bool drained = false;          // this lane saw the queue run dry
     uint32_t n_taken = 0;          // samples composited for the current ray
     RayGeom rg = {};
-    float far = 0, t_ray = 0;
+    float far = 0, t_ray = 0, t_resume = 0;
+    const uint32_t n_hit = __builtin_amdgcn_readfirstlane(a.ray_counter[1]);
     Accum acc = {};
     float an[3] = {0, 0, 0}, ad[3] = {0, 0, 0}, as[3] = {0, 0, 0}, arough = 0;
     unsigned long long n_samples = 0, n_rounds = 0, n_rays = 0;
@@ -164,13 +201,15 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
         float px = 0, py = 0, pz = 0, dt = 0, delta_depth = 0, t_next = 0;
         for (;;) {
             if (ray < 0 && !drained) {
-                const uint32_t id = atomicAdd(a.ray_counter, 1u);       // aggregated to one atomic per wave
-                if (id < a.N) {
+                const uint32_t slot = atomicAdd(a.ray_counter, 1u);     // aggregated to one atomic per wave
+                if (slot < n_hit) {
+                    const uint32_t id = a.hit_ids[slot];
                     ray = (int)id;
                     rg = load_ray(a.rays_o, a.rays_d, id);
                     float near;
                     near_far(rg, a.mk.bound, a.min_near, near, far);
                     t_ray = near;
+                    t_resume = a.hit_t[id];
                     n_taken = 0;
                     acc.ws = acc.depth = acc.r = acc.g = acc.b = 0; acc.t = near;
                     an[0] = an[1] = an[2] = ad[0] = ad[1] = ad[2] = as[0] = as[1] = as[2] = arough = 0;
@@ -180,8 +219,10 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
                 }
             }
             if (ray >= 0 && !have) {
-                float t = t_ray;
-                const float last_t = t;
+                // a freshly fetched ray jumps to the first sample found by the pre-pass; the depth
+                // delta is still measured from where the reference marcher would have started (near)
+                float t = n_taken == 0 ? t_resume : t_ray;
+                const float last_t = t_ray;
                 if (n_taken < a.max_samples && march_next(a.mk, rg, far, t, px, py, pz, dt)) {
                     have = true;
                     delta_depth = t - last_t;
@@ -444,6 +485,7 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
             n_rays += __shfl_down(n_rays, off);
         }
         if (lane == 0) {
+            if (blockIdx.x == 0) atomicAdd(&a.stats[2], (unsigned long long)(a.N - n_hit));   // rays finished by the pre-pass
             atomicAdd(&a.stats[0], n_samples);
             atomicAdd(&a.stats[1], n_rounds);
             atomicAdd(&a.stats[2], n_rays);
@@ -540,7 +582,31 @@ int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const f
     a.ray_counter = ray_counter;
 
     hipStream_t s = as_stream(stream);
-    if (hipMemsetAsync(ray_counter, 0, sizeof(uint32_t), s) != hipSuccess) return check_launch("render_rays memset");
+    // work-list scratch: grows monotonically, allocated only when a larger batch arrives
+    static uint32_t* g_hit_ids = nullptr;
+    static float* g_hit_t = nullptr;
+    static uint32_t* g_counters = nullptr;
+    static uint32_t g_cap = 0;
+    if (N > g_cap || !g_counters) {
+        if (g_hit_ids) (void)hipFree(g_hit_ids);
+        if (g_hit_t) (void)hipFree(g_hit_t);
+        if (!g_counters && hipMalloc(&g_counters, 16) != hipSuccess) return check_launch("render_rays counters alloc");
+        g_cap = N + N / 4;
+        if (hipMalloc(&g_hit_ids, (size_t)g_cap * 4) != hipSuccess || hipMalloc(&g_hit_t, (size_t)g_cap * 4) != hipSuccess) {
+            g_hit_ids = nullptr; g_hit_t = nullptr; g_cap = 0;
+            return check_launch("render_rays work-list alloc");
+        }
+    }
+    (void)ray_counter;   // kept in the ABI for callers that manage their own queue word; the library uses its own pair
+    a.ray_counter = g_counters;
+    a.hit_ids = g_hit_ids;
+    a.hit_t = g_hit_t;
+    if (hipMemsetAsync(g_counters, 0, 8, s) != hipSuccess) return check_launch("render_rays memset");
+    hipLaunchKernelGGL(k_first_hit, dim3(ceil_div(N, kBlock)), dim3(kBlock), 0, s, a, g_hit_ids, g_hit_t, g_counters);
+    {
+        const int rc = check_launch("k_first_hit");
+        if (rc) return rc;
+    }
 
     // persistent grid: 4 single-wave workgroups per CU (one per SIMD; the kernel uses the full
     // 512-register budget so exactly one wave fits a SIMD), fewer when the batch is small

@@ -87,8 +87,11 @@ __device__ __forceinline__ float exit_time(const MarchConsts& k, int n, float d,
 // On success: (x,y,z) is the clamped sample position, dt the step used for alpha, and `t` has
 // already been advanced past the sample (t_after = t_sample + dt).  Returns false when the ray
 // leaves [.., far) without another occupied sample.
+// `t_at` (optional) receives the ray time AT the emitted sample (before the += dt): resuming the
+// marcher from exactly that value re-emits the same sample, which is how the fused renderer's
+// first-hit pre-pass hands rays over without changing any arithmetic.
 __device__ __forceinline__ bool march_next(const MarchConsts& k, const RayGeom& r, float far, float& t,
-                                           float& x, float& y, float& z, float& dt) {
+                                           float& x, float& y, float& z, float& dt, float* t_at = nullptr) {
     while (t < far) {
         x = clampf(r.ox + t * r.dx, -k.bound, k.bound);
         y = clampf(r.oy + t * r.dy, -k.bound, k.bound);
@@ -111,6 +114,7 @@ __device__ __forceinline__ bool march_next(const MarchConsts& k, const RayGeom& 
         const bool occupied = k.grid[bit >> 3] & (1u << (bit & 7));
 
         if (occupied) {
+            if (t_at) *t_at = t;
             t += dt;
             return true;
         }
