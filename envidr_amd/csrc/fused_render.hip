@@ -40,6 +40,10 @@ using namespace envidr;
 namespace {
 
 constexpr int kLevels = ENVIDR_MAX_LEVELS;
+#ifndef ENVIDR_UNROLL_ENV
+#define ENVIDR_UNROLL_ENV 1
+#endif
+constexpr bool kUnrollEnv = ENVIDR_UNROLL_ENV != 0;
 
 struct HashLevelK {
     uint32_t row0, size, stride1, stride2;
@@ -381,15 +385,9 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
                 for (int s = 0; s < TERMS; ++s) in[s] = grp ? code[2 * s + 1] : code[2 * s];
                 f32x16 ha[ENV_T], hb[ENV_T], o[1];
                 layer_from_lanes<TERMS, ENV_T>(a.env_w[0], a.env_b[0], lane, in, ha);
-#pragma unroll
-                for (int t = 0; t < ENV_T; ++t) ha[t] = relu16(ha[t]);
-                layer_from_tiles<ENV_T, ENV_T>(a.env_w[1], a.env_b[1], lane, ha, hb);
-#pragma unroll
-                for (int t = 0; t < ENV_T; ++t) hb[t] = relu16(hb[t]);
-                layer_from_tiles<ENV_T, ENV_T>(a.env_w[2], a.env_b[2], lane, hb, ha);
-#pragma unroll
-                for (int t = 0; t < ENV_T; ++t) ha[t] = relu16(ha[t]);
-                layer_from_tiles<ENV_T, 1>(a.env_w[3], a.env_b[3], lane, ha, o);
+                layer_from_tiles<ENV_T, ENV_T, true, kUnrollEnv>(a.env_w[1], a.env_b[1], lane, ha, hb);
+                layer_from_tiles<ENV_T, ENV_T, true, kUnrollEnv>(a.env_w[2], a.env_b[2], lane, hb, ha);
+                layer_from_tiles<ENV_T, 1, true, kUnrollEnv>(a.env_w[3], a.env_b[3], lane, ha, o);
                 if (grp == 0) outA = o[0]; else outB = o[0];
             }
             ENVIDR_TICK(5);   // env mlp

@@ -196,11 +196,12 @@ __device__ __forceinline__ void layer_from_lanes(const float* __restrict__ w, co
     mfma_steps<STEPS, MT, PF>(ws, 0u, acc, [&](int s) { return in[s]; });
 }
 
-// Dense layer whose input is KT accumulator tiles of the previous layer (kTileOrder).  For wide
-// layers the loop over input tiles is a real (rolled) loop: each iteration selects the tile into
-// fixed registers (wave-uniform condition) so the 16 x MT MFMA body is emitted once; the weight
-// ring carries across iterations.
-template <int KT, int MT>
+// Dense layer whose input is KT accumulator tiles of the previous layer (kTileOrder).
+//   RELU_IN : apply max(., 0) to the input as it is consumed (one VALU op per step, hidden under the
+//             step's MT MFMAs) instead of a separate pass over the previous layer's accumulators.
+//   UNROLL  : emit all KT blocks (B operands are then compile-time registers, no per-block select);
+//             otherwise the loop over input tiles is rolled and each iteration first selects its tile.
+template <int KT, int MT, bool RELU_IN = false, bool UNROLL = true>
 __device__ __forceinline__ void layer_from_tiles(const float* __restrict__ w, const float* __restrict__ bias,
                                                  uint32_t lane, const f32x16 (&in)[KT], f32x16 (&acc)[MT]) {
     constexpr int PF = prefetch_depth(MT);
@@ -209,10 +210,10 @@ __device__ __forceinline__ void layer_from_tiles(const float* __restrict__ w, co
     WeightStream<PF> ws;
     ws.prime(w, KT * kTileBytes, lane);
     init_acc<MT>(bias, lane, acc);
-    if constexpr (KT <= 2) {
+    if constexpr (UNROLL || KT <= 2) {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
-            mfma_steps<16, MT, PF>(ws, kt * kTileBytes, acc, [&](int s) { return in[kt][s]; });
+            mfma_steps<16, MT, PF>(ws, kt * kTileBytes, acc, [&](int s) { return RELU_IN ? fmaxf(in[kt][s], 0.0f) : in[kt][s]; });
     } else {
 #pragma unroll 1
         for (int kt = 0; kt < KT; ++kt) {
@@ -220,7 +221,7 @@ __device__ __forceinline__ void layer_from_tiles(const float* __restrict__ w, co
 #pragma unroll
             for (int j = 1; j < KT; ++j)
                 if (kt == j) cur = in[j];
-            mfma_steps<16, MT, PF>(ws, (uint32_t)kt * kTileBytes, acc, [&](int s) { return cur[s]; });
+            mfma_steps<16, MT, PF>(ws, (uint32_t)kt * kTileBytes, acc, [&](int s) { return RELU_IN ? fmaxf(cur[s], 0.0f) : cur[s]; });
         }
     }
 }
