@@ -1,0 +1,103 @@
+"""`hashencoder` (encoding_pos = hashgrid_diff): smoothstep multiresolution hash grid with analytic
+input derivative and first/second-order backward, on the HIP library.  Mirrors the reference's
+hashencoder/hashgrid.py (hash_encode :107, HashEncoder :110-169)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from .. import _lib
+
+
+class _HashEncode(Function):
+    @staticmethod
+    def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False):
+        inputs, embeddings, offsets = inputs.float().contiguous(), embeddings.float().contiguous(), offsets.contiguous()
+        B, D = inputs.shape
+        L, C = offsets.shape[0] - 1, embeddings.shape[1]
+        S, H = float(np.log2(per_level_scale)), int(base_resolution)
+        outputs = torch.empty(L, B, C, device=inputs.device, dtype=torch.float32)     # level-major, like the reference
+        dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=torch.float32) if calc_grad_inputs else None
+        _lib.call("hash_encode_forward", inputs, embeddings, offsets, outputs, B, D, C, L, S, H, int(calc_grad_inputs), dy_dx)
+        ctx.save_for_backward(inputs, embeddings, offsets, dy_dx if dy_dx is not None else torch.empty(1, device=inputs.device))
+        ctx.dims = (B, D, C, L, S, H)
+        ctx.calc_grad_inputs = calc_grad_inputs
+        return outputs.permute(1, 0, 2).reshape(B, L * C)
+
+    @staticmethod
+    def backward(ctx, grad):
+        inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
+        B, D, C, L, S, H = ctx.dims
+        grad = grad.view(B, L, C).permute(1, 0, 2).contiguous()
+        grad_inputs, grad_embeddings = _HashEncodeBackward.apply(grad, inputs, embeddings, offsets, B, D, C, L, S, H,
+                                                                 ctx.calc_grad_inputs, dy_dx)
+        return (grad_inputs if ctx.calc_grad_inputs else None), grad_embeddings, None, None, None, None
+
+
+class _HashEncodeBackward(Function):
+    """first backward as a Function so that autograd can differentiate it again (eikonal loss)"""
+
+    @staticmethod
+    def forward(ctx, grad, inputs, embeddings, offsets, B, D, C, L, S, H, calc_grad_inputs, dy_dx):
+        grad_inputs = torch.zeros_like(inputs)
+        # the table gradient is only materialised when somebody can consume it: at inference
+        # (normals only) the reference still zero-fills and scatters into 48.8 MB every iteration
+        need_table = embeddings.requires_grad and torch.is_grad_enabled()
+        grad_embeddings = torch.zeros_like(embeddings) if need_table else None
+        _lib.call("hash_encode_backward", grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H,
+                  int(calc_grad_inputs), dy_dx if calc_grad_inputs else None, grad_inputs if calc_grad_inputs else None)
+        ctx.save_for_backward(grad, inputs, embeddings, offsets, dy_dx)
+        ctx.dims = (B, D, C, L, S, H)
+        ctx.calc_grad_inputs = calc_grad_inputs
+        return grad_inputs, grad_embeddings
+
+    @staticmethod
+    def backward(ctx, grad_grad_inputs, grad_grad_embeddings):
+        grad, inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
+        B, D, C, L, S, H = ctx.dims
+        grad_grad = torch.zeros_like(grad)
+        grad2_embeddings = torch.zeros_like(embeddings)
+        _lib.call("hash_encode_second_backward", grad, inputs, embeddings, offsets, B, D, C, L, S, H, int(ctx.calc_grad_inputs),
+                  dy_dx, grad_grad_inputs.contiguous(), grad_grad, grad2_embeddings)
+        return grad_grad, None, grad2_embeddings, None, None, None, None, None, None, None, None, None
+
+
+hash_encode = _HashEncode.apply
+
+
+class HashEncoder(nn.Module):
+    def __init__(self, input_dim=3, num_levels=16, level_dim=2, per_level_scale=2, base_resolution=16,
+                 log2_hashmap_size=19, desired_resolution=None):
+        super().__init__()
+        if desired_resolution is not None:
+            per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
+        self.input_dim, self.num_levels, self.level_dim = input_dim, num_levels, level_dim
+        self.per_level_scale, self.log2_hashmap_size, self.base_resolution = per_level_scale, log2_hashmap_size, base_resolution
+        self.output_dim = num_levels * level_dim
+        self.max_params = 2 ** log2_hashmap_size
+        offsets, offset = [], 0
+        for i in range(num_levels):
+            resolution = int(np.ceil(base_resolution * per_level_scale ** i))
+            offsets.append(offset)
+            offset += min(self.max_params, resolution ** input_dim)
+        offsets.append(offset)
+        self.register_buffer("offsets", torch.from_numpy(np.array(offsets, dtype=np.int32)))
+        self.n_params = offsets[-1] * level_dim
+        self.embeddings = nn.Parameter(torch.empty(offset, level_dim))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.embeddings.data.uniform_(-1e-4, 1e-4)
+
+    def __repr__(self):
+        return (f"HashEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
+                f"base_resolution={self.base_resolution} per_level_scale={self.per_level_scale} params={tuple(self.embeddings.shape)}")
+
+    def forward(self, inputs, bound=1):
+        inputs = (inputs + bound) / (2 * bound)
+        prefix = list(inputs.shape[:-1])
+        inputs = inputs.view(-1, self.input_dim)
+        out = hash_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution, inputs.requires_grad)
+        return out.view(prefix + [self.output_dim])

@@ -1,0 +1,243 @@
+"""`NeRFNetwork`: ENVIDR's decomposed SDF + environment-lit shading model as a parameter container
+with the reference's module / parameter names (`encoder.embeddings`, `sdf_net.N.weight`,
+`sdf_density.beta`, `env_net`, `diffuse_net`, `color_net`, `renv_net`, buffers `density_bitfield`,
+`aabb_infer`), so a reference checkpoint's `state_dict` loads with `load_state_dict(strict=False)`.
+
+`forward_sigma` / `forward_color` restate nerf/network.py:381-698 for the configuration family the
+shipped configs use (SDF + Laplace density, unit-norm features, sigmoid colours, IDE-fed env MLP,
+optional renv branch); they run on the HIP encoders + torch GEMMs and exist for drop-in
+compatibility and as the operator-level path.  The fast inference path does not call them: it hands
+the same parameters to the fused persistent kernel (`_build_fused`).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..encoding import get_encoder
+from .renderer import NeRFRenderer
+
+
+class LaplaceDensity(nn.Module):
+    """sigma = (1 / beta) * Laplace(0, beta).cdf(-sdf)   (reference network.py:26-44)"""
+
+    def __init__(self, beta, beta_min=0.0001, beta_max=1.0):
+        super().__init__()
+        self.beta = nn.Parameter(torch.tensor(float(beta)))
+        self.beta_min, self.beta_max = beta_min, beta_max
+
+    def get_beta(self):
+        clamped = torch.clamp(self.beta.detach(), self.beta_min, self.beta_max)
+        return self.beta + (clamped - self.beta.detach())      # value = clamp(beta), gradient = d beta
+
+    def forward(self, sdf, beta=None):
+        beta = self.get_beta() if beta is None else beta
+        return (1 / beta) * (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / beta))
+
+
+def _mlp(dims, bias=True):
+    return nn.ModuleList([nn.Linear(dims[i], dims[i + 1], bias=bias) for i in range(len(dims) - 1)])
+
+
+def _run_mlp(net, h):
+    for i, lin in enumerate(net):
+        h = lin(h)
+        if i != len(net) - 1:
+            h = F.relu(h)
+    return h
+
+
+def _feat_act(x, kind):
+    if kind == "unitNorm":
+        return F.normalize(x, dim=-1)
+    if kind == "tanh":
+        return torch.tanh(x)
+    raise NotImplementedError(f"feature activation {kind!r}")
+
+
+class NeRFNetwork(NeRFRenderer):
+    def __init__(self, encoding="hashgrid", encoding_dir="sphere_harmonics", encoding_bg="hashgrid", num_layers=2, hidden_dim=64,
+                 geo_feat_dim=15, num_layers_color=3, hidden_dim_color=64, num_layers_bg=2, hidden_dim_bg=64, bound=1,
+                 num_levels=16, roughness_bias=-1, opt=None, env_opt=None, **kwargs):
+        super().__init__(bound, opt=opt, env_opt=env_opt, **kwargs)
+        if not opt.use_sdf or opt.use_neus_sdf or opt.geometric_init or opt.skip_layers or opt.env_sph_mode:
+            raise NotImplementedError("only the SDF + Laplace-density configuration family (toaster.ini / neural_renderer.ini) is implemented")
+        self.num_layers, self.hidden_dim, self.geo_feat_dim = num_layers, hidden_dim, geo_feat_dim
+        self.num_layers_color, self.hidden_dim_color = num_layers_color, hidden_dim_color
+        self.roughness_bias = roughness_bias
+        self.encoder, self.in_dim = get_encoder(opt.encoding_pos, level_dim=opt.level_dim,
+                                                desired_resolution=bound * opt.desired_resolution,
+                                                base_resolution=opt.base_resolution, num_levels=num_levels,
+                                                log2_hashmap_size=opt.log2_hashmap_size, multires=opt.multires)
+        self.sdf_density = LaplaceDensity(opt.init_beta, opt.beta_min, opt.beta_max)
+        out_dim = 1 + geo_feat_dim + (int(opt.use_roughness) + int(opt.learn_indir_blend) if opt.ensemble_mlp else 0)
+        self.sdf_net = _mlp([self.in_dim] + [hidden_dim] * (num_layers - 1) + [out_dim], bias=opt.mlp_bias)
+        if opt.use_roughness and not opt.ensemble_mlp:
+            self.roughness_layer = nn.Linear(geo_feat_dim, 1)
+
+        self.encoder_dir, self.in_dim_dir = get_encoder(encoding_dir, multires=opt.multires_dir, degree=opt.sh_degree)
+        self.in_normal_dim = self.in_refdir_dim = 0
+        if self.use_normal_with_mlp:
+            self.encoder_normal, self.in_normal_dim = get_encoder(encoding_dir, multires=opt.multires_normal, degree=opt.sh_degree)
+        if self.use_reflected_dir:
+            self.encoder_refdir, self.in_refdir_dim = get_encoder(opt.encoding_ref, multires=opt.multires_refdir, degree=opt.sh_degree)
+            self.diffuse_encoder_refdir, self.in_refdir_dim_diffuse = get_encoder(opt.encoding_ref, multires=opt.multires_refdir,
+                                                                                  degree=opt.sh_degree_diffuse)
+        self.use_viewdir = not opt.wo_viewdir
+        if not self.use_viewdir:
+            self.in_dim_dir = 0
+
+        self.use_env_net = opt.use_env_net
+        self.env_net = self.renv_net = None
+        if self.use_env_net:
+            assert self.use_reflected_dir, "use_env_net requires use_reflected_dir"
+            env_dims = [self.in_refdir_dim] + [opt.hidden_dim_env] * (opt.num_layers_env - 1) + [opt.env_feat_dim]
+            self.env_net = _mlp(env_dims, bias=not opt.env_wo_bias)
+            if opt.split_diffuse_env:
+                self.diffuse_env_net = _mlp([self.in_refdir_dim_diffuse] + [opt.hidden_dim_env_diffuse] * (opt.num_layers_env - 1)
+                                            + [opt.env_feat_dim], bias=not opt.env_wo_bias)
+            self.in_refdir_dim = opt.env_feat_dim
+            if opt.use_renv:
+                self.renv_net = _mlp([4, 64, 64, 64, opt.env_feat_dim], bias=not opt.env_wo_bias)
+        if opt.use_diffuse:
+            d_in = geo_feat_dim + (opt.env_feat_dim if opt.diffuse_with_env and opt.diffuse_env_fusion == "concat" else 0)
+            self.diffuse_net = _mlp([d_in] + [opt.hidden_dim_diffuse] * (opt.num_layers_diffuse - 1) + [3], bias=True)
+        self.n_dot_viewdir_dim = 1 if self.use_n_dot_viewdir else 0
+        c_in = self.in_dim_dir + geo_feat_dim + self.in_normal_dim + self.in_refdir_dim + self.n_dot_viewdir_dim
+        self.color_net = _mlp([c_in] + [hidden_dim_color] * (num_layers_color - 1) + [3], bias=opt.mlp_bias)
+        gain = nn.init.calculate_gain("relu")
+        for net in [self.sdf_net, self.env_net, self.renv_net, getattr(self, "diffuse_net", None), self.color_net]:
+            if net is not None and opt.net_init == "xavier_uniform":
+                for lin in net:
+                    nn.init.xavier_uniform_(lin.weight, gain=gain)
+                    if lin.bias is not None:
+                        nn.init.zeros_(lin.bias)
+        if opt.use_diffuse and opt.mlp_bias:
+            self.color_net[-1].bias.data -= np.log(3)      # lower specular at initialisation
+        self.bg_net = None
+        self.roughness = opt.default_roughness
+        self.blend_weight = None
+        self.metallic = 1.0
+        self.c_diffuse = self.c_specular = 0
+
+    # ---- geometry ---------------------------------------------------------------------------------
+    def forward_geometry(self, xyz, material=None):
+        x = self.encoder(xyz, bound=self.bound)
+        if self.opt.enabled_levels > 0:
+            mask = torch.zeros(self.opt.num_levels, self.opt.level_dim, device=x.device)
+            mask[: self.opt.enabled_levels] += 1
+            x = x * mask.reshape(-1)
+        h = _run_mlp(self.sdf_net, x)
+        sdf = h[..., 0]
+        g = self.geo_feat_dim
+        geo_feat = _feat_act(h[..., 1:1 + g], self.opt.geo_feat_act)
+        if self.opt.use_roughness and not self.opt.diffuse_only and not self.opt.bypass_roughness:
+            raw = h[..., 1 + g:2 + g] if self.opt.ensemble_mlp else self.roughness_layer(geo_feat)
+            if self.opt.learn_indir_blend and self.opt.ensemble_mlp:
+                self.blend_weight = torch.sigmoid(h[..., 2 + g:3 + g])
+            self.roughness = self.opt.roughness_act_scale * F.softplus(raw + self.roughness_bias) * self.opt.roughness_scale
+        else:
+            self.roughness = self.opt.default_roughness
+        self.metallic = 1.0
+        return sdf, None, geo_feat
+
+    def forward_sigma(self, xyzs, material=None, **kwargs):
+        sdfs, _, geo_feats = self.forward_geometry(xyzs, material)
+        normals = eikonal = None
+        if kwargs.get("use_sdf_sigma_grad", False):
+            normals, eikonal = self.compute_normal(sdfs, xyzs, self.opt.eikonal_loss)
+        return sdfs, self.sdf_density(sdfs), geo_feats, normals, eikonal
+
+    def density(self, x, **kwargs):
+        sdf, sigma, geo_feat, normal, eik = self.forward_sigma(x, **kwargs)
+        return {"sdf": sdf, "sigma": sigma, "geo_feat": geo_feat, "normal": normal, "sdf_gradients": eik}
+
+    # ---- shading ----------------------------------------------------------------------------------
+    def _env(self, net, enc):
+        return _feat_act(_run_mlp(net, enc), self.opt.env_feat_act)
+
+    def forward_color(self, geo_feat, d, normal=None, w_r=None, n_dot_w_o=None, use_specular_color=False, env_net_index=0,
+                      n_env_enc=None, r_images=None, roughness=None):
+        opt = self.opt
+        if opt.use_diffuse:
+            h = geo_feat
+            if opt.diffuse_with_env:
+                e = self._env(self.diffuse_env_net if opt.split_diffuse_env else self.env_net, n_env_enc)
+                h = {"concat": lambda: torch.cat([h, e], -1), "add": lambda: h + e, "mul": lambda: h * e}[opt.diffuse_env_fusion]()
+            self.c_diffuse = torch.sigmoid(_run_mlp(self.diffuse_net, h)) * self.metallic
+        else:
+            self.c_diffuse = 0
+        if opt.diffuse_only:
+            self.c_specular = 0
+            return (self.c_diffuse + self.c_specular) * opt.intensity_scale
+
+        h = torch.cat([self.encoder_dir(d), geo_feat], -1) if self.use_viewdir else geo_feat
+        if self.use_normal_with_mlp:
+            h = torch.cat([h, normal], -1)
+        branches, renv_mask, blend = {}, None, 1
+        if w_r is not None and not opt.train_renv:
+            branches["env"] = torch.cat([h, self._env(self.env_net, w_r) if self.use_env_net else w_r], -1)
+        if r_images is not None and opt.use_renv:
+            renv_mask = roughness.squeeze() < opt.indir_roughness_thresh
+            if r_images.shape[-1] == 4:
+                vis = r_images[..., -1]
+                r_images = r_images[..., :3] * vis[..., None].detach()
+                renv_mask = renv_mask & (vis > 0.9)
+            rough = roughness[renv_mask] / opt.roughness_scale
+            remap = torch.sqrt(rough / 0.75)
+            blend = 0.98 * self.blend_weight[renv_mask] if opt.learn_indir_blend else 0.95 * torch.sigmoid(80 * (remap - 0.18))
+            e = _feat_act(_run_mlp(self.renv_net, torch.cat([r_images[renv_mask], remap], -1)), opt.env_feat_act)
+            branches["renv"] = torch.cat([h[renv_mask], e], -1)
+        if not branches:
+            branches["env"] = h
+        colors = {}
+        for k, hc in branches.items():
+            if n_dot_w_o is not None:
+                hc = torch.cat([hc, n_dot_w_o[renv_mask] if k == "renv" else n_dot_w_o], -1)
+            colors[k] = torch.sigmoid(_run_mlp(self.color_net, hc))
+        self.c_specular = colors["env"]
+        if "renv" in colors:
+            if opt.indir_only:
+                self.c_specular = self.c_specular * 0
+            mixed = self.c_specular[renv_mask] * blend + colors["renv"] * (1 - blend)
+            self.c_specular = self.c_specular.masked_scatter(renv_mask[:, None], mixed)
+        return (self.c_diffuse + self.c_specular) * opt.intensity_scale
+
+    def forward(self, x, d, normal=None, w_r=None, n_dot_w_o=None):
+        sdf, sigma, geo_feat, _, _ = self.forward_sigma(x)
+        return sdf, sigma, self.forward_color(geo_feat, d, normal, w_r, n_dot_w_o)
+
+    # ---- fused path -------------------------------------------------------------------------------
+    def supports_fused(self, r_images=None, geometry_only=False, **kwargs) -> bool:
+        """configurations the fused persistent kernel implements (everything else uses the operator loop)"""
+        o = self.opt
+        hash_ok = o.encoding_pos == "hashgrid_diff" and o.level_dim == 2 and o.num_levels <= 16
+        net_ok = (o.num_layers == 3 and o.hidden_dim == 64 and o.geo_feat_dim == 12 and o.ensemble_mlp and o.use_roughness
+                  and o.learn_indir_blend and o.mlp_bias and o.geo_feat_act == "unitNorm" and o.env_feat_act == "unitNorm")
+        shade_ok = (o.use_diffuse and not o.diffuse_only and o.diffuse_with_env and o.diffuse_env_fusion == "concat"
+                    and not o.split_diffuse_env and o.use_env_net and not o.env_wo_bias and o.num_layers_env == 4
+                    and o.env_feat_dim == 12 and (o.sh_degree, o.hidden_dim_env) in [(5, 256), (4, 160), (5, 128), (4, 128)]
+                    and o.wo_viewdir and o.normal_with_mlp and o.multires_normal == 0 and o.use_n_dot_viewdir
+                    and o.use_reflected_dir and o.encoding_ref == "integrated_dir" and o.num_layers_diffuse == 2
+                    and o.hidden_dim_diffuse == 32 and o.num_layers_color == 3 and o.hidden_dim_color == 64
+                    and o.color_act == "sigmoid" and o.normal_anneal_ratio >= 1)
+        return bool(hash_ok and net_ok and shade_ok and r_images is None and not geometry_only and self.bg_radius <= 0
+                    and not self.training)
+
+    def _build_fused(self):
+        from ..fused import FusedOptions, FusedRenderer
+        o = self.opt
+        fo = FusedOptions(bound=self.bound, grid_size=self.grid_size, min_near=self.min_near, max_steps=o.max_steps,
+                          dt_gamma=o.dt_gamma, T_thresh=o.T_thresh, density_scale=self.density_scale,
+                          base_resolution=o.base_resolution, enabled_levels=o.enabled_levels, beta_min=o.beta_min,
+                          beta_max=o.beta_max, roughness_bias=self.roughness_bias, roughness_act_scale=o.roughness_act_scale,
+                          roughness_scale=o.roughness_scale, ide_degree=o.sh_degree, diffuse_kappa_inv=o.diffuse_kappa_inv,
+                          light_intensity_scale=o.light_intensity_scale, intensity_scale=o.intensity_scale)
+        pairs = lambda net: [(l.weight.detach(), l.bias.detach()) for l in net]
+        mlps = {"sdf": pairs(self.sdf_net), "env": pairs(self.env_net), "diffuse": pairs(self.diffuse_net),
+                "specular": pairs(self.color_net)}
+        return FusedRenderer(self.density_bitfield, self.encoder.embeddings.detach(), self.encoder.offsets.cpu().numpy(),
+                             self.encoder.per_level_scale, mlps, float(self.sdf_density.beta.detach()), fo,
+                             device=self.density_bitfield.device)

@@ -1,0 +1,116 @@
+"""The option fields that shape the render hot path, with the reference's names and defaults
+(nerf/options.py) and a preset for configs/scenes/toaster.ini.  The reference drives everything
+from one argparse namespace `opt` that is also splatted into `render(**vars(opt))`; any object with
+these attributes works here (`argparse.Namespace`, this dataclass, ...)."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+
+@dataclass
+class RenderOptions:
+    # geometry / marching
+    bound: float = 1.0
+    scale: float = 0.33
+    cuda_ray: bool = True
+    dt_gamma: float = 0.0
+    max_steps: int = 1024
+    T_thresh: float = 1e-4
+    min_near: float = 0.2
+    density_thresh: float = 10.0
+    bg_radius: float = -1.0
+    max_ray_batch_cuda: int = -1
+    marching_aabb: list = field(default_factory=list)
+    obj_aabb: list | None = None
+    # position encoding
+    encoding_pos: str = "hashgrid_diff"
+    num_levels: int = 16
+    level_dim: int = 2
+    base_resolution: int = 16
+    desired_resolution: int = 2048
+    log2_hashmap_size: int = 19
+    multires: int = 0
+    enabled_levels: int = -1
+    # sdf network
+    use_sdf: bool = True
+    use_neus_sdf: bool = False
+    num_layers: int = 3
+    hidden_dim: int = 64
+    geo_feat_dim: int = 12
+    geo_feat_act: str = "unitNorm"
+    mlp_bias: bool = True
+    ensemble_mlp: bool = True
+    use_roughness: bool = True
+    learn_indir_blend: bool = True
+    skip_layers: list = field(default_factory=list)
+    geometric_init: bool = False
+    init_beta: float = 0.1
+    beta_min: float = 0.0005
+    beta_max: float = 1.0
+    roughness_scale: float = 1.0
+    roughness_act_scale: float = 0.2
+    default_roughness: float = 0.05
+    bypass_roughness: bool = False
+    detach_normal: bool = False
+    normal_anneal_ratio: float = 1.0
+    eikonal_loss: bool = False
+    # shading
+    encoding_dir: str = "frequency"
+    multires_dir: int = 0
+    multires_normal: int = 0
+    multires_refdir: int = 4
+    encoding_ref: str = "integrated_dir"
+    sh_degree: int = 5
+    sh_degree_diffuse: int = 5
+    wo_viewdir: bool = True
+    normal_with_mlp: bool = True
+    use_reflected_dir: bool = True
+    use_n_dot_viewdir: bool = True
+    use_env_net: bool = True
+    num_layers_env: int = 4
+    hidden_dim_env: int = 256
+    hidden_dim_env_diffuse: int = 256
+    env_feat_dim: int = 12
+    env_feat_act: str = "unitNorm"
+    env_wo_bias: bool = False
+    split_diffuse_env: bool = False
+    use_diffuse: bool = True
+    diffuse_only: bool = False
+    diffuse_with_env: bool = True
+    diffuse_env_fusion: str = "concat"
+    diffuse_kappa_inv: float = 0.64
+    num_layers_diffuse: int = 2
+    hidden_dim_diffuse: int = 32
+    num_layers_color: int = 3
+    hidden_dim_color: int = 64
+    color_act: str = "sigmoid"
+    light_intensity_scale: float = 1.0
+    intensity_scale: float = 1.0
+    visual_items: list = field(default_factory=lambda: ["specular", "roughness", "diffuse"])
+    # indirect reflection
+    use_renv: bool = True
+    train_renv: bool = False
+    indir_ref: bool = False
+    indir_only: bool = False
+    indir_max_steps: int = 1024
+    indir_early_stop_steps: int = 32
+    indir_roughness_thresh: float = 0.1
+    grad_rays: bool = False
+    # modes that select other render functions in the reference (not on this path)
+    env_sph_mode: bool = False
+    render_env_on_sphere: bool = False
+    unwrap_env_sphere: bool = False
+    error_bound_sample: bool = False
+    debug: bool = False
+    plot_roughness: bool = False
+    net_init: str = "xavier_uniform"
+
+
+def toaster_options(**overrides) -> RenderOptions:
+    """configs/scenes/toaster.ini resolved against nerf/options.py defaults"""
+    opt = RenderOptions(scale=0.65)
+    for k, v in overrides.items():
+        if not hasattr(opt, k):
+            raise AttributeError(f"unknown render option {k!r}")
+        setattr(opt, k, v)
+    return opt

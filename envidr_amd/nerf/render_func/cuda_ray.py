@@ -1,0 +1,144 @@
+"""`run_cuda`, inference branch: the reference's march -> shade -> composite -> compact loop
+(nerf/render_func/cuda_ray.py:238-359) in two forms.
+
+  * fused (default when the model supports it): ONE persistent-kernel launch for the whole ray batch
+    (envidr_amd.fused.FusedRenderer -> envidr_render_rays);
+  * operator loop: the reference's loop structure on the HIP operators (`raymarching.march_rays`,
+    model.forward_sigma / forward_color on HIP encoders + torch GEMMs, `raymarching.composite_rays`),
+    with the boolean-mask compaction replaced by the device-side `compact_alive` (one 4-byte readback
+    per iteration instead of a nonzero + gather + sync).  Used for geometry-only / renv passes and for
+    model configurations the fused kernel does not implement.
+
+The training branch of run_cuda (march_rays_train + composite_rays_train + losses) belongs to the
+Trainer and is out of scope; its operators exist in envidr_amd.raymarching.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from ... import raymarching
+
+
+def _state(N, nears, device):
+    ids = torch.arange(N, dtype=torch.int32, device=device)
+    return {"ws": torch.zeros(N, device=device), "depth": torch.zeros(N, device=device), "image": torch.zeros(N, 3, device=device),
+            "alive": ids, "buf": ids, "spare": torch.empty(N, dtype=torch.int32, device=device), "t": nears.clone()}
+
+
+def run_cuda(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024,
+             T_thresh=1e-4, get_normal_image=False, use_specular_color=True, early_stop_steps=-1, ray_depth=None,
+             main_pass=True, r_images=None, geometry_only=False, grad_ray=False, bg_sphere=True, env_rot_radian=None,
+             fused=True, **kwargs):
+    self = model
+    if self.training:
+        raise NotImplementedError("run_cuda training branch is out of scope (operators are in envidr_amd.raymarching)")
+    prefix = rays_o.shape[:-1]
+    rays_o = rays_o.contiguous().view(-1, 3)
+    rays_d = rays_d.contiguous().view(-1, 3)
+    N, device = rays_o.shape[0], rays_o.device
+    opt = self.opt
+    if bg_color is None:
+        bg_color = 1
+    visual = list(opt.visual_items) if opt.use_diffuse else []
+
+    # ---------------- fused persistent kernel ----------------
+    scalar_bg = not torch.is_tensor(bg_color)
+    if (fused and ray_depth is None and not perturb and scalar_bg and max_steps == opt.max_steps and T_thresh == opt.T_thresh
+            and dt_gamma == opt.dt_gamma and self.supports_fused(r_images=r_images, geometry_only=geometry_only)):
+        fr = self.fused_renderer()
+        fr.desc.bg_color = float(bg_color)
+        fr.desc.min_near = float(self.min_near)
+        res = fr.render(rays_o, rays_d, env_rot_radian, extras=True)
+        out = {"image": res["image"].view(*prefix, 3), "depth": res["depth"].view(*prefix), "weights_sum": res["weights_sum"].view(*prefix)}
+        if get_normal_image:
+            out["normal_image"] = res["normal_image"].view(*prefix, 3)
+        if "diffuse" in visual:
+            out["diffuse_image"] = res["diffuse_image"]
+        if "specular" in visual:
+            out["specular_image"] = res["specular_image"]
+            out["roughness_image"] = res["roughness_image"][..., None]
+        return out
+
+    # ---------------- operator loop ----------------
+    nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_infer, self.min_near)
+    main = _state(N, nears, device)
+    extra = {}
+    if get_normal_image and not geometry_only:
+        extra["normal"] = _state(N, nears, device)
+    if not geometry_only and "diffuse" in visual:
+        extra["diffuse"] = _state(N, nears, device)
+    if not geometry_only and "specular" in visual:
+        extra["specular"] = _state(N, nears, device)
+    count = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def compact(st):
+        # device-side order-preserving compaction into the state's spare buffer (ping-pong); the
+        # survivor count (4 bytes) is the only thing read back to size the next iteration
+        raymarching.compact_alive(st["alive"], st["spare"], count)
+        n = int(count.item())
+        st["buf"], st["spare"] = st["spare"], st["buf"]
+        st["alive"] = st["buf"][:n]
+
+    def composite(st, n_alive, n_step, sigmas, colors, deltas, accum=True):
+        raymarching.composite_rays(n_alive, n_step, st["alive"], st["t"], sigmas, colors, deltas, st["ws"], st["depth"], st["image"],
+                                   T_thresh, False, accum)
+
+    step = 0
+    while step < max_steps:
+        n_alive = main["alive"].shape[0]
+        if n_alive <= 0:
+            break
+        n_step = max(min(N // n_alive, 8), 1)
+        align = 128
+        _r = None
+        if r_images is not None:
+            _r = r_images[0, main["alive"].long()][:, None, :].expand(-1, n_step, -1).reshape(-1, r_images.shape[-1])
+            align = -1
+        xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, main["alive"], main["t"], rays_o, rays_d, self.bound,
+                                                    self.density_bitfield, self.cascade, self.grid_size, nears, fars, align,
+                                                    perturb if step == 0 else False, dt_gamma, max_steps)
+        with torch.enable_grad():
+            xyzs.requires_grad_(True)
+            sdfs, sigmas, geo_feats, normals, _ = self.forward_sigma(xyzs, use_sdf_sigma_grad=True, dirs=dirs, dists=deltas[..., 0])
+        roughness = self.roughness
+        sigmas = (self.density_scale * sigmas).detach()
+        normals = normals.detach()
+        if geometry_only:
+            composite(main, n_alive, n_step, sigmas, normals, deltas)
+        else:
+            with torch.no_grad():
+                n_enc, w_r_enc, n_dot, n_env_enc = self.get_color_mlp_extra_params(normals, dirs, roughness, env_rot_radian)
+                rgbs = self.forward_color(geo_feats.detach(), dirs, n_enc, w_r_enc, n_dot, use_specular_color,
+                                          n_env_enc=n_env_enc, r_images=_r, roughness=roughness)
+            composite(main, n_alive, n_step, sigmas, rgbs, deltas)
+            if "diffuse" in extra:
+                composite(extra["diffuse"], n_alive, n_step, sigmas, self.c_diffuse, deltas)
+                compact(extra["diffuse"])
+            if "specular" in extra:
+                accum = True
+                if torch.is_tensor(roughness):
+                    deltas[..., 1:] = roughness.detach()       # roughness rides in the depth slot (reference :329-333)
+                    accum = False
+                composite(extra["specular"], n_alive, n_step, sigmas, self.c_specular, deltas, accum)
+                compact(extra["specular"])
+            if "normal" in extra:
+                composite(extra["normal"], n_alive, n_step, sigmas, normals, deltas)
+                compact(extra["normal"])
+        compact(main)
+        step += n_step
+
+    results = {"depth": main["depth"].view(*prefix), "weights_sum": main["ws"].view(*prefix)}
+    if geometry_only:
+        results["image"] = None
+        results["normal_image"] = F.normalize(main["image"], dim=-1, eps=1e-10).view(*prefix, 3)
+        return results
+    results["image"] = (main["image"] + (1 - main["ws"]).unsqueeze(-1) * bg_color).view(*prefix, 3)
+    if "normal" in extra:
+        results["normal_image"] = F.normalize(extra["normal"]["image"], dim=-1, eps=1e-10).view(*prefix, 3)
+    if "diffuse" in extra:
+        results["diffuse_image"] = extra["diffuse"]["image"]
+    if "specular" in extra:
+        results["specular_image"] = extra["specular"]["image"]
+        results["roughness_image"] = extra["specular"]["depth"][..., None]
+    return results
