@@ -135,12 +135,14 @@ class FusedRenderer:
         self._keep: list[torch.Tensor] = []
 
         def up(arr, dtype=torch.float32):
-            t = torch.as_tensor(np.ascontiguousarray(arr)).to(device=dev, dtype=dtype).contiguous()
+            # tensors already on the device are used in place (no copy of the 48.8 MB table)
+            t = arr.detach() if isinstance(arr, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(arr))
+            t = t.to(device=dev, dtype=dtype).contiguous()
             self._keep.append(t)
             return t
 
         self.bitfield = up(bitfield, torch.uint8)
-        self.table = up(_np32(table))
+        self.table = up(table if isinstance(table, torch.Tensor) else _np32(table))
         offsets = np.asarray(offsets, dtype=np.int32)
         self.num_levels = offsets.shape[0] - 1
         if self.num_levels > MAX_LEVELS or self.table.shape[1] != 2:

