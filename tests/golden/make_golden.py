@@ -299,6 +299,12 @@ def main():
     golden_shading(model, opt, "toaster_rot", env_rot=0.7)
     golden_frame(model, opt, "toaster_48", 48, 48)
     golden_frame(model, opt, "toaster_rot_40", 40, 40, env_rot=2.1, theta=200.0, phi=-35.0)
+    # BASELINE config #4: use_renv + indir_ref (three passes) on a concave shape so that reflected rays
+    # hit the object again; sdf / beta chosen so that surfaces are opaque enough for weights_sum > 0.9
+    scene4 = scenes.toaster_scene(shape=scenes.torus(), seed=3)
+    model4, opt4 = build_reference_model(scene4, extra_argv=["--indir_ref"])
+    assert opt4.indir_ref and opt4.use_renv
+    golden_frame(model4, opt4, "toaster_indir_40", 40, 40, theta=40.0, phi=-50.0)
 
 
 if __name__ == "__main__":

@@ -105,3 +105,23 @@ def test_encoder_modules_have_reference_surface():
     (gx ** 2).sum().backward()
     # like the reference, the double backward reaches the table (and the upstream gradient), not the inputs
     assert torch.isfinite(enc.embeddings.grad).all() and enc.embeddings.grad.abs().sum() > 0
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_indirect_three_pass_matches_reference(fused):
+    """BASELINE config #4 (use_renv + indir_ref): geometry pass -> reflected rays -> main pass with the
+    renv branch (renderer.py:437-513 orchestration), against the reference's own three-pass render."""
+    import torch
+    model, opt = build_model(scenes.toaster_scene(shape=scenes.torus(), seed=3), indir_ref=True)
+    g = np.load(GOLD / "frame_toaster_indir_40.npz")
+    H, W = int(g["H"]), int(g["W"])
+    ro, rd = scenes.camera_rays(H, W, theta=float(g["theta"]), phi=float(g["phi"]))
+    res = model.render(torch.from_numpy(ro).cuda()[None], torch.from_numpy(rd).cuda()[None], staged=True, bg_color=1, perturb=False,
+                       get_normal_image=True, env_rot_radian=None, fused=fused, max_steps=opt.max_steps, T_thresh=opt.T_thresh,
+                       dt_gamma=opt.dt_gamma, early_stop_steps=-1)
+    torch.cuda.synchronize()
+    for key in KEYS:
+        got = res[key].detach().cpu().numpy().reshape(H * W, -1)
+        want = g[key].reshape(H * W, -1)
+        err = rel_l2(got, want)
+        assert err <= 1e-4, f"{key} (fused={fused}): rel-L2 {err:.3e}"
