@@ -44,6 +44,10 @@ constexpr int kLevels = ENVIDR_MAX_LEVELS;
 #define ENVIDR_UNROLL_ENV 1
 #endif
 constexpr bool kUnrollEnv = ENVIDR_UNROLL_ENV != 0;
+#ifndef ENVIDR_MAX_GROUP
+#define ENVIDR_MAX_GROUP 8
+#endif
+constexpr uint32_t kMaxGroup = ENVIDR_MAX_GROUP;   // largest number of lanes (consecutive samples) per ray in tail mode
 
 struct HashLevelK {
     uint32_t row0, size, stride1, stride2;
@@ -199,10 +203,69 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
         ray = -1;
     };
 
+    // ---- tail mode ---------------------------------------------------------------------------
+    // Once the queue is empty a wave would finish its last rays one sample per round with most lanes
+    // idle.  Instead the surviving rays are re-packed and each gets k = 2, 4, 8 adjacent lanes that
+    // shade k CONSECUTIVE samples of it per round -- the reference's own n_step batching
+    // (cuda_ray.py:287), applied per wave.  All k lanes keep an identical copy of the ray state.
+    uint32_t k = 1;
+    __shared__ int s_src[64];
+
     for (;;) {
+        if (__any(drained)) {
+            drained = true;                                  // the queue head only grows: empty for one is empty for all
+            const uint32_t sub0 = lane & (k - 1);
+            const unsigned long long leaders = __ballot(ray >= 0 && sub0 == 0);
+            const uint32_t active = (uint32_t)__popcll(leaders);
+            uint32_t nk = k;
+            while (nk < kMaxGroup && active * nk * 2 <= 64) nk *= 2;
+            if (nk != k && active > 0) {
+                // leader of the r-th surviving ray publishes its lane; lanes [r nk, (r+1) nk) adopt that ray
+                if (ray >= 0 && sub0 == 0) s_src[__popcll(leaders & ((1ull << lane) - 1ull))] = (int)lane;
+                __syncthreads();
+                const uint32_t g = lane / nk;
+                const int src = g < active ? s_src[g] : 0;
+                const bool on = g < active;
+                const int ray_src = __shfl(ray, src);    // every lane must execute the shuffle (source lanes push their data)
+                ray = on ? ray_src : -1;
+                far = __shfl(far, src); t_ray = __shfl(t_ray, src); t_resume = __shfl(t_resume, src);
+                n_taken = __shfl(n_taken, src);
+                acc.ws = __shfl(acc.ws, src); acc.depth = __shfl(acc.depth, src); acc.t = __shfl(acc.t, src);
+                acc.r = __shfl(acc.r, src); acc.g = __shfl(acc.g, src); acc.b = __shfl(acc.b, src);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { an[d] = __shfl(an[d], src); ad[d] = __shfl(ad[d], src); as[d] = __shfl(as[d], src); }
+                arough = __shfl(arough, src);
+                if (ray >= 0) rg = load_ray(a.rays_o, a.rays_d, (uint32_t)ray);
+                __syncthreads();
+                k = nk;
+            }
+        }
+        const uint32_t sub = lane & (k - 1);
+
         // ================= refill + march: every lane ends with a sample or idle =================
         bool have = false;
         float px = 0, py = 0, pz = 0, dt = 0, delta_depth = 0, t_next = 0;
+        if (k > 1) {
+            // lane `sub` of a group takes the (sub+1)-th next occupied sample of the group's ray
+            if (ray >= 0) {
+                float t = n_taken == 0 ? t_resume : t_ray;
+                float last_t = t_ray;
+                bool ok = true;
+                for (uint32_t i = 0; i <= sub && ok; ++i) {
+                    if (i) last_t = t;
+                    ok = (n_taken + i) < a.max_samples && march_next(a.mk, rg, far, t, px, py, pz, dt);
+                }
+                have = ok;
+                delta_depth = t - last_t;
+            }
+            // a ray whose NEXT sample does not exist is finished here, so that every ray still open
+            // after this point has at least its leader's sample
+            const bool lead_have = __shfl((int)have, (int)(lane & ~(k - 1))) != 0;
+            if (ray >= 0 && !lead_have) {
+                if (sub == 0) finish_ray(); else ray = -1;
+                have = false;
+            }
+        } else
         for (;;) {
             if (ray < 0 && !drained) {
                 const uint32_t slot = atomicAdd(a.ray_counter, 1u);     // aggregated to one atomic per wave
@@ -455,23 +518,63 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
 
         ENVIDR_TICK(6);   // heads (+ env unpack)
         // ================= composite (raymarching.cu:996-1030 recurrence) =========================
-        if (have) {
-            const float alpha = 1.0f - expf(-sigma * dt);
-            const float T = 1 - acc.ws;
-            const float w = alpha * T;
-            acc.ws += w;
-            acc.t = acc.t + delta_depth;
-            acc.depth += w * acc.t;
-            const float cr = (cd[0] + cs[0]) * a.intensity_scale, cg = (cd[1] + cs[1]) * a.intensity_scale,
-                        cb = (cd[2] + cs[2]) * a.intensity_scale;
-            acc.r += w * cr; acc.g += w * cg; acc.b += w * cb;
+        if (k == 1) {
+            if (have) {
+                const float alpha = 1.0f - expf(-sigma * dt);
+                const float T = 1 - acc.ws;
+                const float w = alpha * T;
+                acc.ws += w;
+                acc.t = acc.t + delta_depth;
+                acc.depth += w * acc.t;
+                const float cr = (cd[0] + cs[0]) * a.intensity_scale, cg = (cd[1] + cs[1]) * a.intensity_scale,
+                            cb = (cd[2] + cs[2]) * a.intensity_scale;
+                acc.r += w * cr; acc.g += w * cg; acc.b += w * cb;
 #pragma unroll
-            for (int d = 0; d < 3; ++d) { an[d] += w * nrm[d]; ad[d] += w * cd[d]; as[d] += w * cs[d]; }
-            arough += w * rough;
-            t_ray = acc.t;            // the reference resumes the marcher from the composited time
-            (void)t_next;
-            ++n_taken;
-            if (T < a.T_thresh) finish_ray();
+                for (int d = 0; d < 3; ++d) { an[d] += w * nrm[d]; ad[d] += w * cd[d]; as[d] += w * cs[d]; }
+                arough += w * rough;
+                t_ray = acc.t;            // the reference resumes the marcher from the composited time
+                (void)t_next;
+                ++n_taken;
+                if (T < a.T_thresh) finish_ray();
+            }
+        } else {
+            // the k samples of a group are composited in order by EVERY lane of the group (identical
+            // copies of the ray state); sample j comes from lane leader + j
+            const int leader = (int)(lane & ~(k - 1));
+            const float alpha_own = 1.0f - expf(-sigma * dt);
+            bool open = ray >= 0;
+            for (uint32_t j = 0; j < k; ++j) {
+                const int src = leader + (int)j;
+                const bool have_j = __shfl((int)have, src) != 0;
+                const float alpha = __shfl(alpha_own, src), dd = __shfl(delta_depth, src), rg_j = __shfl(rough, src);
+                float cdj[3], csj[3], nj[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { cdj[d] = __shfl(cd[d], src); csj[d] = __shfl(cs[d], src); nj[d] = __shfl(nrm[d], src); }
+                if (open) {
+                    if (!have_j) {                       // the ray left the scene before its j-th sample
+                        if (sub == 0) finish_ray(); else ray = -1;
+                        open = false;
+                    } else {
+                        const float T = 1 - acc.ws;
+                        const float w = alpha * T;
+                        acc.ws += w;
+                        acc.t = acc.t + dd;
+                        acc.depth += w * acc.t;
+                        acc.r += w * ((cdj[0] + csj[0]) * a.intensity_scale);
+                        acc.g += w * ((cdj[1] + csj[1]) * a.intensity_scale);
+                        acc.b += w * ((cdj[2] + csj[2]) * a.intensity_scale);
+#pragma unroll
+                        for (int d = 0; d < 3; ++d) { an[d] += w * nj[d]; ad[d] += w * cdj[d]; as[d] += w * csj[d]; }
+                        arough += w * rg_j;
+                        ++n_taken;
+                        if (T < a.T_thresh) {
+                            if (sub == 0) finish_ray(); else ray = -1;
+                            open = false;
+                        }
+                    }
+                }
+            }
+            if (open) t_ray = acc.t;
         }
         ENVIDR_TICK(7);   // composite
     }

@@ -57,12 +57,15 @@ def test_fused_matches_reference_frames(renderer, tag):
 
 def test_fused_matches_oracle_one_sample_schedule(scene, renderer):
     """against the CPU oracle run with the schedule the kernel is equivalent to (n_step = 1) and the
-    exact IDE: sample counts identical, images to fp32 rounding."""
+    exact IDE: images to fp32 rounding."""
     from oracle.py import render_oracle as ro
     rays_o, rays_d = scenes.camera_rays(36, 36, theta=75.0, phi=-10.0)
     want = ro.render_rays(scene, rays_o, rays_d, ro.RenderOptions(ide_mode="exact"), None, force_n_step=1)
     out = _render(renderer, rays_o, rays_d)
-    assert int(out["stats"][0]) == want["n_samples"]
+    # every composited sample is shaded exactly once; the tail mode (k consecutive samples per ray
+    # once the queue is empty) may shade a few samples past a ray's termination, like the reference's n_step > 1
+    shaded = int(out["stats"][0])
+    assert want["n_samples"] <= shaded <= want["n_samples"] * 1.05 + 512, (shaded, want["n_samples"])
     for key in KEYS:
         err = rel_l2(out[key], want[key].reshape(out[key].shape))
         assert err <= 2e-5, f"{key}: rel-L2 {err:.3e}"
