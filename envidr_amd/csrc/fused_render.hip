@@ -33,6 +33,7 @@
 #include "../../include/envidr_render.h"
 
 #include <float.h>
+#include <type_traits>
 #include <vector>
 
 using namespace envidr;
@@ -67,21 +68,14 @@ struct RenderArgs {
     HashLevelK lv[kLevels];
     uint32_t num_levels;
     float bound2;                 // 2 * bound
-    // sdf net
-    const float* sdf_w[3];
-    const float* sdf_b[3];
-    const float* sdf_w2t;
-    const float* sdf_w1t;
-    const float* sdf_w3r0;
+    // weights in consumption order, one blob per pass (see envidr_render.h), padded to whole 16 KiB chunks
+    const float* sdf_blob;
+    const float* env_blob;
+    const float* head_blob;
+    const float* sdf_w3r0;      // row 0 of the last SDF layer as a packed row vector
     float inv_beta, beta;
     float rough_bias, rough_act_scale, rough_scale;
     // env / heads
-    const float* env_w[4];
-    const float* env_b[4];
-    const float* dif_w[2];
-    const float* dif_b[2];
-    const float* spc_w[3];
-    const float* spc_b[3];
     float kappa_diffuse, light_scale, intensity_scale;
     int has_rot;
     float rot[9];
@@ -162,10 +156,58 @@ __global__ void __launch_bounds__(kBlock) k_first_hit(const RenderArgs a, uint32
     if (hit) hit_ids[base + __popcll(mask & ((1ull << lane) - 1ull))] = id;
 }
 
+// position of the n-th set bit of mask (n < popcount(mask))
+__device__ __forceinline__ uint32_t nth_set_bit(unsigned long long mask, uint32_t n) {
+    uint32_t pos = 0;
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) {
+        const uint32_t cnt = (uint32_t)__popcll((mask >> pos) & ((1ull << w) - 1ull));
+        if (n >= cnt) { n -= cnt; pos += (uint32_t)w; }
+    }
+    return pos;
+}
+
+// fragment layout of the three weight passes (must match envidr_amd/fused.py and envidr_render.h)
+// (every forward layer carries its bias as one extra leading step; the two gradient layers have none)
+constexpr int kSdfW1 = 0, kSdfW2 = kSdfW1 + lane_layer_frags(16, 2, true), kSdfW3 = kSdfW2 + tile_layer_frags(2, 2, true),
+              kSdfW2t = kSdfW3 + tile_layer_frags(2, 1, true), kSdfW1t = kSdfW2t + tile_layer_frags(2, 2, false),
+              kSdfFrags = kSdfW1t + tile_layer_frags(2, 1, false);
+constexpr int kHeadD1 = 0, kHeadD2 = kHeadD1 + lane_layer_frags(12, 1, true), kHeadS1 = kHeadD2 + tile_layer_frags(1, 1, true),
+              kHeadS2 = kHeadS1 + lane_layer_frags(14, 2, true), kHeadS3 = kHeadS2 + tile_layer_frags(2, 2, true),
+              kHeadFrags = kHeadS3 + tile_layer_frags(2, 1, true);
+
+// Weight delivery: 0 = every wave streams the blobs from L2 through its own register ring (single-wave
+// workgroups), 1 = the four waves of a 256-thread workgroup share one LDS stream.  Measured at fp32:
+// the ring is faster (the per-chunk barrier of the shared stream costs more than the 4x L2 traffic it
+// saves); the shared stream is what a faster MFMA mode needs.
+#ifndef ENVIDR_SHARED_WEIGHTS
+#define ENVIDR_SHARED_WEIGHTS 0
+#endif
+constexpr bool kSharedWeights = ENVIDR_SHARED_WEIGHTS != 0;
+#ifndef ENVIDR_RING_DEPTH
+#define ENVIDR_RING_DEPTH 32
+#endif
+constexpr int kRingDepth = ENVIDR_RING_DEPTH;
+#ifndef ENVIDR_NT_GATHER
+#define ENVIDR_NT_GATHER 0
+#endif
+constexpr bool kNtGather = ENVIDR_NT_GATHER != 0;
+constexpr uint32_t kBlockThreads = kSharedWeights ? 256 : 64;
+constexpr int ring_padded(int frags) { return (frags + kRingDepth - 1) / kRingDepth * kRingDepth; }
+
 template <int IDE_DEG, int ENV_T>
-__global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a) {
+__global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const RenderArgs a) {
     constexpr int TERMS = ide_terms(IDE_DEG);      // IDE_DIM = 2 * TERMS input features, TERMS lane-order steps
+    constexpr int kEnv0 = 0, kEnv1 = kEnv0 + lane_layer_frags(TERMS, ENV_T, true), kEnv2 = kEnv1 + tile_layer_frags(ENV_T, ENV_T, true),
+                  kEnv3 = kEnv2 + tile_layer_frags(ENV_T, ENV_T, true), kEnvFrags = kEnv3 + tile_layer_frags(ENV_T, 1, true);
+    constexpr uint32_t kSdfChunks = pass_chunks(kSdfFrags), kEnvChunks = pass_chunks(kEnvFrags), kHeadChunks = pass_chunks(kHeadFrags);
     const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ __attribute__((aligned(16))) float s_weights[kSharedWeights ? 2 * kChunkFloats : 4];
+    std::conditional_t<kSharedWeights, WeightPipe, WeightRing<kRingDepth>> wp;
+    wp.start(s_weights, lane, wave, a.sdf_blob, kSdfChunks);
+    // fragments per pass as the weight source sees them (the ring pads every pass to a multiple of its depth)
+    constexpr int kSdfN = ring_padded(kSdfFrags), kEnvN = ring_padded(kEnvFrags), kHeadN = ring_padded(kHeadFrags);
 
     // ---- per-lane ray slot ---------------------------------------------------------------------
     int ray = -1;
@@ -209,7 +251,6 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
     // shade k CONSECUTIVE samples of it per round -- the reference's own n_step batching
     // (cuda_ray.py:287), applied per wave.  All k lanes keep an identical copy of the ray state.
     uint32_t k = 1;
-    __shared__ int s_src[64];
 
     for (;;) {
         if (__any(drained)) {
@@ -220,12 +261,10 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
             uint32_t nk = k;
             while (nk < kMaxGroup && active * nk * 2 <= 64) nk *= 2;
             if (nk != k && active > 0) {
-                // leader of the r-th surviving ray publishes its lane; lanes [r nk, (r+1) nk) adopt that ray
-                if (ray >= 0 && sub0 == 0) s_src[__popcll(leaders & ((1ull << lane) - 1ull))] = (int)lane;
-                __syncthreads();
+                // lanes [r nk, (r+1) nk) adopt the r-th surviving ray, i.e. the state of the r-th set bit of `leaders`
                 const uint32_t g = lane / nk;
-                const int src = g < active ? s_src[g] : 0;
                 const bool on = g < active;
+                const int src = on ? (int)nth_set_bit(leaders, g) : 0;
                 const int ray_src = __shfl(ray, src);    // every lane must execute the shuffle (source lanes push their data)
                 ray = on ? ray_src : -1;
                 far = __shfl(far, src); t_ray = __shfl(t_ray, src); t_resume = __shfl(t_resume, src);
@@ -236,7 +275,6 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
                 for (int d = 0; d < 3; ++d) { an[d] = __shfl(an[d], src); ad[d] = __shfl(ad[d], src); as[d] = __shfl(as[d], src); }
                 arough = __shfl(arough, src);
                 if (ray >= 0) rg = load_ray(a.rays_o, a.rays_d, (uint32_t)ray);
-                __syncthreads();
                 k = nk;
             }
         }
@@ -301,7 +339,8 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
             const bool again = !have && ray < 0 && !drained;
             if (!__any(again)) break;
         }
-        if (!__any(have)) break;
+        // the four waves share the weight pipe: the block keeps going while any of them has a sample
+        if (kSharedWeights ? !__syncthreads_or((int)have) : !__any(have)) break;
         ENVIDR_TICK(0);   // refill + march
         n_samples += have ? 1 : 0;
         n_rounds += 1;
@@ -321,7 +360,7 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
                     LevelGeom<3> geo;
                     geo.stride[0] = 1; geo.stride[1] = a.lv[l].stride1; geo.stride[2] = a.lv[l].stride2;
                     geo.size = a.lv[l].size; geo.hashed = a.lv[l].hashed != 0; geo.pow2 = a.lv[l].pow2 != 0;
-                    eval_level<3, 2, true, true>(x01, a.table + (size_t)a.lv[l].row0 * 2, geo, a.lv[l].scale, 0.0f, o, g);
+                    eval_level<3, 2, true, true, kNtGather>(x01, a.table + (size_t)a.lv[l].row0 * 2, geo, a.lv[l].scale, 0.0f, o, g);
                 }
                 const float m = a.lv[l].enabled ? 1.0f : 0.0f;     // network.py:390-393 level mask
                 feat[2 * l] = o[0] * m; feat[2 * l + 1] = o[1] * m;
@@ -349,12 +388,12 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
 #pragma unroll
                 for (int s = 0; s < kLevels; ++s) in[s] = grp ? inB[s] : inA[s];
                 f32x16 h1[2], h2[2], o3[1];
-                layer_from_lanes<kLevels, 2>(a.sdf_w[0], a.sdf_b[0], lane, in, h1);
-                h1[0] = relu16(h1[0]); h1[1] = relu16(h1[1]);
-                layer_from_tiles<2, 2>(a.sdf_w[1], a.sdf_b[1], lane, h1, h2);
-                h2[0] = relu16(h2[0]); h2[1] = relu16(h2[1]);
-                layer_from_tiles<2, 1>(a.sdf_w[2], a.sdf_b[2], lane, h2, o3);
+                wp.begin_pass(a.sdf_blob, kSdfChunks, grp == 0 ? a.sdf_blob : a.env_blob, grp == 0 ? kSdfChunks : kEnvChunks);
+                pipe_layer_from_lanes<kLevels, 2, kSdfW1, kSdfN>(wp, lane, in, h1);
+                pipe_layer_from_tiles<2, 2, kSdfW2, kSdfN, true>(wp, lane, h1, h2);
+                pipe_layer_from_tiles<2, 1, kSdfW3, kSdfN, true>(wp, lane, h2, o3);
                 // backward of sdf = o3[row 0]:  g2 = W3[0,:] * [h2 > 0];  g1 = (W2^T g2) * [h1 > 0];  gfeat = W1^T g1
+                // (h1, h2 hold pre-activations: ReLU is applied as the next layer reads them)
                 f32x16 g2[2], g1[2], gf[1];
                 const ParamBuf w3r0 = make_param_buf(a.sdf_w3r0, 2 * 128u, lane);
 #pragma unroll
@@ -363,12 +402,13 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) g2[t][r] = h2[t][r] > 0 ? w[r] : 0.0f;
                 }
-                layer_from_tiles<2, 2>(a.sdf_w2t, nullptr, lane, g2, g1);
+                pipe_layer_from_tiles<2, 2, kSdfW2t, kSdfN, false, false>(wp, lane, g2, g1);
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) g1[t][r] = h1[t][r] > 0 ? g1[t][r] : 0.0f;
-                layer_from_tiles<2, 1>(a.sdf_w1t, nullptr, lane, g1, gf);
+                pipe_layer_from_tiles<2, 1, kSdfW1t, kSdfN, false, false>(wp, lane, g1, gf);
+                wp.template end_pass<kSdfFrags>();
                 if (grp == 0) { outA = o3[0]; gfA = gf[0]; } else { outB = o3[0]; gfB = gf[0]; }
             }
 #pragma unroll
@@ -447,10 +487,13 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
 #pragma unroll
                 for (int s = 0; s < TERMS; ++s) in[s] = grp ? code[2 * s + 1] : code[2 * s];
                 f32x16 ha[ENV_T], hb[ENV_T], o[1];
-                layer_from_lanes<TERMS, ENV_T>(a.env_w[0], a.env_b[0], lane, in, ha);
-                layer_from_tiles<ENV_T, ENV_T, true, kUnrollEnv>(a.env_w[1], a.env_b[1], lane, ha, hb);
-                layer_from_tiles<ENV_T, ENV_T, true, kUnrollEnv>(a.env_w[2], a.env_b[2], lane, hb, ha);
-                layer_from_tiles<ENV_T, 1, true, kUnrollEnv>(a.env_w[3], a.env_b[3], lane, ha, o);
+                const bool last = enc == 1 && grp == 1;
+                wp.begin_pass(a.env_blob, kEnvChunks, last ? a.head_blob : a.env_blob, last ? kHeadChunks : kEnvChunks);
+                pipe_layer_from_lanes<TERMS, ENV_T, kEnv0, kEnvN>(wp, lane, in, ha);
+                pipe_layer_from_tiles<ENV_T, ENV_T, kEnv1, kEnvN, true>(wp, lane, ha, hb);
+                pipe_layer_from_tiles<ENV_T, ENV_T, kEnv2, kEnvN, true>(wp, lane, hb, ha);
+                pipe_layer_from_tiles<ENV_T, 1, kEnv3, kEnvN, true>(wp, lane, ha, o);
+                wp.template end_pass<kEnvFrags>();
                 if (grp == 0) outA = o[0]; else outB = o[0];
             }
             ENVIDR_TICK(5);   // env mlp
@@ -495,14 +538,13 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
 #pragma unroll
                 for (int s = 0; s < 14; ++s) in_s[s] = grp ? sin_[2 * s + 1] : sin_[2 * s];
                 f32x16 d1[1], d2[1], s1[2], s2[2], s3[1];
-                layer_from_lanes<12, 1>(a.dif_w[0], a.dif_b[0], lane, in_d, d1);
-                d1[0] = relu16(d1[0]);
-                layer_from_tiles<1, 1>(a.dif_w[1], a.dif_b[1], lane, d1, d2);
-                layer_from_lanes<14, 2>(a.spc_w[0], a.spc_b[0], lane, in_s, s1);
-                s1[0] = relu16(s1[0]); s1[1] = relu16(s1[1]);
-                layer_from_tiles<2, 2>(a.spc_w[1], a.spc_b[1], lane, s1, s2);
-                s2[0] = relu16(s2[0]); s2[1] = relu16(s2[1]);
-                layer_from_tiles<2, 1>(a.spc_w[2], a.spc_b[2], lane, s2, s3);
+                wp.begin_pass(a.head_blob, kHeadChunks, grp == 0 ? a.head_blob : a.sdf_blob, grp == 0 ? kHeadChunks : kSdfChunks);
+                pipe_layer_from_lanes<12, 1, kHeadD1, kHeadN>(wp, lane, in_d, d1);
+                pipe_layer_from_tiles<1, 1, kHeadD2, kHeadN, true>(wp, lane, d1, d2);
+                pipe_layer_from_lanes<14, 2, kHeadS1, kHeadN>(wp, lane, in_s, s1);
+                pipe_layer_from_tiles<2, 2, kHeadS2, kHeadN, true>(wp, lane, s1, s2);
+                pipe_layer_from_tiles<2, 1, kHeadS3, kHeadN, true>(wp, lane, s2, s3);
+                wp.template end_pass<kHeadFrags>();
                 if (grp == 0) { dA = d2[0]; sA = s3[0]; } else { dB = d2[0]; sB = s3[0]; }
             }
 #pragma unroll
@@ -586,7 +628,7 @@ __global__ void __launch_bounds__(64, 1) k_render_persistent(const RenderArgs a)
             n_rays += __shfl_down(n_rays, off);
         }
         if (lane == 0) {
-            if (blockIdx.x == 0) atomicAdd(&a.stats[2], (unsigned long long)(a.N - n_hit));   // rays finished by the pre-pass
+            if (blockIdx.x == 0 && wave == 0) atomicAdd(&a.stats[2], (unsigned long long)(a.N - n_hit));   // rays finished by the pre-pass
             atomicAdd(&a.stats[0], n_samples);
             atomicAdd(&a.stats[1], n_rounds);
             atomicAdd(&a.stats[2], n_rays);
@@ -618,6 +660,16 @@ extern "C" {
 uint32_t envidr_packed_weight_floats(int k_order, uint32_t k_in, uint32_t m_out) {
     return packed_weight_floats(k_order ? kTileOrder : kLaneOrder, k_in, m_out);
 }
+uint32_t envidr_packed_layer_floats(int k_order, uint32_t k_in, uint32_t m_out, int with_bias) {
+    return packed_weight_floats(k_order ? kTileOrder : kLaneOrder, k_in, m_out, with_bias != 0);
+}
+int envidr_pack_layer(const float* W_host, const float* bias_host, uint32_t m_out, uint32_t k_in, int transpose, int k_order,
+                      float* dst_host) {
+    ENVIDR_REQUIRE(W_host && dst_host && m_out && k_in, "pack_layer: null pointer or empty layer");
+    ENVIDR_REQUIRE(!(bias_host && transpose), "pack_layer: a transposed (gradient) layer carries no bias");
+    pack_linear(W_host, m_out, k_in, transpose != 0, k_order ? kTileOrder : kLaneOrder, dst_host, bias_host);
+    return ENVIDR_OK;
+}
 uint32_t envidr_packed_rowvec_floats(uint32_t m_out) { return packed_bias_floats(m_out); }
 
 int envidr_pack_linear(const float* W_host, uint32_t m_out, uint32_t k_in, int transpose, int k_order, float* dst_host) {
@@ -641,11 +693,8 @@ int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const f
     ENVIDR_REQUIRE(d->num_levels >= 1 && d->num_levels <= ENVIDR_MAX_LEVELS, "render_rays: num_levels %u not in [1,16]", d->num_levels);
     ENVIDR_REQUIRE(d->cascades >= 1 && d->grid_size >= 1 && d->max_steps >= 1, "render_rays: bad grid parameters");
     ENVIDR_REQUIRE(d->beta > 0, "render_rays: beta must be positive");
-    for (int i = 0; i < 3; ++i) ENVIDR_REQUIRE(d->sdf_w[i] && d->sdf_b[i] && d->specular_w[i] && d->specular_b[i], "render_rays: null sdf/specular weights");
-    for (int i = 0; i < 4; ++i) ENVIDR_REQUIRE(d->env_w[i] && d->env_b[i], "render_rays: null env weights");
-    for (int i = 0; i < 2; ++i) ENVIDR_REQUIRE(d->diffuse_w[i] && d->diffuse_b[i], "render_rays: null diffuse weights");
-    ENVIDR_REQUIRE(d->sdf_w2t && d->sdf_w1t && d->sdf_w3_row0, "render_rays: null sdf gradient weights");
-    ENVIDR_REQUIRE(d->num_levels == ENVIDR_MAX_LEVELS || d->num_levels * 2 <= 32, "render_rays: bad level count");
+    ENVIDR_REQUIRE(d->sdf_blob && d->env_blob && d->head_blob && d->sdf_w3_row0, "render_rays: null weight blob");
+    ENVIDR_REQUIRE(d->num_levels == ENVIDR_MAX_LEVELS, "render_rays: the fused kernel is built for 16 hash levels");
 
     RenderArgs a;
     memset(&a, 0, sizeof(a));
@@ -668,10 +717,8 @@ int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const f
         a.lv[l].enabled = (d->enabled_levels <= 0 || (int32_t)l < d->enabled_levels) ? 1u : 0u;
         ENVIDR_REQUIRE(g.hashed || g.stride[0] == 1, "render_rays: unexpected dense stride");
     }
-    for (int i = 0; i < 3; ++i) { a.sdf_w[i] = d->sdf_w[i]; a.sdf_b[i] = d->sdf_b[i]; a.spc_w[i] = d->specular_w[i]; a.spc_b[i] = d->specular_b[i]; }
-    for (int i = 0; i < 4; ++i) { a.env_w[i] = d->env_w[i]; a.env_b[i] = d->env_b[i]; }
-    for (int i = 0; i < 2; ++i) { a.dif_w[i] = d->diffuse_w[i]; a.dif_b[i] = d->diffuse_b[i]; }
-    a.sdf_w2t = d->sdf_w2t; a.sdf_w1t = d->sdf_w1t; a.sdf_w3r0 = d->sdf_w3_row0;
+    a.sdf_blob = d->sdf_blob; a.env_blob = d->env_blob; a.head_blob = d->head_blob;
+    a.sdf_w3r0 = d->sdf_w3_row0;
     a.beta = d->beta; a.inv_beta = 1 / d->beta;
     a.rough_bias = d->roughness_bias; a.rough_act_scale = d->roughness_act_scale; a.rough_scale = d->roughness_scale;
     a.kappa_diffuse = d->diffuse_kappa_inv; a.light_scale = d->light_intensity_scale; a.intensity_scale = d->intensity_scale;
@@ -709,11 +756,11 @@ int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const f
         if (rc) return rc;
     }
 
-    // persistent grid: 4 single-wave workgroups per CU (one per SIMD; the kernel uses the full
+    // persistent grid: one 4-wave workgroup per CU (one wave per SIMD; the kernel uses the full
     // 512-register budget so exactly one wave fits a SIMD), fewer when the batch is small
-    const uint32_t max_waves = (uint32_t)device_cu_count() * 4;
-    const uint32_t waves = std::min(max_waves, ceil_div(N, 64));
-    const dim3 grid(waves), block(64);
+    const uint32_t waves_per_block = kBlockThreads / 64;
+    const uint32_t blocks = std::min((uint32_t)device_cu_count() * (4 / waves_per_block), ceil_div(N, kBlockThreads));
+    const dim3 grid(blocks), block(kBlockThreads);
 #define ENVIDR_LAUNCH(DEG, HT) hipLaunchKernelGGL((k_render_persistent<DEG, HT>), grid, block, 0, s, a)
     if (d->ide_degree == 5 && d->env_hidden == 256) ENVIDR_LAUNCH(5, 8);
     else if (d->ide_degree == 4 && d->env_hidden == 160) ENVIDR_LAUNCH(4, 5);

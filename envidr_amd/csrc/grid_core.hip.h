@@ -86,12 +86,15 @@ __device__ __forceinline__ uint32_t cell_row(const LevelGeom<D>& g, const uint32
 template <int C>
 struct Feat { float v[C]; };
 
-template <int C>
+// NT: non-temporal gathers (the fused renderer uses them so that the 48.8 MB table, which has no
+// reuse at L2 scale, does not evict the < 1 MB of MLP weights every wave keeps re-streaming from L2)
+template <int C, bool NT = false>
 __device__ __forceinline__ Feat<C> load_row(const float* __restrict__ table, uint32_t row) {
     Feat<C> f;
     const float* p = table + (size_t)row * C;
     if constexpr (C == 2) {
-        const float2 t = *reinterpret_cast<const float2*>(p);
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 t = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p)) : *reinterpret_cast<const f32x2*>(p);
         f.v[0] = t.x; f.v[1] = t.y;
     } else if constexpr (C == 4) {
         const float4 t = *reinterpret_cast<const float4*>(p);
@@ -113,7 +116,7 @@ __device__ __forceinline__ Feat<C> load_row(const float* __restrict__ table, uin
 //   dydx    : [D][C] derivative w.r.t. the [0,1] input, written when WITH_GRAD
 // All 2^D corner rows are gathered once (issued back to back so their latencies overlap) and
 // reused for the derivative; the reference re-gathers them, values are identical.
-template <int D, int C, bool SMOOTH, bool WITH_GRAD>
+template <int D, int C, bool SMOOTH, bool WITH_GRAD, bool NT = false>
 __device__ __forceinline__ void eval_level(const float (&x)[D], const float* __restrict__ table,
                                            const LevelGeom<D>& g, float scale, float pos_offset, float (&out)[C],
                                            float (&dydx)[D][C]) {
@@ -141,7 +144,7 @@ __device__ __forceinline__ void eval_level(const float (&x)[D], const float* __r
         uint32_t q[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) q[d] = cell[d] + ((i >> d) & 1);
-        corner[i] = load_row<C>(table, cell_row<D>(g, q));
+        corner[i] = load_row<C, NT>(table, cell_row<D>(g, q));
     }
 
 #pragma unroll

@@ -41,16 +41,29 @@ __host__ __device__ constexpr int k_of_step(KOrder order, int s, int h) {
 }
 constexpr uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 constexpr uint32_t steps_for(KOrder order, uint32_t k_in) { return order == kLaneOrder ? (k_in + 1) / 2 : round_up(k_in, 32) / 2; }
-constexpr uint32_t packed_weight_floats(KOrder order, uint32_t k_in, uint32_t m_out) {
-    return steps_for(order, k_in) * (round_up(m_out, 32) / 32) * 64;
+// with_bias: the layer's bias travels in the weight stream as one extra reduction step placed FIRST
+// (A = bias in lane half 0, zero in half 1; B = 1 in half 0): acc = 0 + 1 * bias, exactly the value a
+// separate bias load would initialise the accumulator with, but prefetched like any other fragment
+// instead of being a synchronous load at the head of every layer.
+constexpr uint32_t packed_weight_floats(KOrder order, uint32_t k_in, uint32_t m_out, bool with_bias = false) {
+    return (steps_for(order, k_in) + (with_bias ? 1u : 0u)) * (round_up(m_out, 32) / 32) * 64;
 }
 constexpr uint32_t packed_bias_floats(uint32_t m_out) { return round_up(m_out, 32); }
 
 // Host-side packing.  W is row-major [m_out][k_in] (torch nn.Linear.weight); `transpose` packs W^T
 // instead (used for the input-gradient layers).  dst: [step][m_tile][64].
-inline void pack_linear(const float* W, uint32_t m_out, uint32_t k_in, bool transpose, KOrder order, float* dst) {
+inline void pack_linear(const float* W, uint32_t m_out, uint32_t k_in, bool transpose, KOrder order, float* dst,
+                        const float* bias = nullptr) {
     const uint32_t M = transpose ? k_in : m_out, K = transpose ? m_out : k_in;   // logical layer: K -> M
     const uint32_t steps = steps_for(order, K), mt = round_up(M, 32) / 32;
+    if (bias) {
+        for (uint32_t t = 0; t < mt; ++t)
+            for (uint32_t lane = 0; lane < 64; ++lane) {
+                const uint32_t m = 32 * t + (lane & 31);
+                dst[(size_t)t * 64 + lane] = (lane < 32 && m < M) ? bias[m] : 0.0f;
+            }
+        dst += (size_t)mt * 64;
+    }
     for (uint32_t s = 0; s < steps; ++s)
         for (uint32_t t = 0; t < mt; ++t)
             for (uint32_t lane = 0; lane < 64; ++lane) {
@@ -225,5 +238,188 @@ __device__ __forceinline__ void layer_from_tiles(const float* __restrict__ w, co
         }
     }
 }
+
+
+// =============================================================================================
+// Workgroup-shared weight pipe (LDS)
+// =============================================================================================
+// The four waves of a workgroup (one per SIMD of a CU) run the same layer sequence, so they consume
+// the same A fragments in the same order.  Instead of every wave streaming every fragment from L2
+// (4x the traffic, and a per-wave register ring to hide the latency), the workgroup streams the
+// weights ONCE through a double-buffered LDS ring in 16 KiB chunks of 64 fragments:
+//
+//   boundary of chunk g:   __syncthreads()                      all waves are done with chunk g-1; chunk g is visible
+//                          staged registers (chunk g+1) -> LDS slot (g+1)&1   (loaded one chunk-time ago: landed)
+//                          issue global loads of chunk g+2 -> staged registers (in flight during chunk g)
+//   inside chunk g:        fragment f = one conflict-free ds_read_b32 (lane-consecutive) per MFMA
+//
+// Each wave moves a quarter of every chunk (4 x 16 B per lane).  Weights are laid out in memory in
+// consumption order ("pass blobs", padded to whole chunks, see pack_pass on the host side), so the
+// stream is a linear copy; at the end of a pass the prefetcher rolls over into the next pass's blob.
+constexpr int kChunkFrags = 64;
+constexpr int kChunkFloats = kChunkFrags * 64;      // 4096 floats = 16 KiB
+constexpr uint32_t kChunkBytes = kChunkFloats * 4;
+
+struct WeightPipe {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    float* lds;                 // workgroup base of float[2][kChunkFloats]
+    uint32_t lane, wave;
+    uint32_t slot;              // LDS slot holding the chunk being consumed
+    const float* frag;          // lds + slot * kChunkFloats + lane  (this lane's column of the current chunk)
+    u32x4 stage[4];             // this wave's quarter of the NEXT-NEXT chunk, in flight / landed
+    __amdgpu_buffer_rsrc_t cur_rsrc, next_rsrc;
+    uint32_t cur_chunks;        // chunks in the current pass
+    uint32_t local;             // index of the chunk being consumed within the current pass
+
+    __device__ __forceinline__ static __amdgpu_buffer_rsrc_t rsrc_of(const float* blob, uint32_t chunks) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(blob), 0, (int)(chunks * kChunkBytes), 0x00020000);
+    }
+    __device__ __forceinline__ uint32_t voff() const { return (wave * 256u + lane) * 16u; }
+    __device__ __forceinline__ void load_stage(__amdgpu_buffer_rsrc_t r, uint32_t chunk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stage[i] = __builtin_amdgcn_raw_buffer_load_b128(r, voff(), chunk * kChunkBytes + (uint32_t)i * 1024u, 0);
+    }
+    __device__ __forceinline__ void store_stage(uint32_t to_slot) {
+        u32x4* dst = reinterpret_cast<u32x4*>(lds + to_slot * kChunkFloats) + wave * 256u + lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i * 64] = stage[i];
+    }
+    // kernel prologue: chunk 0 of the first pass -> slot 0, chunk 1 -> staged
+    __device__ __forceinline__ void start(float* lds_base, uint32_t lane_, uint32_t wave_, const float* first_blob, uint32_t first_chunks) {
+        lds = lds_base; lane = lane_; wave = wave_;
+        cur_rsrc = next_rsrc = rsrc_of(first_blob, first_chunks);
+        cur_chunks = first_chunks;
+        load_stage(cur_rsrc, 0);
+        store_stage(1);                       // boundary 0 flips to slot... see begin_pass: first boundary makes slot 1 -> current
+        load_stage(cur_rsrc, 1);
+        slot = 0;                             // boundary() of the first chunk toggles to 1
+        local = 0xffffffffu;                  // so that the first boundary sees local + 1 == 0
+        frag = lds + lane;
+    }
+    // declare the pass that starts at the next boundary and the blob that follows it
+    __device__ __forceinline__ void begin_pass(const float* blob, uint32_t chunks, const float* next_blob, uint32_t next_chunks) {
+        cur_rsrc = rsrc_of(blob, chunks);
+        next_rsrc = rsrc_of(next_blob, next_chunks);
+        cur_chunks = chunks;
+        local = 0xffffffffu;
+    }
+    // called exactly once per chunk by every wave, before the chunk's first fragment is read
+    __device__ __forceinline__ void boundary() {
+        __syncthreads();
+        ++local;                                           // chunk `local` of the current pass is now consumed
+        slot ^= 1u;                                        // ... from this slot (written at the previous boundary)
+        store_stage(slot ^ 1u);                            // staged chunk local+1 (or the next pass's chunk 0) -> other slot
+        const uint32_t ahead = local + 2;                  // issue loads for the chunk after that
+        if (ahead < cur_chunks) load_stage(cur_rsrc, ahead);
+        else load_stage(next_rsrc, ahead - cur_chunks);
+        frag = lds + slot * kChunkFloats + lane;
+        // pin the prefetch HERE: left alone, the scheduler sinks these loads down to their use (the next
+        // boundary's LDS write) to shorten their live range, which exposes the whole L2 round trip there
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // fragment I of the current pass (I compile-time): chunk boundary every kChunkFrags fragments
+    template <int I, int FRAGS>
+    __device__ __forceinline__ float take() {
+        if constexpr (I % kChunkFrags == 0) boundary();
+        return frag[(I % kChunkFrags) * 64];
+    }
+    template <int FRAGS> __device__ __forceinline__ void end_pass() {}
+};
+
+// Per-wave alternative: every wave streams the pass blobs itself from L2 through a ring of PF registers
+// (fragment I lives in ring[I % PF]; taking it re-issues the load of fragment I + PF).  The ring runs
+// CONTINUOUSLY across layers, passes and rounds -- at the end of a pass it rolls over into the next
+// pass's blob -- so the L2 latency is exposed once per kernel, not once per layer.  Requires every
+// pass to consume a multiple of PF fragments (end_pass pads with dummy takes).
+template <int PF>
+struct WeightRing {
+    __amdgpu_buffer_rsrc_t cur_rsrc, next_rsrc;
+    uint32_t lane_off;
+    float ring[PF];
+    __device__ __forceinline__ static __amdgpu_buffer_rsrc_t rsrc_of(const float* blob, uint32_t chunks) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(blob), 0, (int)(chunks * kChunkBytes), 0x00020000);
+    }
+    __device__ __forceinline__ void start(float*, uint32_t lane, uint32_t, const float* first_blob, uint32_t first_chunks) {
+        cur_rsrc = next_rsrc = rsrc_of(first_blob, first_chunks);
+        lane_off = lane * 4u;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) ring[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, lane_off, (uint32_t)(i * 256), 0));
+    }
+    __device__ __forceinline__ void begin_pass(const float* blob, uint32_t chunks, const float* next_blob, uint32_t next_chunks) {
+        cur_rsrc = rsrc_of(blob, chunks);
+        next_rsrc = rsrc_of(next_blob, next_chunks);
+    }
+    template <int I, int FRAGS>
+    __device__ __forceinline__ float take() {
+        static_assert(FRAGS % PF == 0 || I < FRAGS, "pass length must be a multiple of the ring depth");
+        const float v = ring[I % PF];
+        if constexpr (I + PF < FRAGS) ring[I % PF] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, lane_off, (uint32_t)((I + PF) * 256), 0));
+        else ring[I % PF] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(next_rsrc, lane_off, (uint32_t)((I + PF - FRAGS) * 256), 0));
+        return v;
+    }
+    // consume dummy fragments up to the next multiple of PF so the ring stays aligned for the next pass
+    template <int FRAGS, int I = FRAGS>
+    __device__ __forceinline__ void end_pass() {
+        if constexpr (I % PF != 0) {
+            // the dummy slot must still be refilled with the NEXT pass's fragment that belongs there
+            constexpr int kPadded = (FRAGS + PF - 1) / PF * PF;
+            ring[I % PF] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(next_rsrc, lane_off, (uint32_t)((I + PF - kPadded) * 256), 0));
+            end_pass<FRAGS, I + 1>();
+        }
+    }
+};
+
+template <typename T> struct is_weight_ring { static constexpr bool value = false; };
+template <int PF> struct is_weight_ring<WeightRing<PF>> { static constexpr bool value = true; };
+
+// FRAGS: fragments in the (ring-padded) pass -- where the per-wave ring rolls over into the next blob
+template <int NSTEPS, int MT, int F0, int FRAGS, int S = 0, typename Src, typename BOp>
+__device__ __forceinline__ void pipe_steps(Src& wp, f32x16 (&acc)[MT], BOp&& b) {
+    if constexpr (S < NSTEPS) {
+        const float bv = b(S);
+        [&]<int... T>(std::integer_sequence<int, T...>) {
+            ((acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp.template take<F0 + S * MT + T, FRAGS>(), bv, acc[T], 0, 0, 0)), ...);
+        }(std::make_integer_sequence<int, MT>{});
+        // the register ring is a hand-made software pipeline: keep the scheduler from hoisting its refills
+        if constexpr (is_weight_ring<Src>::value) __builtin_amdgcn_sched_barrier(0);
+        pipe_steps<NSTEPS, MT, F0, FRAGS, S + 1>(wp, acc, b);
+    }
+}
+
+// fragments a layer occupies in its pass
+constexpr int lane_layer_frags(int steps, int mt, bool bias) { return (steps + (bias ? 1 : 0)) * mt; }
+constexpr int tile_layer_frags(int kt, int mt, bool bias) { return (16 * kt + (bias ? 1 : 0)) * mt; }
+
+template <int MT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT]) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+}
+// the bias step: B = 1 in lane half 0 (whose A fragment carries the bias), 0 in half 1
+template <int MT, int F0, int FRAGS, typename Src>
+__device__ __forceinline__ void bias_step(Src& wp, uint32_t lane, f32x16 (&acc)[MT]) {
+    pipe_steps<1, MT, F0, FRAGS>(wp, acc, [&](int) { return lane < 32 ? 1.0f : 0.0f; });
+}
+
+// layer whose input is per-lane-packed registers; F0 = index of its first fragment within the pass
+template <int STEPS, int MT, int F0, int FRAGS, bool BIAS = true, typename Src>
+__device__ __forceinline__ void pipe_layer_from_lanes(Src& wp, uint32_t lane, const float (&in)[STEPS], f32x16 (&acc)[MT]) {
+    zero_acc<MT>(acc);
+    if constexpr (BIAS) bias_step<MT, F0, FRAGS>(wp, lane, acc);
+    pipe_steps<STEPS, MT, F0 + (BIAS ? MT : 0), FRAGS>(wp, acc, [&](int s) { return in[s]; });
+}
+// layer whose input is KT accumulator tiles of the previous layer
+template <int KT, int MT, int F0, int FRAGS, bool RELU_IN = false, bool BIAS = true, typename Src>
+__device__ __forceinline__ void pipe_layer_from_tiles(Src& wp, uint32_t lane, const f32x16 (&in)[KT], f32x16 (&acc)[MT]) {
+    zero_acc<MT>(acc);
+    if constexpr (BIAS) bias_step<MT, F0, FRAGS>(wp, lane, acc);
+    [&]<int... K>(std::integer_sequence<int, K...>) {
+        (pipe_steps<16, MT, F0 + (BIAS ? MT : 0) + K * 16 * MT, FRAGS>(wp, acc, [&](int s) { return RELU_IN ? fmaxf(in[K][s], 0.0f) : in[K][s]; }), ...);
+    }(std::make_integer_sequence<int, KT>{});
+}
+
+constexpr int pass_chunks(int frags) { return (frags + kChunkFrags - 1) / kChunkFrags; }
 
 }  // namespace envidr

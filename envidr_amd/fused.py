@@ -29,12 +29,11 @@ class RenderDesc(ctypes.Structure):
         ("density_scale", ctypes.c_float), ("bg_color", ctypes.c_float),
         ("hash_table", _FP), ("hash_offsets", ctypes.c_int32 * (MAX_LEVELS + 1)), ("num_levels", ctypes.c_uint32),
         ("base_resolution", ctypes.c_uint32), ("log2_per_level_scale", ctypes.c_float), ("enabled_levels", ctypes.c_int32),
-        ("sdf_w", _FP * 3), ("sdf_b", _FP * 3), ("sdf_w2t", _FP), ("sdf_w1t", _FP), ("sdf_w3_row0", _FP),
+        ("sdf_blob", _FP), ("env_blob", _FP), ("head_blob", _FP), ("sdf_w3_row0", _FP),
         ("beta", ctypes.c_float), ("roughness_bias", ctypes.c_float), ("roughness_act_scale", ctypes.c_float),
         ("roughness_scale", ctypes.c_float),
-        ("ide_degree", ctypes.c_uint32), ("env_hidden", ctypes.c_uint32), ("env_w", _FP * 4), ("env_b", _FP * 4),
+        ("ide_degree", ctypes.c_uint32), ("env_hidden", ctypes.c_uint32),
         ("diffuse_kappa_inv", ctypes.c_float), ("light_intensity_scale", ctypes.c_float), ("intensity_scale", ctypes.c_float),
-        ("diffuse_w", _FP * 2), ("diffuse_b", _FP * 2), ("specular_w", _FP * 3), ("specular_b", _FP * 3),
         ("has_env_rot", ctypes.c_int32), ("env_rot", ctypes.c_float * 9),
     ]
 
@@ -78,6 +77,10 @@ def _bind_render(lib):
     lib.envidr_packed_rowvec_floats.restype = ctypes.c_uint32
     lib.envidr_pack_linear.argtypes = [_FP, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, _FP]
     lib.envidr_pack_linear.restype = ctypes.c_int
+    lib.envidr_packed_layer_floats.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int]
+    lib.envidr_packed_layer_floats.restype = ctypes.c_uint32
+    lib.envidr_pack_layer.argtypes = [_FP, _FP, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, _FP]
+    lib.envidr_pack_layer.restype = ctypes.c_int
     lib.envidr_pack_rowvec.argtypes = [_FP, ctypes.c_uint32, _FP]
     lib.envidr_pack_rowvec.restype = ctypes.c_int
     lib.envidr_render_rays.argtypes = [ctypes.POINTER(RenderDesc), _FP, _FP, ctypes.c_uint32, ctypes.POINTER(RenderOut), _FP, _FP]
@@ -100,6 +103,21 @@ def pack_linear(W, k_order: int, transpose: bool = False) -> np.ndarray:
     M, K = (k_in, m_out) if transpose else (m_out, k_in)
     dst = np.empty(lib.envidr_packed_weight_floats(k_order, K, M), np.float32)
     rc = lib.envidr_pack_linear(W.ctypes.data, m_out, k_in, int(transpose), k_order, dst.ctypes.data)
+    if rc:
+        raise _lib.EnvidrError(lib.envidr_last_error().decode())
+    return dst
+
+
+def pack_layer(W, bias, k_order: int, transpose: bool = False) -> np.ndarray:
+    """a layer as the fused kernel streams it: [bias step] + weight steps (bias may be None)"""
+    lib = _lib.load()
+    _bind_render(lib)
+    W = _np32(W)
+    m_out, k_in = W.shape
+    M, K = (k_in, m_out) if transpose else (m_out, k_in)
+    b = None if bias is None else _np32(bias).reshape(-1)
+    dst = np.empty(lib.envidr_packed_layer_floats(k_order, K, M, int(b is not None)), np.float32)
+    rc = lib.envidr_pack_layer(W.ctypes.data, None if b is None else b.ctypes.data, m_out, k_in, int(transpose), k_order, dst.ctypes.data)
     if rc:
         raise _lib.EnvidrError(lib.envidr_last_error().decode())
     return dst
@@ -173,29 +191,24 @@ class FusedRenderer:
         d.log2_per_level_scale = float(np.log2(per_level_scale))
         d.enabled_levels = self.opt.enabled_levels
 
-        def layer(Wb, order, slot_w, slot_b, i):
-            slot_w[i] = up(pack_linear(Wb[0], order)).data_ptr()
-            slot_b[i] = up(pack_rowvec(Wb[1])).data_ptr()
+        def blob(parts):
+            """concatenate packed layers in consumption order, zero-padded to whole 16 KiB LDS chunks"""
+            flat = np.concatenate(parts)
+            pad = (-flat.size) % 4096
+            return up(np.concatenate([flat, np.zeros(pad, np.float32)])).data_ptr()
 
-        layer(sdf[0], 0, d.sdf_w, d.sdf_b, 0)
-        layer(sdf[1], 1, d.sdf_w, d.sdf_b, 1)
-        layer(sdf[2], 1, d.sdf_w, d.sdf_b, 2)
-        d.sdf_w2t = up(pack_linear(sdf[1][0], 1, transpose=True)).data_ptr()
-        d.sdf_w1t = up(pack_linear(sdf[0][0], 1, transpose=True)).data_ptr()
+        L = lambda Wb, order: pack_layer(Wb[0], Wb[1], order)
+        d.sdf_blob = blob([L(sdf[0], 0), L(sdf[1], 1), L(sdf[2], 1),
+                           pack_layer(sdf[1][0], None, 1, transpose=True), pack_layer(sdf[0][0], None, 1, transpose=True)])
+        d.env_blob = blob([L(env[0], 0)] + [L(env[i], 1) for i in (1, 2, 3)])
+        d.head_blob = blob([L(dif[0], 0), L(dif[1], 1), L(spc[0], 0), L(spc[1], 1), L(spc[2], 1)])
         d.sdf_w3_row0 = up(pack_rowvec(_np32(sdf[2][0])[0])).data_ptr()
         d.beta = float(min(max(beta, self.opt.beta_min), self.opt.beta_max))     # LaplaceDensity.get_beta clamp
         d.roughness_bias, d.roughness_act_scale = self.opt.roughness_bias, self.opt.roughness_act_scale
         d.roughness_scale = self.opt.roughness_scale
         d.ide_degree, d.env_hidden = self.opt.ide_degree, env_hidden
-        for i in range(4):
-            layer(env[i], 0 if i == 0 else 1, d.env_w, d.env_b, i)
         d.diffuse_kappa_inv = self.opt.diffuse_kappa_inv
         d.light_intensity_scale, d.intensity_scale = self.opt.light_intensity_scale, self.opt.intensity_scale
-        layer(dif[0], 0, d.diffuse_w, d.diffuse_b, 0)
-        layer(dif[1], 1, d.diffuse_w, d.diffuse_b, 1)
-        layer(spc[0], 0, d.specular_w, d.specular_b, 0)
-        layer(spc[1], 1, d.specular_w, d.specular_b, 1)
-        layer(spc[2], 1, d.specular_w, d.specular_b, 2)
         d.has_env_rot = 0
         self.desc = d
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev)

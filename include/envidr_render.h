@@ -39,6 +39,12 @@ uint32_t envidr_packed_weight_floats(int k_order, uint32_t k_in, uint32_t m_out)
 uint32_t envidr_packed_rowvec_floats(uint32_t m_out);
 int envidr_pack_linear(const float* W_host, uint32_t m_out, uint32_t k_in, int transpose, int k_order,
                        float* dst_host);
+/* A whole layer as the fused kernel consumes it: when bias_host != NULL the bias is packed as one extra
+ * reduction step placed FIRST (it then travels in the prefetched weight stream; the kernel multiplies
+ * it by 1, so the accumulator starts at exactly the bias).  Gradient (transposed) layers have no bias. */
+uint32_t envidr_packed_layer_floats(int k_order, uint32_t k_in, uint32_t m_out, int with_bias);
+int envidr_pack_layer(const float* W_host, const float* bias_host, uint32_t m_out, uint32_t k_in, int transpose,
+                      int k_order, float* dst_host);
 int envidr_pack_rowvec(const float* v_host, uint32_t m_out, float* dst_host);
 
 /* ---- scene / model description ---------------------------------------------------------------- */
@@ -63,12 +69,18 @@ typedef struct envidr_render_desc {
     float log2_per_level_scale;      /* S                                                         */
     int32_t enabled_levels;          /* <= 0: all levels; else features of levels >= this are 0   */
 
-    /* SDF network 2*L -> 64 -> 64 -> (1 + 12 + 1 + 1), packed (device pointers) */
-    const float* sdf_w[3];           /* w[0] lane order, w[1..2] tile order                       */
-    const float* sdf_b[3];           /* packed row vectors                                        */
-    const float* sdf_w2t;            /* W2^T, tile order                                          */
-    const float* sdf_w1t;            /* W1^T, tile order (64 -> 2*L)                              */
-    const float* sdf_w3_row0;        /* row 0 of W3 (d sdf / d h2) as a packed row vector         */
+    /* Weights, packed (envidr_pack_linear) and concatenated in CONSUMPTION ORDER into one device blob
+     * per pass, each blob zero-padded to a multiple of 4096 floats (one 16 KiB LDS chunk).  The four
+     * waves of a workgroup stream a blob through LDS once per pass (envidr_amd/csrc/mlp_mfma.hip.h).
+     * Every forward layer is packed WITH its bias (envidr_pack_layer), the two gradient layers without.
+     *   sdf_blob  : W1+b (lane order, 32->64) | W2+b (tile, 64->64) | W3+b (tile, 64->15) | W2^T (tile) | W1^T (tile, 64->32)
+     *   env_blob  : E1+b (lane, ide_dim->H) | E2+b (tile, H->H) | E3+b (tile, H->H) | E4+b (tile, H->12)
+     *   head_blob : D1+b (lane, 24->32) | D2+b (tile, 32->3) | S1+b (lane, 28->64) | S2+b (tile, 64->64) | S3+b (tile, 64->3) */
+    const float* sdf_blob;
+    const float* env_blob;
+    const float* head_blob;
+    /* SDF network 2*L -> 64 -> 64 -> (1 + 12 + 1 + 1) */
+    const float* sdf_w3_row0;        /* row 0 of W3 (d sdf / d h2) as a packed row vector (envidr_pack_rowvec) */
     float beta;                      /* Laplace density beta (already clamped to [beta_min, max]) */
     float roughness_bias;            /* -1                                                        */
     float roughness_act_scale;       /* 0.2                                                       */
@@ -77,17 +89,11 @@ typedef struct envidr_render_desc {
     /* environment MLP  ide_dim -> H -> H -> H -> 12 (evaluated twice per sample) */
     uint32_t ide_degree;             /* 4 or 5                                                    */
     uint32_t env_hidden;             /* 160 or 256 (multiple of 32)                               */
-    const float* env_w[4];
-    const float* env_b[4];
     float diffuse_kappa_inv;         /* 0.64                                                      */
     float light_intensity_scale;     /* 1                                                         */
     float intensity_scale;           /* 1                                                         */
 
-    /* diffuse head 24 -> 32 -> 3 and specular head 28 -> 64 -> 64 -> 3 */
-    const float* diffuse_w[2];
-    const float* diffuse_b[2];
-    const float* specular_w[3];
-    const float* specular_b[3];
+    /* diffuse head 24 -> 32 -> 3 and specular head 28 -> 64 -> 64 -> 3: in head_blob */
 
     /* optional environment rotation: w_r and the diffuse normal are multiplied (row vector x
      * matrix) by this row-major 3x3; has_env_rot = 0 skips it (renderer.py:160-161,171-172)      */
