@@ -53,7 +53,7 @@ constexpr uint32_t kMaxGroup = ENVIDR_MAX_GROUP;   // largest number of lanes (c
 struct HashLevelK {
     uint32_t row0, size, stride1, stride2;
     float scale;
-    uint32_t hashed, pow2, enabled;
+    uint32_t hashed, pow2, enabled, slow_mod;
 };
 
 struct RenderArgs {
@@ -167,6 +167,82 @@ __device__ __forceinline__ uint32_t nth_set_bit(unsigned long long mask, uint32_
     return pos;
 }
 
+
+// ---- hash-grid level evaluation split into "issue the gathers" and "interpolate" ------------------
+struct HashStage {
+    float w1[3], dw[3];
+    float2 c[8];
+};
+
+// wrap an index that is known to be < 2 * size (dense levels: res (1 + res + res^2) < 2 res^3) or a
+// hashed index (power-of-two table: mask).  Generic modulo only for table geometries that are neither.
+__device__ __forceinline__ uint32_t wrap_row(uint32_t idx, const HashLevelK& lv) {
+    if (lv.pow2) return idx & (lv.size - 1);
+    if (lv.hashed) return idx % lv.size;
+    return lv.slow_mod ? idx % lv.size : (idx >= lv.size ? idx - lv.size : idx);
+}
+
+__device__ __forceinline__ void hash_prepare(const RenderArgs& a, int l, const float (&x)[3], HashStage& st) {
+    const HashLevelK& lv = a.lv[l];
+    uint32_t cell[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float p = x[d] * lv.scale + 0.0f;
+        cell[d] = (uint32_t)floorf(p);
+        p -= (float)cell[d];
+        st.dw[d] = 6 * p * (1.0f - p);                 // smoothstep'
+        st.w1[d] = p * p * (3.0f - 2.0f * p);          // smoothstep
+    }
+    const float2* table = reinterpret_cast<const float2*>(a.table) + lv.row0;
+    if (lv.hashed) {
+        const uint32_t hx[2] = {cell[0], cell[0] + 1u};
+        const uint32_t hy[2] = {cell[1] * 2654435761u, (cell[1] + 1u) * 2654435761u};
+        const uint32_t hz[2] = {cell[2] * 805459861u, (cell[2] + 1u) * 805459861u};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) st.c[i] = table[wrap_row(hx[i & 1] ^ hy[(i >> 1) & 1] ^ hz[(i >> 2) & 1], lv)];
+    } else {
+        const uint32_t ix[2] = {cell[0], cell[0] + 1u};
+        const uint32_t iy[2] = {cell[1] * lv.stride1, (cell[1] + 1u) * lv.stride1};
+        const uint32_t iz[2] = {cell[2] * lv.stride2, (cell[2] + 1u) * lv.stride2};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) st.c[i] = table[wrap_row(ix[i & 1] + iy[(i >> 1) & 1] + iz[(i >> 2) & 1], lv)];
+    }
+}
+
+__device__ __forceinline__ void hash_finish(const RenderArgs& a, int l, const HashStage& st, float (&out)[2], float (&dydx)[3][2]) {
+    const float scale = a.lv[l].scale;
+    out[0] = out[1] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float w = 1;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) w *= ((i >> d) & 1) ? st.w1[d] : 1 - st.w1[d];
+        out[0] += w * st.c[i].x;
+        out[1] += w * st.c[i].y;
+    }
+#pragma unroll
+    for (int gd = 0; gd < 3; ++gd) {
+        float acc0 = 0, acc1 = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float w = scale;
+            int lo = 0;
+#pragma unroll
+            for (int nd = 0; nd < 2; ++nd) {
+                const int d = nd >= gd ? nd + 1 : nd;
+                const int bit = (j >> nd) & 1;
+                w *= bit ? st.w1[d] : 1 - st.w1[d];
+                lo |= bit << d;
+            }
+            const int hi = lo | (1 << gd);
+            acc0 += w * (st.c[hi].x - st.c[lo].x) * st.dw[gd];
+            acc1 += w * (st.c[hi].y - st.c[lo].y) * st.dw[gd];
+        }
+        dydx[gd][0] = acc0;
+        dydx[gd][1] = acc1;
+    }
+}
+
 // fragment layout of the three weight passes (must match envidr_amd/fused.py and envidr_render.h)
 // (every forward layer carries its bias as one extra leading step; the two gradient layers have none)
 constexpr int kSdfW1 = 0, kSdfW2 = kSdfW1 + lane_layer_frags(16, 2, true), kSdfW3 = kSdfW2 + tile_layer_frags(2, 2, true),
@@ -204,6 +280,7 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     __shared__ __attribute__((aligned(16))) float s_weights[kSharedWeights ? 2 * kChunkFloats : 4];
+    __shared__ float s_jac[(kSharedWeights ? 4 : 1) * kLevels * 6 * 64];
     std::conditional_t<kSharedWeights, WeightPipe, WeightRing<kRingDepth>> wp;
     wp.start(s_weights, lane, wave, a.sdf_blob, kSdfChunks);
     // fragments per pass as the weight source sees them (the ring pads every pass to a multiple of its depth)
@@ -347,26 +424,46 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
         if (!have) { px = py = pz = 0; }
 
         // ================= hash grid: features + Jacobian (per lane) ============================
+        // Software-pipelined over levels: the 8 corner gathers of level l+2 are issued before level l is
+        // interpolated, so two levels' worth of (Infinity-Cache) gather latency hides under the VALU work
+        // of the current one.  Arithmetic per level is eval_level's (grid_core.hip.h), op for op.
+        // The 96 Jacobian entries per sample are parked in LDS ([entry][lane]: conflict-free) until the SDF
+        // backward pass needs them; keeping them in VGPRs across the SDF network spills.
         float feat[2 * kLevels];
-        float jac[kLevels][3][2];
+        float* jac_col = s_jac + (kSharedWeights ? wave * (kLevels * 6 * 64) : 0u) + lane;
         {
             // (xyz + bound) / (2 bound)  -- hashencoder/hashgrid.py:161
             const float x01[3] = {(px + a.mk.bound) / a.bound2, (py + a.mk.bound) / a.bound2, (pz + a.mk.bound) / a.bound2};
             const bool inside = x01[0] >= 0 && x01[0] <= 1 && x01[1] >= 0 && x01[1] <= 1 && x01[2] >= 0 && x01[2] <= 1;
-#pragma unroll
-            for (int l = 0; l < kLevels; ++l) {
-                float o[2] = {0, 0}, g[3][2] = {{0, 0}, {0, 0}, {0, 0}};
-                if (l < (int)a.num_levels && inside) {
-                    LevelGeom<3> geo;
-                    geo.stride[0] = 1; geo.stride[1] = a.lv[l].stride1; geo.stride[2] = a.lv[l].stride2;
-                    geo.size = a.lv[l].size; geo.hashed = a.lv[l].hashed != 0; geo.pow2 = a.lv[l].pow2 != 0;
-                    eval_level<3, 2, true, true, kNtGather>(x01, a.table + (size_t)a.lv[l].row0 * 2, geo, a.lv[l].scale, 0.0f, o, g);
-                }
-                const float m = a.lv[l].enabled ? 1.0f : 0.0f;     // network.py:390-393 level mask
+            // outside the unit cube every level contributes zeros (hashencoder.cu:124-149); evaluating
+            // at a clamped position and masking afterwards keeps the gathers in bounds
+            const float xc[3] = {inside ? x01[0] : 0.5f, inside ? x01[1] : 0.5f, inside ? x01[2] : 0.5f};
+            HashStage s0, s1, s2;      // three rotating stages, named so that every access is a compile-time register
+            hash_prepare(a, 0, xc, s0);
+            hash_prepare(a, 1, xc, s1);
+            __builtin_amdgcn_sched_barrier(0);
+            auto level = [&](auto lc, HashStage& cur, HashStage& ahead) {
+                constexpr int l = decltype(lc)::value;
+                if constexpr (l + 2 < kLevels) hash_prepare(a, l + 2, xc, ahead);
+                __builtin_amdgcn_sched_barrier(0);
+                float o[2], g[3][2];
+                hash_finish(a, l, cur, o, g);
+                const float m = (a.lv[l].enabled && inside) ? 1.0f : 0.0f;     // network.py:390-393 level mask
                 feat[2 * l] = o[0] * m; feat[2 * l + 1] = o[1] * m;
 #pragma unroll
-                for (int d = 0; d < 3; ++d) { jac[l][d][0] = g[d][0] * m; jac[l][d][1] = g[d][1] * m; }
-            }
+                for (int d = 0; d < 3; ++d) {
+                    jac_col[((l * 3 + d) * 2 + 0) * 64] = g[d][0] * m;
+                    jac_col[((l * 3 + d) * 2 + 1) * 64] = g[d][1] * m;
+                }
+            };
+#define ENVIDR_L(n) std::integral_constant<int, n>{}
+            level(ENVIDR_L(0), s0, s2);  level(ENVIDR_L(1), s1, s0);  level(ENVIDR_L(2), s2, s1);
+            level(ENVIDR_L(3), s0, s2);  level(ENVIDR_L(4), s1, s0);  level(ENVIDR_L(5), s2, s1);
+            level(ENVIDR_L(6), s0, s2);  level(ENVIDR_L(7), s1, s0);  level(ENVIDR_L(8), s2, s1);
+            level(ENVIDR_L(9), s0, s2);  level(ENVIDR_L(10), s1, s0); level(ENVIDR_L(11), s2, s1);
+            level(ENVIDR_L(12), s0, s2); level(ENVIDR_L(13), s1, s0); level(ENVIDR_L(14), s2, s1);
+            level(ENVIDR_L(15), s0, s2);
+#undef ENVIDR_L
         }
 
         ENVIDR_TICK(1);   // hash grid
@@ -437,8 +534,8 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
             float s = 0;
 #pragma unroll
             for (int l = 0; l < kLevels; ++l) {
-                s += gfeat[2 * l] * jac[l][d][0];
-                s += gfeat[2 * l + 1] * jac[l][d][1];
+                s += gfeat[2 * l] * jac_col[((l * 3 + d) * 2 + 0) * 64];
+                s += gfeat[2 * l + 1] * jac_col[((l * 3 + d) * 2 + 1) * 64];
             }
             nrm[d] = s / a.bound2;                                                      // d x01 / d xyz
         }
@@ -714,6 +811,13 @@ int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const f
         a.lv[l].stride1 = g.stride[1]; a.lv[l].stride2 = g.stride[2];
         a.lv[l].scale = ls.scale[l];
         a.lv[l].hashed = g.hashed; a.lv[l].pow2 = g.pow2;
+        {
+            // dense levels: the largest index a corner can produce (coordinate res on every axis) must stay below 2 * size
+            // for the conditional-subtract wrap; otherwise fall back to a true modulo
+            const unsigned long long res = ls.resolution[l];
+            const unsigned long long max_idx = res + res * (unsigned long long)g.stride[1] + res * (unsigned long long)g.stride[2];
+            a.lv[l].slow_mod = (!g.hashed && !g.pow2 && max_idx >= 2ull * size) ? 1u : 0u;
+        }
         a.lv[l].enabled = (d->enabled_levels <= 0 || (int32_t)l < d->enabled_levels) ? 1u : 0u;
         ENVIDR_REQUIRE(g.hashed || g.stride[0] == 1, "render_rays: unexpected dense stride");
     }
