@@ -211,7 +211,7 @@ def golden_shading(model, opt, tag, env_rot=None, n=1536, seed=5):
     print(f"[golden] shading_{tag}: {n} samples, mean sigma {float(sigmas.mean()):.2f}, mean roughness {float(rough.mean()):.4f}")
 
 
-def golden_frame(model, opt, tag, H, W, env_rot=None, theta=30.0, phi=-20.0):
+def golden_frame(model, opt, tag, H, W, env_rot=None, theta=30.0, phi=-20.0, extra=None):
     import nerf.render_func.cuda_ray as cuda_ray
     ro, rd = scenes.camera_rays(H, W, theta=theta, phi=phi)
     trace = []
@@ -234,9 +234,31 @@ def golden_frame(model, opt, tag, H, W, env_rot=None, theta=30.0, phi=-20.0):
                         image=g(res["image"]), depth=g(res["depth"]), weights_sum=g(res["weights_sum"]),
                         normal_image=g(res["normal_image"]), diffuse_image=g(res["diffuse_image"]),
                         specular_image=g(res["specular_image"]), roughness_image=g(res["roughness_image"]),
-                        trace=np.array(trace, np.int32))
+                        trace=np.array(trace, np.int32), **(extra or {}))
     print(f"[golden] frame_{tag}: {H}x{W}, {len(trace)} loop iterations, {sum(t[3] for t in trace)} samples, "
           f"hit fraction {float((res['weights_sum'] > 0).float().mean()):.3f}, mean rgb {res['image'].mean(dim=(0, 1)).tolist()}")
+
+
+def golden_relight():
+    """README.md:136-146 relighting: toaster.ini + `--sh_degree 4 --hidden_dim_env 160 --intensity_scale=0.8
+    --roughness_scale=0.8`, with the weights the reference SHIPS: ckpts/rendering_mlps.pth (diffuse / specular /
+    renv MLPs, loaded the way utils.py:509-530 does) and ckpts/env_ckpts/env_net_3.pth as the swapped-in
+    environment.  Geometry (table, sdf_net, bitfield) is the seeded synthetic scene.  The shipped tensors are
+    stored in the fixture under their original key names: they are the test's input data."""
+    scene = scenes.toaster_scene(hidden_env=160, ide_deg=4, seed=4)
+    model, opt = build_reference_model(scene, extra_argv=["--sh_degree", "4", "--hidden_dim_env", "160", "--intensity_scale=0.8",
+                                                          "--roughness_scale=0.8"])
+    mlps = torch.load(REFERENCE / "ckpts/rendering_mlps.pth", map_location="cpu")["model"]
+    env = torch.load(REFERENCE / "ckpts/env_ckpts/env_net_3.pth", map_location="cpu")["model"]
+    sub = lambda prefix: {k[len(prefix):]: v for k, v in mlps.items() if k.startswith(prefix)}
+    model.color_net.load_state_dict(sub("color_net."))
+    model.diffuse_net.load_state_dict(sub("diffuse_net."))
+    model.renv_net.load_state_dict(sub("renv_net."))
+    # extract_env_ckpt (sph_loader.py:372) writes 'env_net' + '0.weight': the ModuleList index follows directly
+    model.env_net.load_state_dict({k[len("env_net"):]: v for k, v in env.items()})
+    extra = {f"mlps/{k}": v.numpy() for k, v in mlps.items()}
+    extra.update({f"env/{k}": v.numpy() for k, v in env.items()})
+    golden_frame(model, opt, "relight_40", 40, 40, theta=75.0, phi=-25.0, extra=extra)
 
 
 def golden_ide():
@@ -305,6 +327,7 @@ def main():
     model4, opt4 = build_reference_model(scene4, extra_argv=["--indir_ref"])
     assert opt4.indir_ref and opt4.use_renv
     golden_frame(model4, opt4, "toaster_indir_40", 40, 40, theta=40.0, phi=-50.0)
+    golden_relight()
 
 
 if __name__ == "__main__":

@@ -125,3 +125,32 @@ def test_indirect_three_pass_matches_reference(fused):
         want = g[key].reshape(H * W, -1)
         err = rel_l2(got, want)
         assert err <= 1e-4, f"{key} (fused={fused}): rel-L2 {err:.3e}"
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_relight_with_shipped_checkpoints(fused):
+    """README.md:136-146 relighting (`--sh_degree 4 --hidden_dim_env 160 --intensity_scale=0.8 --roughness_scale=0.8`):
+    the scene is loaded through the checkpoint reader, the reference's shipped rendering MLPs and environment #3 are
+    transplanted by `load_color_mlps` / `swap_env_path`, and the frame must match what the reference rendered with
+    the same weights (fused kernel variant <4,5> and the operator loop)."""
+    import torch
+    from envidr_amd.nerf import checkpoint
+    from tests import relight
+    g = relight.fixture()
+    scene = scenes.toaster_scene(hidden_env=160, ide_deg=4, seed=4)
+    model, opt = build_model(scene, **relight.OVERRIDES)
+    scene_ckpt = {"model": {k: v.clone() for k, v in model.state_dict().items()}}
+    fresh, _ = build_model(scenes.toaster_scene(hidden_env=160, ide_deg=4, seed=9), **relight.OVERRIDES)
+    info = checkpoint.load_checkpoint(fresh, scene_ckpt, swap_env_path=relight.shipped_state(g, "env"))
+    assert not info["missing_keys"] and not info["unexpected_keys"]
+    checkpoint.load_color_mlps(fresh, relight.shipped_state(g, "mlps"))
+    assert fresh.supports_fused()
+    H, W = int(g["H"]), int(g["W"])
+    ro, rd = scenes.camera_rays(H, W, theta=float(g["theta"]), phi=float(g["phi"]))
+    res = fresh.render(torch.from_numpy(ro).cuda()[None], torch.from_numpy(rd).cuda()[None], staged=True, bg_color=1, perturb=False,
+                       get_normal_image=True, fused=fused, max_steps=opt.max_steps, T_thresh=opt.T_thresh, dt_gamma=opt.dt_gamma)
+    torch.cuda.synchronize()
+    for key in KEYS:
+        got = res[key].detach().cpu().numpy().reshape(H * W, -1)
+        err = rel_l2(got, g[key].reshape(H * W, -1))
+        assert err <= 1e-4, f"{key} (fused={fused}): rel-L2 {err:.3e}"
