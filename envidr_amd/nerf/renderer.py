@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import math
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -98,6 +99,111 @@ class NeRFRenderer(nn.Module):
             r = self.opt.normal_anneal_ratio
             normals = F.normalize(normals * r + (1 - r) * F.normalize(xyzs.detach(), dim=-1, eps=1e-10), dim=-1, eps=1e-10)
         return normals, eikonal
+
+    # ---- occupancy-grid maintenance (reference renderer.py:200-359) ------------------------------
+    def _cell_blocks(self, S):
+        """the H^3 cell lattice in S^3 blocks: (coords [n,3] int32, morton indices [n] int64) per block,
+        block order x-major like the reference's nested loops (it fixes the order random jitter is drawn in)"""
+        dev = self.density_bitfield.device
+        axis = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
+        for xs in axis:
+            for ys in axis:
+                for zs in axis:
+                    coords = torch.stack(torch.meshgrid(xs, ys, zs, indexing="ij"), dim=-1).reshape(-1, 3)
+                    yield coords, raymarching.morton3D(coords).long()
+
+    def _cell_centres(self, coords):
+        """2 c / (H - 1) - 1 per axis, from a host-computed (IEEE fp32) table: device division kernels are not
+        guaranteed correctly rounded, and one ulp in a position is visible through a fine hash level"""
+        c = np.arange(self.grid_size, dtype=np.float32)
+        table = torch.from_numpy(np.float32(2) * c / np.float32(self.grid_size - 1) - np.float32(1)).to(coords.device)
+        return table[coords.long()]
+
+    def _cascade_extent(self, cas):
+        bound = min(2 ** cas, self.bound)
+        return bound, bound / self.grid_size            # (half extent of the cascade cube, half a cell)
+
+    # Random draws of the grid update.  `self.grid_rng` (an object with rand(shape) / randint(high, shape))
+    # replaces the device generator; the parity test uses it to replay the reference's CPU random stream.
+    def _unit_noise(self, ref):
+        rng = getattr(self, "grid_rng", None)
+        if rng is not None:
+            return rng.rand(tuple(ref.shape)).to(ref.device, ref.dtype)
+        return torch.rand_like(ref)
+
+    def _randint(self, high, shape, dev):
+        rng = getattr(self, "grid_rng", None)
+        if rng is not None:
+            return rng.randint(high, tuple(shape)).to(dev)
+        return torch.randint(0, high, tuple(shape), device=dev)
+
+    @torch.no_grad()
+    def mark_untrained_grid(self, poses, intrinsic, S=64):
+        """cells no training camera sees get density -1 (never occupied, never updated).
+        poses [B,4,4] camera-to-world, intrinsic (fx, fy, cx, cy)."""
+        if not self.cuda_ray:
+            return
+        dev = self.density_bitfield.device
+        poses = torch.as_tensor(poses, dtype=torch.float32).to(dev)
+        fx, fy, cx, cy = intrinsic
+        seen = torch.zeros_like(self.density_grid)
+        R, t = poses[:, :3, :3], poses[:, :3, 3]
+        for coords, indices in self._cell_blocks(S):
+            centres = self._cell_centres(coords).unsqueeze(0)                                   # [1,n,3] in [-1,1]
+            for cas in range(self.cascade):
+                bound, half_cell = self._cascade_extent(cas)
+                world = centres * (bound - half_cell)
+                for b0 in range(0, poses.shape[0], S):
+                    cam = (world - t[b0:b0 + S].unsqueeze(1)) @ R[b0:b0 + S]                    # world -> camera (R is c2w)
+                    z = cam[:, :, 2]
+                    inside = (z > 0) & (cam[:, :, 0].abs() < cx / fx * z + half_cell * 2) \
+                        & (cam[:, :, 1].abs() < cy / fy * z + half_cell * 2)
+                    seen[cas, indices] += inside.sum(0).reshape(-1)
+        self.density_grid[seen == 0] = -1
+        return int((seen == 0).sum())
+
+    @torch.no_grad()
+    def update_extra_state(self, decay=0.95, S=128, full_update=False):
+        """refresh density_grid (jittered density query per cell, decayed running max) and re-pack the
+        occupancy bitfield; also folds the marcher's step counter into mean_count."""
+        if not self.cuda_ray:
+            return
+        dev = self.density_bitfield.device
+        fresh = -torch.ones_like(self.density_grid)
+
+        def query(cas, coords, indices):
+            bound, half_cell = self._cascade_extent(cas)
+            xyzs = self._cell_centres(coords) * (bound - half_cell)
+            xyzs += (self._unit_noise(xyzs) * 2 - 1) * half_cell
+            sigmas = self.density(xyzs)["sigma"].reshape(-1).detach()
+            sigmas *= self.density_scale
+            fresh[cas, indices] = sigmas
+
+        if self.iter_density < 16 or full_update:
+            for coords, indices in self._cell_blocks(S):
+                for cas in range(self.cascade):
+                    query(cas, coords, indices)
+        else:
+            # a quarter of the cells at random + as many draws (with repetition) from the occupied ones
+            n = self.grid_size ** 3 // 4
+            for cas in range(self.cascade):
+                coords = self._randint(self.grid_size, (n, 3), dev)
+                indices = raymarching.morton3D(coords).long()
+                occupied = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
+                occupied = occupied[self._randint(occupied.shape[0], (n,), dev)]
+                query(cas, torch.cat([coords, raymarching.morton3D_invert(occupied)], 0), torch.cat([indices, occupied], 0))
+
+        live = (self.density_grid >= 0) & (fresh >= 0)
+        self.density_grid[live] = torch.maximum(self.density_grid[live] * decay, fresh[live])
+        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()       # -1 cells count as empty
+        self.iter_density += 1
+        self.density_bitfield = raymarching.packbits(self.density_grid, min(self.mean_density, self.density_thresh),
+                                                     self.density_bitfield)
+        steps = min(16, self.local_step)
+        if steps > 0:
+            self.mean_count = int(self.step_counter[:steps, 0].sum().item() / steps)
+        self.local_step = 0
+        self.invalidate_fused()
 
     # ---- render ----------------------------------------------------------------------------------
     def fused_renderer(self):

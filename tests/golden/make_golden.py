@@ -261,6 +261,48 @@ def golden_relight():
     golden_frame(model, opt, "relight_40", 40, 40, theta=75.0, phi=-25.0, extra=extra)
 
 
+GRID_SCENE = dict(table_scale=0.3, sdf_bias=0.0, beta=0.05, seed=6)
+GRID_POSES = [(20.0, -30.0), (140.0, -10.0), (260.0, -60.0)]
+
+
+def grid_poses():
+    return np.stack([scenes.nerf_matrix_to_ngp(scenes.pose_spherical(th, ph, 4.0), scale=0.65) for th, ph in GRID_POSES])
+
+
+def golden_grid():
+    """occupancy-grid maintenance run by the reference (renderer.py:200-359): mark_untrained_grid on three
+    cameras, two full updates (the second one exercises the decayed running max), one partial update.
+    Random jitter comes from torch's CPU generator seeded with 21; the GPU test replays that stream."""
+    scene = scenes.toaster_scene(**GRID_SCENE)
+    model, opt = build_reference_model(scene)
+    model.density_grid.zero_()
+    model.density_bitfield.zero_()
+    out = {}
+    stride = 61
+
+    def snap(tag):
+        grid = model.density_grid.numpy()
+        out[f"{tag}/grid_sample"] = grid.reshape(-1)[::stride].astype(F).copy()
+        out[f"{tag}/bitfield"] = model.density_bitfield.numpy().copy()
+        out[f"{tag}/mean_density"] = np.float64(model.mean_density)
+        out[f"{tag}/n_negative"] = np.int64((grid < 0).sum())
+        out[f"{tag}/n_above_10"] = np.int64((grid > 10).sum())
+        print(f"[golden] grid {tag}: mean density {model.mean_density:.4f}, untrained {int((grid < 0).sum())}, "
+              f"occupied bits {int(np.unpackbits(model.density_bitfield.numpy()).sum())}")
+
+    torch.manual_seed(21)
+    model.mark_untrained_grid(grid_poses(), scenes.intrinsics_for(800, 800))
+    snap("marked")
+    model.update_extra_state()
+    snap("full1")
+    model.update_extra_state()
+    snap("full2")
+    model.iter_density = 16
+    model.update_extra_state()
+    snap("partial")
+    np.savez_compressed(OUT / "grid_update.npz", stride=stride, **out)
+
+
 def golden_ide():
     from ide_encoder.ide_encoder import IntegratedDirEncoder
     rng = np.random.default_rng(7)
@@ -328,6 +370,7 @@ def main():
     assert opt4.indir_ref and opt4.use_renv
     golden_frame(model4, opt4, "toaster_indir_40", 40, 40, theta=40.0, phi=-50.0)
     golden_relight()
+    golden_grid()
 
 
 if __name__ == "__main__":
