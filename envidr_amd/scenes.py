@@ -195,3 +195,23 @@ def toaster_scene(table_scale: float = 0.1, shape=None, sdf_bias: float = 0.005,
     mlps["specular"][-1][1][:] -= math.log(3)   # network.py:332: lower specular at init
     bitfield = occupancy_bitfield(shape or shell())
     return SceneParams(bitfield=bitfield, offsets=offsets, per_level_scale=pls, table=table, mlps=mlps, beta=beta)
+
+
+def lego_scene(table_scale: float = 0.1, shape=None, sdf_bias: float = 0.005, beta: float = 0.01, sh_degree: int = 4,
+               seed: int = 0) -> SceneParams:
+    """The BASELINE config-#2 network: hash grid + SDF MLP 32-64-64-15, diffuse MLP 12-32-3 on the
+    geometry feature, specular MLP [SH(view dir), geo_feat, SH(normal), n.v] = 45-64-64-3; no environment network."""
+    rng = np.random.default_rng(seed)
+    offsets, pls = hash_level_offsets()
+    table = np.random.default_rng(seed + 1).uniform(-table_scale, table_scale, size=(int(offsets[-1]), 2)).astype(np.float32)
+    sh = sh_degree ** 2
+    mlps = {
+        "sdf": make_mlp(rng, [32, 64, 64, 15]),
+        "diffuse": make_mlp(rng, [12, 32, 3]),
+        "specular": make_mlp(rng, [sh + 12 + sh + 1, 64, 64, 3]),
+    }
+    mlps["sdf"][-1][1][0] = sdf_bias
+    mlps["specular"][-1][1][:] -= math.log(3)
+    return SceneParams(bitfield=occupancy_bitfield(shape or shell()), offsets=offsets, per_level_scale=pls, table=table,
+                       mlps=mlps, beta=beta)
+

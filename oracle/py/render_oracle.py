@@ -156,6 +156,15 @@ def laplace_density(sdf: torch.Tensor, beta: float, opt: RenderOptions) -> torch
     return alpha * (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / b))
 
 
+def sh_encode(dirs: torch.Tensor, degree: int) -> torch.Tensor:
+    """real spherical harmonics of a direction, degree^2 values (shencoder/sphere_harmonics.py:61-89 ->
+    kernel_sh, shencoder/src/shencoder.cu): C oracle"""
+    d = np.ascontiguousarray(dirs.detach().numpy(), F32)
+    out = np.zeros((d.shape[0], degree * degree), F32)
+    clib.oracle().call("sh_encode_forward", d, out, d.shape[0], 3, degree, None)
+    return torch.from_numpy(out)
+
+
 def shade_samples(scene, xyzs: np.ndarray, dirs: np.ndarray, opt: RenderOptions, env_rot_radian: float | None = None,
                   geometry_only: bool = False) -> dict:
     """all per-sample quantities the render loop composites; numpy in, dict of numpy out."""
@@ -183,6 +192,17 @@ def shade_samples(scene, xyzs: np.ndarray, dirs: np.ndarray, opt: RenderOptions,
         with torch.no_grad():
             gf, n, rough = geo_feat.detach(), normals.detach(), roughness.detach()
             w_o = -d
+            if "env" not in scene.mlps:
+                # BASELINE configs[1]: no environment network, no reflected direction; view direction and
+                # normal enter the specular MLP through the SH encoder (network.py:576-584,660-672)
+                deg = math.isqrt((scene.mlps["specular"][0][0].shape[1] - 13) // 2)
+                n_dot = torch.sum(n * w_o, dim=-1, keepdim=True)
+                c_diffuse = torch.sigmoid(_mlp(scene.mlps["diffuse"], gf)) * 1.0
+                h_c = torch.cat([sh_encode(d, deg), gf, sh_encode(n, deg), n_dot], -1)
+                c_specular = torch.sigmoid(_mlp(scene.mlps["specular"], h_c))
+                rgb = (c_diffuse + c_specular) * opt.intensity_scale
+                out.update({"c_diffuse": c_diffuse, "c_specular": c_specular, "rgb": rgb})
+                return {k: v.detach().numpy() for k, v in out.items()}
             w_r = 2 * torch.sum(w_o * n, dim=-1, keepdim=True) * n - w_o          # renderer.py:38
             n_env = n
             if env_rot_radian is not None:                                       # renderer.py:160-161,171-172

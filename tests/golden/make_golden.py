@@ -137,7 +137,8 @@ def install_reference():
                       "march_rays_train", "composite_rays_train_forward", "composite_rays_train_backward", "march_rays",
                       "composite_rays"])
     he = _RefBackend(["hash_encode_forward", "hash_encode_backward", "hash_encode_second_backward"])
-    for pkg, name, backend in [("raymarching", "_raymarching", rm), ("hashencoder", "_hashencoder", he)]:
+    sh = _RefBackend(["sh_encode_forward", "sh_encode_backward"])
+    for pkg, name, backend in [("raymarching", "_raymarching", rm), ("hashencoder", "_hashencoder", he), ("shencoder", "_shencoder", sh)]:
         ext = types.ModuleType(f"{pkg}._ext")
         setattr(ext, name, backend)
         sys.modules[f"{pkg}._ext"] = ext
@@ -145,12 +146,12 @@ def install_reference():
     sys.path.insert(0, str(REFERENCE))
 
 
-def build_reference_model(scene: scenes.SceneParams, extra_argv=()):
+def build_reference_model(scene: scenes.SceneParams, extra_argv=(), config=None):
     """the reference's own option parser + constructor (main_nerf.py:16,59-78), then our seeded weights."""
     from nerf.options import config_parser
     from nerf.network import NeRFNetwork
     old = sys.argv
-    sys.argv = ["main_nerf.py", "--config", str(REFERENCE / "configs/scenes/toaster.ini"), "--test", *extra_argv]
+    sys.argv = ["main_nerf.py", "--config", str(config or REFERENCE / "configs/scenes/toaster.ini"), "--test", *extra_argv]
     try:
         opt = config_parser()
     finally:
@@ -168,7 +169,10 @@ def build_reference_model(scene: scenes.SceneParams, extra_argv=()):
         model.encoder.embeddings.data = torch.from_numpy(scene.table.copy())
         for name, attr in [("sdf", "sdf_net"), ("env", "env_net"), ("diffuse", "diffuse_net"), ("specular", "color_net"),
                            ("renv", "renv_net")]:
-            net = getattr(model, attr)
+            net = getattr(model, attr, None)
+            if net is None:
+                assert name not in scene.mlps, name
+                continue
             assert len(net) == len(scene.mlps[name]), name
             for lin, (W, b) in zip(net, scene.mlps[name]):
                 assert tuple(lin.weight.shape) == W.shape, (name, lin.weight.shape, W.shape)
@@ -203,10 +207,10 @@ def golden_shading(model, opt, tag, env_rot=None, n=1536, seed=5):
     blend = model.blend_weight
     n_enc, w_r_enc, n_dot, n_env_enc = model.get_color_mlp_extra_params(normals, d, rough, env_rot)
     rgb = model.forward_color(geo, d, n_enc, w_r_enc, n_dot, True, n_env_enc=n_env_enc, r_images=None, roughness=rough)
-    g = lambda t: t.detach().numpy().astype(F)
+    g = lambda t: np.zeros(0, F) if t is None else t.detach().numpy().astype(F)
     np.savez_compressed(OUT / f"shading_{tag}.npz", xyz=xyz, dirs=dirs, env_rot=np.array(np.nan if env_rot is None else env_rot),
                         sdf=g(sdfs), sigma=g(sigmas), geo_feat=g(geo), normal=g(normals), roughness=g(rough), blend=g(blend),
-                        w_r_enc=g(w_r_enc), n_env_enc=g(n_env_enc), n_dot=g(n_dot), c_diffuse=g(model.c_diffuse),
+                        w_r_enc=g(w_r_enc), n_env_enc=g(n_env_enc), n_dot=g(n_dot), n_enc=g(n_enc), c_diffuse=g(model.c_diffuse),
                         c_specular=g(model.c_specular), rgb=g(rgb))
     print(f"[golden] shading_{tag}: {n} samples, mean sigma {float(sigmas.mean()):.2f}, mean roughness {float(rough.mean()):.4f}")
 
@@ -371,6 +375,10 @@ def main():
     golden_frame(model4, opt4, "toaster_indir_40", 40, 40, theta=40.0, phi=-50.0)
     golden_relight()
     golden_grid()
+    # BASELINE configs[1]: no environment network, SH-encoded view direction and normal
+    model2, opt2 = build_reference_model(scenes.lego_scene(seed=8), config=OUT / "lego_like.ini")
+    golden_frame(model2, opt2, "lego_48", 48, 48, theta=110.0, phi=-40.0)
+    golden_shading(model2, opt2, "lego", n=1024)
 
 
 if __name__ == "__main__":

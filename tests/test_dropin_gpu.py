@@ -26,7 +26,7 @@ def build_model(scene, **opt_overrides):
     sd = {"encoder.embeddings": torch.from_numpy(scene.table), "sdf_density.beta": torch.tensor(scene.beta),
           "density_bitfield": torch.from_numpy(scene.bitfield)}
     for name, attr in [("sdf", "sdf_net"), ("env", "env_net"), ("diffuse", "diffuse_net"), ("specular", "color_net"), ("renv", "renv_net")]:
-        for i, (W, b) in enumerate(scene.mlps[name]):
+        for i, (W, b) in enumerate(scene.mlps.get(name, [])):
             sd[f"{attr}.{i}.weight"] = torch.from_numpy(W)
             sd[f"{attr}.{i}.bias"] = torch.from_numpy(b)
     missing, unexpected = m.load_state_dict(sd, strict=False)
@@ -148,6 +148,28 @@ def test_relight_with_shipped_checkpoints(fused):
     H, W = int(g["H"]), int(g["W"])
     ro, rd = scenes.camera_rays(H, W, theta=float(g["theta"]), phi=float(g["phi"]))
     res = fresh.render(torch.from_numpy(ro).cuda()[None], torch.from_numpy(rd).cuda()[None], staged=True, bg_color=1, perturb=False,
+                       get_normal_image=True, fused=fused, max_steps=opt.max_steps, T_thresh=opt.T_thresh, dt_gamma=opt.dt_gamma)
+    torch.cuda.synchronize()
+    for key in KEYS:
+        got = res[key].detach().cpu().numpy().reshape(H * W, -1)
+        err = rel_l2(got, g[key].reshape(H * W, -1))
+        assert err <= 1e-4, f"{key} (fused={fused}): rel-L2 {err:.3e}"
+
+
+LEGO = dict(scale=0.8, encoding_dir="sphere_harmonics", sh_degree=4, wo_viewdir=False, use_env_net=False, use_reflected_dir=False,
+            diffuse_with_env=False, use_renv=False)            # tests/golden/lego_like.ini through the reference's parser
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_config1_no_env_network(fused):
+    """BASELINE configs[1]: hash-grid SDF + diffuse / specular MLPs with SH-encoded view direction and normal"""
+    import torch
+    model, opt = build_model(scenes.lego_scene(seed=8), **LEGO)
+    assert model.color_net[0].weight.shape == (64, 45) and model.env_net is None
+    g = np.load(GOLD / "frame_lego_48.npz")
+    H, W = int(g["H"]), int(g["W"])
+    ro, rd = scenes.camera_rays(H, W, theta=float(g["theta"]), phi=float(g["phi"]))
+    res = model.render(torch.from_numpy(ro).cuda()[None], torch.from_numpy(rd).cuda()[None], staged=True, bg_color=1, perturb=False,
                        get_normal_image=True, fused=fused, max_steps=opt.max_steps, T_thresh=opt.T_thresh, dt_gamma=opt.dt_gamma)
     torch.cuda.synchronize()
     for key in KEYS:

@@ -78,6 +78,25 @@ def test_render_loop_matches_reference_frames(scene, tag):
     assert ro.psnr(res["image"], g["image"].reshape(-1, 3)) > 80
 
 
+def test_config1_no_env_network_matches_reference():
+    """BASELINE configs[1] (tests/golden/lego_like.ini): SH-encoded view direction / normal, no env network"""
+    lego = scenes.lego_scene(seed=8)
+    g = np.load(GOLD / "shading_lego.npz")
+    out = ro.shade_samples(lego, g["xyz"], g["dirs"], ro.RenderOptions())
+    for key, tol in [("sdf", 1e-6), ("sigma", 1e-5), ("geo_feat", 1e-6), ("normal", 1e-5), ("roughness", 1e-6),
+                     ("c_diffuse", 1e-6), ("c_specular", 1e-5), ("rgb", 1e-5)]:
+        assert rel_l2(out[key], g[key].reshape(out[key].shape)) <= tol, key
+    g = np.load(GOLD / "frame_lego_48.npz")
+    H, W = int(g["H"]), int(g["W"])
+    rays_o, rays_d = scenes.camera_rays(H, W, theta=float(g["theta"]), phi=float(g["phi"]))
+    trace = []
+    res = ro.render_rays(lego, rays_o, rays_d, ro.RenderOptions(), None, trace=trace)
+    assert [tuple(t) for t in g["trace"][:, :3]] == trace
+    for key in ["image", "depth", "weights_sum", "normal_image", "diffuse_image", "specular_image", "roughness_image"]:
+        want = g[key].reshape(res[key].shape)
+        assert rel_l2(res[key], want) <= 2e-5, f"{key}: rel-L2 {rel_l2(res[key], want):.3e}"
+
+
 def test_ide_oracle_vs_reference_fp32():
     """C-oracle IDE (exact evaluation of the reference's fp32 table) vs the reference's fp32 torch
     output: agreement to fp32 rounding for l <= 8 and within the reference's documented
