@@ -248,9 +248,13 @@ __device__ __forceinline__ void hash_finish(const RenderArgs& a, int l, const Ha
 constexpr int kSdfW1 = 0, kSdfW2 = kSdfW1 + lane_layer_frags(16, 2, true), kSdfW3 = kSdfW2 + tile_layer_frags(2, 2, true),
               kSdfW2t = kSdfW3 + tile_layer_frags(2, 1, true), kSdfW1t = kSdfW2t + tile_layer_frags(2, 2, false),
               kSdfFrags = kSdfW1t + tile_layer_frags(2, 1, false);
-constexpr int kHeadD1 = 0, kHeadD2 = kHeadD1 + lane_layer_frags(12, 1, true), kHeadS1 = kHeadD2 + tile_layer_frags(1, 1, true),
-              kHeadS2 = kHeadS1 + lane_layer_frags(14, 2, true), kHeadS3 = kHeadS2 + tile_layer_frags(2, 2, true),
-              kHeadFrags = kHeadS3 + tile_layer_frags(2, 1, true);
+// heads: diffuse DSTEPS lane steps -> 32 -> 3, specular SSTEPS lane steps -> 64 -> 64 -> 3 (a lane step = 2 input features)
+template <int DSTEPS, int SSTEPS>
+struct HeadLayout {
+    static constexpr int D1 = 0, D2 = D1 + lane_layer_frags(DSTEPS, 1, true), S1 = D2 + tile_layer_frags(1, 1, true),
+                         S2 = S1 + lane_layer_frags(SSTEPS, 2, true), S3 = S2 + tile_layer_frags(2, 2, true),
+                         Frags = S3 + tile_layer_frags(2, 1, true);
+};
 
 // Weight delivery: 0 = every wave streams the blobs from L2 through its own register ring (single-wave
 // workgroups), 1 = the four waves of a 256-thread workgroup share one LDS stream.  Measured at fp32:
@@ -271,8 +275,19 @@ constexpr bool kNtGather = ENVIDR_NT_GATHER != 0;
 constexpr uint32_t kBlockThreads = kSharedWeights ? 256 : 64;
 constexpr int ring_padded(int frags) { return (frags + kRingDepth - 1) / kRingDepth * kRingDepth; }
 
-template <int IDE_DEG, int ENV_T>
+// Two network families:
+//   SH_DEG == 0: environment-MLP family (toaster.ini / neural_renderer.ini): IDE degree IDE_DEG, env hidden 32 ENV_T
+//   SH_DEG  > 0: no environment network (BASELINE configs[1]): diffuse head on geo_feat, specular head on
+//                [SH(view dir) | geo_feat | SH(normal) | n.v] with SH "degree" SH_DEG (SH_DEG^2 values each)
+template <int IDE_DEG, int ENV_T, int SH_DEG>
 __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const RenderArgs a) {
+    constexpr bool kEnvNet = SH_DEG == 0;
+    constexpr int kShDim = SH_DEG * SH_DEG;
+    constexpr int kDiffIn = kEnvNet ? 24 : 12, kSpecIn = kEnvNet ? 28 : 2 * kShDim + 13;
+    constexpr int kDSteps = (kDiffIn + 1) / 2, kSSteps = (kSpecIn + 1) / 2;
+    using Head = HeadLayout<kDSteps, kSSteps>;
+    constexpr int kHeadD1 = Head::D1, kHeadD2 = Head::D2, kHeadS1 = Head::S1, kHeadS2 = Head::S2, kHeadS3 = Head::S3,
+                  kHeadFrags = Head::Frags;
     constexpr int TERMS = ide_terms(IDE_DEG);      // IDE_DIM = 2 * TERMS input features, TERMS lane-order steps
     constexpr int kEnv0 = 0, kEnv1 = kEnv0 + lane_layer_frags(TERMS, ENV_T, true), kEnv2 = kEnv1 + tile_layer_frags(ENV_T, ENV_T, true),
                   kEnv3 = kEnv2 + tile_layer_frags(ENV_T, ENV_T, true), kEnvFrags = kEnv3 + tile_layer_frags(ENV_T, 1, true);
@@ -485,7 +500,8 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
 #pragma unroll
                 for (int s = 0; s < kLevels; ++s) in[s] = grp ? inB[s] : inA[s];
                 f32x16 h1[2], h2[2], o3[1];
-                wp.begin_pass(a.sdf_blob, kSdfChunks, grp == 0 ? a.sdf_blob : a.env_blob, grp == 0 ? kSdfChunks : kEnvChunks);
+                wp.begin_pass(a.sdf_blob, kSdfChunks, grp == 0 ? a.sdf_blob : (kEnvNet ? a.env_blob : a.head_blob),
+                              grp == 0 ? kSdfChunks : (kEnvNet ? kEnvChunks : kHeadChunks));
                 pipe_layer_from_lanes<kLevels, 2, kSdfW1, kSdfN>(wp, lane, in, h1);
                 pipe_layer_from_tiles<2, 2, kSdfW2, kSdfN, true>(wp, lane, h1, h2);
                 pipe_layer_from_tiles<2, 1, kSdfW3, kSdfN, true>(wp, lane, h2, o3);
@@ -565,6 +581,7 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
         ENVIDR_TICK(3);   // geometry terms
         // ================= environment MLP on IDE(normal) and IDE(reflection) =====================
         float env_n[12], env_r[12];
+        if constexpr (kEnvNet)
 #pragma unroll 1
         for (int enc = 0; enc < 2; ++enc) {
             const float vx = enc ? wr[0] : nenv[0], vy = enc ? wr[1] : nenv[1], vz = enc ? wr[2] : nenv[2];
@@ -617,28 +634,42 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
         // ================= diffuse and specular heads ============================================
         float cd[3], cs[3];
         {
-            // diffuse input [geo_feat | env(normal)] (24), specular input [geo_feat | normal | env(refl) | n.v] (28)
-            float din[24], sin_[28];
+            // env family : diffuse input [geo_feat | env(normal)] (24), specular input [geo_feat | normal | env(refl) | n.v] (28)
+            // no-env family: diffuse input geo_feat (12), specular input [SH(d) | geo_feat | SH(normal) | n.v] (network.py:576-584)
+            float din[2 * kDSteps], sin_[2 * kSSteps];
+            if constexpr (kEnvNet) {
 #pragma unroll
-            for (int i = 0; i < 12; ++i) { din[i] = geo[i]; din[12 + i] = env_n[i]; sin_[i] = geo[i]; sin_[15 + i] = env_r[i]; }
-            sin_[12] = nrm[0]; sin_[13] = nrm[1]; sin_[14] = nrm[2]; sin_[27] = ndot;
+                for (int i = 0; i < 12; ++i) { din[i] = geo[i]; din[12 + i] = env_n[i]; sin_[i] = geo[i]; sin_[15 + i] = env_r[i]; }
+                sin_[12] = nrm[0]; sin_[13] = nrm[1]; sin_[14] = nrm[2]; sin_[27] = ndot;
+            } else {
+                float shd[kShDim ? kShDim : 1], shn[kShDim ? kShDim : 1];
+                sh_eval<(SH_DEG ? SH_DEG : 1), false>(rg.dx, rg.dy, rg.dz, shd, nullptr, nullptr, nullptr);
+                sh_eval<(SH_DEG ? SH_DEG : 1), false>(nrm[0], nrm[1], nrm[2], shn, nullptr, nullptr, nullptr);
 #pragma unroll
-            for (int s = 0; s < 12; ++s) pack_pair(din[2 * s], din[2 * s + 1]);
+                for (int i = 0; i < 12; ++i) { din[i] = geo[i]; sin_[kShDim + i] = geo[i]; }
 #pragma unroll
-            for (int s = 0; s < 14; ++s) pack_pair(sin_[2 * s], sin_[2 * s + 1]);
+                for (int i = 0; i < kShDim; ++i) { sin_[i] = shd[i]; sin_[kShDim + 12 + i] = shn[i]; }
+                sin_[2 * kShDim + 12] = ndot;
+#pragma unroll
+                for (int i = kSpecIn; i < 2 * kSSteps; ++i) sin_[i] = 0;      // odd input width: zero pad (weights are zero there too)
+            }
+#pragma unroll
+            for (int s = 0; s < kDSteps; ++s) pack_pair(din[2 * s], din[2 * s + 1]);
+#pragma unroll
+            for (int s = 0; s < kSSteps; ++s) pack_pair(sin_[2 * s], sin_[2 * s + 1]);
             f32x16 dA, dB, sA, sB;
 #pragma unroll 1
             for (int grp = 0; grp < 2; ++grp) {
-                float in_d[12], in_s[14];
+                float in_d[kDSteps], in_s[kSSteps];
 #pragma unroll
-                for (int s = 0; s < 12; ++s) in_d[s] = grp ? din[2 * s + 1] : din[2 * s];
+                for (int s = 0; s < kDSteps; ++s) in_d[s] = grp ? din[2 * s + 1] : din[2 * s];
 #pragma unroll
-                for (int s = 0; s < 14; ++s) in_s[s] = grp ? sin_[2 * s + 1] : sin_[2 * s];
+                for (int s = 0; s < kSSteps; ++s) in_s[s] = grp ? sin_[2 * s + 1] : sin_[2 * s];
                 f32x16 d1[1], d2[1], s1[2], s2[2], s3[1];
                 wp.begin_pass(a.head_blob, kHeadChunks, grp == 0 ? a.head_blob : a.sdf_blob, grp == 0 ? kHeadChunks : kSdfChunks);
-                pipe_layer_from_lanes<12, 1, kHeadD1, kHeadN>(wp, lane, in_d, d1);
+                pipe_layer_from_lanes<kDSteps, 1, kHeadD1, kHeadN>(wp, lane, in_d, d1);
                 pipe_layer_from_tiles<1, 1, kHeadD2, kHeadN, true>(wp, lane, d1, d2);
-                pipe_layer_from_lanes<14, 2, kHeadS1, kHeadN>(wp, lane, in_s, s1);
+                pipe_layer_from_lanes<kSSteps, 2, kHeadS1, kHeadN>(wp, lane, in_s, s1);
                 pipe_layer_from_tiles<2, 2, kHeadS2, kHeadN, true>(wp, lane, s1, s2);
                 pipe_layer_from_tiles<2, 1, kHeadS3, kHeadN, true>(wp, lane, s2, s3);
                 wp.template end_pass<kHeadFrags>();
@@ -790,7 +821,7 @@ int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const f
     ENVIDR_REQUIRE(d->num_levels >= 1 && d->num_levels <= ENVIDR_MAX_LEVELS, "render_rays: num_levels %u not in [1,16]", d->num_levels);
     ENVIDR_REQUIRE(d->cascades >= 1 && d->grid_size >= 1 && d->max_steps >= 1, "render_rays: bad grid parameters");
     ENVIDR_REQUIRE(d->beta > 0, "render_rays: beta must be positive");
-    ENVIDR_REQUIRE(d->sdf_blob && d->env_blob && d->head_blob && d->sdf_w3_row0, "render_rays: null weight blob");
+    ENVIDR_REQUIRE(d->sdf_blob && d->head_blob && d->sdf_w3_row0 && (d->env_blob || d->dir_sh_degree), "render_rays: null weight blob");
     ENVIDR_REQUIRE(d->num_levels == ENVIDR_MAX_LEVELS, "render_rays: the fused kernel is built for 16 hash levels");
 
     RenderArgs a;
@@ -865,11 +896,16 @@ int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const f
     const uint32_t waves_per_block = kBlockThreads / 64;
     const uint32_t blocks = std::min((uint32_t)device_cu_count() * (4 / waves_per_block), ceil_div(N, kBlockThreads));
     const dim3 grid(blocks), block(kBlockThreads);
-#define ENVIDR_LAUNCH(DEG, HT) hipLaunchKernelGGL((k_render_persistent<DEG, HT>), grid, block, 0, s, a)
-    if (d->ide_degree == 5 && d->env_hidden == 256) ENVIDR_LAUNCH(5, 8);
-    else if (d->ide_degree == 4 && d->env_hidden == 160) ENVIDR_LAUNCH(4, 5);
-    else if (d->ide_degree == 5 && d->env_hidden == 128) ENVIDR_LAUNCH(5, 4);
-    else if (d->ide_degree == 4 && d->env_hidden == 128) ENVIDR_LAUNCH(4, 4);
+#define ENVIDR_LAUNCH(DEG, HT, SH) hipLaunchKernelGGL((k_render_persistent<DEG, HT, SH>), grid, block, 0, s, a)
+    if (d->dir_sh_degree == 4) ENVIDR_LAUNCH(4, 0, 4);
+    else if (d->dir_sh_degree != 0) {
+        set_error("render_rays: unsupported dir_sh_degree=%u (no-environment family is built for SH degree 4)", d->dir_sh_degree);
+        return ENVIDR_EINVAL;
+    }
+    else if (d->ide_degree == 5 && d->env_hidden == 256) ENVIDR_LAUNCH(5, 8, 0);
+    else if (d->ide_degree == 4 && d->env_hidden == 160) ENVIDR_LAUNCH(4, 5, 0);
+    else if (d->ide_degree == 5 && d->env_hidden == 128) ENVIDR_LAUNCH(5, 4, 0);
+    else if (d->ide_degree == 4 && d->env_hidden == 128) ENVIDR_LAUNCH(4, 4, 0);
     else {
         set_error("render_rays: unsupported (ide_degree=%u, env_hidden=%u); built variants: (5,256) (4,160) (5,128) (4,128)",
                   d->ide_degree, d->env_hidden);

@@ -34,7 +34,7 @@ class RenderDesc(ctypes.Structure):
         ("roughness_scale", ctypes.c_float),
         ("ide_degree", ctypes.c_uint32), ("env_hidden", ctypes.c_uint32),
         ("diffuse_kappa_inv", ctypes.c_float), ("light_intensity_scale", ctypes.c_float), ("intensity_scale", ctypes.c_float),
-        ("has_env_rot", ctypes.c_int32), ("env_rot", ctypes.c_float * 9),
+        ("has_env_rot", ctypes.c_int32), ("env_rot", ctypes.c_float * 9), ("dir_sh_degree", ctypes.c_uint32),
     ]
 
 
@@ -57,6 +57,7 @@ class FusedOptions:
     bg_color: float = 1.0
     base_resolution: int = 16
     enabled_levels: int = -1
+    dir_sh_degree: int = 0       # > 0: no environment MLP, SH-encoded view direction / normal (BASELINE configs[1])
     beta_min: float = 0.0005
     beta_max: float = 1.0
     roughness_bias: float = -1.0
@@ -138,7 +139,9 @@ class FusedRenderer:
     """Device-resident scene + one-launch renderer.
 
     mlps: dict with keys "sdf" (3 layers), "env" (4), "diffuse" (2), "specular" (3); each a list of
-    (weight [out,in], bias [out]) as numpy arrays or tensors (nn.Linear layout).
+    (weight [out,in], bias [out]) as numpy arrays or tensors (nn.Linear layout).  Without an "env" entry the
+    model is the no-environment family (BASELINE configs[1]): diffuse 12->32->3 on geo_feat, specular
+    [SH(view dir) | geo_feat | SH(normal) | n.v] -> 64 -> 64 -> 3 with SH degree `opt.dir_sh_degree`.
     """
 
     def __init__(self, bitfield, table, offsets, per_level_scale: float, mlps: dict, beta: float,
@@ -165,16 +168,25 @@ class FusedRenderer:
         self.num_levels = offsets.shape[0] - 1
         if self.num_levels > MAX_LEVELS or self.table.shape[1] != 2:
             raise _lib.EnvidrError("fused renderer supports hash grids with <= 16 levels of 2 features")
-        sdf, env, dif, spc = mlps["sdf"], mlps["env"], mlps["diffuse"], mlps["specular"]
-        if len(sdf) != 3 or len(env) != 4 or len(dif) != 2 or len(spc) != 3:
+        sdf, env, dif, spc = mlps["sdf"], mlps.get("env"), mlps["diffuse"], mlps["specular"]
+        if len(sdf) != 3 or (env is not None and len(env) != 4) or len(dif) != 2 or len(spc) != 3:
             raise _lib.EnvidrError("fused renderer expects sdf/env/diffuse/specular MLPs of 3/4/2/3 layers")
         feat = 2 * self.num_levels
         if _np32(sdf[0][0]).shape != (64, feat) or _np32(sdf[1][0]).shape != (64, 64) or _np32(sdf[2][0]).shape[1] != 64:
             raise _lib.EnvidrError("fused renderer expects the SDF network 2L -> 64 -> 64 -> 15")
-        env_hidden = _np32(env[0][0]).shape[0]
-        ide_dim = (2 ** self.opt.ide_degree - 1 + self.opt.ide_degree) * 2
-        if _np32(env[0][0]).shape[1] != ide_dim:
-            raise _lib.EnvidrError(f"env MLP input {_np32(env[0][0]).shape[1]} != IDE dim {ide_dim} of degree {self.opt.ide_degree}")
+        if env is not None:
+            env_hidden = _np32(env[0][0]).shape[0]
+            ide_dim = (2 ** self.opt.ide_degree - 1 + self.opt.ide_degree) * 2
+            if _np32(env[0][0]).shape[1] != ide_dim:
+                raise _lib.EnvidrError(f"env MLP input {_np32(env[0][0]).shape[1]} != IDE dim {ide_dim} of degree {self.opt.ide_degree}")
+            want_d, want_s, sh_degree = 24, 28, 0
+        else:
+            env_hidden, sh_degree = 0, int(self.opt.dir_sh_degree)
+            if sh_degree <= 0:
+                raise _lib.EnvidrError("a model without an environment MLP needs FusedOptions.dir_sh_degree (SH degree of view dir / normal)")
+            want_d, want_s = 12, 2 * sh_degree ** 2 + 13
+        if _np32(dif[0][0]).shape != (32, want_d) or _np32(spc[0][0]).shape != (64, want_s):
+            raise _lib.EnvidrError(f"fused renderer expects diffuse {want_d}->32->3 and specular {want_s}->64->64->3 heads")
 
         d = RenderDesc()
         d.density_bitfield = self.bitfield.data_ptr()
@@ -200,7 +212,8 @@ class FusedRenderer:
         L = lambda Wb, order: pack_layer(Wb[0], Wb[1], order)
         d.sdf_blob = blob([L(sdf[0], 0), L(sdf[1], 1), L(sdf[2], 1),
                            pack_layer(sdf[1][0], None, 1, transpose=True), pack_layer(sdf[0][0], None, 1, transpose=True)])
-        d.env_blob = blob([L(env[0], 0)] + [L(env[i], 1) for i in (1, 2, 3)])
+        d.env_blob = blob([L(env[0], 0)] + [L(env[i], 1) for i in (1, 2, 3)]) if env is not None else None
+        d.dir_sh_degree = sh_degree
         d.head_blob = blob([L(dif[0], 0), L(dif[1], 1), L(spc[0], 0), L(spc[1], 1), L(spc[2], 1)])
         d.sdf_w3_row0 = up(pack_rowvec(_np32(sdf[2][0])[0])).data_ptr()
         d.beta = float(min(max(beta, self.opt.beta_min), self.opt.beta_max))     # LaplaceDensity.get_beta clamp

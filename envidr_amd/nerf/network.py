@@ -65,6 +65,7 @@ class NeRFNetwork(NeRFRenderer):
         if not opt.use_sdf or opt.use_neus_sdf or opt.geometric_init or opt.skip_layers or opt.env_sph_mode:
             raise NotImplementedError("only the SDF + Laplace-density configuration family (toaster.ini / neural_renderer.ini) is implemented")
         self.num_layers, self.hidden_dim, self.geo_feat_dim = num_layers, hidden_dim, geo_feat_dim
+        self._encoding_dir = encoding_dir
         self.num_layers_color, self.hidden_dim_color = num_layers_color, hidden_dim_color
         self.roughness_bias = roughness_bias
         self.encoder, self.in_dim = get_encoder(opt.encoding_pos, level_dim=opt.level_dim,
@@ -223,7 +224,12 @@ class NeRFNetwork(NeRFRenderer):
                     and o.use_reflected_dir and o.encoding_ref == "integrated_dir" and o.num_layers_diffuse == 2
                     and o.hidden_dim_diffuse == 32 and o.num_layers_color == 3 and o.hidden_dim_color == 64
                     and o.color_act == "sigmoid" and o.normal_anneal_ratio >= 1)
-        return bool(hash_ok and net_ok and shade_ok and r_images is None and not geometry_only and self.bg_radius <= 0
+        # the no-environment family (BASELINE configs[1]): SH-encoded view direction and normal into the specular head
+        plain_ok = (o.use_diffuse and not o.diffuse_only and not o.diffuse_with_env and not o.use_env_net and not o.use_reflected_dir
+                    and not o.wo_viewdir and self._encoding_dir == "sphere_harmonics" and o.sh_degree == 4 and o.normal_with_mlp
+                    and o.use_n_dot_viewdir and o.num_layers_diffuse == 2 and o.hidden_dim_diffuse == 32 and o.num_layers_color == 3
+                    and o.hidden_dim_color == 64 and o.color_act == "sigmoid" and o.normal_anneal_ratio >= 1)
+        return bool(hash_ok and net_ok and (shade_ok or plain_ok) and r_images is None and not geometry_only and self.bg_radius <= 0
                     and not self.training)
 
     def _build_fused(self):
@@ -234,10 +240,12 @@ class NeRFNetwork(NeRFRenderer):
                           base_resolution=o.base_resolution, enabled_levels=o.enabled_levels, beta_min=o.beta_min,
                           beta_max=o.beta_max, roughness_bias=self.roughness_bias, roughness_act_scale=o.roughness_act_scale,
                           roughness_scale=o.roughness_scale, ide_degree=o.sh_degree, diffuse_kappa_inv=o.diffuse_kappa_inv,
-                          light_intensity_scale=o.light_intensity_scale, intensity_scale=o.intensity_scale)
+                          light_intensity_scale=o.light_intensity_scale, intensity_scale=o.intensity_scale,
+                          dir_sh_degree=0 if self.use_env_net else o.sh_degree)
         pairs = lambda net: [(l.weight.detach(), l.bias.detach()) for l in net]
-        mlps = {"sdf": pairs(self.sdf_net), "env": pairs(self.env_net), "diffuse": pairs(self.diffuse_net),
-                "specular": pairs(self.color_net)}
+        mlps = {"sdf": pairs(self.sdf_net), "diffuse": pairs(self.diffuse_net), "specular": pairs(self.color_net)}
+        if self.use_env_net:
+            mlps["env"] = pairs(self.env_net)
         return FusedRenderer(self.density_bitfield, self.encoder.embeddings.detach(), self.encoder.offsets.cpu().numpy(),
                              self.encoder.per_level_scale, mlps, float(self.sdf_density.beta.detach()), fo,
                              device=self.density_bitfield.device)

@@ -99,6 +99,15 @@ typedef struct envidr_render_desc {
      * matrix) by this row-major 3x3; has_env_rot = 0 skips it (renderer.py:160-161,171-172)      */
     int32_t has_env_rot;
     float env_rot[9];
+
+    /* Network family without an environment MLP (BASELINE configs[1]; network.py:576-584 with use_env_net,
+     * use_reflected_dir, diffuse_with_env and wo_viewdir off, encoding_dir = sphere_harmonics):
+     *   0     : the environment-MLP family described above;
+     *   1..8  : SH "degree" of the view-direction / normal encoders (deg^2 values each).  Then env_blob, ide_degree,
+     *           env_hidden and the env rotation are ignored and head_blob is
+     *             D1+b (lane, 12->32) | D2+b (tile, 32->3) | S1+b (lane, (2 deg^2 + 13)->64) | S2+b (tile) | S3+b (tile, 64->3)
+     *           with specular input [SH(d) | geo_feat | SH(normal) | n.v].  Built: degree 4. */
+    uint32_t dir_sh_degree;
 } envidr_render_desc;
 
 /* ---- per-call outputs (device pointers; any optional pointer may be NULL) --------------------- */

@@ -89,3 +89,25 @@ def test_fused_edge_cases(renderer):
     assert torch.allclose(one["image"][0], res["image"][31], atol=0, rtol=0)   # a ray's result does not depend on its batch
     # empty batch is a no-op
     renderer.render(torch.zeros(0, 3, device="cuda"), torch.zeros(0, 3, device="cuda"))
+
+
+def test_fused_no_env_family_matches_reference_and_oracle():
+    """BASELINE configs[1] kernel variant <.,0,4>: SH(view dir) / SH(normal) into the specular head, no env MLP"""
+    from envidr_amd.fused import FusedOptions, FusedRenderer
+    from oracle.py import render_oracle as ro
+    lego = scenes.lego_scene(seed=8)
+    r = FusedRenderer.from_scene(lego, FusedOptions(dir_sh_degree=4))
+    g = np.load(GOLD / "frame_lego_48.npz")
+    H, W = int(g["H"]), int(g["W"])
+    rays_o, rays_d = scenes.camera_rays(H, W, theta=float(g["theta"]), phi=float(g["phi"]))
+    out = _render(r, rays_o, rays_d)
+    for key in KEYS:
+        err = rel_l2(out[key], g[key].reshape(out[key].shape))
+        assert err <= 1e-4, f"{key} vs reference frame: rel-L2 {err:.3e}"
+    rays_o, rays_d = scenes.camera_rays(40, 40, theta=15.0, phi=-60.0)
+    want = ro.render_rays(lego, rays_o, rays_d, ro.RenderOptions(), None, force_n_step=1)
+    out = _render(r, rays_o, rays_d)
+    assert want["n_samples"] <= int(out["stats"][0]) <= want["n_samples"] * 1.05 + 512
+    for key in KEYS:
+        err = rel_l2(out[key], want[key].reshape(out[key].shape))
+        assert err <= 2e-5, f"{key} vs oracle: rel-L2 {err:.3e}"
