@@ -41,10 +41,6 @@ using namespace envidr;
 namespace {
 
 constexpr int kLevels = ENVIDR_MAX_LEVELS;
-#ifndef ENVIDR_UNROLL_ENV
-#define ENVIDR_UNROLL_ENV 1
-#endif
-constexpr bool kUnrollEnv = ENVIDR_UNROLL_ENV != 0;
 #ifndef ENVIDR_MAX_GROUP
 #define ENVIDR_MAX_GROUP 8
 #endif
@@ -268,12 +264,144 @@ constexpr bool kSharedWeights = ENVIDR_SHARED_WEIGHTS != 0;
 #define ENVIDR_RING_DEPTH 32
 #endif
 constexpr int kRingDepth = ENVIDR_RING_DEPTH;
-#ifndef ENVIDR_NT_GATHER
-#define ENVIDR_NT_GATHER 0
-#endif
-constexpr bool kNtGather = ENVIDR_NT_GATHER != 0;
 constexpr uint32_t kBlockThreads = kSharedWeights ? 256 : 64;
 constexpr int ring_padded(int frags) { return (frags + kRingDepth - 1) / kRingDepth * kRingDepth; }
+
+// ---- shading of one sample per lane: environment MLP twice (IDE of the rotated normal and of the reflected
+// direction), then the diffuse and specular heads (network.py:524-698).  Shared by the persistent render kernel and
+// the shade-only kernel.  The weight source `wp` must already be streaming env_blob (env family) or head_blob
+// (no-env family) when this is entered; on return it is streaming c.next_blob.
+struct ShadeConsts {
+    const float* env_blob;
+    const float* head_blob;
+    const float* next_blob;      // the blob the caller's next pass consumes
+    uint32_t next_chunks;
+    float kappa_diffuse, light_scale;
+};
+
+template <int IDE_DEG, int ENV_T, int SH_DEG, class WP, class Tick>
+__device__ __forceinline__ void shade_sample(WP& wp, const uint32_t lane, const ShadeConsts c, const float (&nrm)[3],
+                                             const float (&nenv)[3], const float (&wr)[3], const float (&vd)[3], const float ndot,
+                                             const float (&geo)[12], const float rough, float (&cd)[3], float (&cs)[3], Tick&& tick) {
+    constexpr bool kEnvNet = SH_DEG == 0;
+    constexpr int kShDim = SH_DEG * SH_DEG;
+    constexpr int kDiffIn = kEnvNet ? 24 : 12, kSpecIn = kEnvNet ? 28 : 2 * kShDim + 13;
+    constexpr int kDSteps = (kDiffIn + 1) / 2, kSSteps = (kSpecIn + 1) / 2;
+    using Head = HeadLayout<kDSteps, kSSteps>;
+    constexpr int kHeadD1 = Head::D1, kHeadD2 = Head::D2, kHeadS1 = Head::S1, kHeadS2 = Head::S2, kHeadS3 = Head::S3,
+                  kHeadFrags = Head::Frags;
+    constexpr int TERMS = ide_terms(IDE_DEG);
+    constexpr int kEnv0 = 0, kEnv1 = kEnv0 + lane_layer_frags(TERMS, ENV_T, true), kEnv2 = kEnv1 + tile_layer_frags(ENV_T, ENV_T, true),
+                  kEnv3 = kEnv2 + tile_layer_frags(ENV_T, ENV_T, true), kEnvFrags = kEnv3 + tile_layer_frags(ENV_T, 1, true);
+    constexpr uint32_t kEnvChunks = pass_chunks(kEnvFrags), kHeadChunks = pass_chunks(kHeadFrags);
+    constexpr int kEnvN = ring_padded(kEnvFrags), kHeadN = ring_padded(kHeadFrags);
+    // ================= environment MLP on IDE(normal) and IDE(reflection) =====================
+    float env_n[12], env_r[12];
+    if constexpr (kEnvNet)
+#pragma unroll 1
+    for (int enc = 0; enc < 2; ++enc) {
+        const float vx = enc ? wr[0] : nenv[0], vy = enc ? wr[1] : nenv[1], vz = enc ? wr[2] : nenv[2];
+        const float kinv = enc ? rough : c.kappa_diffuse;
+        float code[2 * TERMS];
+        ide_eval<IDE_DEG>(vx, vy, vz, kinv, [&](int j, float re, float im) {
+            code[j] = re * c.light_scale;
+            code[TERMS + j] = im * c.light_scale;
+        });
+#pragma unroll
+        for (int s = 0; s < TERMS; ++s) pack_pair(code[2 * s], code[2 * s + 1]);
+        tick(4);   // IDE
+        f32x16 outA, outB;
+#pragma unroll 1
+        for (int grp = 0; grp < 2; ++grp) {
+            float in[TERMS];
+#pragma unroll
+            for (int s = 0; s < TERMS; ++s) in[s] = grp ? code[2 * s + 1] : code[2 * s];
+            f32x16 ha[ENV_T], hb[ENV_T], o[1];
+            const bool last = enc == 1 && grp == 1;
+            wp.begin_pass(c.env_blob, kEnvChunks, last ? c.head_blob : c.env_blob, last ? kHeadChunks : kEnvChunks);
+            pipe_layer_from_lanes<TERMS, ENV_T, kEnv0, kEnvN>(wp, lane, in, ha);
+            pipe_layer_from_tiles<ENV_T, ENV_T, kEnv1, kEnvN, true>(wp, lane, ha, hb);
+            pipe_layer_from_tiles<ENV_T, ENV_T, kEnv2, kEnvN, true>(wp, lane, hb, ha);
+            pipe_layer_from_tiles<ENV_T, 1, kEnv3, kEnvN, true>(wp, lane, ha, o);
+            wp.template end_pass<kEnvFrags>();
+            if (grp == 0) outA = o[0]; else outB = o[0];
+        }
+        tick(5);   // env mlp
+        float e[16];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float u = outA[r], v = outB[r];
+            unpack_pair(u, v);
+            e[tile_row(r, 0)] = u; e[tile_row(r, 1)] = v;     // rows 0-3, 8-11 and 4-7, 12-15
+        }
+        float e12[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) e12[i] = e[i];
+        normalize_n<12>(e12, 1e-12f);                                               // network.py:541,600
+        if (enc == 0) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) env_n[i] = e12[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) env_r[i] = e12[i];
+        }
+    }
+
+    // ================= diffuse and specular heads ============================================
+    {
+        // env family : diffuse input [geo_feat | env(normal)] (24), specular input [geo_feat | normal | env(refl) | n.v] (28)
+        // no-env family: diffuse input geo_feat (12), specular input [SH(d) | geo_feat | SH(normal) | n.v] (network.py:576-584)
+        float din[2 * kDSteps], sin_[2 * kSSteps];
+        if constexpr (kEnvNet) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { din[i] = geo[i]; din[12 + i] = env_n[i]; sin_[i] = geo[i]; sin_[15 + i] = env_r[i]; }
+            sin_[12] = nrm[0]; sin_[13] = nrm[1]; sin_[14] = nrm[2]; sin_[27] = ndot;
+        } else {
+            float shd[kShDim ? kShDim : 1], shn[kShDim ? kShDim : 1];
+            sh_eval<(SH_DEG ? SH_DEG : 1), false>(vd[0], vd[1], vd[2], shd, nullptr, nullptr, nullptr);
+            sh_eval<(SH_DEG ? SH_DEG : 1), false>(nrm[0], nrm[1], nrm[2], shn, nullptr, nullptr, nullptr);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { din[i] = geo[i]; sin_[kShDim + i] = geo[i]; }
+#pragma unroll
+            for (int i = 0; i < kShDim; ++i) { sin_[i] = shd[i]; sin_[kShDim + 12 + i] = shn[i]; }
+            sin_[2 * kShDim + 12] = ndot;
+#pragma unroll
+            for (int i = kSpecIn; i < 2 * kSSteps; ++i) sin_[i] = 0;      // odd input width: zero pad (weights are zero there too)
+        }
+#pragma unroll
+        for (int s = 0; s < kDSteps; ++s) pack_pair(din[2 * s], din[2 * s + 1]);
+#pragma unroll
+        for (int s = 0; s < kSSteps; ++s) pack_pair(sin_[2 * s], sin_[2 * s + 1]);
+        f32x16 dA, dB, sA, sB;
+#pragma unroll 1
+        for (int grp = 0; grp < 2; ++grp) {
+            float in_d[kDSteps], in_s[kSSteps];
+#pragma unroll
+            for (int s = 0; s < kDSteps; ++s) in_d[s] = grp ? din[2 * s + 1] : din[2 * s];
+#pragma unroll
+            for (int s = 0; s < kSSteps; ++s) in_s[s] = grp ? sin_[2 * s + 1] : sin_[2 * s];
+            f32x16 d1[1], d2[1], s1[2], s2[2], s3[1];
+            wp.begin_pass(c.head_blob, kHeadChunks, grp == 0 ? c.head_blob : c.next_blob, grp == 0 ? kHeadChunks : c.next_chunks);
+            pipe_layer_from_lanes<kDSteps, 1, kHeadD1, kHeadN>(wp, lane, in_d, d1);
+            pipe_layer_from_tiles<1, 1, kHeadD2, kHeadN, true>(wp, lane, d1, d2);
+            pipe_layer_from_lanes<kSSteps, 2, kHeadS1, kHeadN>(wp, lane, in_s, s1);
+            pipe_layer_from_tiles<2, 2, kHeadS2, kHeadN, true>(wp, lane, s1, s2);
+            pipe_layer_from_tiles<2, 1, kHeadS3, kHeadN, true>(wp, lane, s2, s3);
+            wp.template end_pass<kHeadFrags>();
+            if (grp == 0) { dA = d2[0]; sA = s3[0]; } else { dB = d2[0]; sB = s3[0]; }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {      // rows 0..2 live in registers 0..2 of lane half 0
+            float u = dA[r], v = dB[r];
+            unpack_pair(u, v);
+            cd[r] = sigmoidf(u);                                                    // color_act, metallic = 1
+            float p = sA[r], q = sB[r];
+            unpack_pair(p, q);
+            cs[r] = sigmoidf(p);
+        }
+    }
+
+}
 
 // Two network families:
 //   SH_DEG == 0: environment-MLP family (toaster.ini / neural_renderer.ini): IDE degree IDE_DEG, env hidden 32 ENV_T
@@ -579,113 +707,14 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
         }
 
         ENVIDR_TICK(3);   // geometry terms
-        // ================= environment MLP on IDE(normal) and IDE(reflection) =====================
-        float env_n[12], env_r[12];
-        if constexpr (kEnvNet)
-#pragma unroll 1
-        for (int enc = 0; enc < 2; ++enc) {
-            const float vx = enc ? wr[0] : nenv[0], vy = enc ? wr[1] : nenv[1], vz = enc ? wr[2] : nenv[2];
-            const float kinv = enc ? rough : a.kappa_diffuse;
-            float code[2 * TERMS];
-            ide_eval<IDE_DEG>(vx, vy, vz, kinv, [&](int j, float re, float im) {
-                code[j] = re * a.light_scale;
-                code[TERMS + j] = im * a.light_scale;
-            });
-#pragma unroll
-            for (int s = 0; s < TERMS; ++s) pack_pair(code[2 * s], code[2 * s + 1]);
-            ENVIDR_TICK(4);   // IDE
-            f32x16 outA, outB;
-#pragma unroll 1
-            for (int grp = 0; grp < 2; ++grp) {
-                float in[TERMS];
-#pragma unroll
-                for (int s = 0; s < TERMS; ++s) in[s] = grp ? code[2 * s + 1] : code[2 * s];
-                f32x16 ha[ENV_T], hb[ENV_T], o[1];
-                const bool last = enc == 1 && grp == 1;
-                wp.begin_pass(a.env_blob, kEnvChunks, last ? a.head_blob : a.env_blob, last ? kHeadChunks : kEnvChunks);
-                pipe_layer_from_lanes<TERMS, ENV_T, kEnv0, kEnvN>(wp, lane, in, ha);
-                pipe_layer_from_tiles<ENV_T, ENV_T, kEnv1, kEnvN, true>(wp, lane, ha, hb);
-                pipe_layer_from_tiles<ENV_T, ENV_T, kEnv2, kEnvN, true>(wp, lane, hb, ha);
-                pipe_layer_from_tiles<ENV_T, 1, kEnv3, kEnvN, true>(wp, lane, ha, o);
-                wp.template end_pass<kEnvFrags>();
-                if (grp == 0) outA = o[0]; else outB = o[0];
-            }
-            ENVIDR_TICK(5);   // env mlp
-            float e[16];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                float u = outA[r], v = outB[r];
-                unpack_pair(u, v);
-                e[tile_row(r, 0)] = u; e[tile_row(r, 1)] = v;     // rows 0-3, 8-11 and 4-7, 12-15
-            }
-            float e12[12];
-#pragma unroll
-            for (int i = 0; i < 12; ++i) e12[i] = e[i];
-            normalize_n<12>(e12, 1e-12f);                                               // network.py:541,600
-            if (enc == 0) {
-#pragma unroll
-                for (int i = 0; i < 12; ++i) env_n[i] = e12[i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < 12; ++i) env_r[i] = e12[i];
-            }
-        }
-
-        // ================= diffuse and specular heads ============================================
+        // ================= shading: environment MLP x2 + diffuse / specular heads ===================
         float cd[3], cs[3];
         {
-            // env family : diffuse input [geo_feat | env(normal)] (24), specular input [geo_feat | normal | env(refl) | n.v] (28)
-            // no-env family: diffuse input geo_feat (12), specular input [SH(d) | geo_feat | SH(normal) | n.v] (network.py:576-584)
-            float din[2 * kDSteps], sin_[2 * kSSteps];
-            if constexpr (kEnvNet) {
-#pragma unroll
-                for (int i = 0; i < 12; ++i) { din[i] = geo[i]; din[12 + i] = env_n[i]; sin_[i] = geo[i]; sin_[15 + i] = env_r[i]; }
-                sin_[12] = nrm[0]; sin_[13] = nrm[1]; sin_[14] = nrm[2]; sin_[27] = ndot;
-            } else {
-                float shd[kShDim ? kShDim : 1], shn[kShDim ? kShDim : 1];
-                sh_eval<(SH_DEG ? SH_DEG : 1), false>(rg.dx, rg.dy, rg.dz, shd, nullptr, nullptr, nullptr);
-                sh_eval<(SH_DEG ? SH_DEG : 1), false>(nrm[0], nrm[1], nrm[2], shn, nullptr, nullptr, nullptr);
-#pragma unroll
-                for (int i = 0; i < 12; ++i) { din[i] = geo[i]; sin_[kShDim + i] = geo[i]; }
-#pragma unroll
-                for (int i = 0; i < kShDim; ++i) { sin_[i] = shd[i]; sin_[kShDim + 12 + i] = shn[i]; }
-                sin_[2 * kShDim + 12] = ndot;
-#pragma unroll
-                for (int i = kSpecIn; i < 2 * kSSteps; ++i) sin_[i] = 0;      // odd input width: zero pad (weights are zero there too)
-            }
-#pragma unroll
-            for (int s = 0; s < kDSteps; ++s) pack_pair(din[2 * s], din[2 * s + 1]);
-#pragma unroll
-            for (int s = 0; s < kSSteps; ++s) pack_pair(sin_[2 * s], sin_[2 * s + 1]);
-            f32x16 dA, dB, sA, sB;
-#pragma unroll 1
-            for (int grp = 0; grp < 2; ++grp) {
-                float in_d[kDSteps], in_s[kSSteps];
-#pragma unroll
-                for (int s = 0; s < kDSteps; ++s) in_d[s] = grp ? din[2 * s + 1] : din[2 * s];
-#pragma unroll
-                for (int s = 0; s < kSSteps; ++s) in_s[s] = grp ? sin_[2 * s + 1] : sin_[2 * s];
-                f32x16 d1[1], d2[1], s1[2], s2[2], s3[1];
-                wp.begin_pass(a.head_blob, kHeadChunks, grp == 0 ? a.head_blob : a.sdf_blob, grp == 0 ? kHeadChunks : kSdfChunks);
-                pipe_layer_from_lanes<kDSteps, 1, kHeadD1, kHeadN>(wp, lane, in_d, d1);
-                pipe_layer_from_tiles<1, 1, kHeadD2, kHeadN, true>(wp, lane, d1, d2);
-                pipe_layer_from_lanes<kSSteps, 2, kHeadS1, kHeadN>(wp, lane, in_s, s1);
-                pipe_layer_from_tiles<2, 2, kHeadS2, kHeadN, true>(wp, lane, s1, s2);
-                pipe_layer_from_tiles<2, 1, kHeadS3, kHeadN, true>(wp, lane, s2, s3);
-                wp.template end_pass<kHeadFrags>();
-                if (grp == 0) { dA = d2[0]; sA = s3[0]; } else { dB = d2[0]; sB = s3[0]; }
-            }
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {      // rows 0..2 live in registers 0..2 of lane half 0
-                float u = dA[r], v = dB[r];
-                unpack_pair(u, v);
-                cd[r] = sigmoidf(u);                                                    // color_act, metallic = 1
-                float p = sA[r], q = sB[r];
-                unpack_pair(p, q);
-                cs[r] = sigmoidf(p);
-            }
+            const ShadeConsts sc = {a.env_blob, a.head_blob, a.sdf_blob, kSdfChunks, a.kappa_diffuse, a.light_scale};
+            const float vd[3] = {rg.dx, rg.dy, rg.dz};
+            shade_sample<IDE_DEG, ENV_T, SH_DEG>(wp, lane, sc, nrm, nenv, wr, vd, ndot, geo, rough, cd, cs,
+                                                 [&](int i) { (void)i; ENVIDR_TICK(i); });
         }
-
         ENVIDR_TICK(6);   // heads (+ env unpack)
         // ================= composite (raymarching.cu:996-1030 recurrence) =========================
         if (k == 1) {
@@ -763,6 +792,72 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
 #ifdef ENVIDR_SECTION_TIMERS
             for (int i = 0; i < 8; ++i) atomicAdd(&a.stats[4 + i], tsec[i]);
 #endif
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Shade-only kernel: the shading half of the loop for samples whose geometry is already known
+// (surface rendering as in demo.ipynb cell 17, re-lighting / env rotation of cached geometry).
+// ------------------------------------------------------------------------------------------
+struct ShadeArgs {
+    const float* normals;       // [M,3] unit
+    const float* dirs;          // [M,3] unit view directions (camera -> sample)
+    const float* geo_feat;      // [M,12] (stride 12) or one shared [12] (stride 0), already unit-normalised
+    const float* roughness;     // [M] (stride 1) or one shared value (stride 0): the IDE kappa_inv of the reflected direction
+    uint32_t geo_stride, rough_stride, M;
+    const float* env_blob;
+    const float* head_blob;
+    float kappa_diffuse, light_scale;
+    int has_rot;
+    float rot[9];
+    float* c_diffuse;           // [M,3]
+    float* c_specular;          // [M,3]
+};
+
+template <int IDE_DEG, int ENV_T>
+__global__ void __launch_bounds__(kBlockThreads, 1) k_shade_samples(const ShadeArgs a) {
+    constexpr int TERMS = ide_terms(IDE_DEG);
+    constexpr int kEnvFrags = lane_layer_frags(TERMS, ENV_T, true) + 2 * tile_layer_frags(ENV_T, ENV_T, true) + tile_layer_frags(ENV_T, 1, true);
+    constexpr uint32_t kEnvChunks = pass_chunks(kEnvFrags);
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ __attribute__((aligned(16))) float s_weights[kSharedWeights ? 2 * kChunkFloats : 4];
+    std::conditional_t<kSharedWeights, WeightPipe, WeightRing<kRingDepth>> wp;
+    wp.start(s_weights, lane, wave, a.env_blob, kEnvChunks);
+    const ShadeConsts sc = {a.env_blob, a.head_blob, a.env_blob, kEnvChunks, a.kappa_diffuse, a.light_scale};
+    const uint32_t waves = gridDim.x * (kBlockThreads / 64);
+    // every wave of a block runs the same number of rounds (the shared weight stream has block-wide barriers)
+    for (uint32_t base = (blockIdx.x * (kBlockThreads / 64)) * 64; base < a.M; base += waves * 64) {
+        const uint32_t id = base + wave * 64 + lane;
+        const bool on = id < a.M;
+        const size_t i = on ? id : 0;
+        float nrm[3], vd[3], geo[12];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { nrm[d] = on ? a.normals[3 * i + d] : 0.0f; vd[d] = on ? a.dirs[3 * i + d] : 0.0f; }
+#pragma unroll
+        for (int j = 0; j < 12; ++j) geo[j] = a.geo_feat[(size_t)a.geo_stride * i + j];
+        const float rough = a.roughness[(size_t)a.rough_stride * i];
+        // renderer.py:147-180 (same statements as the persistent kernel)
+        const float wo[3] = {-vd[0], -vd[1], -vd[2]};
+        const float ndot = nrm[0] * wo[0] + nrm[1] * wo[1] + nrm[2] * wo[2];
+        float wr[3], nenv[3] = {nrm[0], nrm[1], nrm[2]};
+        const float c2 = 2 * ndot;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) wr[d] = c2 * nrm[d] - wo[d];
+        if (a.has_rot) {
+            const float w0 = wr[0], w1 = wr[1], w2 = wr[2], n0 = nenv[0], n1 = nenv[1], n2 = nenv[2];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                wr[j] = w0 * a.rot[j] + w1 * a.rot[3 + j] + w2 * a.rot[6 + j];
+                nenv[j] = n0 * a.rot[j] + n1 * a.rot[3 + j] + n2 * a.rot[6 + j];
+            }
+        }
+        float cd[3], cs[3];
+        shade_sample<IDE_DEG, ENV_T, 0>(wp, lane, sc, nrm, nenv, wr, vd, ndot, geo, rough, cd, cs, [](int) {});
+        if (on) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { a.c_diffuse[3 * i + d] = cd[d]; a.c_specular[3 * i + d] = cs[d]; }
         }
     }
 }
@@ -913,6 +1008,43 @@ int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const f
     }
 #undef ENVIDR_LAUNCH
     return check_launch("k_render_persistent");
+}
+
+int envidr_shade_samples(const envidr_render_desc* d, const float* normals, const float* dirs, const float* geo_feat,
+                         uint32_t geo_feat_stride, const float* roughness, uint32_t roughness_stride, uint32_t M,
+                         float* c_diffuse, float* c_specular, envidr_stream_t stream) {
+    ENVIDR_REQUIRE(d, "shade_samples: null descriptor");
+    if (M == 0) return ENVIDR_OK;
+    ENVIDR_REQUIRE(normals && dirs && geo_feat && roughness && c_diffuse && c_specular, "shade_samples: null pointer");
+    ENVIDR_REQUIRE(d->env_blob && d->head_blob, "shade_samples: null weight blob");
+    ENVIDR_REQUIRE(d->dir_sh_degree == 0, "shade_samples: implemented for the environment-MLP family");
+    ENVIDR_REQUIRE((geo_feat_stride == 0 || geo_feat_stride == 12) && roughness_stride <= 1,
+                   "shade_samples: geo_feat_stride must be 0 or 12 and roughness_stride 0 or 1");
+    ShadeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.normals = normals; a.dirs = dirs; a.geo_feat = geo_feat; a.roughness = roughness;
+    a.geo_stride = geo_feat_stride; a.rough_stride = roughness_stride; a.M = M;
+    a.env_blob = d->env_blob; a.head_blob = d->head_blob;
+    a.kappa_diffuse = d->diffuse_kappa_inv; a.light_scale = d->light_intensity_scale;
+    a.has_rot = d->has_env_rot;
+    for (int i = 0; i < 9; ++i) a.rot[i] = d->env_rot[i];
+    a.c_diffuse = c_diffuse; a.c_specular = c_specular;
+    const uint32_t waves_per_block = kBlockThreads / 64;
+    const uint32_t blocks = std::min((uint32_t)device_cu_count() * (4 / waves_per_block), ceil_div(M, kBlockThreads));
+    const dim3 grid(blocks), block(kBlockThreads);
+    hipStream_t s = as_stream(stream);
+#define ENVIDR_LAUNCH(DEG, HT) hipLaunchKernelGGL((k_shade_samples<DEG, HT>), grid, block, 0, s, a)
+    if (d->ide_degree == 5 && d->env_hidden == 256) ENVIDR_LAUNCH(5, 8);
+    else if (d->ide_degree == 4 && d->env_hidden == 160) ENVIDR_LAUNCH(4, 5);
+    else if (d->ide_degree == 5 && d->env_hidden == 128) ENVIDR_LAUNCH(5, 4);
+    else if (d->ide_degree == 4 && d->env_hidden == 128) ENVIDR_LAUNCH(4, 4);
+    else {
+        set_error("shade_samples: unsupported (ide_degree=%u, env_hidden=%u); built variants: (5,256) (4,160) (5,128) (4,128)",
+                  d->ide_degree, d->env_hidden);
+        return ENVIDR_EINVAL;
+    }
+#undef ENVIDR_LAUNCH
+    return check_launch("k_shade_samples");
 }
 
 }  // extern "C"

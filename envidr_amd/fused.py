@@ -86,6 +86,9 @@ def _bind_render(lib):
     lib.envidr_pack_rowvec.restype = ctypes.c_int
     lib.envidr_render_rays.argtypes = [ctypes.POINTER(RenderDesc), _FP, _FP, ctypes.c_uint32, ctypes.POINTER(RenderOut), _FP, _FP]
     lib.envidr_render_rays.restype = ctypes.c_int
+    lib.envidr_shade_samples.argtypes = [ctypes.POINTER(RenderDesc), _FP, _FP, _FP, ctypes.c_uint32, _FP, ctypes.c_uint32,
+                                         ctypes.c_uint32, _FP, _FP, _FP]
+    lib.envidr_shade_samples.restype = ctypes.c_int
     lib._envidr_render_bound = True
 
 
@@ -133,6 +136,82 @@ def pack_rowvec(v) -> np.ndarray:
     if rc:
         raise _lib.EnvidrError(lib.envidr_last_error().decode())
     return dst
+
+
+def _set_env_rotation(desc, radian) -> None:
+    """rot_theta(radian)[:3,:3] (nerf/utils.py:48-52) into the descriptor; None switches the rotation off"""
+    if radian is None:
+        desc.has_env_rot = 0
+        return
+    c, s = math.cos(radian), math.sin(radian)
+    R = np.array([[c, 0, -s], [0, 1, 0], [s, 0, c]], dtype=np.float64).astype(np.float32)
+    for i, v in enumerate(R.reshape(-1)):
+        desc.env_rot[i] = float(v)
+    desc.has_env_rot = 1
+
+
+def _shade(lib, desc, normals, dirs, geo_feat, roughness, env_rot_radian, out):
+    """envidr_shade_samples on torch device tensors"""
+    dev = normals.device
+    normals = normals.contiguous().view(-1, 3).float()
+    dirs = dirs.contiguous().view(-1, 3).float()
+    M = normals.shape[0]
+    geo_feat = torch.as_tensor(geo_feat, dtype=torch.float32, device=dev).contiguous()
+    roughness = torch.as_tensor(roughness, dtype=torch.float32, device=dev).contiguous()
+    geo_stride = 0 if geo_feat.numel() == 12 else 12
+    rough_stride = 0 if roughness.numel() == 1 else 1
+    if (geo_stride and geo_feat.numel() != 12 * M) or (rough_stride and roughness.numel() != M) or dirs.shape[0] != M:
+        raise _lib.EnvidrError("shade: geo_feat must be [12] or [M,12], roughness a scalar or [M], dirs [M,3]")
+    res = out if out is not None else {}
+    for name in ("c_diffuse", "c_specular"):
+        if name not in res or res[name].shape != (M, 3):
+            res[name] = torch.empty(M, 3, dtype=torch.float32, device=dev)
+    _set_env_rotation(desc, env_rot_radian)
+    rc = lib.envidr_shade_samples(ctypes.byref(desc), normals.data_ptr(), dirs.data_ptr(), geo_feat.data_ptr(), geo_stride,
+                                  roughness.data_ptr(), rough_stride, M, res["c_diffuse"].data_ptr(), res["c_specular"].data_ptr(),
+                                  torch.cuda.current_stream(dev).cuda_stream)
+    if rc:
+        raise _lib.EnvidrError(f"envidr_shade_samples failed ({rc}): {lib.envidr_last_error().decode()}")
+    return res
+
+
+class FusedShader:
+    """Shading MLPs only (environment MLP + diffuse / specular heads) resident on the device, for samples whose
+    geometry is known: surface rendering as in the reference's demo.ipynb (BASELINE configs[0]) and re-lighting.
+
+    mlps: {"env": 4 layers, "diffuse": 2, "specular": 3} of (weight [out,in], bias [out])."""
+
+    def __init__(self, mlps: dict, ide_degree: int = 4, diffuse_kappa_inv: float = 0.64, light_intensity_scale: float = 1.0,
+                 device: str | torch.device = "cuda"):
+        self.lib = _lib.load()
+        _bind_render(self.lib)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.EnvidrError("FusedShader needs a GPU device; envidr_amd has no CPU path")
+        env, dif, spc = mlps["env"], mlps["diffuse"], mlps["specular"]
+        ide_dim = (2 ** ide_degree - 1 + ide_degree) * 2
+        if len(env) != 4 or _np32(env[0][0]).shape[1] != ide_dim or _np32(dif[0][0]).shape != (32, 24) or _np32(spc[0][0]).shape != (64, 28):
+            raise _lib.EnvidrError("FusedShader expects env ide_dim->H->H->H->12, diffuse 24->32->3, specular 28->64->64->3")
+        self._keep = []
+
+        def blob(parts):
+            flat = np.concatenate(parts)
+            t = torch.from_numpy(np.concatenate([flat, np.zeros((-flat.size) % 4096, np.float32)])).to(self.device)
+            self._keep.append(t)
+            return t.data_ptr()
+
+        L = lambda Wb, order: pack_layer(Wb[0], Wb[1], order)
+        d = RenderDesc()
+        d.env_blob = blob([L(env[0], 0)] + [L(env[i], 1) for i in (1, 2, 3)])
+        d.head_blob = blob([L(dif[0], 0), L(dif[1], 1), L(spc[0], 0), L(spc[1], 1), L(spc[2], 1)])
+        d.ide_degree, d.env_hidden = ide_degree, _np32(env[0][0]).shape[0]
+        d.diffuse_kappa_inv, d.light_intensity_scale, d.intensity_scale = diffuse_kappa_inv, light_intensity_scale, 1.0
+        self.desc = d
+
+    def shade(self, normals, dirs, geo_feat, roughness, env_rot_radian: float | None = None, out: dict | None = None) -> dict:
+        """normals, dirs [M,3] (unit, on the GPU); geo_feat [12] or [M,12] (unit); roughness scalar or [M].
+        Returns {"c_diffuse": [M,3], "c_specular": [M,3]}."""
+        return _shade(self.lib, self.desc, normals, dirs, geo_feat, roughness, env_rot_radian, out)
 
 
 class FusedRenderer:
@@ -234,14 +313,11 @@ class FusedRenderer:
 
     def set_env_rotation(self, radian: float | None) -> None:
         """w_r and the diffuse normal are multiplied by rot_theta(radian)[:3,:3] (renderer.py:160-172)."""
-        if radian is None:
-            self.desc.has_env_rot = 0
-            return
-        c, s = math.cos(radian), math.sin(radian)
-        R = np.array([[c, 0, -s], [0, 1, 0], [s, 0, c]], dtype=np.float64).astype(np.float32)
-        for i, v in enumerate(R.reshape(-1)):
-            self.desc.env_rot[i] = float(v)
-        self.desc.has_env_rot = 1
+        _set_env_rotation(self.desc, radian)
+
+    def shade(self, normals, dirs, geo_feat, roughness, env_rot_radian: float | None = None, out: dict | None = None) -> dict:
+        """shading only, for samples with known geometry (envidr_shade_samples); environment-MLP family"""
+        return _shade(self.lib, self.desc, normals, dirs, geo_feat, roughness, env_rot_radian, out)
 
     def render(self, rays_o: torch.Tensor, rays_d: torch.Tensor, env_rot_radian: float | None = None,
                extras: bool = True, stats: bool = False, out: dict | None = None) -> dict:

@@ -131,6 +131,21 @@ typedef struct envidr_render_out {
 int envidr_render_rays(const envidr_render_desc* desc, const float* rays_o, const float* rays_d, uint32_t N,
                        const envidr_render_out* out, uint32_t* ray_counter, envidr_stream_t stream);
 
+/* Shade M samples whose geometry is already known: the per-sample shading of the loop
+ *     nerf/renderer.py:147-180   get_color_mlp_extra_params (reflection, env rotation, IDE x2, n.v)
+ *     nerf/network.py:524-698    forward_color               (env MLP x2, diffuse + specular heads)
+ * without marching, hash grid and SDF network.  This is the whole of demo.ipynb cell 17 after the
+ * ray / sphere intersection (surface rendering, BASELINE configs[0]) and the per-frame part of re-lighting
+ * or rotating the environment around cached geometry.  Uses desc->env_blob, head_blob, ide_degree, env_hidden,
+ * diffuse_kappa_inv, light_intensity_scale and the env rotation; every other field is ignored.
+ *   normals, dirs : device [M,3], unit;  dirs = view direction (camera -> sample)
+ *   geo_feat      : device [M,12] (stride 12) or ONE shared [12] (stride 0), unit-normalised
+ *   roughness     : device [M] (stride 1) or ONE shared value (stride 0): kappa_inv of the reflected-direction IDE
+ *   c_diffuse, c_specular : device [M,3] out, sigmoid colours (the caller adds them and applies intensity_scale) */
+int envidr_shade_samples(const envidr_render_desc* desc, const float* normals, const float* dirs, const float* geo_feat,
+                         uint32_t geo_feat_stride, const float* roughness, uint32_t roughness_stride, uint32_t M,
+                         float* c_diffuse, float* c_specular, envidr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -224,6 +224,31 @@ def shade_samples(scene, xyzs: np.ndarray, dirs: np.ndarray, opt: RenderOptions,
     return {k: v.detach().numpy() for k, v in out.items()}
 
 
+def shade_surface(mlps: dict, normals: np.ndarray, dirs: np.ndarray, geo_feat: np.ndarray, kappa_inv, opt: RenderOptions,
+                  env_rot_radian: float | None = None) -> dict:
+    """shading with known geometry: renderer.py:147-180 + network.py:524-698, which is also demo.ipynb cell 17
+    ("Run MLPs") -- the reference's CPU-runnable case.  geo_feat [12] or [M,12] (unit), kappa_inv scalar or [M,1]."""
+    ide = ide_torch if opt.ide_mode == "torch" else ide_exact
+    with torch.no_grad():
+        n = torch.from_numpy(np.ascontiguousarray(normals, F32))
+        d = torch.from_numpy(np.ascontiguousarray(dirs, F32))
+        gf = torch.from_numpy(np.ascontiguousarray(geo_feat, F32)).reshape(-1, 12).expand(n.shape[0], 12)
+        kinv = kappa_inv if np.isscalar(kappa_inv) else torch.from_numpy(np.ascontiguousarray(kappa_inv, F32)).reshape(-1, 1)
+        w_o = -d
+        w_r = 2 * torch.sum(w_o * n, dim=-1, keepdim=True) * n - w_o
+        n_env = n
+        if env_rot_radian is not None:
+            c, s = math.cos(env_rot_radian), math.sin(env_rot_radian)
+            R = torch.tensor([[c, 0, -s], [0, 1, 0], [s, 0, c]], dtype=torch.float64).float()
+            w_r, n_env = w_r @ R, n @ R
+        n_dot = torch.sum(n * w_o, dim=-1, keepdim=True)
+        e_n = Fn.normalize(_mlp(mlps["env"], ide(n_env, opt.diffuse_kappa_inv, opt.ide_deg) * opt.light_intensity_scale), dim=-1)
+        e_r = Fn.normalize(_mlp(mlps["env"], ide(w_r, kinv, opt.ide_deg) * opt.light_intensity_scale), dim=-1)
+        c_diffuse = torch.sigmoid(_mlp(mlps["diffuse"], torch.cat([gf, e_n], -1)))
+        c_specular = torch.sigmoid(_mlp(mlps["specular"], torch.cat([gf, n, e_r, n_dot], -1)))
+    return {"c_diffuse": c_diffuse.numpy(), "c_specular": c_specular.numpy()}
+
+
 # ------------------------------------------------------------------------------------------------
 # inference render loop
 # ------------------------------------------------------------------------------------------------

@@ -265,6 +265,55 @@ def golden_relight():
     golden_frame(model, opt, "relight_40", 40, 40, theta=75.0, phi=-25.0, extra=extra)
 
 
+def golden_demo(res=200):
+    """BASELINE configs[0]: the reference's own CPU-runnable case, demo.ipynb cell 17 (one surface sample per ray
+    on the unit sphere, constant hash feature, IDE degree 4, env MLP 38-160-160-160-12 twice, diffuse / specular
+    heads) executed from the notebook's code cells as they are, with the shipped demo/ weights.  Only the image
+    size is changed (800 -> `res`, intrinsics recomputed by the notebook's own formula).  The weights are stored
+    in the fixture as input data; the 400x400 mean-RGB anchors of SURVEY.md section 6 are recomputed and stored too."""
+    import json
+    import os
+    nb = json.load(open(REFERENCE / "demo.ipynb"))
+    code = {i: "".join(c["source"]) for i, c in enumerate(nb["cells"]) if c["cell_type"] == "code"}
+    plt = MagicMock()
+    np.math = math
+    for mod in ("matplotlib", "matplotlib.pyplot"):
+        if mod not in sys.modules:
+            try:
+                __import__(mod)
+            except Exception:
+                sys.modules[mod] = MagicMock()
+    cwd = os.getcwd()
+    os.chdir(REFERENCE)
+    try:
+        def run(size):
+            env = {"__name__": "demo"}
+            for i in (1, 3, 5):
+                exec(code[i], env)
+            env["plt"] = plt
+            exec(f"W, H = {size}, {size}\nfocal = W / (2 * np.tan(camera_angle_x / 2))\nintrinsics = np.array([focal, focal, W/2, H/2])", env)
+            for i in (7, 9, 10, 13, 14):
+                exec(code[i], env)
+            exec(code[16], env)                               # the rendering parameters (theta, phi, material, env)
+            exec(code[17].split("out_img = {}")[0], env)      # rendering steps, without the plotting tail
+            return env
+        env = run(400)
+        mean400 = env["image"].mean(0).numpy()
+        print("[golden] demo 400x400 mean rgb", mean400.tolist(), "(SURVEY.md section 6 anchor: 0.62849, 0.70200, 0.82242)")
+        env = run(res)
+    finally:
+        os.chdir(cwd)
+    out = {"res": res, "theta": env["theta"], "phi": env["phi"], "radius": env["radius"], "roughness": env["roughness"],
+           "metallic": env["metallic"], "base_color": np.array(env["base_color"], F), "mean_rgb_400": mean400.astype(F),
+           "xyz_encoding": env["xyz_encoding"].numpy(), "image": env["image"].numpy(), "diffuse": env["diffuse"].numpy(),
+           "specular": env["specular"].numpy(), "mask": env["mask"].numpy(), "kappa_inv": env["kappa_inv"].numpy()}
+    for name in ("sdf_net", "env_net", "diffuse_net", "specular_net"):
+        for k, v in env[name].state_dict().items():
+            out[f"{name}/{k}"] = v.numpy()
+    np.savez_compressed(OUT / "demo_sphere.npz", **out)
+    print(f"[golden] demo_sphere: {res}x{res}, {int(env['mask'].sum())} hit rays, mean rgb {env['image'].mean(0).tolist()}")
+
+
 GRID_SCENE = dict(table_scale=0.3, sdf_bias=0.0, beta=0.05, seed=6)
 GRID_POSES = [(20.0, -30.0), (140.0, -10.0), (260.0, -60.0)]
 
@@ -375,6 +424,7 @@ def main():
     golden_frame(model4, opt4, "toaster_indir_40", 40, 40, theta=40.0, phi=-50.0)
     golden_relight()
     golden_grid()
+    golden_demo()
     # BASELINE configs[1]: no environment network, SH-encoded view direction and normal
     model2, opt2 = build_reference_model(scenes.lego_scene(seed=8), config=OUT / "lego_like.ini")
     golden_frame(model2, opt2, "lego_48", 48, 48, theta=110.0, phi=-40.0)

@@ -97,6 +97,37 @@ def test_config1_no_env_network_matches_reference():
         assert rel_l2(res[key], want) <= 2e-5, f"{key}: rel-L2 {rel_l2(res[key], want):.3e}"
 
 
+def test_config0_demo_sphere_matches_notebook():
+    """BASELINE configs[0], the reference's own CPU-runnable case: demo.ipynb cell 17 executed as shipped
+    (tests/golden/make_golden.py golden_demo) vs the oracle's shading restatement"""
+    import torch
+    import torch.nn.functional as F
+    g = np.load(GOLD / "demo_sphere.npz")
+    res = int(g["res"])
+    seq = lambda name: [(g[f"{name}/{i}.weight"], g[f"{name}/{i}.bias"])
+                        for i in sorted({int(k.split("/")[1].split(".")[0]) for k in g.files if k.startswith(name + "/")})]
+    pose = scenes.nerf_matrix_to_ngp(scenes.pose_spherical(float(g["theta"]), -float(g["phi"]), float(g["radius"])), scale=1.0)
+    ro_, rd_ = scenes.get_rays(pose, scenes.intrinsics_for(res, res), res, res)
+    o, d = torch.from_numpy(ro_), torch.from_numpy(rd_)
+    b = (d * o).sum(-1, keepdim=True)
+    nabla = b ** 2 - (o.norm(2, 1, keepdim=True) ** 2 - 1.0)
+    mask = (nabla >= -1e-4)[..., 0]
+    assert np.array_equal(mask.numpy(), g["mask"])
+    near = -b - torch.sqrt(nabla.clamp_min(0.0))
+    dirs, normals = d[mask], o[mask] + d[mask] * near[mask]
+    h = torch.cat([torch.from_numpy(g["xyz_encoding"]), torch.tensor([float(g["roughness"]), float(g["metallic"])]),
+                   torch.from_numpy(g["base_color"])])[None]
+    h = ro._mlp(seq("sdf_net"), h)
+    geo = F.normalize(h[..., 1:13], dim=-1)[0].numpy()
+    kinv = float(F.softplus(h[..., -1] - 1)[0])
+    out = ro.shade_surface({"env": seq("env_net"), "diffuse": seq("diffuse_net"), "specular": seq("specular_net")},
+                           normals.numpy(), dirs.numpy(), geo, kinv, ro.RenderOptions(ide_deg=4))
+    image = np.ones((res * res, 3), np.float32)
+    image[mask.numpy()] = out["c_diffuse"] + out["c_specular"]
+    assert rel_l2(image, g["image"]) <= 1e-6
+    assert np.allclose(g["mean_rgb_400"], [0.62849, 0.70200, 0.82242], atol=2e-5)       # SURVEY.md section 6 anchor
+
+
 def test_ide_oracle_vs_reference_fp32():
     """C-oracle IDE (exact evaluation of the reference's fp32 table) vs the reference's fp32 torch
     output: agreement to fp32 rounding for l <= 8 and within the reference's documented

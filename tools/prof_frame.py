@@ -6,8 +6,14 @@ from envidr_amd import scenes
 from envidr_amd.fused import FusedRenderer
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 800
-scene = scenes.toaster_scene()
-r = FusedRenderer.from_scene(scene)
+kind = sys.argv[3] if len(sys.argv) > 3 else "toaster"
+if kind == "lego":      # BASELINE configs[1]: no environment MLP
+    from envidr_amd.fused import FusedOptions
+    scene = scenes.lego_scene()
+    r = FusedRenderer.from_scene(scene, FusedOptions(dir_sh_degree=4))
+else:
+    scene = scenes.toaster_scene()
+    r = FusedRenderer.from_scene(scene)
 ro8, rd8 = scenes.camera_rays(H, H)
 o8, d8 = torch.from_numpy(ro8).cuda(), torch.from_numpy(rd8).cuda()
 out = {}
