@@ -75,6 +75,12 @@ struct RenderArgs {
     float kappa_diffuse, light_scale, intensity_scale;
     int has_rot;
     float rot[9];
+    // pass selection (indirect-reflection rendering, renderer.py:437-513)
+    int geometry_only;           // composite normals only: no shading passes at all
+    const float* r_images;       // [N,4] per-ray reflected radiance (rgb, visibility) or null
+    const float* renv_blob;      // R1..R4 of the reflected-radiance feature MLP 4 -> 64 -> 64 -> 64 -> 12
+    const float* spec2_blob;     // S1..S3: the specular head once more, for the renv branch
+    float indir_rough_thresh;
     // outputs
     float* image; float* depth; float* ws; float* normal; float* diffuse; float* specular; float* roughness;
     unsigned long long* stats;
@@ -267,6 +273,12 @@ constexpr int kRingDepth = ENVIDR_RING_DEPTH;
 constexpr uint32_t kBlockThreads = kSharedWeights ? 256 : 64;
 constexpr int ring_padded(int frags) { return (frags + kRingDepth - 1) / kRingDepth * kRingDepth; }
 
+// reflected-radiance branch (network.py:612-659): renv MLP 4 -> 64 -> 64 -> 64 -> 12, then the specular head again
+constexpr int kRenv1 = 0, kRenv2 = kRenv1 + lane_layer_frags(2, 2, true), kRenv3 = kRenv2 + tile_layer_frags(2, 2, true),
+              kRenv4 = kRenv3 + tile_layer_frags(2, 2, true), kRenvFrags = kRenv4 + tile_layer_frags(2, 1, true);
+constexpr int kSpec2S1 = 0, kSpec2S2 = kSpec2S1 + lane_layer_frags(14, 2, true), kSpec2S3 = kSpec2S2 + tile_layer_frags(2, 2, true),
+              kSpec2Frags = kSpec2S3 + tile_layer_frags(2, 1, true);
+
 // ---- shading of one sample per lane: environment MLP twice (IDE of the rotated normal and of the reflected
 // direction), then the diffuse and specular heads (network.py:524-698).  Shared by the persistent render kernel and
 // the shade-only kernel.  The weight source `wp` must already be streaming env_blob (env family) or head_blob
@@ -282,7 +294,7 @@ struct ShadeConsts {
 template <int IDE_DEG, int ENV_T, int SH_DEG, class WP, class Tick>
 __device__ __forceinline__ void shade_sample(WP& wp, const uint32_t lane, const ShadeConsts c, const float (&nrm)[3],
                                              const float (&nenv)[3], const float (&wr)[3], const float (&vd)[3], const float ndot,
-                                             const float (&geo)[12], const float rough, float (&cd)[3], float (&cs)[3], Tick&& tick) {
+                                             const float (&geo)[12], const float rough, float (&cd)[3], float (&cs)[3], float (&env_r)[12], Tick&& tick) {
     constexpr bool kEnvNet = SH_DEG == 0;
     constexpr int kShDim = SH_DEG * SH_DEG;
     constexpr int kDiffIn = kEnvNet ? 24 : 12, kSpecIn = kEnvNet ? 28 : 2 * kShDim + 13;
@@ -296,7 +308,7 @@ __device__ __forceinline__ void shade_sample(WP& wp, const uint32_t lane, const 
     constexpr uint32_t kEnvChunks = pass_chunks(kEnvFrags), kHeadChunks = pass_chunks(kHeadFrags);
     constexpr int kEnvN = ring_padded(kEnvFrags), kHeadN = ring_padded(kHeadFrags);
     // ================= environment MLP on IDE(normal) and IDE(reflection) =====================
-    float env_n[12], env_r[12];
+    float env_n[12];
     if constexpr (kEnvNet)
 #pragma unroll 1
     for (int enc = 0; enc < 2; ++enc) {
@@ -438,6 +450,7 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
     const uint32_t n_hit = __builtin_amdgcn_readfirstlane(a.ray_counter[1]);
     Accum acc = {};
     float an[3] = {0, 0, 0}, ad[3] = {0, 0, 0}, as[3] = {0, 0, 0}, arough = 0;
+    float rimg[4] = {0, 0, 0, 0};      // this ray's reflected radiance (rgb, visibility) when a.r_images is given
     unsigned long long n_samples = 0, n_rounds = 0, n_rays = 0;
 #ifdef ENVIDR_SECTION_TIMERS
     // per-wave cycle accounting (s_memtime), build with -DENVIDR_SECTION_TIMERS; stats[4..11]
@@ -494,7 +507,13 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
 #pragma unroll
                 for (int d = 0; d < 3; ++d) { an[d] = __shfl(an[d], src); ad[d] = __shfl(ad[d], src); as[d] = __shfl(as[d], src); }
                 arough = __shfl(arough, src);
-                if (ray >= 0) rg = load_ray(a.rays_o, a.rays_d, (uint32_t)ray);
+                if (ray >= 0) {
+                    rg = load_ray(a.rays_o, a.rays_d, (uint32_t)ray);
+                    if (a.r_images) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) rimg[j] = a.r_images[4 * (size_t)ray + j];
+                    }
+                }
                 k = nk;
             }
         }
@@ -531,6 +550,10 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
                     const uint32_t id = a.hit_ids[slot];
                     ray = (int)id;
                     rg = load_ray(a.rays_o, a.rays_d, id);
+                    if (a.r_images) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) rimg[j] = a.r_images[4 * (size_t)id + j];
+                    }
                     float near;
                     near_far(rg, a.mk.bound, a.min_near, near, far);
                     t_ray = near;
@@ -628,8 +651,9 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
 #pragma unroll
                 for (int s = 0; s < kLevels; ++s) in[s] = grp ? inB[s] : inA[s];
                 f32x16 h1[2], h2[2], o3[1];
-                wp.begin_pass(a.sdf_blob, kSdfChunks, grp == 0 ? a.sdf_blob : (kEnvNet ? a.env_blob : a.head_blob),
-                              grp == 0 ? kSdfChunks : (kEnvNet ? kEnvChunks : kHeadChunks));
+                const bool to_sdf = grp == 0 || a.geometry_only;       // geometry-only: the SDF blob is the only one streamed
+                wp.begin_pass(a.sdf_blob, kSdfChunks, to_sdf ? a.sdf_blob : (kEnvNet ? a.env_blob : a.head_blob),
+                              to_sdf ? kSdfChunks : (kEnvNet ? kEnvChunks : kHeadChunks));
                 pipe_layer_from_lanes<kLevels, 2, kSdfW1, kSdfN>(wp, lane, in, h1);
                 pipe_layer_from_tiles<2, 2, kSdfW2, kSdfN, true>(wp, lane, h1, h2);
                 pipe_layer_from_tiles<2, 1, kSdfW3, kSdfN, true>(wp, lane, h2, o3);
@@ -708,12 +732,78 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
 
         ENVIDR_TICK(3);   // geometry terms
         // ================= shading: environment MLP x2 + diffuse / specular heads ===================
-        float cd[3], cs[3];
-        {
-            const ShadeConsts sc = {a.env_blob, a.head_blob, a.sdf_blob, kSdfChunks, a.kappa_diffuse, a.light_scale};
+        float cd[3] = {0, 0, 0}, cs[3] = {0, 0, 0};
+        if (!a.geometry_only) {
+            const bool renv = kEnvNet && a.r_images != nullptr;
+            constexpr uint32_t kRenvChunks = pass_chunks(kRenvFrags), kSpec2Chunks = pass_chunks(kSpec2Frags);
+            const ShadeConsts sc = {a.env_blob, a.head_blob, renv ? a.renv_blob : a.sdf_blob, renv ? kRenvChunks : kSdfChunks,
+                                    a.kappa_diffuse, a.light_scale};
             const float vd[3] = {rg.dx, rg.dy, rg.dz};
-            shade_sample<IDE_DEG, ENV_T, SH_DEG>(wp, lane, sc, nrm, nenv, wr, vd, ndot, geo, rough, cd, cs,
+            float env_r[12];
+            shade_sample<IDE_DEG, ENV_T, SH_DEG>(wp, lane, sc, nrm, nenv, wr, vd, ndot, geo, rough, cd, cs, env_r,
                                                  [&](int i) { (void)i; ENVIDR_TICK(i); });
+            if constexpr (kEnvNet) if (renv) {
+                // ---- reflected radiance of this ray -> 12 features -> specular head again -> blend (network.py:612-659,683-690)
+                constexpr int kRenvN = ring_padded(kRenvFrags), kSpec2N = ring_padded(kSpec2Frags);
+                const float vis = rimg[3];
+                const float remap = sqrtf(rough / a.rough_scale / 0.75f);
+                float rin[4] = {rimg[0] * vis, rimg[1] * vis, rimg[2] * vis, remap};
+                pack_pair(rin[0], rin[1]);
+                pack_pair(rin[2], rin[3]);
+                f32x16 eA, eB;
+#pragma unroll 1
+                for (int grp = 0; grp < 2; ++grp) {
+                    float in[2] = {grp ? rin[1] : rin[0], grp ? rin[3] : rin[2]};
+                    f32x16 r1[2], r2[2], r3[1];
+                    wp.begin_pass(a.renv_blob, kRenvChunks, grp == 0 ? a.renv_blob : a.spec2_blob, grp == 0 ? kRenvChunks : kSpec2Chunks);
+                    pipe_layer_from_lanes<2, 2, kRenv1, kRenvN>(wp, lane, in, r1);
+                    pipe_layer_from_tiles<2, 2, kRenv2, kRenvN, true>(wp, lane, r1, r2);
+                    pipe_layer_from_tiles<2, 2, kRenv3, kRenvN, true>(wp, lane, r2, r1);
+                    pipe_layer_from_tiles<2, 1, kRenv4, kRenvN, true>(wp, lane, r1, r3);
+                    wp.template end_pass<kRenvFrags>();
+                    if (grp == 0) eA = r3[0]; else eB = r3[0];
+                }
+                float e[16];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    float u = eA[r], v = eB[r];
+                    unpack_pair(u, v);
+                    e[tile_row(r, 0)] = u; e[tile_row(r, 1)] = v;
+                }
+                float e12[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) e12[i] = e[i];
+                normalize_n<12>(e12, 1e-12f);
+                float sin2[28];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) { sin2[i] = geo[i]; sin2[15 + i] = e12[i]; }
+                sin2[12] = nrm[0]; sin2[13] = nrm[1]; sin2[14] = nrm[2]; sin2[27] = ndot;
+#pragma unroll
+                for (int s = 0; s < 14; ++s) pack_pair(sin2[2 * s], sin2[2 * s + 1]);
+                f32x16 cA, cB;
+#pragma unroll 1
+                for (int grp = 0; grp < 2; ++grp) {
+                    float in_s[14];
+#pragma unroll
+                    for (int s = 0; s < 14; ++s) in_s[s] = grp ? sin2[2 * s + 1] : sin2[2 * s];
+                    f32x16 s1[2], s2[2], s3[1];
+                    wp.begin_pass(a.spec2_blob, kSpec2Chunks, grp == 0 ? a.spec2_blob : a.sdf_blob, grp == 0 ? kSpec2Chunks : kSdfChunks);
+                    pipe_layer_from_lanes<14, 2, kSpec2S1, kSpec2N>(wp, lane, in_s, s1);
+                    pipe_layer_from_tiles<2, 2, kSpec2S2, kSpec2N, true>(wp, lane, s1, s2);
+                    pipe_layer_from_tiles<2, 1, kSpec2S3, kSpec2N, true>(wp, lane, s2, s3);
+                    wp.template end_pass<kSpec2Frags>();
+                    if (grp == 0) cA = s3[0]; else cB = s3[0];
+                }
+                const bool masked = rough < a.indir_rough_thresh && vis > 0.9f;
+                const float blend = 0.98f * sigmoidf(h3[14]);                              // learn_indir_blend, network.py:443-446,630
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    float p = cA[r], q = cB[r];
+                    unpack_pair(p, q);
+                    const float c_renv = sigmoidf(p);
+                    if (masked) cs[r] = cs[r] * blend + c_renv * (1 - blend);
+                }
+            }
         }
         ENVIDR_TICK(6);   // heads (+ env unpack)
         // ================= composite (raymarching.cu:996-1030 recurrence) =========================
@@ -853,8 +943,8 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_shade_samples(const ShadeA
                 nenv[j] = n0 * a.rot[j] + n1 * a.rot[3 + j] + n2 * a.rot[6 + j];
             }
         }
-        float cd[3], cs[3];
-        shade_sample<IDE_DEG, ENV_T, 0>(wp, lane, sc, nrm, nenv, wr, vd, ndot, geo, rough, cd, cs, [](int) {});
+        float cd[3], cs[3], env_r[12];
+        shade_sample<IDE_DEG, ENV_T, 0>(wp, lane, sc, nrm, nenv, wr, vd, ndot, geo, rough, cd, cs, env_r, [](int) {});
         if (on) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) { a.c_diffuse[3 * i + d] = cd[d]; a.c_specular[3 * i + d] = cs[d]; }
@@ -954,6 +1044,13 @@ int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const f
     a.kappa_diffuse = d->diffuse_kappa_inv; a.light_scale = d->light_intensity_scale; a.intensity_scale = d->intensity_scale;
     a.has_rot = d->has_env_rot;
     for (int i = 0; i < 9; ++i) a.rot[i] = d->env_rot[i];
+    a.geometry_only = d->geometry_only;
+    if (d->r_images && !d->geometry_only) {
+        ENVIDR_REQUIRE(d->renv_blob && d->spec2_blob, "render_rays: r_images given without the renv / second specular blobs");
+        ENVIDR_REQUIRE(d->dir_sh_degree == 0, "render_rays: the reflected-radiance branch belongs to the environment-MLP family");
+        a.r_images = d->r_images; a.renv_blob = d->renv_blob; a.spec2_blob = d->spec2_blob;
+        a.indir_rough_thresh = d->indir_roughness_thresh;
+    }
     a.image = out->image; a.depth = out->depth; a.ws = out->weights_sum; a.normal = out->normal_image;
     a.diffuse = out->diffuse_image; a.specular = out->specular_image; a.roughness = out->roughness_image;
     a.stats = reinterpret_cast<unsigned long long*>(out->stats);

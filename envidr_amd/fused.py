@@ -35,6 +35,8 @@ class RenderDesc(ctypes.Structure):
         ("ide_degree", ctypes.c_uint32), ("env_hidden", ctypes.c_uint32),
         ("diffuse_kappa_inv", ctypes.c_float), ("light_intensity_scale", ctypes.c_float), ("intensity_scale", ctypes.c_float),
         ("has_env_rot", ctypes.c_int32), ("env_rot", ctypes.c_float * 9), ("dir_sh_degree", ctypes.c_uint32),
+        ("geometry_only", ctypes.c_int32), ("r_images", _FP), ("renv_blob", _FP), ("spec2_blob", _FP),
+        ("indir_roughness_thresh", ctypes.c_float),
     ]
 
 
@@ -57,6 +59,7 @@ class FusedOptions:
     bg_color: float = 1.0
     base_resolution: int = 16
     enabled_levels: int = -1
+    indir_roughness_thresh: float = 0.1
     dir_sh_degree: int = 0       # > 0: no environment MLP, SH-encoded view direction / normal (BASELINE configs[1])
     beta_min: float = 0.0005
     beta_max: float = 1.0
@@ -294,6 +297,13 @@ class FusedRenderer:
         d.env_blob = blob([L(env[0], 0)] + [L(env[i], 1) for i in (1, 2, 3)]) if env is not None else None
         d.dir_sh_degree = sh_degree
         d.head_blob = blob([L(dif[0], 0), L(dif[1], 1), L(spc[0], 0), L(spc[1], 1), L(spc[2], 1)])
+        renv = mlps.get("renv")
+        if renv is not None and env is not None:
+            if len(renv) != 4 or _np32(renv[0][0]).shape != (64, 4) or _np32(renv[3][0]).shape != (12, 64):
+                raise _lib.EnvidrError("fused renderer expects the renv MLP 4 -> 64 -> 64 -> 64 -> 12")
+            d.renv_blob = blob([L(renv[0], 0)] + [L(renv[i], 1) for i in (1, 2, 3)])
+            d.spec2_blob = blob([L(spc[0], 0), L(spc[1], 1), L(spc[2], 1)])
+        d.indir_roughness_thresh = self.opt.indir_roughness_thresh
         d.sdf_w3_row0 = up(pack_rowvec(_np32(sdf[2][0])[0])).data_ptr()
         d.beta = float(min(max(beta, self.opt.beta_min), self.opt.beta_max))     # LaplaceDensity.get_beta clamp
         d.roughness_bias, d.roughness_act_scale = self.opt.roughness_bias, self.opt.roughness_act_scale
@@ -320,9 +330,12 @@ class FusedRenderer:
         return _shade(self.lib, self.desc, normals, dirs, geo_feat, roughness, env_rot_radian, out)
 
     def render(self, rays_o: torch.Tensor, rays_d: torch.Tensor, env_rot_radian: float | None = None,
-               extras: bool = True, stats: bool = False, out: dict | None = None) -> dict:
+               extras: bool = True, stats: bool = False, out: dict | None = None, geometry_only: bool = False,
+               r_images: torch.Tensor | None = None) -> dict:
         """rays_o, rays_d: [N,3] fp32 on the GPU.  Returns image [N,3], depth [N], weights_sum [N]
-        (+ normal_image, diffuse_image, specular_image, roughness_image when `extras`)."""
+        (+ normal_image, diffuse_image, specular_image, roughness_image when `extras`).
+        geometry_only: depth / weights_sum / normal_image only (first pass of indirect rendering).
+        r_images: [N,4] reflected radiance + visibility per ray (third pass of indirect rendering)."""
         if not (rays_o.is_cuda and rays_d.is_cuda):
             raise _lib.EnvidrError("render: rays must live on the GPU")
         rays_o = rays_o.contiguous().view(-1, 3).float()
@@ -349,6 +362,15 @@ class FusedRenderer:
             res["stats"] = torch.zeros(12, dtype=torch.int64, device=dev)
             o.stats = res["stats"].data_ptr()
         self.set_env_rotation(env_rot_radian)
+        self.desc.geometry_only = int(bool(geometry_only))
+        self.desc.r_images = None
+        if r_images is not None and not geometry_only:
+            if not self.desc.renv_blob:
+                raise _lib.EnvidrError("render: r_images given but the model has no renv MLP")
+            r_images = r_images.contiguous().view(-1, 4).float()
+            if r_images.shape[0] != N or not r_images.is_cuda:
+                raise _lib.EnvidrError("render: r_images must be [N,4] on the GPU")
+            self.desc.r_images = r_images.data_ptr()
         stream = torch.cuda.current_stream(dev).cuda_stream
         rc = self.lib.envidr_render_rays(ctypes.byref(self.desc), rays_o.data_ptr(), rays_d.data_ptr(), N, ctypes.byref(o),
                                          self.counter.data_ptr(), stream)

@@ -6,8 +6,8 @@
   * operator loop: the reference's loop structure on the HIP operators (`raymarching.march_rays`,
     model.forward_sigma / forward_color on HIP encoders + torch GEMMs, `raymarching.composite_rays`),
     with the boolean-mask compaction replaced by the device-side `compact_alive` (one 4-byte readback
-    per iteration instead of a nonzero + gather + sync).  Used for geometry-only / renv passes and for
-    model configurations the fused kernel does not implement.
+    per iteration instead of a nonzero + gather + sync).  Used for model configurations the fused kernel
+    does not implement (and on request, `fused=False`).
 
 The training branch of run_cuda (march_rays_train + composite_rays_train + losses) belongs to the
 Trainer and is out of scope; its operators exist in envidr_amd.raymarching.
@@ -49,8 +49,13 @@ def run_cuda(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, fo
         fr = self.fused_renderer()
         fr.desc.bg_color = float(bg_color)
         fr.desc.min_near = float(self.min_near)
-        res = fr.render(rays_o, rays_d, env_rot_radian, extras=True)
+        res = fr.render(rays_o, rays_d, env_rot_radian, extras=True, geometry_only=geometry_only,
+                        r_images=None if r_images is None else r_images[0])
         out = {"image": res["image"].view(*prefix, 3), "depth": res["depth"].view(*prefix), "weights_sum": res["weights_sum"].view(*prefix)}
+        if geometry_only:
+            out["image"] = None
+            out["normal_image"] = res["normal_image"].view(*prefix, 3)
+            return out
         if get_normal_image:
             out["normal_image"] = res["normal_image"].view(*prefix, 3)
         if "diffuse" in visual:

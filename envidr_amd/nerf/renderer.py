@@ -260,7 +260,7 @@ class NeRFRenderer(nn.Module):
         with the reflected radiance fed to the renv branch."""
         dt = 2 * SQRT3 / self.opt.indir_max_steps
         geo = self._run(rays_o, rays_d, get_normal_image=get_normal_image, main_pass=False, geometry_only=True,
-                        env_rot_radian=env_rot_radian, fused=False, **kwargs)
+                        env_rot_radian=env_rot_radian, fused=fused, **kwargs)
         normals = geo["normal_image"]
         depth = geo["depth"].squeeze() - dt
         ws = geo["weights_sum"].squeeze()
@@ -285,7 +285,7 @@ class NeRFRenderer(nn.Module):
         kw3 = dict(kwargs, bg_color=0)
         res = self._run(rays_o[:, ray_mask, :], rays_d[:, ray_mask, :], get_normal_image=get_normal_image,
                         use_specular_color=use_specular_color, env_net_index=env_net_index, main_pass=True, r_images=r_images,
-                        bg_sphere=False, env_rot_radian=env_rot_radian, fused=False, **kw3)
+                        bg_sphere=False, env_rot_radian=env_rot_radian, fused=fused, **kw3)
         res["normal_image"] = normals
         res["depth"] = depth[None, :]
         for k in ("image", "specular_image", "diffuse_image", "roughness_image"):

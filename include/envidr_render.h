@@ -108,6 +108,23 @@ typedef struct envidr_render_desc {
      *             D1+b (lane, 12->32) | D2+b (tile, 32->3) | S1+b (lane, (2 deg^2 + 13)->64) | S2+b (tile) | S3+b (tile, 64->3)
      *           with specular input [SH(d) | geo_feat | SH(normal) | n.v].  Built: degree 4. */
     uint32_t dir_sh_degree;
+
+    /* Pass selection for indirect-reflection rendering (nerf/renderer.py:437-513 runs the loop three times).
+     *   geometry_only != 0 : run_cuda's `geometry_only` branch (cuda_ray.py:303-305): no shading; depth, weights_sum and
+     *                        the composited normals (normal_image) are produced, image = (1 - weights_sum) * bg_color.
+     *   r_images != NULL   : the main pass with reflected radiance (network.py:612-659,683-690): device [N,4] per ray
+     *                        (rgb, visibility) as gathered at cuda_ray.py:291-293.  Samples with roughness <
+     *                        indir_roughness_thresh and visibility > 0.9 blend the specular colour with the colour obtained
+     *                        from the reflected-radiance features: renv MLP [rgb * vis, sqrt(roughness / roughness_scale /
+     *                        0.75)] -> 64 -> 64 -> 64 -> 12, unit-normalised, through the specular head again; blend weight
+     *                        0.98 * sigmoid(sdf-network output 14) (learn_indir_blend).
+     *   renv_blob  : R1+b (lane, 4->64) | R2+b (tile) | R3+b (tile) | R4+b (tile, 64->12)
+     *   spec2_blob : S1+b (lane, 28->64) | S2+b (tile) | S3+b (tile, 64->3)   (the specular head, as in head_blob) */
+    int32_t geometry_only;
+    const float* r_images;
+    const float* renv_blob;
+    const float* spec2_blob;
+    float indir_roughness_thresh;    /* 0.1 */
 } envidr_render_desc;
 
 /* ---- per-call outputs (device pointers; any optional pointer may be NULL) --------------------- */
