@@ -331,11 +331,26 @@ __device__ __forceinline__ void shade_sample(WP& wp, const uint32_t lane, const 
             f32x16 ha[ENV_T], hb[ENV_T], o[1];
             const bool last = enc == 1 && grp == 1;
             wp.begin_pass(c.env_blob, kEnvChunks, last ? c.head_blob : c.env_blob, last ? kHeadChunks : kEnvChunks);
+#ifdef ENVIDR_ENV_PROBE
+            tick(5);
+#endif
             pipe_layer_from_lanes<TERMS, ENV_T, kEnv0, kEnvN>(wp, lane, in, ha);
+#ifdef ENVIDR_ENV_PROBE
+            tick(0);
+#endif
             pipe_layer_from_tiles<ENV_T, ENV_T, kEnv1, kEnvN, true>(wp, lane, ha, hb);
+#ifdef ENVIDR_ENV_PROBE
+            tick(1);
+#endif
             pipe_layer_from_tiles<ENV_T, ENV_T, kEnv2, kEnvN, true>(wp, lane, hb, ha);
+#ifdef ENVIDR_ENV_PROBE
+            tick(2);
+#endif
             pipe_layer_from_tiles<ENV_T, 1, kEnv3, kEnvN, true>(wp, lane, ha, o);
             wp.template end_pass<kEnvFrags>();
+#ifdef ENVIDR_ENV_PROBE
+            tick(3);
+#endif
             if (grp == 0) outA = o[0]; else outB = o[0];
         }
         tick(5);   // env mlp
@@ -436,6 +451,10 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     __shared__ __attribute__((aligned(16))) float s_weights[kSharedWeights ? 2 * kChunkFloats : 4];
     __shared__ float s_jac[(kSharedWeights ? 4 : 1) * kLevels * 6 * 64];
+    // per-ray state that is only touched by march and blend, parked here while a sample is shaded (it would
+    // otherwise sit in -- or be spilled from -- registers the 256-wide layers need)
+    constexpr int kParked = 26;
+    __shared__ float s_park[(kSharedWeights ? 4 : 1) * kParked * 64];
     std::conditional_t<kSharedWeights, WeightPipe, WeightRing<kRingDepth>> wp;
     wp.start(s_weights, lane, wave, a.sdf_blob, kSdfChunks);
     // fragments per pass as the weight source sees them (the ring pads every pass to a multiple of its depth)
@@ -456,9 +475,16 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
     // per-wave cycle accounting (s_memtime), build with -DENVIDR_SECTION_TIMERS; stats[4..11]
     unsigned long long tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tmark = __builtin_amdgcn_s_memtime();
+#ifdef ENVIDR_ENV_PROBE
+    // probe build: slots 0..3 are re-used for the four layers of an env pass, the sections that normally own them go to slot 7
+#define ENVIDR_TICK(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tsec[(i) < 4 ? 7 : (i)] += now_ - tmark; tmark = now_; } while (0)
+#else
 #define ENVIDR_TICK(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tsec[i] += now_ - tmark; tmark = now_; } while (0)
+#endif
+#define ENVIDR_PROBE_TICK(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tsec[i] += now_ - tmark; tmark = now_; } while (0)
 #else
 #define ENVIDR_TICK(i) do {} while (0)
+#define ENVIDR_PROBE_TICK(i) do {} while (0)
 #endif
 
     auto finish_ray = [&]() {
@@ -588,6 +614,15 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
         n_samples += have ? 1 : 0;
         n_rounds += 1;
         if (!have) { px = py = pz = 0; }
+        float* park = s_park + (kSharedWeights ? wave * (kParked * 64) : 0u) + lane;
+        {
+            const float v[kParked] = {rg.ox, rg.oy, rg.oz, rg.rdx, rg.rdy, rg.rdz, far, t_ray, t_resume, acc.ws, acc.depth, acc.r, acc.g,
+                                      acc.b, acc.t, an[0], an[1], an[2], ad[0], ad[1], ad[2], as[0], as[1], as[2], arough,
+                                      __uint_as_float(n_taken)};
+#pragma unroll
+            for (int i = 0; i < kParked; ++i) park[i * 64] = v[i];
+            asm volatile("" ::: "memory");      // the values must really leave the registers: no store-to-load forwarding
+        }
 
         // ================= hash grid: features + Jacobian (per lane) ============================
         // Software-pipelined over levels: the 8 corner gathers of level l+2 are issued before level l is
@@ -741,7 +776,7 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
             const float vd[3] = {rg.dx, rg.dy, rg.dz};
             float env_r[12];
             shade_sample<IDE_DEG, ENV_T, SH_DEG>(wp, lane, sc, nrm, nenv, wr, vd, ndot, geo, rough, cd, cs, env_r,
-                                                 [&](int i) { (void)i; ENVIDR_TICK(i); });
+                                                 [&](int i) { (void)i; ENVIDR_PROBE_TICK(i); });
             if constexpr (kEnvNet) if (renv) {
                 // ---- reflected radiance of this ray -> 12 features -> specular head again -> blend (network.py:612-659,683-690)
                 constexpr int kRenvN = ring_padded(kRenvFrags), kSpec2N = ring_padded(kSpec2Frags);
@@ -806,6 +841,16 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
             }
         }
         ENVIDR_TICK(6);   // heads (+ env unpack)
+        {
+            asm volatile("" ::: "memory");
+            float v[kParked];
+#pragma unroll
+            for (int i = 0; i < kParked; ++i) v[i] = park[i * 64];
+            rg.ox = v[0]; rg.oy = v[1]; rg.oz = v[2]; rg.rdx = v[3]; rg.rdy = v[4]; rg.rdz = v[5]; far = v[6]; t_ray = v[7];
+            t_resume = v[8]; acc.ws = v[9]; acc.depth = v[10]; acc.r = v[11]; acc.g = v[12]; acc.b = v[13]; acc.t = v[14];
+            an[0] = v[15]; an[1] = v[16]; an[2] = v[17]; ad[0] = v[18]; ad[1] = v[19]; ad[2] = v[20]; as[0] = v[21]; as[1] = v[22];
+            as[2] = v[23]; arough = v[24]; n_taken = __float_as_uint(v[25]);
+        }
         // ================= composite (raymarching.cu:996-1030 recurrence) =========================
         if (k == 1) {
             if (have) {

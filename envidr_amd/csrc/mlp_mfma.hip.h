@@ -372,7 +372,9 @@ struct WeightRing {
 template <typename T> struct is_weight_ring { static constexpr bool value = false; };
 template <int PF> struct is_weight_ring<WeightRing<PF>> { static constexpr bool value = true; };
 
-// FRAGS: fragments in the (ring-padded) pass -- where the per-wave ring rolls over into the next blob
+// FRAGS: fragments in the (ring-padded) pass -- where the per-wave ring rolls over into the next blob.
+// b(S) must be a plain register read: any vector-ALU work between two MFMAs of the same wave stalls the matrix
+// pipe (see pipe_layer_from_tiles).
 template <int NSTEPS, int MT, int F0, int FRAGS, int S = 0, typename Src, typename BOp>
 __device__ __forceinline__ void pipe_steps(Src& wp, f32x16 (&acc)[MT], BOp&& b) {
     if constexpr (S < NSTEPS) {
@@ -380,7 +382,6 @@ __device__ __forceinline__ void pipe_steps(Src& wp, f32x16 (&acc)[MT], BOp&& b) 
         [&]<int... T>(std::integer_sequence<int, T...>) {
             ((acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp.template take<F0 + S * MT + T, FRAGS>(), bv, acc[T], 0, 0, 0)), ...);
         }(std::make_integer_sequence<int, MT>{});
-        // the register ring is a hand-made software pipeline: keep the scheduler from hoisting its refills
         if constexpr (is_weight_ring<Src>::value) __builtin_amdgcn_sched_barrier(0);
         pipe_steps<NSTEPS, MT, F0, FRAGS, S + 1>(wp, acc, b);
     }
@@ -410,13 +411,31 @@ __device__ __forceinline__ void pipe_layer_from_lanes(Src& wp, uint32_t lane, co
     if constexpr (BIAS) bias_step<MT, F0, FRAGS>(wp, lane, acc);
     pipe_steps<STEPS, MT, F0 + (BIAS ? MT : 0), FRAGS>(wp, acc, [&](int s) { return in[s]; });
 }
-// layer whose input is KT accumulator tiles of the previous layer
+// max(x, 0) as exactly one v_max_f32 (fmaxf() adds a canonicalising v_max x, x in front)
+__device__ __forceinline__ float relu1(float x) {
+    float y;
+    asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+    return y;
+}
+
+// layer whose input is KT accumulator tiles of the previous layer.
+// The 16 B operands of one input tile are produced (accumulator read + ReLU) as ONE cluster of vector-ALU
+// instructions ahead of that tile's 16 x MT MFMAs.  Measured on gfx950 (tools/probe/valu_overlap_probe.hip,
+// env_pass_probe.hip): a wave's own vector-ALU instruction between two of its MFMAs costs ~10 cycles of matrix-pipe
+// idle time plus ~20 more when the MFMA consumes its result, so ReLU "as the operand is fetched" (one small VALU
+// chain per step) cost 30 cycles per step = 8 % of an environment pass; one cluster per tile costs < 1 %.
 template <int KT, int MT, int F0, int FRAGS, bool RELU_IN = false, bool BIAS = true, typename Src>
 __device__ __forceinline__ void pipe_layer_from_tiles(Src& wp, uint32_t lane, const f32x16 (&in)[KT], f32x16 (&acc)[MT]) {
     zero_acc<MT>(acc);
     if constexpr (BIAS) bias_step<MT, F0, FRAGS>(wp, lane, acc);
     [&]<int... K>(std::integer_sequence<int, K...>) {
-        (pipe_steps<16, MT, F0 + (BIAS ? MT : 0) + K * 16 * MT, FRAGS>(wp, acc, [&](int s) { return RELU_IN ? fmaxf(in[K][s], 0.0f) : in[K][s]; }), ...);
+        ([&] {
+            float bq[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bq[r] = RELU_IN ? relu1(in[K][r]) : in[K][r];
+            if constexpr (is_weight_ring<Src>::value) __builtin_amdgcn_sched_barrier(0);
+            pipe_steps<16, MT, F0 + (BIAS ? MT : 0) + K * 16 * MT, FRAGS>(wp, acc, [&](int s) { return bq[s]; });
+        }(), ...);
     }(std::make_integer_sequence<int, KT>{});
 }
 
