@@ -60,6 +60,33 @@ def test_errors_without_gpu_are_reported():
     assert rc == 0
 
 
+def test_render_entry_points_validate_their_descriptor():
+    """envidr_render_rays / envidr_shade_samples reject inconsistent descriptors before launching anything"""
+    from envidr_amd import _lib, fused
+    lib = _lib.load()
+    fused._bind_render(lib)
+    d = fused.RenderDesc()
+    o = fused.RenderOut()
+    assert lib.envidr_render_rays(ctypes.byref(d), None, None, 0, ctypes.byref(o), None, None) == 0      # N = 0: no-op
+    assert lib.envidr_render_rays(None, None, None, 8, ctypes.byref(o), None, None) == -1
+    assert b"null descriptor" in lib.envidr_last_error()
+    assert lib.envidr_render_rays(ctypes.byref(d), None, None, 8, ctypes.byref(o), None, None) == -1
+    assert b"null ray pointers" in lib.envidr_last_error()
+    assert lib.envidr_shade_samples(ctypes.byref(d), None, None, None, 0, None, 0, 0, None, None, None) == 0   # M = 0
+    assert lib.envidr_shade_samples(ctypes.byref(d), None, None, None, 0, None, 0, 4, None, None, None) == -1
+    assert b"null pointer" in lib.envidr_last_error()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.envidr_shade_samples(ctypes.byref(d), p, p, p, 12, p, 1, 4, p, p, None) == -1
+    assert b"null weight blob" in lib.envidr_last_error()
+    d.env_blob = d.head_blob = p
+    assert lib.envidr_shade_samples(ctypes.byref(d), p, p, p, 7, p, 1, 4, p, p, None) == -1
+    assert b"geo_feat_stride" in lib.envidr_last_error()
+    d.dir_sh_degree = 4
+    assert lib.envidr_shade_samples(ctypes.byref(d), p, p, p, 12, p, 1, 4, p, p, None) == -1
+    assert b"environment-MLP family" in lib.envidr_last_error()
+
+
 def _tile_row(r, h):
     return (r & 3) + 8 * (r >> 2) + 4 * h
 
