@@ -152,40 +152,8 @@ def main() -> None:
                          "hbm_view": {"bound": "hbm", "achieved": samples * HASH_BYTES_PER_SAMPLE / (kernel_ms * 1e-3) / 1e9,
                                       "peak": 8000.0, "unit": "GB/s"}},
         }
-        # BASELINE configs[1] (no environment MLP; gather/latency-bound regime) on the same camera, for reference:
-        # a parity-test configuration, not the headline workload
-        from envidr_amd.fused import FusedOptions
-        plain = FusedRenderer.from_scene(scenes.lego_scene(), FusedOptions(dir_sh_degree=4), device=dev)
-        pout: dict = {}
-        plain.render(rays_o, rays_d, None, extras=True, stats=True, out=pout)
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        for _ in range(5):
-            plain.render(rays_o, rays_d, None, extras=True, stats=True, out=pout)
-        torch.cuda.synchronize(dev)
-        pdt = (time.perf_counter() - t1) / 5
-        psamples = int(pout["stats"][0].item())
-        result["other_configs"] = {"configs[1] hash-grid SDF + diffuse/specular MLPs (SH view dir, no env MLP), 800x800, 1 GPU": {
-            "rays_per_s": N / pdt, "ms_per_frame": pdt * 1e3, "samples_per_s": psamples / pdt,
-            "hbm_algorithmic_GBps": psamples * HASH_BYTES_PER_SAMPLE / pdt / 1e9,
-            "mfma_algorithmic_TFLOPs": psamples * 41_984 / pdt / 1e12}}
-        # BASELINE configs[3]: use_renv + indir_ref, three fused passes per frame (geometry -> reflected rays -> main pass
-        # with reflected radiance) through the NeRFRenderer.render() drop-in surface, concave (torus) scene
-        from envidr_amd.nerf.network import NeRFNetwork
-        from envidr_amd.nerf.options import toaster_options
-        iopt = toaster_options(indir_ref=True)
-        imodel = NeRFNetwork.from_scene(scenes.toaster_scene(shape=scenes.torus(), seed=3), iopt, device=dev)
-        ikw = dict(staged=True, bg_color=1, perturb=False, get_normal_image=True, max_steps=iopt.max_steps, T_thresh=iopt.T_thresh,
-                   dt_gamma=iopt.dt_gamma)
-        imodel.render(rays_o[None], rays_d[None], **ikw)
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        for _ in range(3):
-            imodel.render(rays_o[None], rays_d[None], **ikw)
-        torch.cuda.synchronize(dev)
-        idt = (time.perf_counter() - t1) / 3
-        result["other_configs"]["configs[3] toaster network + use_renv + indir_ref (3 passes per frame), torus scene, 800x800, 1 GPU"] = {
-            "primary_rays_per_s": N / idt, "ms_per_frame": idt * 1e3}
+        if world == 1:
+            other_configs(result, scenes, FusedRenderer, rays_o, rays_d, dev, N)
         prof = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(prof):
             try:
@@ -206,6 +174,43 @@ def main() -> None:
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def other_configs(result, scenes, FusedRenderer, rays_o, rays_d, dev, N) -> None:
+    """the other single-GPU BASELINE configurations on the same camera (parity-test configurations, not the headline)"""
+    # BASELINE configs[1] (no environment MLP; gather/latency-bound regime)
+    from envidr_amd.fused import FusedOptions
+    plain = FusedRenderer.from_scene(scenes.lego_scene(), FusedOptions(dir_sh_degree=4), device=dev)
+    pout: dict = {}
+    plain.render(rays_o, rays_d, None, extras=True, stats=True, out=pout)
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    for _ in range(5):
+        plain.render(rays_o, rays_d, None, extras=True, stats=True, out=pout)
+    torch.cuda.synchronize(dev)
+    pdt = (time.perf_counter() - t1) / 5
+    psamples = int(pout["stats"][0].item())
+    result["other_configs"] = {"configs[1] hash-grid SDF + diffuse/specular MLPs (SH view dir, no env MLP), 800x800, 1 GPU": {
+        "rays_per_s": N / pdt, "ms_per_frame": pdt * 1e3, "samples_per_s": psamples / pdt,
+        "hbm_algorithmic_GBps": psamples * HASH_BYTES_PER_SAMPLE / pdt / 1e9,
+        "mfma_algorithmic_TFLOPs": psamples * 41_984 / pdt / 1e12}}
+    # BASELINE configs[3]: use_renv + indir_ref, three fused passes per frame (geometry -> reflected rays -> main pass
+    # with reflected radiance) through the NeRFRenderer.render() drop-in surface, concave (torus) scene
+    from envidr_amd.nerf.network import NeRFNetwork
+    from envidr_amd.nerf.options import toaster_options
+    iopt = toaster_options(indir_ref=True)
+    imodel = NeRFNetwork.from_scene(scenes.toaster_scene(shape=scenes.torus(), seed=3), iopt, device=dev)
+    ikw = dict(staged=True, bg_color=1, perturb=False, get_normal_image=True, max_steps=iopt.max_steps, T_thresh=iopt.T_thresh,
+               dt_gamma=iopt.dt_gamma)
+    imodel.render(rays_o[None], rays_d[None], **ikw)
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    for _ in range(3):
+        imodel.render(rays_o[None], rays_d[None], **ikw)
+    torch.cuda.synchronize(dev)
+    idt = (time.perf_counter() - t1) / 3
+    result["other_configs"]["configs[3] toaster network + use_renv + indir_ref (3 passes per frame), torus scene, 800x800, 1 GPU"] = {
+        "primary_rays_per_s": N / idt, "ms_per_frame": idt * 1e3}
 
 
 if __name__ == "__main__":

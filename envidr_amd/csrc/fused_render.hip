@@ -270,6 +270,10 @@ constexpr bool kSharedWeights = ENVIDR_SHARED_WEIGHTS != 0;
 #define ENVIDR_RING_DEPTH 32
 #endif
 constexpr int kRingDepth = ENVIDR_RING_DEPTH;
+#ifndef ENVIDR_HASH_AHEAD
+#define ENVIDR_HASH_AHEAD 2
+#endif
+constexpr int kHashAhead = ENVIDR_HASH_AHEAD;     // hash levels whose corner gathers are in flight ahead of the one being interpolated
 constexpr uint32_t kBlockThreads = kSharedWeights ? 256 : 64;
 constexpr int ring_padded(int frags) { return (frags + kRingDepth - 1) / kRingDepth * kRingDepth; }
 
@@ -639,13 +643,14 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
             // outside the unit cube every level contributes zeros (hashencoder.cu:124-149); evaluating
             // at a clamped position and masking afterwards keeps the gathers in bounds
             const float xc[3] = {inside ? x01[0] : 0.5f, inside ? x01[1] : 0.5f, inside ? x01[2] : 0.5f};
-            HashStage s0, s1, s2;      // three rotating stages, named so that every access is a compile-time register
-            hash_prepare(a, 0, xc, s0);
-            hash_prepare(a, 1, xc, s1);
+            HashStage st[kHashAhead + 1];      // rotating stages; every index below is a compile-time constant
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                (hash_prepare(a, I, xc, st[I]), ...);
+            }(std::make_integer_sequence<int, kHashAhead>{});
             __builtin_amdgcn_sched_barrier(0);
             auto level = [&](auto lc, HashStage& cur, HashStage& ahead) {
                 constexpr int l = decltype(lc)::value;
-                if constexpr (l + 2 < kLevels) hash_prepare(a, l + 2, xc, ahead);
+                if constexpr (l + kHashAhead < kLevels) hash_prepare(a, l + kHashAhead, xc, ahead);
                 __builtin_amdgcn_sched_barrier(0);
                 float o[2], g[3][2];
                 hash_finish(a, l, cur, o, g);
@@ -657,14 +662,9 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
                     jac_col[((l * 3 + d) * 2 + 1) * 64] = g[d][1] * m;
                 }
             };
-#define ENVIDR_L(n) std::integral_constant<int, n>{}
-            level(ENVIDR_L(0), s0, s2);  level(ENVIDR_L(1), s1, s0);  level(ENVIDR_L(2), s2, s1);
-            level(ENVIDR_L(3), s0, s2);  level(ENVIDR_L(4), s1, s0);  level(ENVIDR_L(5), s2, s1);
-            level(ENVIDR_L(6), s0, s2);  level(ENVIDR_L(7), s1, s0);  level(ENVIDR_L(8), s2, s1);
-            level(ENVIDR_L(9), s0, s2);  level(ENVIDR_L(10), s1, s0); level(ENVIDR_L(11), s2, s1);
-            level(ENVIDR_L(12), s0, s2); level(ENVIDR_L(13), s1, s0); level(ENVIDR_L(14), s2, s1);
-            level(ENVIDR_L(15), s0, s2);
-#undef ENVIDR_L
+            [&]<int... L>(std::integer_sequence<int, L...>) {
+                (level(std::integral_constant<int, L>{}, st[L % (kHashAhead + 1)], st[(L + kHashAhead) % (kHashAhead + 1)]), ...);
+            }(std::make_integer_sequence<int, kLevels>{});
         }
 
         ENVIDR_TICK(1);   // hash grid
