@@ -12,11 +12,11 @@ if [ "$2" != "quick" ]; then
 fi
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" >> $OUT/bench.err
 # kernel trace + stats of the same command (CPU leg skipped: it launches no kernels)
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/trace.log 2>&1 )
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --headline-only > $OUT/trace.log 2>&1 )
 # PMC passes, each on its own (no trace domains mixed in)
 for SET in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
   N=$(echo $SET | tr ' ' '_' | cut -c1-30)
-  ( cd /tmp && rocprofv3 --pmc $SET --output-format csv -d $OUT/pmc_$N -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$N.log 2>&1 )
+  ( cd /tmp && rocprofv3 --pmc $SET --output-format csv -d $OUT/pmc_$N -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --headline-only > $OUT/pmc_$N.log 2>&1 )
 done
 python - <<PY
 import csv, glob, json, collections, os
