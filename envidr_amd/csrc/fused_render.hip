@@ -335,26 +335,11 @@ __device__ __forceinline__ void shade_sample(WP& wp, const uint32_t lane, const 
             f32x16 ha[ENV_T], hb[ENV_T], o[1];
             const bool last = enc == 1 && grp == 1;
             wp.begin_pass(c.env_blob, kEnvChunks, last ? c.head_blob : c.env_blob, last ? kHeadChunks : kEnvChunks);
-#ifdef ENVIDR_ENV_PROBE
-            tick(5);
-#endif
             pipe_layer_from_lanes<TERMS, ENV_T, kEnv0, kEnvN>(wp, lane, in, ha);
-#ifdef ENVIDR_ENV_PROBE
-            tick(0);
-#endif
             pipe_layer_from_tiles<ENV_T, ENV_T, kEnv1, kEnvN, true>(wp, lane, ha, hb);
-#ifdef ENVIDR_ENV_PROBE
-            tick(1);
-#endif
             pipe_layer_from_tiles<ENV_T, ENV_T, kEnv2, kEnvN, true>(wp, lane, hb, ha);
-#ifdef ENVIDR_ENV_PROBE
-            tick(2);
-#endif
             pipe_layer_from_tiles<ENV_T, 1, kEnv3, kEnvN, true>(wp, lane, ha, o);
             wp.template end_pass<kEnvFrags>();
-#ifdef ENVIDR_ENV_PROBE
-            tick(3);
-#endif
             if (grp == 0) outA = o[0]; else outB = o[0];
         }
         tick(5);   // env mlp
@@ -479,16 +464,9 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
     // per-wave cycle accounting (s_memtime), build with -DENVIDR_SECTION_TIMERS; stats[4..11]
     unsigned long long tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tmark = __builtin_amdgcn_s_memtime();
-#ifdef ENVIDR_ENV_PROBE
-    // probe build: slots 0..3 are re-used for the four layers of an env pass, the sections that normally own them go to slot 7
-#define ENVIDR_TICK(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tsec[(i) < 4 ? 7 : (i)] += now_ - tmark; tmark = now_; } while (0)
-#else
 #define ENVIDR_TICK(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tsec[i] += now_ - tmark; tmark = now_; } while (0)
-#endif
-#define ENVIDR_PROBE_TICK(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tsec[i] += now_ - tmark; tmark = now_; } while (0)
 #else
 #define ENVIDR_TICK(i) do {} while (0)
-#define ENVIDR_PROBE_TICK(i) do {} while (0)
 #endif
 
     auto finish_ray = [&]() {
@@ -776,7 +754,7 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
             const float vd[3] = {rg.dx, rg.dy, rg.dz};
             float env_r[12];
             shade_sample<IDE_DEG, ENV_T, SH_DEG>(wp, lane, sc, nrm, nenv, wr, vd, ndot, geo, rough, cd, cs, env_r,
-                                                 [&](int i) { (void)i; ENVIDR_PROBE_TICK(i); });
+                                                 [&](int i) { (void)i; ENVIDR_TICK(i); });
             if constexpr (kEnvNet) if (renv) {
                 // ---- reflected radiance of this ray -> 12 features -> specular head again -> blend (network.py:612-659,683-690)
                 constexpr int kRenvN = ring_padded(kRenvFrags), kSpec2N = ring_padded(kSpec2Frags);

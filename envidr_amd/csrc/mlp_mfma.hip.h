@@ -139,107 +139,6 @@ __device__ __forceinline__ f32x16 load_rowvec(const ParamBuf& p, int tile) {
     return v;
 }
 
-__device__ __forceinline__ f32x16 relu16(f32x16 v) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
-    return v;
-}
-
-// Software-pipelined stream of A fragments: a ring of PF registers holds fragments i .. i+PF-1 of the
-// layer's packed weights; taking fragment i immediately re-issues the load of fragment i+PF into the
-// freed register, so PF loads (PF * 256 B per wave) stay in flight under the MFMAs.  With one wave per
-// SIMD there is no other wave to hide the L2 round trip behind, this ring is what hides it.
-template <int PF>
-struct WeightStream {
-    ParamBuf w;
-    float ring[PF];
-    __device__ __forceinline__ void prime(const float* base, uint32_t bytes, uint32_t lane) {
-        w = make_param_buf(base, bytes, lane);
-#pragma unroll
-        for (int i = 0; i < PF; ++i) ring[i] = param_load(w, (uint32_t)(i * 256));
-    }
-    // fragment at flat index block0 + I  (I compile-time, block0_bytes wave-uniform, (block0 % PF) == 0)
-    template <int I>
-    __device__ __forceinline__ float take(uint32_t block0_bytes) {
-        const float v = ring[I % PF];
-        ring[I % PF] = param_load(w, block0_bytes + (uint32_t)((I + PF) * 256));
-        return v;
-    }
-};
-
-template <int NSTEPS, int MT, int PF, int S = 0, typename BOp>
-__device__ __forceinline__ void mfma_steps(WeightStream<PF>& ws, uint32_t block0_bytes, f32x16 (&acc)[MT], BOp&& b) {
-    if constexpr (S < NSTEPS) {
-        const float bv = b(S);
-        // one step: MT output tiles share the B operand
-        [&]<int... T>(std::integer_sequence<int, T...>) {
-            ((acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.template take<S * MT + T>(block0_bytes), bv, acc[T], 0, 0, 0)), ...);
-        }(std::make_integer_sequence<int, MT>{});
-        // pin the software pipeline: without this the scheduler hoists every refill load of the layer
-        // to its top (they have no dependences), blows the register file and reloads them from scratch
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_steps<NSTEPS, MT, PF, S + 1>(ws, block0_bytes, acc, b);
-    }
-}
-
-template <int MT>
-__device__ __forceinline__ void init_acc(const float* __restrict__ bias, uint32_t lane, f32x16 (&acc)[MT]) {
-    if (bias) {
-        const ParamBuf bb = make_param_buf(bias, MT * 128u, lane);
-#pragma unroll
-        for (int t = 0; t < MT; ++t) acc[t] = load_rowvec(bb, t);
-    } else {
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-    }
-}
-
-constexpr int prefetch_depth(int mt) { return mt >= 8 ? 32 : 16; }   // must divide 16 * MT (tile-order blocks)
-
-// Dense layer whose input is per-lane-packed registers in[STEPS] (kLaneOrder).  bias == nullptr: zero.
-template <int STEPS, int MT>
-__device__ __forceinline__ void layer_from_lanes(const float* __restrict__ w, const float* __restrict__ bias,
-                                                 uint32_t lane, const float (&in)[STEPS], f32x16 (&acc)[MT]) {
-    constexpr int PF = (STEPS * MT >= 32 && MT >= 8) ? 32 : 16;
-    WeightStream<PF> ws;
-    ws.prime(w, (uint32_t)(STEPS * MT * 256), lane);
-    init_acc<MT>(bias, lane, acc);
-    mfma_steps<STEPS, MT, PF>(ws, 0u, acc, [&](int s) { return in[s]; });
-}
-
-// Dense layer whose input is KT accumulator tiles of the previous layer (kTileOrder).
-//   RELU_IN : apply max(., 0) to the input as it is consumed (one VALU op per step, hidden under the
-//             step's MT MFMAs) instead of a separate pass over the previous layer's accumulators.
-//   UNROLL  : emit all KT blocks (B operands are then compile-time registers, no per-block select);
-//             otherwise the loop over input tiles is rolled and each iteration first selects its tile.
-template <int KT, int MT, bool RELU_IN = false, bool UNROLL = true>
-__device__ __forceinline__ void layer_from_tiles(const float* __restrict__ w, const float* __restrict__ bias,
-                                                 uint32_t lane, const f32x16 (&in)[KT], f32x16 (&acc)[MT]) {
-    constexpr int PF = prefetch_depth(MT);
-    static_assert((16 * MT) % PF == 0, "ring position must be block-invariant");
-    constexpr uint32_t kTileBytes = 16u * MT * 256u;
-    WeightStream<PF> ws;
-    ws.prime(w, KT * kTileBytes, lane);
-    init_acc<MT>(bias, lane, acc);
-    if constexpr (UNROLL || KT <= 2) {
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-            mfma_steps<16, MT, PF>(ws, kt * kTileBytes, acc, [&](int s) { return RELU_IN ? fmaxf(in[kt][s], 0.0f) : in[kt][s]; });
-    } else {
-#pragma unroll 1
-        for (int kt = 0; kt < KT; ++kt) {
-            f32x16 cur = in[0];
-#pragma unroll
-            for (int j = 1; j < KT; ++j)
-                if (kt == j) cur = in[j];
-            mfma_steps<16, MT, PF>(ws, (uint32_t)kt * kTileBytes, acc, [&](int s) { return RELU_IN ? fmaxf(cur[s], 0.0f) : cur[s]; });
-        }
-    }
-}
-
-
 // =============================================================================================
 // Workgroup-shared weight pipe (LDS)
 // =============================================================================================
