@@ -81,6 +81,11 @@ struct RenderArgs {
     const float* renv_blob;      // R1..R4 of the reflected-radiance feature MLP 4 -> 64 -> 64 -> 64 -> 12
     const float* spec2_blob;     // S1..S3: the specular head once more, for the renv branch
     float indir_rough_thresh;
+    // per-sample geometry export (geometry cache for re-lighting / env rotation; only with geometry_only)
+    uint32_t* ex_counter;        // [1] records appended (keeps counting past ex_capacity: the caller sizes a retry from it)
+    uint32_t ex_capacity;
+    uint32_t* ex_ray; uint32_t* ex_idx;      // [cap] ray id, index of the sample within its ray
+    float* ex_w; float* ex_normal; float* ex_geo; float* ex_rough;   // [cap] compositing weight, [cap,3], [cap,12], [cap]
     // outputs
     float* image; float* depth; float* ws; float* normal; float* diffuse; float* specular; float* roughness;
     unsigned long long* stats;
@@ -830,6 +835,9 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
             as[2] = v[23]; arough = v[24]; n_taken = __float_as_uint(v[25]);
         }
         // ================= composite (raymarching.cu:996-1030 recurrence) =========================
+        bool ex_on = false;          // this lane's sample was composited (-> one geometry record when exporting)
+        float ex_w = 0;
+        uint32_t ex_idx = 0, ex_ray = 0;
         if (k == 1) {
             if (have) {
                 const float alpha = 1.0f - expf(-sigma * dt);
@@ -846,6 +854,7 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
                 arough += w * rough;
                 t_ray = acc.t;            // the reference resumes the marcher from the composited time
                 (void)t_next;
+                ex_on = true; ex_w = w; ex_idx = n_taken; ex_ray = (uint32_t)ray;
                 ++n_taken;
                 if (T < a.T_thresh) finish_ray();
             }
@@ -878,6 +887,7 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
 #pragma unroll
                         for (int d = 0; d < 3; ++d) { an[d] += w * nj[d]; ad[d] += w * cdj[d]; as[d] += w * csj[d]; }
                         arough += w * rg_j;
+                        if (sub == j) { ex_on = true; ex_w = w; ex_idx = n_taken; ex_ray = (uint32_t)ray; }   // this lane shaded sample j
                         ++n_taken;
                         if (T < a.T_thresh) {
                             if (sub == 0) finish_ray(); else ray = -1;
@@ -887,6 +897,21 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
                 }
             }
             if (open) t_ray = acc.t;
+        }
+        if (a.ex_counter) {
+            // append one record per composited sample: wave-aggregated slot allocation, any order (the host sorts by (ray, idx))
+            const unsigned long long em = __ballot(ex_on);
+            uint32_t base = 0;
+            if (lane == 0 && em) base = atomicAdd(a.ex_counter, (uint32_t)__popcll(em));
+            base = __shfl(base, 0);
+            const uint32_t slot = base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
+            if (ex_on && slot < a.ex_capacity) {
+                a.ex_ray[slot] = ex_ray; a.ex_idx[slot] = ex_idx; a.ex_w[slot] = ex_w; a.ex_rough[slot] = rough;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) a.ex_normal[3 * (size_t)slot + d] = nrm[d];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) a.ex_geo[12 * (size_t)slot + i] = geo[i];
+            }
         }
         ENVIDR_TICK(7);   // composite
     }
@@ -973,6 +998,31 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_shade_samples(const ShadeA
             for (int d = 0; d < 3; ++d) { a.c_diffuse[3 * i + d] = cd[d]; a.c_specular[3 * i + d] = cs[d]; }
         }
     }
+}
+
+// Composite shaded colours of cached geometry: one lane per ray, its samples contiguous and in march order, the
+// compositing weights already known (they depend on geometry only).  Same accumulation order and arithmetic as the
+// blend section of the persistent kernel.
+__global__ void __launch_bounds__(kBlock) k_composite_shaded(const uint32_t* __restrict__ offsets, const float* __restrict__ w,
+                                                             const float* __restrict__ cd, const float* __restrict__ cs,
+                                                             const float* __restrict__ ws, uint32_t N, float intensity, float bg,
+                                                             float* __restrict__ image, float* __restrict__ diffuse,
+                                                             float* __restrict__ specular) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    float ar = 0, ag = 0, ab = 0, d0 = 0, d1 = 0, d2 = 0, s0 = 0, s1 = 0, s2 = 0;
+    for (uint32_t i = offsets[r]; i < offsets[r + 1]; ++i) {
+        const float wi = w[i];
+        const float c0 = cd[3 * (size_t)i], c1 = cd[3 * (size_t)i + 1], c2 = cd[3 * (size_t)i + 2];
+        const float e0 = cs[3 * (size_t)i], e1 = cs[3 * (size_t)i + 1], e2 = cs[3 * (size_t)i + 2];
+        ar += wi * ((c0 + e0) * intensity); ag += wi * ((c1 + e1) * intensity); ab += wi * ((c2 + e2) * intensity);
+        d0 += wi * c0; d1 += wi * c1; d2 += wi * c2;
+        s0 += wi * e0; s1 += wi * e1; s2 += wi * e2;
+    }
+    const float rest = 1 - ws[r];
+    image[3 * (size_t)r] = ar + rest * bg; image[3 * (size_t)r + 1] = ag + rest * bg; image[3 * (size_t)r + 2] = ab + rest * bg;
+    if (diffuse) { diffuse[3 * (size_t)r] = d0; diffuse[3 * (size_t)r + 1] = d1; diffuse[3 * (size_t)r + 2] = d2; }
+    if (specular) { specular[3 * (size_t)r] = s0; specular[3 * (size_t)r + 1] = s1; specular[3 * (size_t)r + 2] = s2; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1074,6 +1124,14 @@ int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const f
         a.r_images = d->r_images; a.renv_blob = d->renv_blob; a.spec2_blob = d->spec2_blob;
         a.indir_rough_thresh = d->indir_roughness_thresh;
     }
+    if (d->geometry_export) {
+        const envidr_geometry_export* e = d->geometry_export;
+        ENVIDR_REQUIRE(d->geometry_only, "render_rays: geometry_export requires geometry_only");
+        ENVIDR_REQUIRE(e->counter && e->ray && e->idx && e->w && e->normal && e->geo_feat && e->roughness,
+                       "render_rays: null pointer in geometry_export");
+        a.ex_counter = e->counter; a.ex_capacity = e->capacity; a.ex_ray = e->ray; a.ex_idx = e->idx; a.ex_w = e->w;
+        a.ex_normal = e->normal; a.ex_geo = e->geo_feat; a.ex_rough = e->roughness;
+    }
     a.image = out->image; a.depth = out->depth; a.ws = out->weights_sum; a.normal = out->normal_image;
     a.diffuse = out->diffuse_image; a.specular = out->specular_image; a.roughness = out->roughness_image;
     a.stats = reinterpret_cast<unsigned long long*>(out->stats);
@@ -1165,6 +1223,16 @@ int envidr_shade_samples(const envidr_render_desc* d, const float* normals, cons
     }
 #undef ENVIDR_LAUNCH
     return check_launch("k_shade_samples");
+}
+
+int envidr_composite_shaded(const uint32_t* offsets, const float* w, const float* c_diffuse, const float* c_specular,
+                            const float* weights_sum, uint32_t N, float intensity_scale, float bg_color, float* image,
+                            float* diffuse_image, float* specular_image, envidr_stream_t stream) {
+    if (N == 0) return ENVIDR_OK;
+    ENVIDR_REQUIRE(offsets && w && c_diffuse && c_specular && weights_sum && image, "composite_shaded: null pointer");
+    hipLaunchKernelGGL(k_composite_shaded, dim3(ceil_div(N, kBlock)), dim3(kBlock), 0, as_stream(stream), offsets, w, c_diffuse,
+                       c_specular, weights_sum, N, intensity_scale, bg_color, image, diffuse_image, specular_image);
+    return check_launch("k_composite_shaded");
 }
 
 }  // extern "C"

@@ -21,6 +21,12 @@ MAX_LEVELS = 16
 _FP = ctypes.c_void_p
 
 
+class GeometryExport(ctypes.Structure):
+    """mirror of `envidr_geometry_export`"""
+    _fields_ = [("counter", _FP), ("capacity", ctypes.c_uint32), ("ray", _FP), ("idx", _FP), ("w", _FP), ("normal", _FP),
+                ("geo_feat", _FP), ("roughness", _FP)]
+
+
 class RenderDesc(ctypes.Structure):
     """mirror of `envidr_render_desc` (include/envidr_render.h) -- keep field order in sync"""
     _fields_ = [
@@ -36,7 +42,7 @@ class RenderDesc(ctypes.Structure):
         ("diffuse_kappa_inv", ctypes.c_float), ("light_intensity_scale", ctypes.c_float), ("intensity_scale", ctypes.c_float),
         ("has_env_rot", ctypes.c_int32), ("env_rot", ctypes.c_float * 9), ("dir_sh_degree", ctypes.c_uint32),
         ("geometry_only", ctypes.c_int32), ("r_images", _FP), ("renv_blob", _FP), ("spec2_blob", _FP),
-        ("indir_roughness_thresh", ctypes.c_float),
+        ("indir_roughness_thresh", ctypes.c_float), ("geometry_export", ctypes.POINTER(GeometryExport)),
     ]
 
 
@@ -92,6 +98,8 @@ def _bind_render(lib):
     lib.envidr_shade_samples.argtypes = [ctypes.POINTER(RenderDesc), _FP, _FP, _FP, ctypes.c_uint32, _FP, ctypes.c_uint32,
                                          ctypes.c_uint32, _FP, _FP, _FP]
     lib.envidr_shade_samples.restype = ctypes.c_int
+    lib.envidr_composite_shaded.argtypes = [_FP, _FP, _FP, _FP, _FP, ctypes.c_uint32, ctypes.c_float, ctypes.c_float, _FP, _FP, _FP, _FP]
+    lib.envidr_composite_shaded.restype = ctypes.c_int
     lib._envidr_render_bound = True
 
 
@@ -176,6 +184,28 @@ def _shade(lib, desc, normals, dirs, geo_feat, roughness, env_rot_radian, out):
     if rc:
         raise _lib.EnvidrError(f"envidr_shade_samples failed ({rc}): {lib.envidr_last_error().decode()}")
     return res
+
+
+@dataclass
+class GeometryCache:
+    """everything about one camera's frame that does not depend on the environment: per composited
+    sample, sorted by (ray, sample index): compositing weight, normal, view direction, geometry feature, roughness;
+    per ray: sample offsets and the environment-independent images"""
+    n_rays: int
+    offsets: torch.Tensor          # [N+1] int32
+    w: torch.Tensor                # [M]
+    normals: torch.Tensor          # [M,3]
+    dirs: torch.Tensor             # [M,3]
+    geo_feat: torch.Tensor         # [M,12]
+    roughness: torch.Tensor        # [M]
+    depth: torch.Tensor            # [N]
+    weights_sum: torch.Tensor      # [N]
+    normal_image: torch.Tensor     # [N,3]
+    roughness_image: torch.Tensor  # [N]
+
+    @property
+    def n_samples(self) -> int:
+        return int(self.w.shape[0])
 
 
 class FusedShader:
@@ -328,6 +358,64 @@ class FusedRenderer:
     def shade(self, normals, dirs, geo_feat, roughness, env_rot_radian: float | None = None, out: dict | None = None) -> dict:
         """shading only, for samples with known geometry (envidr_shade_samples); environment-MLP family"""
         return _shade(self.lib, self.desc, normals, dirs, geo_feat, roughness, env_rot_radian, out)
+
+    # ---- geometry cache: march / hash / SDF once per camera, shading per environment -----------------
+    def cache_geometry(self, rays_o: torch.Tensor, rays_d: torch.Tensor, samples_per_ray_hint: float = 16.0) -> GeometryCache:
+        """one geometry-only render that also exports every composited sample; retried once with the exact size if the
+        first guess of the record capacity was too small"""
+        rays_o = rays_o.contiguous().view(-1, 3).float()
+        rays_d = rays_d.contiguous().view(-1, 3).float()
+        N, dev = rays_o.shape[0], rays_o.device
+        cap = max(int(N * samples_per_ray_hint), 1024)
+        for _ in range(2):
+            counter = torch.zeros(1, dtype=torch.int32, device=dev)
+            rec = {"ray": torch.empty(cap, dtype=torch.int32, device=dev), "idx": torch.empty(cap, dtype=torch.int32, device=dev),
+                   "w": torch.empty(cap, device=dev), "normal": torch.empty(cap, 3, device=dev),
+                   "geo": torch.empty(cap, 12, device=dev), "rough": torch.empty(cap, device=dev)}
+            ex = GeometryExport(counter.data_ptr(), cap, rec["ray"].data_ptr(), rec["idx"].data_ptr(), rec["w"].data_ptr(),
+                                rec["normal"].data_ptr(), rec["geo"].data_ptr(), rec["rough"].data_ptr())
+            self.desc.geometry_export = ctypes.pointer(ex)
+            try:
+                res = self.render(rays_o, rays_d, None, extras=True, geometry_only=True)
+            finally:
+                self.desc.geometry_export = None
+            M = int(counter.item())
+            if M <= cap:
+                break
+            cap = M
+        else:
+            raise _lib.EnvidrError("geometry export: record count changed between two identical renders")
+        ray = rec["ray"][:M].long()
+        order = torch.argsort(ray * 4096 + rec["idx"][:M].long())          # (ray, sample index): at most 1024 samples per ray
+        ray = ray[order]
+        offsets = torch.zeros(N + 1, dtype=torch.int32, device=dev)
+        offsets[1:] = torch.cumsum(torch.bincount(ray, minlength=N), 0).int()
+        return GeometryCache(n_rays=N, offsets=offsets, w=rec["w"][:M][order].contiguous(),
+                             normals=rec["normal"][:M][order].contiguous(), dirs=rays_d[ray].contiguous(),
+                             geo_feat=rec["geo"][:M][order].contiguous(), roughness=rec["rough"][:M][order].contiguous(),
+                             depth=res["depth"].clone(), weights_sum=res["weights_sum"].clone(),
+                             normal_image=res["normal_image"].clone(), roughness_image=None)
+
+    def render_cached(self, cache: GeometryCache, env_rot_radian: float | None = None, out: dict | None = None) -> dict:
+        """re-light a cached frame: envidr_shade_samples over its samples + envidr_composite_shaded; bit-identical to
+        render() of the same rays with the same environment rotation"""
+        dev = cache.w.device
+        res = out if out is not None else {}
+        shaded = _shade(self.lib, self.desc, cache.normals, cache.dirs, cache.geo_feat, cache.roughness, env_rot_radian,
+                        res.setdefault("_shaded", {}))
+        N = cache.n_rays
+        for name in ("image", "diffuse_image", "specular_image"):
+            if name not in res or res[name].shape != (N, 3):
+                res[name] = torch.empty(N, 3, device=dev)
+        rc = self.lib.envidr_composite_shaded(cache.offsets.data_ptr(), cache.w.data_ptr(), shaded["c_diffuse"].data_ptr(),
+                                              shaded["c_specular"].data_ptr(), cache.weights_sum.data_ptr(), N,
+                                              float(self.desc.intensity_scale), float(self.desc.bg_color), res["image"].data_ptr(),
+                                              res["diffuse_image"].data_ptr(), res["specular_image"].data_ptr(),
+                                              torch.cuda.current_stream(dev).cuda_stream)
+        if rc:
+            raise _lib.EnvidrError(f"envidr_composite_shaded failed ({rc}): {self.lib.envidr_last_error().decode()}")
+        res.update(depth=cache.depth, weights_sum=cache.weights_sum, normal_image=cache.normal_image)
+        return res
 
     def render(self, rays_o: torch.Tensor, rays_d: torch.Tensor, env_rot_radian: float | None = None,
                extras: bool = True, stats: bool = False, out: dict | None = None, geometry_only: bool = False,

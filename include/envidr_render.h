@@ -47,6 +47,22 @@ int envidr_pack_layer(const float* W_host, const float* bias_host, uint32_t m_ou
                       int k_order, float* dst_host);
 int envidr_pack_rowvec(const float* v_host, uint32_t m_out, float* dst_host);
 
+/* ---- geometry cache ----------------------------------------------------------
+ * For a fixed camera everything up to the compositing weights is independent of the environment: positions, densities,
+ * normals, geometry features, roughness.  A geometry_only render with this struct attached appends one record per
+ * composited sample (any order; sort by (ray, idx)); envidr_shade_samples + envidr_composite_shaded then re-light the
+ * frame for any environment rotation / swapped environment MLP without marching, hash lookups or the SDF network. */
+typedef struct envidr_geometry_export {
+    uint32_t* counter;     /* device [1], zeroed by the caller; ends at the number of records (may exceed capacity) */
+    uint32_t capacity;     /* records the arrays below can hold; records beyond it are counted but not written     */
+    uint32_t* ray;         /* [capacity]    ray id                                                                */
+    uint32_t* idx;         /* [capacity]    index of the sample within its ray (march order)                       */
+    float* w;              /* [capacity]    compositing weight alpha_i * T_i                                        */
+    float* normal;         /* [capacity,3]                                                                          */
+    float* geo_feat;       /* [capacity,12] unit-normalised                                                         */
+    float* roughness;      /* [capacity]                                                                            */
+} envidr_geometry_export;
+
 /* ---- scene / model description ---------------------------------------------------------------- */
 typedef struct envidr_render_desc {
     /* occupancy grid marching (NeRFRenderer state + render kwargs) */
@@ -125,6 +141,8 @@ typedef struct envidr_render_desc {
     const float* renv_blob;
     const float* spec2_blob;
     float indir_roughness_thresh;    /* 0.1 */
+
+    const envidr_geometry_export* geometry_export;   /* HOST pointer or NULL; only with geometry_only != 0 */
 } envidr_render_desc;
 
 /* ---- per-call outputs (device pointers; any optional pointer may be NULL) --------------------- */
@@ -162,6 +180,14 @@ int envidr_render_rays(const envidr_render_desc* desc, const float* rays_o, cons
 int envidr_shade_samples(const envidr_render_desc* desc, const float* normals, const float* dirs, const float* geo_feat,
                          uint32_t geo_feat_stride, const float* roughness, uint32_t roughness_stride, uint32_t M,
                          float* c_diffuse, float* c_specular, envidr_stream_t stream);
+
+/* Composite shaded colours over cached geometry: ray r owns records offsets[r] .. offsets[r+1]-1 (sorted by (ray, idx)).
+ *   image[r] = sum_i w_i (c_diffuse_i + c_specular_i) intensity_scale + (1 - weights_sum[r]) bg_color, and the optional
+ *   diffuse / specular images = sum_i w_i c_i: the blend of the render loop (cuda_ray.py:318-340) with known weights,
+ *   same accumulation order. */
+int envidr_composite_shaded(const uint32_t* offsets, const float* w, const float* c_diffuse, const float* c_specular,
+                            const float* weights_sum, uint32_t N, float intensity_scale, float bg_color, float* image,
+                            float* diffuse_image, float* specular_image, envidr_stream_t stream);
 
 #ifdef __cplusplus
 }
