@@ -279,6 +279,10 @@ constexpr int kRingDepth = ENVIDR_RING_DEPTH;
 #define ENVIDR_HASH_AHEAD 2
 #endif
 constexpr int kHashAhead = ENVIDR_HASH_AHEAD;     // hash levels whose corner gathers are in flight ahead of the one being interpolated
+#ifndef ENVIDR_PLAIN_WAVES
+#define ENVIDR_PLAIN_WAVES 1
+#endif
+constexpr int kPlainWaves = ENVIDR_PLAIN_WAVES;   // waves per SIMD the no-environment family is built for (it is latency-, not MFMA-bound)
 constexpr uint32_t kBlockThreads = kSharedWeights ? 256 : 64;
 constexpr int ring_padded(int frags) { return (frags + kRingDepth - 1) / kRingDepth * kRingDepth; }
 
@@ -429,7 +433,7 @@ __device__ __forceinline__ void shade_sample(WP& wp, const uint32_t lane, const 
 //   SH_DEG  > 0: no environment network (BASELINE configs[1]): diffuse head on geo_feat, specular head on
 //                [SH(view dir) | geo_feat | SH(normal) | n.v] with SH "degree" SH_DEG (SH_DEG^2 values each)
 template <int IDE_DEG, int ENV_T, int SH_DEG>
-__global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const RenderArgs a) {
+__global__ void __launch_bounds__(kBlockThreads, (SH_DEG > 0 ? kPlainWaves : 1)) k_render_persistent(const RenderArgs a) {
     constexpr bool kEnvNet = SH_DEG == 0;
     constexpr int kShDim = SH_DEG * SH_DEG;
     constexpr int kDiffIn = kEnvNet ? 24 : 12, kSpecIn = kEnvNet ? 28 : 2 * kShDim + 13;
@@ -1167,7 +1171,8 @@ int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const f
     // persistent grid: one 4-wave workgroup per CU (one wave per SIMD; the kernel uses the full
     // 512-register budget so exactly one wave fits a SIMD), fewer when the batch is small
     const uint32_t waves_per_block = kBlockThreads / 64;
-    const uint32_t blocks = std::min((uint32_t)device_cu_count() * (4 / waves_per_block), ceil_div(N, kBlockThreads));
+    const uint32_t waves_per_simd = d->dir_sh_degree ? (uint32_t)kPlainWaves : 1u;
+    const uint32_t blocks = std::min((uint32_t)device_cu_count() * (4 / waves_per_block) * waves_per_simd, ceil_div(N, kBlockThreads));
     const dim3 grid(blocks), block(kBlockThreads);
 #define ENVIDR_LAUNCH(DEG, HT, SH) hipLaunchKernelGGL((k_render_persistent<DEG, HT, SH>), grid, block, 0, s, a)
     if (d->dir_sh_degree == 4) ENVIDR_LAUNCH(4, 0, 4);
