@@ -32,9 +32,13 @@ class LaplaceDensity(nn.Module):
         clamped = torch.clamp(self.beta.detach(), self.beta_min, self.beta_max)
         return self.beta + (clamped - self.beta.detach())      # value = clamp(beta), gradient = d beta
 
-    def forward(self, sdf, beta=None):
+    def density_func(self, sdf, beta=None, alpha=None):
         beta = self.get_beta() if beta is None else beta
-        return (1 / beta) * (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / beta))
+        alpha = 1 / beta if alpha is None else alpha
+        return alpha * (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / beta))
+
+    def forward(self, sdf, beta=None):
+        return self.density_func(sdf, beta=beta)
 
 
 def _mlp(dims, bias=True):
@@ -231,6 +235,17 @@ class NeRFNetwork(NeRFRenderer):
     def forward(self, x, d, normal=None, w_r=None, n_dot_w_o=None):
         sdf, sigma, geo_feat, _, _ = self.forward_sigma(x)
         return sdf, sigma, self.forward_color(geo_feat, d, normal, w_r, n_dot_w_o)
+
+    def color(self, x, d, mask=None, geo_feat=None, normal=None, w_r=None, n_dot_w_o=None, **kwargs):
+        """rgb of the samples selected by `mask` (all when None), zeros elsewhere (reference network.py:745-770)"""
+        if mask is None:
+            return self.forward_color(geo_feat, d, normal, w_r, n_dot_w_o)
+        rgbs = torch.zeros(mask.shape[0], 3, dtype=x.dtype, device=x.device)
+        if not mask.any():
+            return rgbs
+        pick = lambda t: None if t is None else t[mask]
+        rgbs[mask] = self.forward_color(geo_feat[mask], d[mask], pick(normal), pick(w_r), pick(n_dot_w_o)).to(rgbs.dtype)
+        return rgbs
 
     # ---- fused path -------------------------------------------------------------------------------
     def supports_fused(self, r_images=None, geometry_only=False, **kwargs) -> bool:

@@ -100,6 +100,17 @@ class NeRFRenderer(nn.Module):
             normals = F.normalize(normals * r + (1 - r) * F.normalize(xyzs.detach(), dim=-1, eps=1e-10), dim=-1, eps=1e-10)
         return normals, eikonal
 
+    def reset_extra_state(self):
+        """empty density grid and step statistics (reference renderer.py:131-141)"""
+        if not self.cuda_ray:
+            return
+        self.density_grid.zero_()
+        self.mean_density = 0
+        self.iter_density = 0
+        self.step_counter.zero_()
+        self.mean_count = 0
+        self.local_step = 0
+
     # ---- occupancy-grid maintenance (reference renderer.py:200-359) ------------------------------
     def _cell_blocks(self, S):
         """the H^3 cell lattice in S^3 blocks: (coords [n,3] int32, morton indices [n] int64) per block,
