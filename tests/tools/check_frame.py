@@ -1,3 +1,5 @@
+"""Developer check (needs a GPU): one small frame against the oracle, then 800x800 timings.  Lives under tests/ because it uses
+the oracle (test infrastructure); run as `python tests/tools/check_frame.py` from the repository root."""
 import sys, time, numpy as np, torch
 sys.path.insert(0, '.')
 from envidr_amd import scenes

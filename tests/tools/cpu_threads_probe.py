@@ -1,3 +1,4 @@
+"""Developer probe: oracle render time vs torch thread count on this host (the cpu_baseline leg of bench.py picks the best of a few)."""
 import os, sys, time
 sys.path.insert(0, '.')
 import torch, numpy as np
