@@ -31,6 +31,8 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        # the host driver only supports dmabuf IPC; without this RCCL fails with hipIpcGetMemHandle: invalid argument
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
