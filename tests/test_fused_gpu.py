@@ -111,3 +111,29 @@ def test_fused_no_env_family_matches_reference_and_oracle():
     for key in KEYS:
         err = rel_l2(out[key], want[key].reshape(out[key].shape))
         assert err <= 2e-5, f"{key} vs oracle: rel-L2 {err:.3e}"
+
+
+def test_fused_two_cascades_growing_steps_short_rays():
+    """render knobs away from the toaster defaults: bound 2 (two occupancy cascades, hash grid sized for 4096), growing
+    step size (dt_gamma > 0), a 384-sample cap, looser termination, near plane 0.05, 8 enabled hash levels, non-unit
+    intensity / roughness scales; against the oracle on the kernel's schedule"""
+    import torch
+    from envidr_amd.fused import FusedOptions, FusedRenderer
+    from oracle.py import render_oracle as ro
+    rng = np.random.default_rng(12)
+    offsets, pls = scenes.hash_level_offsets(desired_resolution=2 * 2048)
+    base = scenes.toaster_scene(seed=12)
+    scene = scenes.SceneParams(bitfield=scenes.occupancy_bitfield(scenes.shell(1.1, 0.12), bound=2.0, cascades=2), offsets=offsets,
+                               per_level_scale=pls, table=rng.uniform(-0.1, 0.1, size=(int(offsets[-1]), 2)).astype(np.float32),
+                               mlps=base.mlps, beta=0.02, bound=2.0, cascades=2)
+    knobs = dict(bound=2.0, min_near=0.05, max_steps=384, dt_gamma=1 / 128, T_thresh=1e-3, enabled_levels=8, intensity_scale=0.7,
+                 roughness_scale=1.5)
+    r = FusedRenderer.from_scene(scene, FusedOptions(**knobs))
+    rays_o, rays_d = scenes.camera_rays(40, 40, theta=140.0, phi=-30.0, radius=4.0, scale=1.2)
+    want = ro.render_rays(scene, rays_o, rays_d, ro.RenderOptions(cascades=2, ide_mode="exact", **knobs), None, force_n_step=1)
+    out = _render(r, rays_o, rays_d)
+    assert want["n_samples"] > 5000
+    assert want["n_samples"] <= int(out["stats"][0]) <= want["n_samples"] * 1.05 + 512
+    for key in KEYS:
+        err = rel_l2(out[key], want[key].reshape(out[key].shape))
+        assert err <= 2e-5, f"{key}: rel-L2 {err:.3e}"
