@@ -204,3 +204,37 @@ def test_fused_indirect_passes_equal_the_operator_loop():
         assert rel_l2(x, y) <= 2e-5, f"{key}: {rel_l2(x, y):.3e}"
     # the branch did something: specular differs from the render without reflected radiance
     assert rel_l2(a["specular_image"].cpu().numpy(), plain["specular_image"].cpu().numpy()) > 1e-3
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_fused_vs_operator_loop_on_random_scenes(seed):
+    """randomised cross-check of the two render paths: random blobby occupancy, random (non-camera) rays including rays
+    that start inside the box, random env rotation and render knobs; fused kernel vs the reference-shaped operator loop"""
+    import torch
+    rng = np.random.default_rng(100 + seed)
+    centres = rng.uniform(-0.6, 0.6, size=(6, 3))
+    radii = rng.uniform(0.12, 0.3, size=6)
+    blobs = lambda p: (np.linalg.norm(p[:, None, :] - centres[None], axis=-1) < radii[None]).any(1)
+    scene = scenes.toaster_scene(table_scale=float(rng.uniform(0.05, 0.3)), shape=blobs, sdf_bias=float(rng.uniform(-0.01, 0.02)),
+                                 beta=float(rng.uniform(0.01, 0.05)), seed=50 + seed)
+    knobs = dict(max_steps=int(rng.choice([256, 512, 1024])), T_thresh=float(rng.choice([1e-4, 1e-3])),
+                 dt_gamma=float(rng.choice([0.0, 1 / 256])))
+    model, opt = build_model(scene, **knobs, enabled_levels=int(rng.choice([-1, 10])), intensity_scale=float(rng.uniform(0.5, 1.0)))
+    model.min_near = float(rng.choice([0.0, 0.2]))
+    n = 3000 + 7 * seed
+    o = rng.uniform(-1.6, 1.6, size=(n, 3))
+    o[: n // 4] *= 0.4                                                       # some origins inside the scene box
+    target = rng.uniform(-0.7, 0.7, size=(n, 3))
+    d = target - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    ro, rd = torch.from_numpy(o.astype(np.float32)).cuda()[None], torch.from_numpy(d.astype(np.float32)).cuda()[None]
+    kw = dict(staged=True, bg_color=float(rng.uniform(0, 1)), perturb=False, get_normal_image=True,
+              env_rot_radian=float(rng.uniform(0, 6.28)), **knobs)
+    assert model.supports_fused()
+    a = model.render(ro, rd, fused=True, **kw)
+    b = model.render(ro, rd, fused=False, **kw)
+    torch.cuda.synchronize()
+    assert float(b["weights_sum"].max()) > 0.5
+    for key in KEYS:
+        x, y = a[key].cpu().numpy().reshape(n, -1), b[key].cpu().numpy().reshape(n, -1)
+        assert rel_l2(x, y) <= 3e-5, f"seed {seed} {key}: {rel_l2(x, y):.3e}"
