@@ -97,13 +97,16 @@ def main() -> None:
     rays_o, rays_d = (torch.from_numpy(a).to(dev) for a in scenes.camera_rays(H, W))
     N = H * W
     out: dict = {}
+    # scheduling hint (DESIGN.md "work-list order"): samples per ray of the previous frame of this camera; orders the
+    # persistent kernel's work list longest ray first.  Order only: every frame still marches and shades every sample.
+    ray_cost = torch.zeros(N, dtype=torch.int16, device=dev)
     gather_list = [torch.empty(N, 3, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
 
     def env_rot(view: int) -> float:
         return 2 * math.pi * (view % 200) / 200
 
     def step(i: int) -> None:
-        res = renderer.render(rays_o, rays_d, env_rot(i * world + rank), extras=True, stats=True, out=out)
+        res = renderer.render(rays_o, rays_d, env_rot(i * world + rank), extras=True, stats=True, out=out, ray_cost=ray_cost)
         if world > 1:
             dist.gather(res["image"], gather_list=gather_list, dst=0)
 
@@ -121,7 +124,8 @@ def main() -> None:
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev[i][0].record()                      # same stream the kernel is launched on (torch's current stream)
-        res = renderer.render(rays_o, rays_d, env_rot((args.warmup + i) * world + rank), extras=True, stats=True, out=out)
+        res = renderer.render(rays_o, rays_d, env_rot((args.warmup + i) * world + rank), extras=True, stats=True, out=out,
+                              ray_cost=ray_cost)
         ev[i][1].record()
         if world > 1:
             dist.gather(res["image"], gather_list=gather_list, dst=0)

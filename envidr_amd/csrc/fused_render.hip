@@ -90,6 +90,7 @@ struct RenderArgs {
     float* image; float* depth; float* ws; float* normal; float* diffuse; float* specular; float* roughness;
     unsigned long long* stats;
     uint32_t* ray_counter;      // [0] queue head, [1] number of hit rays (written by k_first_hit)
+    uint16_t* ray_cost;         // [N] optional scheduling hint, in: samples each ray took in an earlier render, out: this render's
     const uint32_t* hit_ids;    // [N] compacted ids of rays that have at least one sample
     const float* hit_t;         // [N] per RAY: marcher time at its first sample
 };
@@ -129,6 +130,15 @@ __device__ __forceinline__ void normalize_n(float (&v)[N], float eps) {
     for (int i = 0; i < N; ++i) v[i] = v[i] * inv;
 }
 
+// cost buckets of the optional scheduling hint: 256 buckets of 2^kCostShift samples (coarse buckets keep image-space
+// neighbours, whose hash gathers share cache lines, together)
+#ifndef ENVIDR_COST_SHIFT
+#define ENVIDR_COST_SHIFT 4
+#endif
+constexpr uint32_t kCostShift = ENVIDR_COST_SHIFT;
+constexpr uint32_t kCostBuckets = 256, kCostBase = 4;      // counters: [0] queue head, [1] hits, [4..] bucket counts, then bucket cursors
+__device__ __forceinline__ uint32_t cost_bucket(uint32_t cost) { return min(cost >> kCostShift, kCostBuckets - 1); }
+
 // First-hit pre-pass: one lane per ray, full occupancy.  Empty-space skipping is cheap per ray but
 // long and divergent; inside the persistent kernel it would stall 63 shading lanes behind one
 // marching lane.  Rays with no occupied sample are finished here (background only); the others are
@@ -157,10 +167,66 @@ __global__ void __launch_bounds__(kBlock) k_first_hit(const RenderArgs a, uint32
     }
     const unsigned long long mask = __ballot(hit);
     const uint32_t lane = threadIdx.x & 63;
+    if (a.ray_cost) {
+        // cost-ordered work list: count the hit rays per cost bucket here, k_order_hits places them
+        if (id < a.N) { if (!hit) hit_t[id] = -1.0f; }
+        const uint32_t bucket = hit ? cost_bucket(a.ray_cost[id]) : 0u;
+        unsigned long long todo = mask;
+        while (todo) {                                       // one atomic per distinct bucket in the wave
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t b = __shfl(bucket, leader);
+            const unsigned long long same = __ballot(hit && bucket == b);
+            if ((int)lane == leader) atomicAdd(&counters[kCostBase + b], (uint32_t)__popcll(same));
+            todo &= ~same;
+        }
+        if (lane == 0 && mask) atomicAdd(&counters[1], (uint32_t)__popcll(mask));
+        return;
+    }
     uint32_t base = 0;
     if (lane == 0 && mask) base = atomicAdd(&counters[1], (uint32_t)__popcll(mask));
     base = __shfl(base, 0);
     if (hit) hit_ids[base + __popcll(mask & ((1ull << lane) - 1ull))] = id;
+}
+
+// Second half of the cost-ordered work list (longest rays first: the persistent waves then run out of work together
+// instead of a few waves finishing long rays alone; a poor hint only costs balance, never correctness).  Bucket b's
+// rays go to [start_b, start_b + count_b) with start_b = number of hit rays in more expensive buckets; inside a bucket
+// the rays of one wave stay together.
+__global__ void __launch_bounds__(kBlock) k_order_hits(const RenderArgs a, uint32_t* __restrict__ hit_ids, const float* __restrict__ hit_t,
+                                                       uint32_t* __restrict__ counters) {
+    __shared__ uint32_t start[kCostBuckets];
+    if (threadIdx.x < 64) {
+        // exclusive suffix sum over the bucket counts, by one wave
+        uint32_t run = 0;
+        for (int hi = kCostBuckets - 64; hi >= 0; hi -= 64) {
+            const int b = hi + 63 - (int)threadIdx.x;                 // lane 0 takes the most expensive bucket of the group
+            const uint32_t c = counters[kCostBase + b];
+            uint32_t incl = c;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off);
+                if ((int)threadIdx.x >= off) incl += up;
+            }
+            start[b] = run + incl - c;
+            run += __shfl(incl, 63);
+        }
+    }
+    __syncthreads();
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63;
+    const bool hit = id < a.N && hit_t[id] >= 0.0f;
+    const uint32_t bucket = hit ? cost_bucket(a.ray_cost[id]) : 0u;
+    if (id < a.N && !hit) a.ray_cost[id] = 0;
+    unsigned long long todo = __ballot(hit);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t b = __shfl(bucket, leader);
+        const unsigned long long same = __ballot(hit && bucket == b);
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&counters[kCostBase + kCostBuckets + b], (uint32_t)__popcll(same));
+        base = __shfl(base, leader);
+        if (hit && bucket == b) hit_ids[start[b] + base + __popcll(same & ((1ull << lane) - 1ull))] = id;
+        todo &= ~same;
+    }
 }
 
 // position of the n-th set bit of mask (n < popcount(mask))
@@ -492,6 +558,7 @@ __global__ void __launch_bounds__(kBlockThreads, (SH_DEG > 0 ? kPlainWaves : 1))
         if (a.diffuse) { a.diffuse[3 * id] = ad[0]; a.diffuse[3 * id + 1] = ad[1]; a.diffuse[3 * id + 2] = ad[2]; }
         if (a.specular) { a.specular[3 * id] = as[0]; a.specular[3 * id + 1] = as[1]; a.specular[3 * id + 2] = as[2]; }
         if (a.roughness) a.roughness[id] = arough;
+        if (a.ray_cost) a.ray_cost[id] = (uint16_t)min(n_taken, 65535u);
         ray = -1;
     };
 
@@ -1150,7 +1217,7 @@ int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const f
     if (N > g_cap || !g_counters) {
         if (g_hit_ids) (void)hipFree(g_hit_ids);
         if (g_hit_t) (void)hipFree(g_hit_t);
-        if (!g_counters && hipMalloc(&g_counters, 16) != hipSuccess) return check_launch("render_rays counters alloc");
+        if (!g_counters && hipMalloc(&g_counters, (kCostBase + 2 * kCostBuckets) * 4) != hipSuccess) return check_launch("render_rays counters alloc");
         g_cap = N + N / 4;
         if (hipMalloc(&g_hit_ids, (size_t)g_cap * 4) != hipSuccess || hipMalloc(&g_hit_t, (size_t)g_cap * 4) != hipSuccess) {
             g_hit_ids = nullptr; g_hit_t = nullptr; g_cap = 0;
@@ -1161,10 +1228,16 @@ int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const f
     a.ray_counter = g_counters;
     a.hit_ids = g_hit_ids;
     a.hit_t = g_hit_t;
-    if (hipMemsetAsync(g_counters, 0, 8, s) != hipSuccess) return check_launch("render_rays memset");
+    a.ray_cost = d->ray_cost;
+    if (hipMemsetAsync(g_counters, 0, (kCostBase + 2 * kCostBuckets) * 4, s) != hipSuccess) return check_launch("render_rays memset");
     hipLaunchKernelGGL(k_first_hit, dim3(ceil_div(N, kBlock)), dim3(kBlock), 0, s, a, g_hit_ids, g_hit_t, g_counters);
     {
         const int rc = check_launch("k_first_hit");
+        if (rc) return rc;
+    }
+    if (a.ray_cost) {
+        hipLaunchKernelGGL(k_order_hits, dim3(ceil_div(N, kBlock)), dim3(kBlock), 0, s, a, g_hit_ids, g_hit_t, g_counters);
+        const int rc = check_launch("k_order_hits");
         if (rc) return rc;
     }
 

@@ -43,6 +43,7 @@ class RenderDesc(ctypes.Structure):
         ("has_env_rot", ctypes.c_int32), ("env_rot", ctypes.c_float * 9), ("dir_sh_degree", ctypes.c_uint32),
         ("geometry_only", ctypes.c_int32), ("r_images", _FP), ("renv_blob", _FP), ("spec2_blob", _FP),
         ("indir_roughness_thresh", ctypes.c_float), ("geometry_export", ctypes.POINTER(GeometryExport)),
+        ("ray_cost", _FP),
     ]
 
 
@@ -419,11 +420,13 @@ class FusedRenderer:
 
     def render(self, rays_o: torch.Tensor, rays_d: torch.Tensor, env_rot_radian: float | None = None,
                extras: bool = True, stats: bool = False, out: dict | None = None, geometry_only: bool = False,
-               r_images: torch.Tensor | None = None) -> dict:
+               r_images: torch.Tensor | None = None, ray_cost: torch.Tensor | None = None) -> dict:
         """rays_o, rays_d: [N,3] fp32 on the GPU.  Returns image [N,3], depth [N], weights_sum [N]
         (+ normal_image, diffuse_image, specular_image, roughness_image when `extras`).
         geometry_only: depth / weights_sum / normal_image only (first pass of indirect rendering).
-        r_images: [N,4] reflected radiance + visibility per ray (third pass of indirect rendering)."""
+        r_images: [N,4] reflected radiance + visibility per ray (third pass of indirect rendering).
+        ray_cost: int16 [N] scheduling hint kept by the caller between renders of the same rays (zeros at first): samples
+        per ray of the previous render in, of this render out; orders the work list longest ray first (same outputs)."""
         if not (rays_o.is_cuda and rays_d.is_cuda):
             raise _lib.EnvidrError("render: rays must live on the GPU")
         rays_o = rays_o.contiguous().view(-1, 3).float()
@@ -459,6 +462,11 @@ class FusedRenderer:
             if r_images.shape[0] != N or not r_images.is_cuda:
                 raise _lib.EnvidrError("render: r_images must be [N,4] on the GPU")
             self.desc.r_images = r_images.data_ptr()
+        self.desc.ray_cost = None
+        if ray_cost is not None:
+            if ray_cost.dtype != torch.int16 or ray_cost.numel() != N or not ray_cost.is_cuda or not ray_cost.is_contiguous():
+                raise _lib.EnvidrError("render: ray_cost must be a contiguous int16 [N] tensor on the GPU")
+            self.desc.ray_cost = ray_cost.data_ptr()
         stream = torch.cuda.current_stream(dev).cuda_stream
         rc = self.lib.envidr_render_rays(ctypes.byref(self.desc), rays_o.data_ptr(), rays_d.data_ptr(), N, ctypes.byref(o),
                                          self.counter.data_ptr(), stream)

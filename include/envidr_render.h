@@ -143,6 +143,13 @@ typedef struct envidr_render_desc {
     float indir_roughness_thresh;    /* 0.1 */
 
     const envidr_geometry_export* geometry_export;   /* HOST pointer or NULL; only with geometry_only != 0 */
+
+    /* Optional scheduling hint, device uint16 [N], caller-owned, read AND written by the call: on entry the number of
+     * samples each of these N rays took in an earlier render (zeros if unknown), on return the numbers of this render.
+     * The work list is then ordered longest ray first, so the persistent waves run dry together (video frames of one
+     * camera: the previous frame's counts are exact).  It changes the order in which rays are processed and nothing
+     * else: every output is bit-identical with or without it. */
+    uint16_t* ray_cost;
 } envidr_render_desc;
 
 /* ---- per-call outputs (device pointers; any optional pointer may be NULL) --------------------- */

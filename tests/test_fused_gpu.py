@@ -137,3 +137,32 @@ def test_fused_two_cascades_growing_steps_short_rays():
     for key in KEYS:
         err = rel_l2(out[key], want[key].reshape(out[key].shape))
         assert err <= 2e-5, f"{key}: rel-L2 {err:.3e}"
+
+
+def test_ray_cost_hint_changes_order_only(scene, renderer):
+    """the scheduling hint (work list ordered longest ray first, from the previous render's per-ray sample counts)
+    must leave every output bit-identical, and must come back holding this render's counts"""
+    import torch
+    rays_o, rays_d = (torch.from_numpy(a).cuda() for a in scenes.camera_rays(160, 160, theta=20.0, phi=-35.0))
+    N = rays_o.shape[0]
+    plain = {k: v.clone() for k, v in renderer.render(rays_o, rays_d, 1.3, extras=True).items()}
+    cost = torch.zeros(N, dtype=torch.int16, device="cuda")
+    first = {k: v.clone() for k, v in renderer.render(rays_o, rays_d, 1.3, extras=True, ray_cost=cost).items()}   # no history yet
+    counts1 = cost.clone()
+    second = renderer.render(rays_o, rays_d, 1.3, extras=True, stats=True, ray_cost=cost)                         # ordered by counts1
+    torch.cuda.synchronize()
+    for k in KEYS:
+        assert torch.equal(first[k], plain[k]) and torch.equal(second[k], plain[k]), k
+    assert torch.equal(cost, counts1)                                  # same rays, same counts
+    hit = plain["weights_sum"] > 0
+    assert torch.all(counts1[~hit] == 0) and torch.all(counts1[hit] > 0)
+    cache = renderer.cache_geometry(rays_o, rays_d)
+    assert torch.equal((cache.offsets[1:] - cache.offsets[:-1]).to(torch.int16), counts1)
+    assert int(second["stats"][2]) == N
+    # a garbage hint is still only a hint
+    junk = torch.randint(0, 900, (N,), dtype=torch.int16, device="cuda")
+    third = renderer.render(rays_o, rays_d, 1.3, extras=True, ray_cost=junk)
+    torch.cuda.synchronize()
+    for k in KEYS:
+        assert torch.equal(third[k], plain[k]), k
+    assert torch.equal(junk, counts1)

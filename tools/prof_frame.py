@@ -17,9 +17,10 @@ else:
 ro8, rd8 = scenes.camera_rays(H, H)
 o8, d8 = torch.from_numpy(ro8).cuda(), torch.from_numpy(rd8).cuda()
 out = {}
+cost = torch.zeros(H * H, dtype=torch.int16, device="cuda") if (len(sys.argv) > 4 and sys.argv[4] == "hint") else None
 for i in range(n):
     torch.cuda.synchronize(); t0 = time.time()
-    res = r.render(o8, d8, None, extras=True, stats=True, out=out); torch.cuda.synchronize(); dt = time.time() - t0
+    res = r.render(o8, d8, None, extras=True, stats=True, out=out, ray_cost=cost); torch.cuda.synchronize(); dt = time.time() - t0
     st = res["stats"].tolist()
     if sum(st[4:]) > 0:
         tot = sum(st[4:]); names = ["march", "hash", "sdf", "geom", "ide", "env", "heads", "comp"]
