@@ -49,8 +49,16 @@ def run_cuda(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, fo
         fr = self.fused_renderer()
         fr.desc.bg_color = float(bg_color)
         fr.desc.min_near = float(self.min_near)
+        # scheduling hint: per-ray sample counts of the previous render with this many rays (the frames of a video share
+        # their rays; for other rays it is merely a poor hint -- outputs never depend on it)
+        hints = self.__dict__.setdefault("_ray_cost_hints", {})
+        key = (N, bool(geometry_only), r_images is not None)
+        if key not in hints or hints[key].device != device:
+            if len(hints) > 8:
+                hints.clear()
+            hints[key] = torch.zeros(N, dtype=torch.int16, device=device)
         res = fr.render(rays_o, rays_d, env_rot_radian, extras=True, geometry_only=geometry_only,
-                        r_images=None if r_images is None else r_images[0])
+                        r_images=None if r_images is None else r_images[0], ray_cost=hints[key])
         out = {"image": res["image"].view(*prefix, 3), "depth": res["depth"].view(*prefix), "weights_sum": res["weights_sum"].view(*prefix)}
         if geometry_only:
             out["image"] = None
