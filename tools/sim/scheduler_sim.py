@@ -110,3 +110,15 @@ def sim_intk(order, kmax, intk):
 for kmax, intk in [(8, False), (8, True), (16, True), (64, True)]:
     t, tot, mean = sim_intk(lpt, kmax, intk)
     print(f"LPT kmax {kmax} integer-k {intk}: makespan {t}, wave-rounds {tot}, mean finish {mean:.1f}, util {c.sum()/(tot*64):.3f}")
+
+print("---- bucket shapes (tail mode kmax 8)")
+def key_var(cost, thresh, wide, fine):
+    return np.where(cost >= thresh, (thresh >> fine) + ((cost - thresh) >> wide) + 1, cost >> fine)
+print("cost histogram (hit rays):", np.histogram(c[hit], bins=[1, 8, 16, 24, 32, 40, 48, 56, 64, 80])[0])
+for name, key in [("uniform 16", c[hit] >> 4), ("uniform 4", c[hit] >> 2), ("uniform 1", c[hit]),
+                  ("16 above 32, 2 below", key_var(c[hit], 32, 4, 1)), ("16 above 48, 4 below", key_var(c[hit], 48, 4, 2)),
+                  ("16 above 16, 1 below", key_var(c[hit], 16, 4, 0))]:
+    order = hit[np.argsort(-key, kind='stable')]
+    t, tot, mean = sim_intk(order, 8, False)
+    print(f"{name:24s}: makespan {t}, mean finish {mean:.1f}, util {c.sum()/(tot*64):.3f}, distinct buckets {len(np.unique(key))}")
+
