@@ -122,3 +122,27 @@ for name, key in [("uniform 16", c[hit] >> 4), ("uniform 4", c[hit] >> 2), ("uni
     t, tot, mean = sim_intk(order, 8, False)
     print(f"{name:24s}: makespan {t}, mean finish {mean:.1f}, util {c.sum()/(tot*64):.3f}, distinct buckets {len(np.unique(key))}")
 
+
+print("---- k lanes per ray from the start (k0), doubling in tail mode up to kmax")
+def sim_k0(order, k0, kmax=8, waves=1024):
+    q = list(order); qpos = 0
+    slots = 64 // k0
+    rem = np.zeros((waves, slots), np.int64); t = 0; rounds = 0; last = np.zeros(waves, np.int64)
+    while True:
+        need = rem == 0; n_need = int(need.sum())
+        if qpos < len(q):
+            take = min(n_need, len(q) - qpos); idx = np.argwhere(need)
+            sel = idx[:take] if take == n_need else idx[np.random.default_rng(0).permutation(n_need)[:take]]
+            rem[sel[:, 0], sel[:, 1]] = c[q[qpos:qpos + take]]; qpos += take
+        act = rem > 0; r = act.sum(1)
+        if r.sum() == 0: break
+        k = np.full(waves, k0, np.int64)
+        if qpos >= len(q):
+            for kk in (2, 4, 8, 16, 32, 64):
+                if k0 < kk <= kmax: k = np.where((r > 0) & (r * kk <= 64), kk, k)
+        rem = np.maximum(rem - k[:, None] * act, 0); t += 1
+        rounds += int((r > 0).sum()); last[r > 0] = t
+    return t, rounds, last.mean()
+for k0 in (1, 2, 4):
+    t, tot, mean = sim_k0(lpt, k0)
+    print(f"k0 {k0}: makespan {t} rounds, wave-rounds {tot}, mean finish {mean:.1f}  (ideal {c.sum()/65536:.1f})")
