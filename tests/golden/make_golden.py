@@ -356,6 +356,18 @@ def golden_grid():
     np.savez_compressed(OUT / "grid_update.npz", stride=stride, **out)
 
 
+def golden_rays():
+    """the reference's get_rays (nerf/utils.py:109-209, full-image branch) on a non-square image and two poses"""
+    from nerf.utils import get_rays
+    poses = np.stack([scenes.nerf_matrix_to_ngp(scenes.pose_spherical(33.0, -27.0, 4.0), scale=0.65),
+                      scenes.nerf_matrix_to_ngp(scenes.pose_spherical(250.0, -70.0, 3.0), scale=0.8)]).astype(F)
+    H, W = 12, 20
+    intr = np.array([31.5, 29.0, 10.25, 5.75])
+    r = get_rays(torch.from_numpy(poses), intr, H, W, -1)
+    np.savez_compressed(OUT / "get_rays.npz", poses=poses, intrinsics=intr, H=H, W=W, rays_o=r["rays_o"].numpy(), rays_d=r["rays_d"].numpy())
+    print("[golden] get_rays:", tuple(r["rays_d"].shape))
+
+
 def golden_ide():
     from ide_encoder.ide_encoder import IntegratedDirEncoder
     rng = np.random.default_rng(7)
@@ -408,6 +420,7 @@ def main():
     torch.set_num_threads(8)
     install_reference()
     golden_ops()
+    golden_rays()
     golden_ide()
     scene = scenes.toaster_scene()
     model, opt = build_reference_model(scene)

@@ -149,3 +149,18 @@ def test_ide_oracle_vs_reference_fp32():
         # the coefficient table itself: fp32-identical to the reference's registered buffer
         mat = g[f"mat{deg}"]
         assert mat.dtype == np.float32
+
+
+def test_get_rays_matches_reference():
+    """both ray generators (torch, used by the drop-in surface; numpy, used by scenes / bench) against the
+    reference's get_rays on a non-square image"""
+    import torch
+    from envidr_amd.nerf.utils import get_rays
+    g = np.load(GOLD / "get_rays.npz")
+    H, W = int(g["H"]), int(g["W"])
+    r = get_rays(torch.from_numpy(g["poses"]), g["intrinsics"], H, W, -1)
+    assert r["rays_d"].shape == (2, H * W, 3)
+    assert np.allclose(r["rays_d"].numpy(), g["rays_d"], atol=1e-6, rtol=0) and np.allclose(r["rays_o"].numpy(), g["rays_o"], atol=0)
+    for b in range(2):
+        o, d = scenes.get_rays(g["poses"][b], g["intrinsics"], H, W)
+        assert np.allclose(d, g["rays_d"][b], atol=1e-6, rtol=0) and np.allclose(o, g["rays_o"][b], atol=0)
