@@ -137,6 +137,7 @@ __device__ __forceinline__ void normalize_n(float (&v)[N], float eps) {
 #endif
 constexpr uint32_t kCostShift = ENVIDR_COST_SHIFT;
 constexpr uint32_t kCostBuckets = 256, kCostBase = 4;      // counters: [0] queue head, [1] hits, [4..] bucket counts, then bucket cursors
+constexpr uint32_t kScratchCounterWords = kCostBase + 2 * kCostBuckets;
 __device__ __forceinline__ uint32_t cost_bucket(uint32_t cost) { return min(cost >> kCostShift, kCostBuckets - 1); }
 
 // First-hit pre-pass: one lane per ray, full occupancy.  Empty-space skipping is cheap per ray but
@@ -1140,6 +1141,8 @@ int envidr_pack_rowvec(const float* v_host, uint32_t m_out, float* dst_host) {
     return ENVIDR_OK;
 }
 
+uint64_t envidr_render_scratch_bytes(uint32_t N) { return (uint64_t)kScratchCounterWords * 4 + (uint64_t)N * 8; }
+
 int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const float* rays_d, uint32_t N,
                        const envidr_render_out* out, uint32_t* ray_counter, envidr_stream_t stream) {
     ENVIDR_REQUIRE(d && out, "render_rays: null descriptor");
@@ -1209,34 +1212,45 @@ int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const f
     a.ray_counter = ray_counter;
 
     hipStream_t s = as_stream(stream);
-    // work-list scratch: grows monotonically, allocated only when a larger batch arrives
-    static uint32_t* g_hit_ids = nullptr;
-    static float* g_hit_t = nullptr;
-    static uint32_t* g_counters = nullptr;
-    static uint32_t g_cap = 0;
-    if (N > g_cap || !g_counters) {
-        if (g_hit_ids) (void)hipFree(g_hit_ids);
-        if (g_hit_t) (void)hipFree(g_hit_t);
-        if (!g_counters && hipMalloc(&g_counters, (kCostBase + 2 * kCostBuckets) * 4) != hipSuccess) return check_launch("render_rays counters alloc");
-        g_cap = N + N / 4;
-        if (hipMalloc(&g_hit_ids, (size_t)g_cap * 4) != hipSuccess || hipMalloc(&g_hit_t, (size_t)g_cap * 4) != hipSuccess) {
-            g_hit_ids = nullptr; g_hit_t = nullptr; g_cap = 0;
-            return check_launch("render_rays work-list alloc");
+    // work-list scratch: the caller's (desc->scratch: one per in-flight render, so that renders on different streams may
+    // overlap) or the library's own (grows monotonically; one render at a time)
+    uint32_t* hit_ids; float* hit_t; uint32_t* counters;
+    if (d->scratch) {
+        ENVIDR_REQUIRE(d->scratch_bytes >= envidr_render_scratch_bytes(N), "render_rays: scratch of %llu bytes, need %llu",
+                       (unsigned long long)d->scratch_bytes, (unsigned long long)envidr_render_scratch_bytes(N));
+        counters = reinterpret_cast<uint32_t*>(d->scratch);
+        hit_ids = counters + kScratchCounterWords;
+        hit_t = reinterpret_cast<float*>(hit_ids + N);
+    } else {
+        static uint32_t* g_hit_ids = nullptr;
+        static float* g_hit_t = nullptr;
+        static uint32_t* g_counters = nullptr;
+        static uint32_t g_cap = 0;
+        if (N > g_cap || !g_counters) {
+            if (g_hit_ids) (void)hipFree(g_hit_ids);
+            if (g_hit_t) (void)hipFree(g_hit_t);
+            if (!g_counters && hipMalloc(&g_counters, kScratchCounterWords * 4) != hipSuccess) return check_launch("render_rays counters alloc");
+            g_cap = N + N / 4;
+            if (hipMalloc(&g_hit_ids, (size_t)g_cap * 4) != hipSuccess || hipMalloc(&g_hit_t, (size_t)g_cap * 4) != hipSuccess) {
+                g_hit_ids = nullptr; g_hit_t = nullptr; g_cap = 0;
+                return check_launch("render_rays work-list alloc");
+            }
         }
+        hit_ids = g_hit_ids; hit_t = g_hit_t; counters = g_counters;
     }
     (void)ray_counter;   // kept in the ABI for callers that manage their own queue word; the library uses its own pair
-    a.ray_counter = g_counters;
-    a.hit_ids = g_hit_ids;
-    a.hit_t = g_hit_t;
+    a.ray_counter = counters;
+    a.hit_ids = hit_ids;
+    a.hit_t = hit_t;
     a.ray_cost = d->ray_cost;
-    if (hipMemsetAsync(g_counters, 0, (kCostBase + 2 * kCostBuckets) * 4, s) != hipSuccess) return check_launch("render_rays memset");
-    hipLaunchKernelGGL(k_first_hit, dim3(ceil_div(N, kBlock)), dim3(kBlock), 0, s, a, g_hit_ids, g_hit_t, g_counters);
+    if (hipMemsetAsync(counters, 0, kScratchCounterWords * 4, s) != hipSuccess) return check_launch("render_rays memset");
+    hipLaunchKernelGGL(k_first_hit, dim3(ceil_div(N, kBlock)), dim3(kBlock), 0, s, a, hit_ids, hit_t, counters);
     {
         const int rc = check_launch("k_first_hit");
         if (rc) return rc;
     }
     if (a.ray_cost) {
-        hipLaunchKernelGGL(k_order_hits, dim3(ceil_div(N, kBlock)), dim3(kBlock), 0, s, a, g_hit_ids, g_hit_t, g_counters);
+        hipLaunchKernelGGL(k_order_hits, dim3(ceil_div(N, kBlock)), dim3(kBlock), 0, s, a, hit_ids, hit_t, counters);
         const int rc = check_launch("k_order_hits");
         if (rc) return rc;
     }

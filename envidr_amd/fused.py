@@ -43,7 +43,7 @@ class RenderDesc(ctypes.Structure):
         ("has_env_rot", ctypes.c_int32), ("env_rot", ctypes.c_float * 9), ("dir_sh_degree", ctypes.c_uint32),
         ("geometry_only", ctypes.c_int32), ("r_images", _FP), ("renv_blob", _FP), ("spec2_blob", _FP),
         ("indir_roughness_thresh", ctypes.c_float), ("geometry_export", ctypes.POINTER(GeometryExport)),
-        ("ray_cost", _FP),
+        ("ray_cost", _FP), ("scratch", _FP), ("scratch_bytes", ctypes.c_uint64),
     ]
 
 
@@ -96,6 +96,8 @@ def _bind_render(lib):
     lib.envidr_pack_rowvec.restype = ctypes.c_int
     lib.envidr_render_rays.argtypes = [ctypes.POINTER(RenderDesc), _FP, _FP, ctypes.c_uint32, ctypes.POINTER(RenderOut), _FP, _FP]
     lib.envidr_render_rays.restype = ctypes.c_int
+    lib.envidr_render_scratch_bytes.argtypes = [ctypes.c_uint32]
+    lib.envidr_render_scratch_bytes.restype = ctypes.c_uint64
     lib.envidr_shade_samples.argtypes = [ctypes.POINTER(RenderDesc), _FP, _FP, _FP, ctypes.c_uint32, _FP, ctypes.c_uint32,
                                          ctypes.c_uint32, _FP, _FP, _FP]
     lib.envidr_shade_samples.restype = ctypes.c_int
@@ -467,6 +469,10 @@ class FusedRenderer:
             if ray_cost.dtype != torch.int16 or ray_cost.numel() != N or not ray_cost.is_cuda or not ray_cost.is_contiguous():
                 raise _lib.EnvidrError("render: ray_cost must be a contiguous int16 [N] tensor on the GPU")
             self.desc.ray_cost = ray_cost.data_ptr()
+        # work-list scratch from torch's stream-aware allocator: renders issued on different streams never share it
+        need = int(self.lib.envidr_render_scratch_bytes(N))
+        scratch = torch.empty((need + 3) // 4, dtype=torch.int32, device=dev)
+        self.desc.scratch, self.desc.scratch_bytes = scratch.data_ptr(), scratch.numel() * 4
         stream = torch.cuda.current_stream(dev).cuda_stream
         rc = self.lib.envidr_render_rays(ctypes.byref(self.desc), rays_o.data_ptr(), rays_d.data_ptr(), N, ctypes.byref(o),
                                          self.counter.data_ptr(), stream)

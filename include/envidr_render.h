@@ -150,6 +150,13 @@ typedef struct envidr_render_desc {
      * camera: the previous frame's counts are exact).  It changes the order in which rays are processed and nothing
      * else: every output is bit-identical with or without it. */
     uint16_t* ray_cost;
+
+    /* Optional caller-owned work-list scratch (device, >= envidr_render_scratch_bytes(N) bytes, 4-byte aligned), one per
+     * render that may be in flight: renders issued on different streams with different scratch (and outputs) overlap --
+     * the next frame's waves start on the SIMDs the current frame's finished waves have left.  NULL: the library's own
+     * scratch, one render at a time. */
+    void* scratch;
+    uint64_t scratch_bytes;
 } envidr_render_desc;
 
 /* ---- per-call outputs (device pointers; any optional pointer may be NULL) --------------------- */
@@ -164,6 +171,8 @@ typedef struct envidr_render_out {
     uint64_t* stats;        /* [12]   optional: {samples shaded, wave rounds, rays, reserved, 8 x section cycles
                              *         (only when the library is built with -DENVIDR_SECTION_TIMERS)}; caller zeroes */
 } envidr_render_out;
+
+uint64_t envidr_render_scratch_bytes(uint32_t N);
 
 /* Render N rays (rays_o, rays_d: device [N,3], unit directions).  `ray_counter` is a device uint32
  * the kernel uses as its work queue head; the call zeroes it on `stream` before launching.
