@@ -154,6 +154,8 @@ def main() -> None:
             "roofline": {"bound": "mfma", "achieved": flops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": flops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                          "kernel": "k_render_persistent<5,8,0>", "kernel_ms": kernel_ms,
+                         "kernel_ms_note": "HIP events around one envidr_render_rays call on its stream: the persistent kernel plus "
+                                           "its two pre-pass kernels (k_first_hit + k_order_hits, about 0.5 ms)",
                          "algorithmic_flop_per_sample": FLOP_PER_SAMPLE, "samples_per_launch": samples,
                          "hbm_view": {"bound": "hbm", "achieved": samples * HASH_BYTES_PER_SAMPLE / (kernel_ms * 1e-3) / 1e9,
                                       "peak": 8000.0, "unit": "GB/s"}},
