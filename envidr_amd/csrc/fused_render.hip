@@ -49,7 +49,7 @@ constexpr uint32_t kMaxGroup = ENVIDR_MAX_GROUP;   // largest number of lanes (c
 struct HashLevelK {
     uint32_t row0, size, stride1, stride2;
     float scale;
-    uint32_t hashed, pow2, enabled, slow_mod;
+    uint32_t hashed, andmask, enabled, slow_mod;
 };
 
 struct RenderArgs {
@@ -248,12 +248,37 @@ struct HashStage {
     float2 c[8];
 };
 
-// wrap an index that is known to be < 2 * size (dense levels: res (1 + res + res^2) < 2 res^3) or a
-// hashed index (power-of-two table: mask).  Generic modulo only for table geometries that are neither.
-__device__ __forceinline__ uint32_t wrap_row(uint32_t idx, const HashLevelK& lv) {
-    if (lv.pow2) return idx & (lv.size - 1);
-    if (lv.hashed) return idx % lv.size;
-    return lv.slow_mod ? idx % lv.size : (idx >= lv.size ? idx - lv.size : idx);
+// Row index -> row inside the level's table, branch-free for the two geometries real tables have: hashed levels have
+// a power-of-two size (mask), dense levels produce indices below 2 * size (host-checked), where one conditional
+// subtract -- written as min(idx, idx - size) on unsigned values -- is the modulo.  `andmask` is size - 1 or ~0.
+// (Run-time branches per corner split this section into dozens of basic blocks; the waits the compiler then places at
+// their joins drained the gather pipeline.)
+__device__ __forceinline__ uint32_t wrap_fast(uint32_t idx, const HashLevelK& lv) {
+    idx &= lv.andmask;
+    return min(idx, idx - lv.size);
+}
+
+template <bool SLOW>
+__device__ __forceinline__ void hash_gather(const HashLevelK& lv, const float2* __restrict__ table, const uint32_t (&cell)[3], HashStage& st) {
+    if (lv.hashed) {
+        const uint32_t hx[2] = {cell[0], cell[0] + 1u};
+        const uint32_t hy[2] = {cell[1] * 2654435761u, (cell[1] + 1u) * 2654435761u};
+        const uint32_t hz[2] = {cell[2] * 805459861u, (cell[2] + 1u) * 805459861u};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t idx = hx[i & 1] ^ hy[(i >> 1) & 1] ^ hz[(i >> 2) & 1];
+            st.c[i] = table[SLOW ? idx % lv.size : wrap_fast(idx, lv)];
+        }
+    } else {
+        const uint32_t ix[2] = {cell[0], cell[0] + 1u};
+        const uint32_t iy[2] = {cell[1] * lv.stride1, (cell[1] + 1u) * lv.stride1};
+        const uint32_t iz[2] = {cell[2] * lv.stride2, (cell[2] + 1u) * lv.stride2};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t idx = ix[i & 1] + iy[(i >> 1) & 1] + iz[(i >> 2) & 1];
+            st.c[i] = table[SLOW ? idx % lv.size : wrap_fast(idx, lv)];
+        }
+    }
 }
 
 __device__ __forceinline__ void hash_prepare(const RenderArgs& a, int l, const float (&x)[3], HashStage& st) {
@@ -268,19 +293,8 @@ __device__ __forceinline__ void hash_prepare(const RenderArgs& a, int l, const f
         st.w1[d] = p * p * (3.0f - 2.0f * p);          // smoothstep
     }
     const float2* table = reinterpret_cast<const float2*>(a.table) + lv.row0;
-    if (lv.hashed) {
-        const uint32_t hx[2] = {cell[0], cell[0] + 1u};
-        const uint32_t hy[2] = {cell[1] * 2654435761u, (cell[1] + 1u) * 2654435761u};
-        const uint32_t hz[2] = {cell[2] * 805459861u, (cell[2] + 1u) * 805459861u};
-#pragma unroll
-        for (int i = 0; i < 8; ++i) st.c[i] = table[wrap_row(hx[i & 1] ^ hy[(i >> 1) & 1] ^ hz[(i >> 2) & 1], lv)];
-    } else {
-        const uint32_t ix[2] = {cell[0], cell[0] + 1u};
-        const uint32_t iy[2] = {cell[1] * lv.stride1, (cell[1] + 1u) * lv.stride1};
-        const uint32_t iz[2] = {cell[2] * lv.stride2, (cell[2] + 1u) * lv.stride2};
-#pragma unroll
-        for (int i = 0; i < 8; ++i) st.c[i] = table[wrap_row(ix[i & 1] + iy[(i >> 1) & 1] + iz[(i >> 2) & 1], lv)];
-    }
+    if (lv.slow_mod) hash_gather<true>(lv, table, cell, st);       // table geometries that are neither (never for HashEncoder's own sizing)
+    else hash_gather<false>(lv, table, cell, st);
 }
 
 __device__ __forceinline__ void hash_finish(const RenderArgs& a, int l, const HashStage& st, float (&out)[2], float (&dydx)[3][2]) {
@@ -1173,13 +1187,14 @@ int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const f
         a.lv[l].size = size;
         a.lv[l].stride1 = g.stride[1]; a.lv[l].stride2 = g.stride[2];
         a.lv[l].scale = ls.scale[l];
-        a.lv[l].hashed = g.hashed; a.lv[l].pow2 = g.pow2;
+        a.lv[l].hashed = g.hashed;
+        a.lv[l].andmask = (g.hashed && g.pow2) ? size - 1u : 0xffffffffu;
         {
             // dense levels: the largest index a corner can produce (coordinate res on every axis) must stay below 2 * size
             // for the conditional-subtract wrap; otherwise fall back to a true modulo
             const unsigned long long res = ls.resolution[l];
             const unsigned long long max_idx = res + res * (unsigned long long)g.stride[1] + res * (unsigned long long)g.stride[2];
-            a.lv[l].slow_mod = (!g.hashed && !g.pow2 && max_idx >= 2ull * size) ? 1u : 0u;
+            a.lv[l].slow_mod = ((g.hashed && !g.pow2) || (!g.hashed && max_idx >= 2ull * size)) ? 1u : 0u;
         }
         a.lv[l].enabled = (d->enabled_levels <= 0 || (int32_t)l < d->enabled_levels) ? 1u : 0u;
         ENVIDR_REQUIRE(g.hashed || g.stride[0] == 1, "render_rays: unexpected dense stride");
