@@ -23,7 +23,10 @@ struct MarchConsts {
     float Hf;          // H as float
     float rH;          // 1/H
     float H3;          // H*H*H evaluated in uint32 then converted, like the reference's `H * H * H`
+    float half_H;      // 0.5 * H
     uint32_t H;
+    uint32_t H_pow2;   // H is a power of two (the reference's grid_size is always 128; Morton indexing of the bitfield does
+                       // not even stay inside H^3 otherwise, so the fp64 path below is kept only for arithmetic fidelity)
     const uint8_t* __restrict__ grid;
 };
 
@@ -39,7 +42,9 @@ __host__ __device__ inline MarchConsts make_march_consts(float bound, float dt_g
     k.Hf = (float)H;
     k.rH = 1 / (float)H;
     k.H3 = (float)(H * H * H);
+    k.half_H = 0.5f * (float)H;
     k.H = H;
+    k.H_pow2 = (H & (H - 1)) == 0 ? 1u : 0u;
     k.grid = grid;
     return k;
 }
@@ -72,9 +77,12 @@ __device__ __forceinline__ int clamp_level(const MarchConsts& k, float mag) {
 
 // voxel coordinate along one axis: the reference evaluates 0.5 * (p * rbound + 1) * H in double
 // (the literal 0.5 promotes), narrows to float for the clamp, then truncates to int.
+// POW2: H is a power of two, so 0.5 * inner * H is a power-of-two scaling of an fp32 value: exact in double, exactly
+// representable in fp32, hence equal to the single fp32 multiplication inner * (H / 2) -- same bits, no fp64 on the path.
+template <bool POW2>
 __device__ __forceinline__ int voxel_coord(const MarchConsts& k, float p, float mip_rbound) {
     const float inner = p * mip_rbound + 1;
-    const float scaled = (float)(0.5 * (double)inner * (double)k.H);
+    const float scaled = POW2 ? inner * k.half_H : (float)(0.5 * (double)inner * (double)k.H);
     return (int)clampf(scaled, 0.0f, (float)(k.H - 1));
 }
 
@@ -90,8 +98,9 @@ __device__ __forceinline__ float exit_time(const MarchConsts& k, int n, float d,
 // `t_at` (optional) receives the ray time AT the emitted sample (before the += dt): resuming the
 // marcher from exactly that value re-emits the same sample, which is how the fused renderer's
 // first-hit pre-pass hands rays over without changing any arithmetic.
-__device__ __forceinline__ bool march_next(const MarchConsts& k, const RayGeom& r, float far, float& t,
-                                           float& x, float& y, float& z, float& dt, float* t_at = nullptr) {
+template <bool POW2>
+__device__ __forceinline__ bool march_next_impl(const MarchConsts& k, const RayGeom& r, float far, float& t,
+                                                float& x, float& y, float& z, float& dt, float* t_at) {
     while (t < far) {
         x = clampf(r.ox + t * r.dx, -k.bound, k.bound);
         y = clampf(r.oy + t * r.dy, -k.bound, k.bound);
@@ -99,15 +108,16 @@ __device__ __forceinline__ bool march_next(const MarchConsts& k, const RayGeom& 
         dt = step_size(k, t);
 
         const int lvl_pos = clamp_level(k, fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))));
-        const int lvl_dt = clamp_level(k, (float)((double)(dt * k.Hf) * 0.5));
+        // the reference's (dt * H) * 0.5 promotes to double: halving is exact, so the fp32 product has the same bits
+        const int lvl_dt = clamp_level(k, (dt * k.Hf) * 0.5f);
         const int level = max(lvl_pos, lvl_dt);
 
         const float mip_bound = fminf(scalbnf(1.0f, level), k.bound);
         const float mip_rbound = 1 / mip_bound;
 
-        const int nx = voxel_coord(k, x, mip_rbound);
-        const int ny = voxel_coord(k, y, mip_rbound);
-        const int nz = voxel_coord(k, z, mip_rbound);
+        const int nx = voxel_coord<POW2>(k, x, mip_rbound);
+        const int ny = voxel_coord<POW2>(k, y, mip_rbound);
+        const int nz = voxel_coord<POW2>(k, z, mip_rbound);
 
         // level * H3 + morton is a float expression in the reference (H3 is float)
         const uint32_t bit = (uint32_t)((float)level * k.H3 + (float)morton_encode(nx, ny, nz));
@@ -127,6 +137,12 @@ __device__ __forceinline__ bool march_next(const MarchConsts& k, const RayGeom& 
         } while (t < tt);
     }
     return false;
+}
+
+// one wave-uniform choice per call, outside the marching loops
+__device__ __forceinline__ bool march_next(const MarchConsts& k, const RayGeom& r, float far, float& t,
+                                           float& x, float& y, float& z, float& dt, float* t_at = nullptr) {
+    return k.H_pow2 ? march_next_impl<true>(k, r, far, t, x, y, z, dt, t_at) : march_next_impl<false>(k, r, far, t, x, y, z, dt, t_at);
 }
 
 // One compositing update (reference raymarching.cu:996-1030, inference form: transmittance is
