@@ -24,6 +24,7 @@ struct MarchConsts {
     float rH;          // 1/H
     float H3;          // H*H*H evaluated in uint32 then converted, like the reference's `H * H * H`
     float half_H;      // 0.5 * H
+    float rbound;      // 1 / bound (correctly rounded, like the division it replaces)
     uint32_t H;
     uint32_t H_pow2;   // H is a power of two (the reference's grid_size is always 128; Morton indexing of the bitfield does
                        // not even stay inside H^3 otherwise, so the fp64 path below is kept only for arithmetic fidelity)
@@ -43,6 +44,7 @@ __host__ __device__ inline MarchConsts make_march_consts(float bound, float dt_g
     k.rH = 1 / (float)H;
     k.H3 = (float)(H * H * H);
     k.half_H = 0.5f * (float)H;
+    k.rbound = 1 / bound;
     k.H = H;
     k.H_pow2 = (H & (H - 1)) == 0 ? 1u : 0u;
     k.grid = grid;
@@ -112,8 +114,11 @@ __device__ __forceinline__ bool march_next_impl(const MarchConsts& k, const RayG
         const int lvl_dt = clamp_level(k, (dt * k.Hf) * 0.5f);
         const int level = max(lvl_pos, lvl_dt);
 
-        const float mip_bound = fminf(scalbnf(1.0f, level), k.bound);
-        const float mip_rbound = 1 / mip_bound;
+        // mip_bound = min(2^level, bound); its reciprocal is exactly 2^-level, or the precomputed 1 / bound: the reference's
+        // `1 / mip_bound` without a division per step
+        const float pow2 = scalbnf(1.0f, level);
+        const float mip_bound = fminf(pow2, k.bound);
+        const float mip_rbound = pow2 <= k.bound ? scalbnf(1.0f, -level) : k.rbound;
 
         const int nx = voxel_coord<POW2>(k, x, mip_rbound);
         const int ny = voxel_coord<POW2>(k, y, mip_rbound);
