@@ -1030,6 +1030,11 @@ struct ShadeArgs {
     const float* geo_feat;      // [M,12] (stride 12) or one shared [12] (stride 0), already unit-normalised
     const float* roughness;     // [M] (stride 1) or one shared value (stride 0): the IDE kappa_inv of the reflected direction
     uint32_t geo_stride, rough_stride, M;
+    // record mode (two-phase frames): the view direction of record i is rays_d[ray_ids[i]] and the number of records is
+    // read on the device (min(*m_dev, M)), so the host never waits for the geometry pass
+    const uint32_t* ray_ids;
+    const float* rays_d;
+    const uint32_t* m_dev;
     const float* env_blob;
     const float* head_blob;
     float kappa_diffuse, light_scale;
@@ -1051,14 +1056,16 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_shade_samples(const ShadeA
     wp.start(s_weights, lane, wave, a.env_blob, kEnvChunks);
     const ShadeConsts sc = {a.env_blob, a.head_blob, a.env_blob, kEnvChunks, a.kappa_diffuse, a.light_scale};
     const uint32_t waves = gridDim.x * (kBlockThreads / 64);
+    const uint32_t M = a.m_dev ? min(__builtin_amdgcn_readfirstlane(*a.m_dev), a.M) : a.M;
     // every wave of a block runs the same number of rounds (the shared weight stream has block-wide barriers)
-    for (uint32_t base = (blockIdx.x * (kBlockThreads / 64)) * 64; base < a.M; base += waves * 64) {
+    for (uint32_t base = (blockIdx.x * (kBlockThreads / 64)) * 64; base < M; base += waves * 64) {
         const uint32_t id = base + wave * 64 + lane;
-        const bool on = id < a.M;
+        const bool on = id < M;
         const size_t i = on ? id : 0;
         float nrm[3], vd[3], geo[12];
+        const float* dir = a.ray_ids ? a.rays_d + 3 * (size_t)a.ray_ids[i] : a.dirs + 3 * i;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { nrm[d] = on ? a.normals[3 * i + d] : 0.0f; vd[d] = on ? a.dirs[3 * i + d] : 0.0f; }
+        for (int d = 0; d < 3; ++d) { nrm[d] = on ? a.normals[3 * i + d] : 0.0f; vd[d] = on ? dir[d] : 0.0f; }
 #pragma unroll
         for (int j = 0; j < 12; ++j) geo[j] = a.geo_feat[(size_t)a.geo_stride * i + j];
         const float rough = a.roughness[(size_t)a.rough_stride * i];
@@ -1101,6 +1108,40 @@ __global__ void __launch_bounds__(kBlock) k_composite_shaded(const uint32_t* __r
         const float wi = w[i];
         const float c0 = cd[3 * (size_t)i], c1 = cd[3 * (size_t)i + 1], c2 = cd[3 * (size_t)i + 2];
         const float e0 = cs[3 * (size_t)i], e1 = cs[3 * (size_t)i + 1], e2 = cs[3 * (size_t)i + 2];
+        ar += wi * ((c0 + e0) * intensity); ag += wi * ((c1 + e1) * intensity); ab += wi * ((c2 + e2) * intensity);
+        d0 += wi * c0; d1 += wi * c1; d2 += wi * c2;
+        s0 += wi * e0; s1 += wi * e1; s2 += wi * e2;
+    }
+    const float rest = 1 - ws[r];
+    image[3 * (size_t)r] = ar + rest * bg; image[3 * (size_t)r + 1] = ag + rest * bg; image[3 * (size_t)r + 2] = ab + rest * bg;
+    if (diffuse) { diffuse[3 * (size_t)r] = d0; diffuse[3 * (size_t)r + 1] = d1; diffuse[3 * (size_t)r + 2] = d2; }
+    if (specular) { specular[3 * (size_t)r] = s0; specular[3 * (size_t)r + 1] = s1; specular[3 * (size_t)r + 2] = s2; }
+}
+
+// Two-phase frames: records sit in the order the geometry pass appended them; ray r's samples are found through
+// perm[offsets[r] + idx] = record (offsets = exclusive prefix sum of the per-ray sample counts).
+__global__ void __launch_bounds__(kBlock) k_place_records(const uint32_t* __restrict__ ray, const uint32_t* __restrict__ idx,
+                                                          const uint32_t* __restrict__ m_dev, uint32_t capacity,
+                                                          const uint32_t* __restrict__ offsets, uint32_t* __restrict__ perm) {
+    const uint32_t M = *m_dev;
+    if (M > capacity) return;        // the frame did not fit: the host sees the count and redoes it with larger buffers
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) perm[offsets[ray[i]] + idx[i]] = i;
+}
+
+__global__ void __launch_bounds__(kBlock) k_composite_records(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ perm,
+                                                              const float* __restrict__ w, const float* __restrict__ cd,
+                                                              const float* __restrict__ cs, const float* __restrict__ ws, uint32_t N,
+                                                              float intensity, float bg, float* __restrict__ image,
+                                                              float* __restrict__ diffuse, float* __restrict__ specular,
+                                                              const uint32_t* __restrict__ m_dev, uint32_t capacity) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N || *m_dev > capacity) return;
+    float ar = 0, ag = 0, ab = 0, d0 = 0, d1 = 0, d2 = 0, s0 = 0, s1 = 0, s2 = 0;
+    for (uint32_t j = offsets[r]; j < offsets[r + 1]; ++j) {
+        const size_t i = perm[j];
+        const float wi = w[i];
+        const float c0 = cd[3 * i], c1 = cd[3 * i + 1], c2 = cd[3 * i + 2];
+        const float e0 = cs[3 * i], e1 = cs[3 * i + 1], e2 = cs[3 * i + 2];
         ar += wi * ((c0 + e0) * intensity); ag += wi * ((c1 + e1) * intensity); ab += wi * ((c2 + e2) * intensity);
         d0 += wi * c0; d1 += wi * c1; d2 += wi * c2;
         s0 += wi * e0; s1 += wi * e1; s2 += wi * e2;
@@ -1295,27 +1336,15 @@ int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const f
     return check_launch("k_render_persistent");
 }
 
-int envidr_shade_samples(const envidr_render_desc* d, const float* normals, const float* dirs, const float* geo_feat,
-                         uint32_t geo_feat_stride, const float* roughness, uint32_t roughness_stride, uint32_t M,
-                         float* c_diffuse, float* c_specular, envidr_stream_t stream) {
-    ENVIDR_REQUIRE(d, "shade_samples: null descriptor");
-    if (M == 0) return ENVIDR_OK;
-    ENVIDR_REQUIRE(normals && dirs && geo_feat && roughness && c_diffuse && c_specular, "shade_samples: null pointer");
-    ENVIDR_REQUIRE(d->env_blob && d->head_blob, "shade_samples: null weight blob");
-    ENVIDR_REQUIRE(d->dir_sh_degree == 0, "shade_samples: implemented for the environment-MLP family");
-    ENVIDR_REQUIRE((geo_feat_stride == 0 || geo_feat_stride == 12) && roughness_stride <= 1,
-                   "shade_samples: geo_feat_stride must be 0 or 12 and roughness_stride 0 or 1");
-    ShadeArgs a;
-    memset(&a, 0, sizeof(a));
-    a.normals = normals; a.dirs = dirs; a.geo_feat = geo_feat; a.roughness = roughness;
-    a.geo_stride = geo_feat_stride; a.rough_stride = roughness_stride; a.M = M;
+static int launch_shade(const envidr_render_desc* d, ShadeArgs& a, envidr_stream_t stream, const char* who) {
+    ENVIDR_REQUIRE(d->env_blob && d->head_blob, "%s: null weight blob", who);
+    ENVIDR_REQUIRE(d->dir_sh_degree == 0, "%s: implemented for the environment-MLP family", who);
     a.env_blob = d->env_blob; a.head_blob = d->head_blob;
     a.kappa_diffuse = d->diffuse_kappa_inv; a.light_scale = d->light_intensity_scale;
     a.has_rot = d->has_env_rot;
     for (int i = 0; i < 9; ++i) a.rot[i] = d->env_rot[i];
-    a.c_diffuse = c_diffuse; a.c_specular = c_specular;
     const uint32_t waves_per_block = kBlockThreads / 64;
-    const uint32_t blocks = std::min((uint32_t)device_cu_count() * (4 / waves_per_block), ceil_div(M, kBlockThreads));
+    const uint32_t blocks = std::min((uint32_t)device_cu_count() * (4 / waves_per_block), ceil_div(a.M, kBlockThreads));
     const dim3 grid(blocks), block(kBlockThreads);
     hipStream_t s = as_stream(stream);
 #define ENVIDR_LAUNCH(DEG, HT) hipLaunchKernelGGL((k_shade_samples<DEG, HT>), grid, block, 0, s, a)
@@ -1324,12 +1353,61 @@ int envidr_shade_samples(const envidr_render_desc* d, const float* normals, cons
     else if (d->ide_degree == 5 && d->env_hidden == 128) ENVIDR_LAUNCH(5, 4);
     else if (d->ide_degree == 4 && d->env_hidden == 128) ENVIDR_LAUNCH(4, 4);
     else {
-        set_error("shade_samples: unsupported (ide_degree=%u, env_hidden=%u); built variants: (5,256) (4,160) (5,128) (4,128)",
+        set_error("%s: unsupported (ide_degree=%u, env_hidden=%u); built variants: (5,256) (4,160) (5,128) (4,128)", who,
                   d->ide_degree, d->env_hidden);
         return ENVIDR_EINVAL;
     }
 #undef ENVIDR_LAUNCH
     return check_launch("k_shade_samples");
+}
+
+int envidr_shade_samples(const envidr_render_desc* d, const float* normals, const float* dirs, const float* geo_feat,
+                         uint32_t geo_feat_stride, const float* roughness, uint32_t roughness_stride, uint32_t M,
+                         float* c_diffuse, float* c_specular, envidr_stream_t stream) {
+    ENVIDR_REQUIRE(d, "shade_samples: null descriptor");
+    if (M == 0) return ENVIDR_OK;
+    ENVIDR_REQUIRE(normals && dirs && geo_feat && roughness && c_diffuse && c_specular, "shade_samples: null pointer");
+    ENVIDR_REQUIRE((geo_feat_stride == 0 || geo_feat_stride == 12) && roughness_stride <= 1,
+                   "shade_samples: geo_feat_stride must be 0 or 12 and roughness_stride 0 or 1");
+    ShadeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.normals = normals; a.dirs = dirs; a.geo_feat = geo_feat; a.roughness = roughness;
+    a.geo_stride = geo_feat_stride; a.rough_stride = roughness_stride; a.M = M;
+    a.c_diffuse = c_diffuse; a.c_specular = c_specular;
+    return launch_shade(d, a, stream, "shade_samples");
+}
+
+int envidr_shade_records(const envidr_render_desc* d, const envidr_geometry_export* rec, const float* rays_d, float* c_diffuse,
+                         float* c_specular, envidr_stream_t stream) {
+    ENVIDR_REQUIRE(d && rec, "shade_records: null descriptor / records");
+    if (rec->capacity == 0) return ENVIDR_OK;
+    ENVIDR_REQUIRE(rec->counter && rec->ray && rec->normal && rec->geo_feat && rec->roughness && rays_d && c_diffuse && c_specular,
+                   "shade_records: null pointer");
+    ShadeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.normals = rec->normal; a.geo_feat = rec->geo_feat; a.roughness = rec->roughness;
+    a.geo_stride = 12; a.rough_stride = 1; a.M = rec->capacity;
+    a.ray_ids = rec->ray; a.rays_d = rays_d; a.m_dev = rec->counter;
+    a.c_diffuse = c_diffuse; a.c_specular = c_specular;
+    return launch_shade(d, a, stream, "shade_records");
+}
+
+int envidr_composite_records(const envidr_geometry_export* rec, const uint32_t* offsets, uint32_t* perm, const float* c_diffuse,
+                             const float* c_specular, const float* weights_sum, uint32_t N, float intensity_scale, float bg_color,
+                             float* image, float* diffuse_image, float* specular_image, envidr_stream_t stream) {
+    if (N == 0) return ENVIDR_OK;
+    ENVIDR_REQUIRE(rec && rec->counter && rec->ray && rec->idx && rec->w && offsets && perm && c_diffuse && c_specular && weights_sum && image,
+                   "composite_records: null pointer");
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(k_place_records, dim3(std::min(ceil_div(rec->capacity ? rec->capacity : 1u, kBlock), 16384u)), dim3(kBlock), 0, s,
+                       rec->ray, rec->idx, rec->counter, rec->capacity, offsets, perm);
+    {
+        const int rc = check_launch("k_place_records");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_composite_records, dim3(ceil_div(N, kBlock)), dim3(kBlock), 0, s, offsets, perm, rec->w, c_diffuse, c_specular,
+                       weights_sum, N, intensity_scale, bg_color, image, diffuse_image, specular_image, rec->counter, rec->capacity);
+    return check_launch("k_composite_records");
 }
 
 int envidr_composite_shaded(const uint32_t* offsets, const float* w, const float* c_diffuse, const float* c_specular,

@@ -103,6 +103,11 @@ def _bind_render(lib):
     lib.envidr_shade_samples.restype = ctypes.c_int
     lib.envidr_composite_shaded.argtypes = [_FP, _FP, _FP, _FP, _FP, ctypes.c_uint32, ctypes.c_float, ctypes.c_float, _FP, _FP, _FP, _FP]
     lib.envidr_composite_shaded.restype = ctypes.c_int
+    lib.envidr_shade_records.argtypes = [ctypes.POINTER(RenderDesc), ctypes.POINTER(GeometryExport), _FP, _FP, _FP, _FP]
+    lib.envidr_shade_records.restype = ctypes.c_int
+    lib.envidr_composite_records.argtypes = [ctypes.POINTER(GeometryExport), _FP, _FP, _FP, _FP, _FP, ctypes.c_uint32, ctypes.c_float,
+                                             ctypes.c_float, _FP, _FP, _FP, _FP]
+    lib.envidr_composite_records.restype = ctypes.c_int
     lib._envidr_render_bound = True
 
 
@@ -398,6 +403,80 @@ class FusedRenderer:
                              geo_feat=rec["geo"][:M][order].contiguous(), roughness=rec["rough"][:M][order].contiguous(),
                              depth=res["depth"].clone(), weights_sum=res["weights_sum"].clone(),
                              normal_image=res["normal_image"].clone(), roughness_image=None)
+
+    # ---- two-phase frame: geometry pass -> shading pass, everything recomputed every frame ---------------------
+    def render_two_phase(self, rays_o: torch.Tensor, rays_d: torch.Tensor, env_rot_radian: float | None = None,
+                         out: dict | None = None, ray_cost: torch.Tensor | None = None, samples_per_ray_hint: float = 24.0,
+                         timers: dict | None = None) -> dict:
+        """The same frame as render() (bit-identical outputs, environment-MLP family), scheduled as two passes:
+          1. geometry: march + hash grid + SDF network + normals + compositing weights for every sample, one record per
+             composited sample appended to device buffers (a geometry_only launch of the persistent kernel);
+          2. shading: the records streamed through IDE + environment MLP x2 + heads (k_shade_samples: nothing but dense
+             layers, every lane busy every round), then composited per ray.
+        The per-sample records cross HBM once (80 B per sample); in exchange the shading kernel has no ray tail, no
+        divergent marching and no idle lanes.  `ray_cost` as in render().  Buffers are kept between calls."""
+        rays_o = rays_o.contiguous().view(-1, 3).float()
+        rays_d = rays_d.contiguous().view(-1, 3).float()
+        N, dev = rays_o.shape[0], rays_o.device
+        res = out if out is not None else {}
+        st = self.__dict__.setdefault("_two_phase", {})
+        if ray_cost is None:
+            if st.get("cost_n") != N:
+                st["cost"], st["cost_n"] = torch.zeros(N, dtype=torch.int16, device=dev), N
+            ray_cost = st["cost"]
+        cap = st.get("cap", 0)
+        if cap < 1024 or st.get("cap_n") != N:
+            cap = max(int(N * samples_per_ray_hint), 1024)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timers is not None else None
+        for attempt in range(2):
+            if st.get("cap") != cap or st.get("cap_n") != N:
+                st.update(cap=cap, cap_n=N, counter=torch.zeros(1, dtype=torch.int32, device=dev),
+                          ray=torch.empty(cap, dtype=torch.int32, device=dev), idx=torch.empty(cap, dtype=torch.int32, device=dev),
+                          w=torch.empty(cap, device=dev), normal=torch.empty(cap, 3, device=dev), geo=torch.empty(cap, 12, device=dev),
+                          rough=torch.empty(cap, device=dev), perm=torch.empty(cap, dtype=torch.int32, device=dev),
+                          cd=torch.empty(cap, 3, device=dev), cs=torch.empty(cap, 3, device=dev))
+            ex = GeometryExport(st["counter"].data_ptr(), cap, st["ray"].data_ptr(), st["idx"].data_ptr(), st["w"].data_ptr(),
+                                st["normal"].data_ptr(), st["geo"].data_ptr(), st["rough"].data_ptr())
+            st["counter"].zero_()
+            if ev: ev[0].record()
+            self.desc.geometry_export = ctypes.pointer(ex)
+            try:
+                self.render(rays_o, rays_d, None, extras=True, geometry_only=True, out=res, ray_cost=ray_cost)
+            finally:
+                self.desc.geometry_export = None
+            if ev: ev[1].record()
+            # shading is enqueued without waiting for the count (the kernel reads it on the device) ...
+            _set_env_rotation(self.desc, env_rot_radian)
+            rc = self.lib.envidr_shade_records(ctypes.byref(self.desc), ctypes.byref(ex), rays_d.data_ptr(), st["cd"].data_ptr(),
+                                               st["cs"].data_ptr(), stream)
+            if rc:
+                raise _lib.EnvidrError(f"envidr_shade_records failed ({rc}): {self.lib.envidr_last_error().decode()}")
+            if ev: ev[2].record()
+            offsets = torch.zeros(N + 1, dtype=torch.int32, device=dev)
+            torch.cumsum(ray_cost, 0, dtype=torch.int32, out=offsets[1:])
+            for name in ("image", "diffuse_image", "specular_image"):
+                if name not in res or res[name].shape != (N, 3):
+                    res[name] = torch.empty(N, 3, device=dev)
+            rc = self.lib.envidr_composite_records(ctypes.byref(ex), offsets.data_ptr(), st["perm"].data_ptr(), st["cd"].data_ptr(),
+                                                   st["cs"].data_ptr(), res["weights_sum"].data_ptr(), N,
+                                                   float(self.desc.intensity_scale), float(self.desc.bg_color), res["image"].data_ptr(),
+                                                   res["diffuse_image"].data_ptr(), res["specular_image"].data_ptr(), stream)
+            if rc:
+                raise _lib.EnvidrError(f"envidr_composite_records failed ({rc}): {self.lib.envidr_last_error().decode()}")
+            if ev: ev[3].record()
+            # ... and only now is the count looked at: a frame that did not fit is redone with buffers of the right size
+            M = int(st["counter"].item())
+            if M <= cap:
+                break
+            cap = M + M // 8
+        else:
+            raise _lib.EnvidrError("two-phase render: record count changed between two identical geometry passes")
+        res["n_records"] = M
+        if timers is not None:
+            torch.cuda.synchronize(dev)
+            timers.update(geometry_ms=ev[0].elapsed_time(ev[1]), shade_ms=ev[1].elapsed_time(ev[2]), composite_ms=ev[2].elapsed_time(ev[3]))
+        return res
 
     def render_cached(self, cache: GeometryCache, env_rot_radian: float | None = None, out: dict | None = None) -> dict:
         """re-light a cached frame: envidr_shade_samples over its samples + envidr_composite_shaded; bit-identical to

@@ -197,6 +197,20 @@ int envidr_shade_samples(const envidr_render_desc* desc, const float* normals, c
                          uint32_t geo_feat_stride, const float* roughness, uint32_t roughness_stride, uint32_t M,
                          float* c_diffuse, float* c_specular, envidr_stream_t stream);
 
+/* Two-phase frames (geometry pass -> shading pass): the records of a geometry_only render are shaded where they lie, in the
+ * order they were appended (the count is read on the device: the host does not wait for the geometry pass), and
+ * composited through a permutation built from the per-ray sample counts.
+ *   envidr_shade_records    : c_diffuse / c_specular [capacity,3] for records 0 .. min(*counter, capacity) - 1;
+ *                             view direction of record i = rays_d[ray[i]]
+ *   envidr_composite_records: offsets = exclusive prefix sum of the per-ray counts (device uint32 [N+1]; the counts are what
+ *                             desc.ray_cost holds after the geometry pass); perm = device scratch uint32 [capacity];
+ *                             then as envidr_composite_shaded.  Same bits as envidr_render_rays on the same rays. */
+int envidr_shade_records(const envidr_render_desc* desc, const envidr_geometry_export* records, const float* rays_d,
+                         float* c_diffuse, float* c_specular, envidr_stream_t stream);
+int envidr_composite_records(const envidr_geometry_export* records, const uint32_t* offsets, uint32_t* perm, const float* c_diffuse,
+                             const float* c_specular, const float* weights_sum, uint32_t N, float intensity_scale, float bg_color,
+                             float* image, float* diffuse_image, float* specular_image, envidr_stream_t stream);
+
 /* Composite shaded colours over cached geometry: ray r owns records offsets[r] .. offsets[r+1]-1 (sorted by (ray, idx)).
  *   image[r] = sum_i w_i (c_diffuse_i + c_specular_i) intensity_scale + (1 - weights_sum[r]) bg_color, and the optional
  *   diffuse / specular images = sum_i w_i c_i: the blend of the render loop (cuda_ray.py:318-340) with known weights,

@@ -166,3 +166,20 @@ def test_ray_cost_hint_changes_order_only(scene, renderer):
     for k in KEYS:
         assert torch.equal(third[k], plain[k]), k
     assert torch.equal(junk, counts1)
+
+
+def test_two_phase_frame_is_bit_identical(scene, renderer):
+    """render_two_phase (geometry pass -> records -> shading pass -> per-ray composite) against render(): same bits on every
+    output, including when the record buffers have to grow and with the scheduling hint"""
+    import torch
+    rays_o, rays_d = (torch.from_numpy(a).cuda() for a in scenes.camera_rays(150, 130, theta=65.0, phi=-15.0))
+    for rot in (None, 2.2):
+        want = {k: v.clone() for k, v in renderer.render(rays_o, rays_d, rot, extras=True).items()}
+        renderer.__dict__.pop("_two_phase", None)
+        got = renderer.render_two_phase(rays_o, rays_d, rot, samples_per_ray_hint=1.0)        # forces one regrow
+        again = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in renderer.render_two_phase(rays_o, rays_d, rot).items()}
+        torch.cuda.synchronize()
+        for k in ("image", "depth", "weights_sum", "normal_image", "diffuse_image", "specular_image", "roughness_image"):
+            assert torch.equal(got[k], want[k]), f"rot {rot}: {k}"
+            assert torch.equal(again[k], want[k]), f"rot {rot} (second call): {k}"
+        assert again["n_records"] == got["n_records"] > 0
