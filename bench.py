@@ -35,6 +35,8 @@ sys.path.insert(0, ROOT)
 
 H = W = 800
 FLOP_PER_SAMPLE = 650_880          # dense-layer FLOPs per shaded sample, toaster network
+FLOP_PER_SAMPLE_SHADING = 624_192  # of which in the shading pass: env MLP 305 152 x 2 + diffuse 1 728 + specular 12 160
+                                   # (the other 26 688 -- SDF network forward + input gradient -- run in the geometry pass)
 HASH_BYTES_PER_SAMPLE = 1024       # 16 levels x 8 corners x 8 B gathered per sample
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 CPU_SAMPLE_RES = 400               # cpu_baseline renders a 400x400 frame of the same scene/camera
@@ -78,6 +80,8 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (profiling runs)")
+    ap.add_argument("--path", choices=["two-phase", "fused"], default="two-phase",
+                    help="two-phase: geometry pass + shading pass per frame (default, faster); fused: one persistent kernel per frame")
     ap.add_argument("--headline-only", action="store_true", help="skip the CPU leg and the other_configs renders, so that a "
                     "profiler sees only the headline kernel's launches")
     args = ap.parse_args()
@@ -105,8 +109,20 @@ def main() -> None:
     def env_rot(view: int) -> float:
         return 2 * math.pi * (view % 200) / 200
 
+    two_phase = args.path == "two-phase"
+
+    def frame(view: int, events=None):
+        if two_phase:
+            return renderer.render_two_phase(rays_o, rays_d, env_rot(view), out=out, ray_cost=ray_cost, events=events)
+        if events:
+            events[0].record()
+        res = renderer.render(rays_o, rays_d, env_rot(view), extras=True, stats=True, out=out, ray_cost=ray_cost)
+        if events:
+            events[1].record()
+        return res
+
     def step(i: int) -> None:
-        res = renderer.render(rays_o, rays_d, env_rot(i * world + rank), extras=True, stats=True, out=out, ray_cost=ray_cost)
+        res = frame(i * world + rank)
         if world > 1:
             dist.gather(res["image"], gather_list=gather_list, dst=0)
 
@@ -118,21 +134,23 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # HIP events on the stream the kernels are launched on (torch's current stream), recorded at the pass boundaries
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     samples = 0
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ev[i][0].record()                      # same stream the kernel is launched on (torch's current stream)
-        res = renderer.render(rays_o, rays_d, env_rot((args.warmup + i) * world + rank), extras=True, stats=True, out=out,
-                              ray_cost=ray_cost)
-        ev[i][1].record()
+        res = frame((args.warmup + i) * world + rank, ev[i])
         if world > 1:
             dist.gather(res["image"], gather_list=gather_list, dst=0)
     fence()
     dt = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    samples = int(out["stats"][0].item())      # samples shaded in the last frame
+    if two_phase:
+        geometry_ms, kernel_ms, composite_ms = (float(np.mean([e[j].elapsed_time(e[j + 1]) for e in ev])) for j in range(3))
+        samples = int(res["n_records"])        # samples composited = records shaded in the last frame
+    else:
+        kernel_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        samples = int(out["stats"][0].item())  # samples shaded in the last frame
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -140,7 +158,7 @@ def main() -> None:
 
     if rank == 0:
         rays_per_s = world * N * args.steps / dt
-        flops = samples * FLOP_PER_SAMPLE / (kernel_ms * 1e-3) / 1e12
+        flops = samples * (FLOP_PER_SAMPLE_SHADING if two_phase else FLOP_PER_SAMPLE) / (kernel_ms * 1e-3) / 1e12
         result = {
             "metric": "rendered rays/s at 800x800, 1024 max samples/ray", "value": rays_per_s, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -149,17 +167,27 @@ def main() -> None:
                                    "72-256-256-256-12 x2 + diffuse/specular heads) on a synthetic shell scene, 800x800 view per GPU per "
                                    "step, env-rotation video frames sharded by view, normal/diffuse/specular/roughness images on",
                        "rays_per_step_per_gpu": N, "samples_per_frame": samples, "samples_per_ray": samples / N,
-                       "max_steps": 1024, "T_thresh": 1e-4, "parallelism": f"views x{world} + RCCL image gather"},
+                       "max_steps": 1024, "T_thresh": 1e-4, "parallelism": f"views x{world} + RCCL image gather",
+                       "schedule": ("two-phase frame: geometry pass (march + hash grid + SDF network + normals, one record per "
+                                    "composited sample) -> shading pass (k_shade_samples) -> per-ray composite; every frame from scratch"
+                                    if two_phase else "one persistent kernel per frame")},
             "samples_per_s": world * samples * args.steps / dt,
             "roofline": {"bound": "mfma", "achieved": flops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": flops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "k_render_persistent<5,8,0>", "kernel_ms": kernel_ms,
-                         "kernel_ms_note": "HIP events around one envidr_render_rays call on its stream: the persistent kernel plus "
-                                           "its two pre-pass kernels (k_first_hit + k_order_hits, about 0.5 ms)",
-                         "algorithmic_flop_per_sample": FLOP_PER_SAMPLE, "samples_per_launch": samples,
+                         "kernel": "k_shade_samples<5,8>" if two_phase else "k_render_persistent<5,8,0>", "kernel_ms": kernel_ms,
+                         "kernel_ms_note": ("HIP events around the shading launch (envidr_shade_records) on its stream" if two_phase else
+                                            "HIP events around one envidr_render_rays call on its stream: the persistent kernel plus "
+                                            "its two pre-pass kernels (k_first_hit + k_order_hits, about 0.5 ms)"),
+                         "algorithmic_flop_per_sample": FLOP_PER_SAMPLE_SHADING if two_phase else FLOP_PER_SAMPLE,
+                         "samples_per_launch": samples,
                          "hbm_view": {"bound": "hbm", "achieved": samples * HASH_BYTES_PER_SAMPLE / (kernel_ms * 1e-3) / 1e9,
                                       "peak": 8000.0, "unit": "GB/s"}},
         }
+        if two_phase:
+            result["frame"] = {"geometry_ms": geometry_ms, "shading_ms": kernel_ms, "composite_ms": composite_ms,
+                               "whole_frame_mfma_TFLOPs": samples * FLOP_PER_SAMPLE / (dt / args.steps) / 1e12,
+                               "whole_frame_mfma_frac": samples * FLOP_PER_SAMPLE / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                               "hbm_record_bytes_per_sample": 80}
         if world == 1 and not args.headline_only:
             other_configs(result, scenes, FusedRenderer, rays_o, rays_d, dev, N)
         prof = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -202,6 +230,20 @@ def other_configs(result, scenes, FusedRenderer, rays_o, rays_d, dev, N) -> None
         "rays_per_s": N / pdt, "ms_per_frame": pdt * 1e3, "samples_per_s": psamples / pdt,
         "hbm_algorithmic_GBps": psamples * HASH_BYTES_PER_SAMPLE / pdt / 1e9,
         "mfma_algorithmic_TFLOPs": psamples * 41_984 / pdt / 1e12}}
+    # the same headline frames through the single persistent kernel (the default of the drop-in renderer)
+    one = FusedRenderer.from_scene(scenes.toaster_scene(), device=dev)
+    oout: dict = {}
+    ocost = torch.zeros(N, dtype=torch.int16, device=dev)
+    for i in range(2):
+        one.render(rays_o, rays_d, 0.1 * i, extras=True, out=oout, ray_cost=ocost)
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    for i in range(5):
+        one.render(rays_o, rays_d, 2 * math.pi * i / 200, extras=True, out=oout, ray_cost=ocost)
+    torch.cuda.synchronize(dev)
+    odt = (time.perf_counter() - t1) / 5
+    result.setdefault("other_configs", {})["headline workload as ONE persistent kernel per frame (envidr_render_rays), 800x800, 1 GPU"] = {
+        "rays_per_s": N / odt, "ms_per_frame": odt * 1e3}
     # BASELINE configs[4] with the geometry cache (NOT the headline, where every frame marches and shades
     # from scratch): fixed camera, rotating environment: geometry once, then shading + compositing per frame
     headline = FusedRenderer.from_scene(scenes.toaster_scene(), device=dev)

@@ -407,14 +407,15 @@ class FusedRenderer:
     # ---- two-phase frame: geometry pass -> shading pass, everything recomputed every frame ---------------------
     def render_two_phase(self, rays_o: torch.Tensor, rays_d: torch.Tensor, env_rot_radian: float | None = None,
                          out: dict | None = None, ray_cost: torch.Tensor | None = None, samples_per_ray_hint: float = 24.0,
-                         timers: dict | None = None) -> dict:
+                         events: list | None = None) -> dict:
         """The same frame as render() (bit-identical outputs, environment-MLP family), scheduled as two passes:
           1. geometry: march + hash grid + SDF network + normals + compositing weights for every sample, one record per
              composited sample appended to device buffers (a geometry_only launch of the persistent kernel);
           2. shading: the records streamed through IDE + environment MLP x2 + heads (k_shade_samples: nothing but dense
              layers, every lane busy every round), then composited per ray.
         The per-sample records cross HBM once (80 B per sample); in exchange the shading kernel has no ray tail, no
-        divergent marching and no idle lanes.  `ray_cost` as in render().  Buffers are kept between calls."""
+        divergent marching and no idle lanes.  `ray_cost` as in render().  Buffers are kept between calls.
+        `events`: four torch.cuda.Event(enable_timing=True) recorded at the pass boundaries (geometry | shading | composite)."""
         rays_o = rays_o.contiguous().view(-1, 3).float()
         rays_d = rays_d.contiguous().view(-1, 3).float()
         N, dev = rays_o.shape[0], rays_o.device
@@ -428,7 +429,7 @@ class FusedRenderer:
         if cap < 1024 or st.get("cap_n") != N:
             cap = max(int(N * samples_per_ray_hint), 1024)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timers is not None else None
+        ev = events
         for attempt in range(2):
             if st.get("cap") != cap or st.get("cap_n") != N:
                 st.update(cap=cap, cap_n=N, counter=torch.zeros(1, dtype=torch.int32, device=dev),
@@ -473,9 +474,6 @@ class FusedRenderer:
         else:
             raise _lib.EnvidrError("two-phase render: record count changed between two identical geometry passes")
         res["n_records"] = M
-        if timers is not None:
-            torch.cuda.synchronize(dev)
-            timers.update(geometry_ms=ev[0].elapsed_time(ev[1]), shade_ms=ev[1].elapsed_time(ev[2]), composite_ms=ev[2].elapsed_time(ev[3]))
         return res
 
     def render_cached(self, cache: GeometryCache, env_rot_radian: float | None = None, out: dict | None = None) -> dict:

@@ -34,9 +34,10 @@ cout = {}
 print("shade + composite (cached)     %.2f ms" % timeit(lambda: r.render_cached(cache, 0.4, out=cout)))
 print("full fused render              %.2f ms" % timeit(lambda: r.render(ro, rd, 0.4, extras=True, out=out, ray_cost=cost)))
 tp = {}
-timers = {}
+evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
 r.render_two_phase(ro, rd, 0.4, out=tp, ray_cost=cost)
 print("two-phase frame                %.2f ms" % timeit(lambda: r.render_two_phase(ro, rd, 0.4, out=tp, ray_cost=cost)))
-r.render_two_phase(ro, rd, 0.4, out=tp, ray_cost=cost, timers=timers); print(timers, tp["n_records"])
+r.render_two_phase(ro, rd, 0.4, out=tp, ray_cost=cost, events=evs); torch.cuda.synchronize()
+print("geometry %.2f  shade %.2f  composite %.2f ms" % tuple(evs[i].elapsed_time(evs[i + 1]) for i in range(3)), tp["n_records"])
 ref = r.render(ro, rd, 0.4, extras=True)
 print("identical:", all(torch.equal(tp[k], ref[k]) for k in ("image", "depth", "weights_sum", "normal_image", "diffuse_image", "specular_image", "roughness_image")))

@@ -25,11 +25,19 @@ summary = {}
 for f in glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True):
     rows = list(csv.DictReader(open(f)))
     summary["kernel_stats"] = rows[:8]
-pmc = collections.defaultdict(list)
+# per-launch PMC means of this library's kernels; the dominant one (the shading kernel of the two-phase frame, else the
+# persistent render kernel) is what bench.py's roofline.traffic refers to
+per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "render_persistent" in row.get("Kernel_Name", ""):
-            pmc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+        name = row.get("Kernel_Name", "")
+        for key in ("shade_samples", "render_persistent", "first_hit", "order_hits", "place_records", "composite_records"):
+            if key in name:
+                per_kernel[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
+summary["pmc_per_launch_mean_by_kernel"] = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in per_kernel.items()}
+dominant = "shade_samples" if "shade_samples" in per_kernel else "render_persistent"
+summary["dominant_kernel"] = dominant
+pmc = per_kernel[dominant]
 summary["pmc_per_launch_mean"] = {k: sum(v) / len(v) for k, v in pmc.items()}
 summary["pmc_launches"] = {k: len(v) for k, v in pmc.items()}
 p = summary["pmc_per_launch_mean"]
