@@ -758,24 +758,35 @@ __global__ void __launch_bounds__(kBlockThreads, (SH_DEG > 0 ? kPlainWaves : 1))
                 const bool to_sdf = grp == 0 || a.geometry_only;       // geometry-only: the SDF blob is the only one streamed
                 wp.begin_pass(a.sdf_blob, kSdfChunks, to_sdf ? a.sdf_blob : (kEnvNet ? a.env_blob : a.head_blob),
                               to_sdf ? kSdfChunks : (kEnvNet ? kEnvChunks : kHeadChunks));
+                // forward; of the two hidden pre-activations only their signs are needed again (the ReLU masks of the backward
+                // pass): they are kept as one bit per feature (bit 16 t + r of a lane = register r of tile t), which frees 64
+                // registers while the backward layers run
+                uint32_t pos1 = 0, pos2 = 0;
                 pipe_layer_from_lanes<kLevels, 2, kSdfW1, kSdfN>(wp, lane, in, h1);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pos1 |= (h1[t][r] > 0 ? 1u : 0u) << (16 * t + r);
                 pipe_layer_from_tiles<2, 2, kSdfW2, kSdfN, true>(wp, lane, h1, h2);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pos2 |= (h2[t][r] > 0 ? 1u : 0u) << (16 * t + r);
                 pipe_layer_from_tiles<2, 1, kSdfW3, kSdfN, true>(wp, lane, h2, o3);
                 // backward of sdf = o3[row 0]:  g2 = W3[0,:] * [h2 > 0];  g1 = (W2^T g2) * [h1 > 0];  gfeat = W1^T g1
-                // (h1, h2 hold pre-activations: ReLU is applied as the next layer reads them)
                 f32x16 g2[2], g1[2], gf[1];
                 const ParamBuf w3r0 = make_param_buf(a.sdf_w3r0, 2 * 128u, lane);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const f32x16 w = load_rowvec(w3r0, t);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) g2[t][r] = h2[t][r] > 0 ? w[r] : 0.0f;
+                    for (int r = 0; r < 16; ++r) g2[t][r] = (pos2 >> (16 * t + r)) & 1u ? w[r] : 0.0f;
                 }
                 pipe_layer_from_tiles<2, 2, kSdfW2t, kSdfN, false, false>(wp, lane, g2, g1);
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) g1[t][r] = h1[t][r] > 0 ? g1[t][r] : 0.0f;
+                    for (int r = 0; r < 16; ++r) g1[t][r] = (pos1 >> (16 * t + r)) & 1u ? g1[t][r] : 0.0f;
                 pipe_layer_from_tiles<2, 1, kSdfW1t, kSdfN, false, false>(wp, lane, g1, gf);
                 wp.template end_pass<kSdfFrags>();
                 if (grp == 0) { outA = o3[0]; gfA = gf[0]; } else { outB = o3[0]; gfB = gf[0]; }
