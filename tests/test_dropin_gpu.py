@@ -39,6 +39,22 @@ def model_and_opt():
     return build_model(scenes.toaster_scene())
 
 
+def test_two_phase_schedule_through_the_drop_in_surface(model_and_opt):
+    """run_cuda picks the two-phase schedule for large batches; forced here on a small frame: same frame as the reference's"""
+    import torch
+    model, opt = model_and_opt
+    g = np.load(GOLD / "frame_toaster_rot_40.npz")
+    H, W = int(g["H"]), int(g["W"])
+    ro, rd = scenes.camera_rays(H, W, theta=float(g["theta"]), phi=float(g["phi"]))
+    res = model.render(torch.from_numpy(ro).cuda()[None], torch.from_numpy(rd).cuda()[None], staged=True, bg_color=1, perturb=False,
+                       get_normal_image=True, env_rot_radian=float(g["env_rot"]), two_phase=True, max_steps=opt.max_steps,
+                       T_thresh=opt.T_thresh, dt_gamma=opt.dt_gamma)
+    torch.cuda.synchronize()
+    for key in KEYS:
+        err = rel_l2(res[key].detach().cpu().numpy().reshape(H * W, -1), g[key].reshape(H * W, -1))
+        assert err <= 1e-4, f"{key}: rel-L2 {err:.3e}"
+
+
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("tag", ["toaster_48", "toaster_rot_40"])
 def test_render_matches_reference_frames(model_and_opt, tag, fused):
