@@ -30,3 +30,17 @@ torch.cuda.synchronize()
 print(f"100 frames: {(time.time()-t0)*10:.2f} ms/frame, memory growth {torch.cuda.memory_allocated()-mem0} B")
 assert torch.isfinite(res["image"]).all()
 print("soak ok")
+# two-phase frames: 100 frames, then a different batch size (buffers re-keyed), then back
+mem0 = torch.cuda.memory_allocated()
+t0 = time.time()
+for i in range(100):
+    res = r.render_two_phase(ro, rd, 2 * math.pi * i / 100, out=out)
+torch.cuda.synchronize()
+print(f"100 two-phase frames: {(time.time()-t0)*10:.2f} ms/frame, memory growth {(torch.cuda.memory_allocated()-mem0)/2**20:.0f} MiB (record buffers)")
+ref = r.render(ro, rd, 2 * math.pi * 99 / 100, extras=True)
+assert torch.equal(res["image"], ref["image"]) and torch.isfinite(res["image"]).all()
+small = r.render_two_phase(ro[:70001], rd[:70001], 0.5)
+assert torch.equal(small["image"], r.render(ro[:70001], rd[:70001], 0.5, extras=True)["image"])
+again = r.render_two_phase(ro, rd, 0.5)
+assert torch.equal(again["image"], r.render(ro, rd, 0.5, extras=True)["image"])
+print("two-phase soak ok")
