@@ -513,7 +513,9 @@ __device__ __forceinline__ void shade_sample(WP& wp, const uint32_t lane, const 
 //   SH_DEG == 0: environment-MLP family (toaster.ini / neural_renderer.ini): IDE degree IDE_DEG, env hidden 32 ENV_T
 //   SH_DEG  > 0: no environment network (BASELINE configs[1]): diffuse head on geo_feat, specular head on
 //                [SH(view dir) | geo_feat | SH(normal) | n.v] with SH "degree" SH_DEG (SH_DEG^2 values each)
-template <int IDE_DEG, int ENV_T, int SH_DEG>
+// GEOM: geometry-only launches (first pass of indirect rendering, geometry pass of a two-phase frame) get their own
+// instantiation without any shading code
+template <int IDE_DEG, int ENV_T, int SH_DEG, bool GEOM = false>
 __global__ void __launch_bounds__(kBlockThreads, (SH_DEG > 0 ? kPlainWaves : 1)) k_render_persistent(const RenderArgs a) {
     constexpr bool kEnvNet = SH_DEG == 0;
     constexpr int kShDim = SH_DEG * SH_DEG;
@@ -755,7 +757,7 @@ __global__ void __launch_bounds__(kBlockThreads, (SH_DEG > 0 ? kPlainWaves : 1))
 #pragma unroll
                 for (int s = 0; s < kLevels; ++s) in[s] = grp ? inB[s] : inA[s];
                 f32x16 h1[2], h2[2], o3[1];
-                const bool to_sdf = grp == 0 || a.geometry_only;       // geometry-only: the SDF blob is the only one streamed
+                const bool to_sdf = grp == 0 || GEOM || a.geometry_only;       // geometry-only: the SDF blob is the only one streamed
                 wp.begin_pass(a.sdf_blob, kSdfChunks, to_sdf ? a.sdf_blob : (kEnvNet ? a.env_blob : a.head_blob),
                               to_sdf ? kSdfChunks : (kEnvNet ? kEnvChunks : kHeadChunks));
                 // forward; of the two hidden pre-activations only their signs are needed again (the ReLU masks of the backward
@@ -848,7 +850,7 @@ __global__ void __launch_bounds__(kBlockThreads, (SH_DEG > 0 ? kPlainWaves : 1))
         ENVIDR_TICK(3);   // geometry terms
         // ================= shading: environment MLP x2 + diffuse / specular heads ===================
         float cd[3] = {0, 0, 0}, cs[3] = {0, 0, 0};
-        if (!a.geometry_only) {
+        if constexpr (!GEOM) if (!a.geometry_only) {
             const bool renv = kEnvNet && a.r_images != nullptr;
             constexpr uint32_t kRenvChunks = pass_chunks(kRenvFrags), kSpec2Chunks = pass_chunks(kSpec2Frags);
             const ShadeConsts sc = {a.env_blob, a.head_blob, renv ? a.renv_blob : a.sdf_blob, renv ? kRenvChunks : kSdfChunks,
@@ -1329,7 +1331,8 @@ int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const f
     const uint32_t blocks = std::min((uint32_t)device_cu_count() * (4 / waves_per_block) * waves_per_simd, ceil_div(N, kBlockThreads));
     const dim3 grid(blocks), block(kBlockThreads);
 #define ENVIDR_LAUNCH(DEG, HT, SH) hipLaunchKernelGGL((k_render_persistent<DEG, HT, SH>), grid, block, 0, s, a)
-    if (d->dir_sh_degree == 4) ENVIDR_LAUNCH(4, 0, 4);
+    if (d->geometry_only && !kSharedWeights) hipLaunchKernelGGL((k_render_persistent<4, 4, 0, true>), grid, block, 0, s, a);
+    else if (d->dir_sh_degree == 4) ENVIDR_LAUNCH(4, 0, 4);
     else if (d->dir_sh_degree != 0) {
         set_error("render_rays: unsupported dir_sh_degree=%u (no-environment family is built for SH degree 4)", d->dir_sh_degree);
         return ENVIDR_EINVAL;
