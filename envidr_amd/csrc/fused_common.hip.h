@@ -1,0 +1,191 @@
+// Per-sample device code shared by the fused render kernels (fused_render.hip) and the geometry pipeline
+// (geometry_pass.hip): slab test, hash-grid level evaluation split into "issue the gathers" / "interpolate",
+// the fragment layout of the SDF weight blob, small math helpers.  Both translation units evaluate a sample with
+// exactly these statements, so their per-sample results are the same bits.
+#pragma once
+#include "grid_core.hip.h"
+#include "march_core.hip.h"
+#include "mlp_mfma.hip.h"
+
+#include "../../include/envidr_render.h"
+
+#include <float.h>
+
+namespace envidr {
+
+constexpr int kLevels = ENVIDR_MAX_LEVELS;
+
+struct HashLevelK {
+    uint32_t row0, size, stride1, stride2;
+    float scale;
+    uint32_t hashed, andmask, enabled, slow_mod;
+};
+
+// slab test, identical arithmetic to k_near_far_from_aabb (raymarching.hip)
+__device__ __forceinline__ void near_far(const RayGeom& r, float bound, float min_near, float& near, float& far) {
+    near = (-bound - r.ox) * r.rdx; far = (bound - r.ox) * r.rdx;
+    if (near > far) { const float c = near; near = far; far = c; }
+    float ny = (-bound - r.oy) * r.rdy, fy = (bound - r.oy) * r.rdy;
+    if (ny > fy) { const float c = ny; ny = fy; fy = c; }
+    bool miss = near > fy || ny > far;
+    if (!miss) {
+        if (ny > near) near = ny;
+        if (fy < far) far = fy;
+        float nz = (-bound - r.oz) * r.rdz, fz = (bound - r.oz) * r.rdz;
+        if (nz > fz) { const float c = nz; nz = fz; fz = c; }
+        miss = near > fz || nz > far;
+        if (!miss) {
+            if (nz > near) near = nz;
+            if (fz < far) far = fz;
+            if (near < min_near) near = min_near;
+        }
+    }
+    if (miss) near = far = FLT_MAX;
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float softplusf(float x) { return x > 20.0f ? x : log1pf(expf(x)); }   // torch: beta 1, threshold 20
+
+template <int N>
+__device__ __forceinline__ void normalize_n(float (&v)[N], float eps) {
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) s += v[i] * v[i];
+    const float inv = 1.0f / fmaxf(sqrtf(s), eps);    // F.normalize: v / max(||v||, eps)
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = v[i] * inv;
+}
+
+// position of the n-th set bit of mask (n < popcount(mask))
+__device__ __forceinline__ uint32_t nth_set_bit(unsigned long long mask, uint32_t n) {
+    uint32_t pos = 0;
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) {
+        const uint32_t cnt = (uint32_t)__popcll((mask >> pos) & ((1ull << w) - 1ull));
+        if (n >= cnt) { n -= cnt; pos += (uint32_t)w; }
+    }
+    return pos;
+}
+
+// ---- hash-grid level evaluation split into "issue the gathers" and "interpolate" ------------------
+struct HashStage {
+    float w1[3], dw[3];
+    float2 c[8];
+};
+
+// Row index -> row inside the level's table, branch-free for the two geometries real tables have: hashed levels have
+// a power-of-two size (mask), dense levels produce indices below 2 * size (host-checked), where one conditional
+// subtract -- written as min(idx, idx - size) on unsigned values -- is the modulo.  `andmask` is size - 1 or ~0.
+// (Run-time branches per corner split this section into dozens of basic blocks; the waits the compiler then places at
+// their joins drained the gather pipeline.)
+__device__ __forceinline__ uint32_t wrap_fast(uint32_t idx, const HashLevelK& lv) {
+    idx &= lv.andmask;
+    return min(idx, idx - lv.size);
+}
+
+template <bool SLOW>
+__device__ __forceinline__ void hash_gather(const HashLevelK& lv, const float2* __restrict__ table, const uint32_t (&cell)[3], HashStage& st) {
+    if (lv.hashed) {
+        const uint32_t hx[2] = {cell[0], cell[0] + 1u};
+        const uint32_t hy[2] = {cell[1] * 2654435761u, (cell[1] + 1u) * 2654435761u};
+        const uint32_t hz[2] = {cell[2] * 805459861u, (cell[2] + 1u) * 805459861u};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t idx = hx[i & 1] ^ hy[(i >> 1) & 1] ^ hz[(i >> 2) & 1];
+            st.c[i] = table[SLOW ? idx % lv.size : wrap_fast(idx, lv)];
+        }
+    } else {
+        const uint32_t ix[2] = {cell[0], cell[0] + 1u};
+        const uint32_t iy[2] = {cell[1] * lv.stride1, (cell[1] + 1u) * lv.stride1};
+        const uint32_t iz[2] = {cell[2] * lv.stride2, (cell[2] + 1u) * lv.stride2};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t idx = ix[i & 1] + iy[(i >> 1) & 1] + iz[(i >> 2) & 1];
+            st.c[i] = table[SLOW ? idx % lv.size : wrap_fast(idx, lv)];
+        }
+    }
+}
+
+// `table_base` is the whole table ([rows, 2] floats); x is the position in [0, 1]^3
+__device__ __forceinline__ void hash_prepare(const HashLevelK& lv, const float* __restrict__ table_base, const float (&x)[3], HashStage& st) {
+    uint32_t cell[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float p = x[d] * lv.scale + 0.0f;
+        cell[d] = (uint32_t)floorf(p);
+        p -= (float)cell[d];
+        st.dw[d] = 6 * p * (1.0f - p);                 // smoothstep'
+        st.w1[d] = p * p * (3.0f - 2.0f * p);          // smoothstep
+    }
+    const float2* table = reinterpret_cast<const float2*>(table_base) + lv.row0;
+    if (lv.slow_mod) hash_gather<true>(lv, table, cell, st);       // table geometries that are neither (never for HashEncoder's own sizing)
+    else hash_gather<false>(lv, table, cell, st);
+}
+
+__device__ __forceinline__ void hash_finish(const float scale, const HashStage& st, float (&out)[2], float (&dydx)[3][2]) {
+    out[0] = out[1] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float w = 1;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) w *= ((i >> d) & 1) ? st.w1[d] : 1 - st.w1[d];
+        out[0] += w * st.c[i].x;
+        out[1] += w * st.c[i].y;
+    }
+#pragma unroll
+    for (int gd = 0; gd < 3; ++gd) {
+        float acc0 = 0, acc1 = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float w = scale;
+            int lo = 0;
+#pragma unroll
+            for (int nd = 0; nd < 2; ++nd) {
+                const int d = nd >= gd ? nd + 1 : nd;
+                const int bit = (j >> nd) & 1;
+                w *= bit ? st.w1[d] : 1 - st.w1[d];
+                lo |= bit << d;
+            }
+            const int hi = lo | (1 << gd);
+            acc0 += w * (st.c[hi].x - st.c[lo].x) * st.dw[gd];
+            acc1 += w * (st.c[hi].y - st.c[lo].y) * st.dw[gd];
+        }
+        dydx[gd][0] = acc0;
+        dydx[gd][1] = acc1;
+    }
+}
+
+// host: per-level constants of the fused kernels from the render descriptor; returns an error message or nullptr
+inline const char* fill_hash_levels(const envidr_render_desc* d, HashLevelK (&lv)[kLevels]) {
+    const LevelScale ls = make_level_scale(d->num_levels, d->log2_per_level_scale, d->base_resolution);
+    for (uint32_t l = 0; l < d->num_levels; ++l) {
+        const uint32_t size = (uint32_t)(d->hash_offsets[l + 1] - d->hash_offsets[l]);
+        const LevelGeom<3> g = make_level_geom<3>(size, ls.resolution[l], true);
+        lv[l].row0 = (uint32_t)d->hash_offsets[l];
+        lv[l].size = size;
+        lv[l].stride1 = g.stride[1]; lv[l].stride2 = g.stride[2];
+        lv[l].scale = ls.scale[l];
+        lv[l].hashed = g.hashed;
+        lv[l].andmask = (g.hashed && g.pow2) ? size - 1u : 0xffffffffu;
+        {
+            // dense levels: the largest index a corner can produce (coordinate res on every axis) must stay below 2 * size
+            // for the conditional-subtract wrap; otherwise fall back to a true modulo
+            const unsigned long long res = ls.resolution[l];
+            const unsigned long long max_idx = res + res * (unsigned long long)g.stride[1] + res * (unsigned long long)g.stride[2];
+            lv[l].slow_mod = ((g.hashed && !g.pow2) || (!g.hashed && max_idx >= 2ull * size)) ? 1u : 0u;
+        }
+        lv[l].enabled = (d->enabled_levels <= 0 || (int32_t)l < d->enabled_levels) ? 1u : 0u;
+        if (!(g.hashed || g.stride[0] == 1)) return "unexpected dense stride";
+    }
+    return nullptr;
+}
+
+// fragment layout of the SDF weight pass (must match envidr_amd/fused.py and envidr_render.h)
+// (every forward layer carries its bias as one extra leading step; the two gradient layers have none)
+constexpr int kSdfW1 = 0, kSdfW2 = kSdfW1 + lane_layer_frags(16, 2, true), kSdfW3 = kSdfW2 + tile_layer_frags(2, 2, true),
+              kSdfW2t = kSdfW3 + tile_layer_frags(2, 1, true), kSdfW1t = kSdfW2t + tile_layer_frags(2, 2, false),
+              kSdfFrags = kSdfW1t + tile_layer_frags(2, 1, false);
+
+int device_cu_count();   // fused_render.hip
+
+}  // namespace envidr

@@ -25,14 +25,9 @@
 // reference loop with n_step = 1; its per-ray compositing recurrence is the reference's.  The
 // reference's larger n_step only changes where the fp32 ray time is re-derived from the summed
 // deltas (ulp-level), see DESIGN.md.
-#include "grid_core.hip.h"
-#include "march_core.hip.h"
-#include "mlp_mfma.hip.h"
+#include "fused_common.hip.h"
 #include "sh_core.hip.h"
 
-#include "../../include/envidr_render.h"
-
-#include <float.h>
 #include <type_traits>
 #include <vector>
 
@@ -40,17 +35,10 @@ using namespace envidr;
 
 namespace {
 
-constexpr int kLevels = ENVIDR_MAX_LEVELS;
 #ifndef ENVIDR_MAX_GROUP
 #define ENVIDR_MAX_GROUP 8
 #endif
 constexpr uint32_t kMaxGroup = ENVIDR_MAX_GROUP;   // largest number of lanes (consecutive samples) per ray in tail mode
-
-struct HashLevelK {
-    uint32_t row0, size, stride1, stride2;
-    float scale;
-    uint32_t hashed, andmask, enabled, slow_mod;
-};
 
 struct RenderArgs {
     const float* rays_o;
@@ -94,41 +82,6 @@ struct RenderArgs {
     const uint32_t* hit_ids;    // [N] compacted ids of rays that have at least one sample
     const float* hit_t;         // [N] per RAY: marcher time at its first sample
 };
-
-// slab test, identical arithmetic to k_near_far_from_aabb (raymarching.hip)
-__device__ __forceinline__ void near_far(const RayGeom& r, float bound, float min_near, float& near, float& far) {
-    near = (-bound - r.ox) * r.rdx; far = (bound - r.ox) * r.rdx;
-    if (near > far) { const float c = near; near = far; far = c; }
-    float ny = (-bound - r.oy) * r.rdy, fy = (bound - r.oy) * r.rdy;
-    if (ny > fy) { const float c = ny; ny = fy; fy = c; }
-    bool miss = near > fy || ny > far;
-    if (!miss) {
-        if (ny > near) near = ny;
-        if (fy < far) far = fy;
-        float nz = (-bound - r.oz) * r.rdz, fz = (bound - r.oz) * r.rdz;
-        if (nz > fz) { const float c = nz; nz = fz; fz = c; }
-        miss = near > fz || nz > far;
-        if (!miss) {
-            if (nz > near) near = nz;
-            if (fz < far) far = fz;
-            if (near < min_near) near = min_near;
-        }
-    }
-    if (miss) near = far = FLT_MAX;
-}
-
-__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float softplusf(float x) { return x > 20.0f ? x : log1pf(expf(x)); }   // torch: beta 1, threshold 20
-
-template <int N>
-__device__ __forceinline__ void normalize_n(float (&v)[N], float eps) {
-    float s = 0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) s += v[i] * v[i];
-    const float inv = 1.0f / fmaxf(sqrtf(s), eps);    // F.normalize: v / max(||v||, eps)
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = v[i] * inv;
-}
 
 // cost buckets of the optional scheduling hint: 256 buckets of 2^kCostShift samples (coarse buckets keep image-space
 // neighbours, whose hash gathers share cache lines, together)
@@ -230,112 +183,6 @@ __global__ void __launch_bounds__(kBlock) k_order_hits(const RenderArgs a, uint3
     }
 }
 
-// position of the n-th set bit of mask (n < popcount(mask))
-__device__ __forceinline__ uint32_t nth_set_bit(unsigned long long mask, uint32_t n) {
-    uint32_t pos = 0;
-#pragma unroll
-    for (int w = 32; w >= 1; w >>= 1) {
-        const uint32_t cnt = (uint32_t)__popcll((mask >> pos) & ((1ull << w) - 1ull));
-        if (n >= cnt) { n -= cnt; pos += (uint32_t)w; }
-    }
-    return pos;
-}
-
-
-// ---- hash-grid level evaluation split into "issue the gathers" and "interpolate" ------------------
-struct HashStage {
-    float w1[3], dw[3];
-    float2 c[8];
-};
-
-// Row index -> row inside the level's table, branch-free for the two geometries real tables have: hashed levels have
-// a power-of-two size (mask), dense levels produce indices below 2 * size (host-checked), where one conditional
-// subtract -- written as min(idx, idx - size) on unsigned values -- is the modulo.  `andmask` is size - 1 or ~0.
-// (Run-time branches per corner split this section into dozens of basic blocks; the waits the compiler then places at
-// their joins drained the gather pipeline.)
-__device__ __forceinline__ uint32_t wrap_fast(uint32_t idx, const HashLevelK& lv) {
-    idx &= lv.andmask;
-    return min(idx, idx - lv.size);
-}
-
-template <bool SLOW>
-__device__ __forceinline__ void hash_gather(const HashLevelK& lv, const float2* __restrict__ table, const uint32_t (&cell)[3], HashStage& st) {
-    if (lv.hashed) {
-        const uint32_t hx[2] = {cell[0], cell[0] + 1u};
-        const uint32_t hy[2] = {cell[1] * 2654435761u, (cell[1] + 1u) * 2654435761u};
-        const uint32_t hz[2] = {cell[2] * 805459861u, (cell[2] + 1u) * 805459861u};
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const uint32_t idx = hx[i & 1] ^ hy[(i >> 1) & 1] ^ hz[(i >> 2) & 1];
-            st.c[i] = table[SLOW ? idx % lv.size : wrap_fast(idx, lv)];
-        }
-    } else {
-        const uint32_t ix[2] = {cell[0], cell[0] + 1u};
-        const uint32_t iy[2] = {cell[1] * lv.stride1, (cell[1] + 1u) * lv.stride1};
-        const uint32_t iz[2] = {cell[2] * lv.stride2, (cell[2] + 1u) * lv.stride2};
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const uint32_t idx = ix[i & 1] + iy[(i >> 1) & 1] + iz[(i >> 2) & 1];
-            st.c[i] = table[SLOW ? idx % lv.size : wrap_fast(idx, lv)];
-        }
-    }
-}
-
-__device__ __forceinline__ void hash_prepare(const RenderArgs& a, int l, const float (&x)[3], HashStage& st) {
-    const HashLevelK& lv = a.lv[l];
-    uint32_t cell[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        float p = x[d] * lv.scale + 0.0f;
-        cell[d] = (uint32_t)floorf(p);
-        p -= (float)cell[d];
-        st.dw[d] = 6 * p * (1.0f - p);                 // smoothstep'
-        st.w1[d] = p * p * (3.0f - 2.0f * p);          // smoothstep
-    }
-    const float2* table = reinterpret_cast<const float2*>(a.table) + lv.row0;
-    if (lv.slow_mod) hash_gather<true>(lv, table, cell, st);       // table geometries that are neither (never for HashEncoder's own sizing)
-    else hash_gather<false>(lv, table, cell, st);
-}
-
-__device__ __forceinline__ void hash_finish(const RenderArgs& a, int l, const HashStage& st, float (&out)[2], float (&dydx)[3][2]) {
-    const float scale = a.lv[l].scale;
-    out[0] = out[1] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        float w = 1;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) w *= ((i >> d) & 1) ? st.w1[d] : 1 - st.w1[d];
-        out[0] += w * st.c[i].x;
-        out[1] += w * st.c[i].y;
-    }
-#pragma unroll
-    for (int gd = 0; gd < 3; ++gd) {
-        float acc0 = 0, acc1 = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float w = scale;
-            int lo = 0;
-#pragma unroll
-            for (int nd = 0; nd < 2; ++nd) {
-                const int d = nd >= gd ? nd + 1 : nd;
-                const int bit = (j >> nd) & 1;
-                w *= bit ? st.w1[d] : 1 - st.w1[d];
-                lo |= bit << d;
-            }
-            const int hi = lo | (1 << gd);
-            acc0 += w * (st.c[hi].x - st.c[lo].x) * st.dw[gd];
-            acc1 += w * (st.c[hi].y - st.c[lo].y) * st.dw[gd];
-        }
-        dydx[gd][0] = acc0;
-        dydx[gd][1] = acc1;
-    }
-}
-
-// fragment layout of the three weight passes (must match envidr_amd/fused.py and envidr_render.h)
-// (every forward layer carries its bias as one extra leading step; the two gradient layers have none)
-constexpr int kSdfW1 = 0, kSdfW2 = kSdfW1 + lane_layer_frags(16, 2, true), kSdfW3 = kSdfW2 + tile_layer_frags(2, 2, true),
-              kSdfW2t = kSdfW3 + tile_layer_frags(2, 1, true), kSdfW1t = kSdfW2t + tile_layer_frags(2, 2, false),
-              kSdfFrags = kSdfW1t + tile_layer_frags(2, 1, false);
 // heads: diffuse DSTEPS lane steps -> 32 -> 3, specular SSTEPS lane steps -> 64 -> 64 -> 3 (a lane step = 2 input features)
 template <int DSTEPS, int SSTEPS>
 struct HeadLayout {
@@ -716,15 +563,15 @@ __global__ void __launch_bounds__(kBlockThreads, (SH_DEG > 0 ? kPlainWaves : 1))
             const float xc[3] = {inside ? x01[0] : 0.5f, inside ? x01[1] : 0.5f, inside ? x01[2] : 0.5f};
             HashStage st[kHashAhead + 1];      // rotating stages; every index below is a compile-time constant
             [&]<int... I>(std::integer_sequence<int, I...>) {
-                (hash_prepare(a, I, xc, st[I]), ...);
+                (hash_prepare(a.lv[I], a.table, xc, st[I]), ...);
             }(std::make_integer_sequence<int, kHashAhead>{});
             __builtin_amdgcn_sched_barrier(0);
             auto level = [&](auto lc, HashStage& cur, HashStage& ahead) {
                 constexpr int l = decltype(lc)::value;
-                if constexpr (l + kHashAhead < kLevels) hash_prepare(a, l + kHashAhead, xc, ahead);
+                if constexpr (l + kHashAhead < kLevels) hash_prepare(a.lv[l + kHashAhead], a.table, xc, ahead);
                 __builtin_amdgcn_sched_barrier(0);
                 float o[2], g[3][2];
-                hash_finish(a, l, cur, o, g);
+                hash_finish(a.lv[l].scale, cur, o, g);
                 const float m = (a.lv[l].enabled && inside) ? 1.0f : 0.0f;     // network.py:390-393 level mask
                 feat[2 * l] = o[0] * m; feat[2 * l + 1] = o[1] * m;
 #pragma unroll
@@ -1048,6 +895,7 @@ struct ShadeArgs {
     const uint32_t* ray_ids;
     const float* rays_d;
     const uint32_t* m_dev;
+    const uint32_t* slot;       // record mode, optional: normals / geo_feat / roughness of record i live at index slot[i]
     const float* env_blob;
     const float* head_blob;
     float kappa_diffuse, light_scale;
@@ -1069,19 +917,22 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_shade_samples(const ShadeA
     wp.start(s_weights, lane, wave, a.env_blob, kEnvChunks);
     const ShadeConsts sc = {a.env_blob, a.head_blob, a.env_blob, kEnvChunks, a.kappa_diffuse, a.light_scale};
     const uint32_t waves = gridDim.x * (kBlockThreads / 64);
-    const uint32_t M = a.m_dev ? min(__builtin_amdgcn_readfirstlane(*a.m_dev), a.M) : a.M;
+    // a frame whose records did not fit (count beyond the capacity) is not shaded at all: the host redoes it
+    uint32_t M = a.M;
+    if (a.m_dev) { const uint32_t md = __builtin_amdgcn_readfirstlane(*a.m_dev); M = md > a.M ? 0u : md; }
     // every wave of a block runs the same number of rounds (the shared weight stream has block-wide barriers)
     for (uint32_t base = (blockIdx.x * (kBlockThreads / 64)) * 64; base < M; base += waves * 64) {
         const uint32_t id = base + wave * 64 + lane;
         const bool on = id < M;
         const size_t i = on ? id : 0;
+        const size_t gi = a.slot ? (size_t)a.slot[i] : i;          // where this record's geometry lives
         float nrm[3], vd[3], geo[12];
         const float* dir = a.ray_ids ? a.rays_d + 3 * (size_t)a.ray_ids[i] : a.dirs + 3 * i;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { nrm[d] = on ? a.normals[3 * i + d] : 0.0f; vd[d] = on ? dir[d] : 0.0f; }
+        for (int d = 0; d < 3; ++d) { nrm[d] = on ? a.normals[3 * gi + d] : 0.0f; vd[d] = on ? dir[d] : 0.0f; }
 #pragma unroll
-        for (int j = 0; j < 12; ++j) geo[j] = a.geo_feat[(size_t)a.geo_stride * i + j];
-        const float rough = a.roughness[(size_t)a.rough_stride * i];
+        for (int j = 0; j < 12; ++j) geo[j] = a.geo_feat[(size_t)a.geo_stride * gi + j];
+        const float rough = a.roughness[(size_t)a.rough_stride * gi];
         // renderer.py:147-180 (same statements as the persistent kernel)
         const float wo[3] = {-vd[0], -vd[1], -vd[2]};
         const float ndot = nrm[0] * wo[0] + nrm[1] * wo[1] + nrm[2] * wo[2];
@@ -1168,6 +1019,9 @@ __global__ void __launch_bounds__(kBlock) k_composite_records(const uint32_t* __
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+}  // namespace
+
+namespace envidr {
 int device_cu_count() {
     static int cus = 0;
     if (!cus) {
@@ -1178,8 +1032,7 @@ int device_cu_count() {
     }
     return cus;
 }
-
-}  // namespace
+}  // namespace envidr
 
 extern "C" {
 
@@ -1233,25 +1086,9 @@ int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const f
     a.table = d->hash_table;
     a.num_levels = d->num_levels;
     a.bound2 = 2 * d->bound;
-    const LevelScale ls = make_level_scale(d->num_levels, d->log2_per_level_scale, d->base_resolution);
-    for (uint32_t l = 0; l < d->num_levels; ++l) {
-        const uint32_t size = (uint32_t)(d->hash_offsets[l + 1] - d->hash_offsets[l]);
-        const LevelGeom<3> g = make_level_geom<3>(size, ls.resolution[l], true);
-        a.lv[l].row0 = (uint32_t)d->hash_offsets[l];
-        a.lv[l].size = size;
-        a.lv[l].stride1 = g.stride[1]; a.lv[l].stride2 = g.stride[2];
-        a.lv[l].scale = ls.scale[l];
-        a.lv[l].hashed = g.hashed;
-        a.lv[l].andmask = (g.hashed && g.pow2) ? size - 1u : 0xffffffffu;
-        {
-            // dense levels: the largest index a corner can produce (coordinate res on every axis) must stay below 2 * size
-            // for the conditional-subtract wrap; otherwise fall back to a true modulo
-            const unsigned long long res = ls.resolution[l];
-            const unsigned long long max_idx = res + res * (unsigned long long)g.stride[1] + res * (unsigned long long)g.stride[2];
-            a.lv[l].slow_mod = ((g.hashed && !g.pow2) || (!g.hashed && max_idx >= 2ull * size)) ? 1u : 0u;
-        }
-        a.lv[l].enabled = (d->enabled_levels <= 0 || (int32_t)l < d->enabled_levels) ? 1u : 0u;
-        ENVIDR_REQUIRE(g.hashed || g.stride[0] == 1, "render_rays: unexpected dense stride");
+    {
+        const char* err = fill_hash_levels(d, a.lv);
+        ENVIDR_REQUIRE(!err, "render_rays: %s", err);
     }
     a.sdf_blob = d->sdf_blob; a.env_blob = d->env_blob; a.head_blob = d->head_blob;
     a.sdf_w3r0 = d->sdf_w3_row0;
@@ -1402,6 +1239,7 @@ int envidr_shade_records(const envidr_render_desc* d, const envidr_geometry_expo
     a.normals = rec->normal; a.geo_feat = rec->geo_feat; a.roughness = rec->roughness;
     a.geo_stride = 12; a.rough_stride = 1; a.M = rec->capacity;
     a.ray_ids = rec->ray; a.rays_d = rays_d; a.m_dev = rec->counter;
+    a.slot = rec->slot;
     a.c_diffuse = c_diffuse; a.c_specular = c_specular;
     return launch_shade(d, a, stream, "shade_records");
 }

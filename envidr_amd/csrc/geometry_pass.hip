@@ -1,0 +1,861 @@
+// Geometry pipeline of the fused renderer for gfx950 (include/envidr_render.h, envidr_geometry_*).
+//
+// The geometry half of a frame -- march -> hash grid -> SDF network forward + input gradient -> density, normal,
+// geometry feature, roughness -> compositing weights -- as a device-driven sequence of two kinds of launches:
+//
+//   k_geo_rays   one lane per ray still alive: composites the samples its ray got evaluated in the previous round
+//                (reference recurrence, raymarching.cu:996-1030), finishes rays that terminated or left the scene,
+//                and marches the next chunk of samples of the others (march_core.hip.h, the standalone operator's
+//                bit-exact code) into a compact sample list.  Chunks grow geometrically (16, 32, 64 ...): a ray that
+//                terminates early wastes at most the rest of its current chunk, a ray that never does is done in a
+//                handful of rounds.  No host round trip: counts and the alive list live on the device, the host
+//                enqueues a fixed number of rounds.
+//   k_geo_eval   one lane per SAMPLE of the round's list, nothing per ray: 16-level hash gathers with analytic
+//                Jacobian, SDF network forward and backward on the matrix cores, per-sample geometry terms.  Every
+//                lane has work every round; two waves per SIMD (one in its gather / interpolation phase while the
+//                other owns the matrix pipe); the SDF weights are read from HBM once per workgroup and stay in LDS;
+//                the Jacobian of a sample is held half in registers, half in LDS until the backward pass needs it.
+//
+// Sample positions are those of the reference loop with one sample per ray per iteration (the marcher is resumed
+// from the composited ray time after every sample, which does not depend on the densities), i.e. exactly the samples
+// of envidr_render_rays; the per-sample arithmetic is fused_common.hip.h's, shared with that kernel.
+#include "fused_common.hip.h"
+#include "hash_lean.hip.h"
+
+#include <algorithm>
+#include <utility>
+
+using namespace envidr;
+
+namespace {
+
+// ---- SDF weights resident in LDS ----------------------------------------------------------------------------
+// Fragment I of the SDF blob (mlp_mfma.hip.h: [fragment][64 lanes]) is one conflict-free ds_read_b32.  The reads run
+// PF fragments ahead of the MFMAs that consume them through a small register ring, pinned with one sched_barrier per
+// reduction step (pipe_steps): left to itself the scheduler hoists dozens of these reads ahead of their use and the
+// kernel no longer fits two waves per SIMD.  Every pass streams the same blob, so the ring wraps around to fragment 0;
+// end_pass pads a pass to a multiple of PF so that fragment j always sits in slot j % PF.
+template <int PF>
+struct WeightLdsRing {
+    const float* frag;     // LDS base of the blob + lane
+    float ring[PF];
+    __device__ __forceinline__ void start(const float* lds_blob_lane) {
+        frag = lds_blob_lane;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) ring[i] = frag[i * 64];
+    }
+    __device__ __forceinline__ void begin_pass(const float*, uint32_t, const float*, uint32_t) {}
+    template <int I, int FRAGS>
+    __device__ __forceinline__ float take() {
+        static_assert(FRAGS % PF == 0, "pass length must be a multiple of the ring depth");
+        const float v = ring[I % PF];
+        ring[I % PF] = frag[((I + PF) % FRAGS) * 64];
+        return v;
+    }
+    template <int FRAGS, int I = FRAGS>
+    __device__ __forceinline__ void end_pass() {
+        if constexpr (I % PF != 0) {
+            constexpr int kPadded = (FRAGS + PF - 1) / PF * PF;
+            ring[I % PF] = frag[((I + PF) % kPadded) * 64];      // the next pass's fragment that belongs in this slot
+            end_pass<FRAGS, I + 1>();
+        }
+    }
+};
+}  // namespace
+namespace envidr {
+template <int PF> struct is_weight_ring<WeightLdsRing<PF>> { static constexpr bool value = true; };
+}
+namespace {
+
+#ifndef ENVIDR_GEO_RING
+#define ENVIDR_GEO_RING 8
+#endif
+constexpr int kGeoRing = ENVIDR_GEO_RING;
+#ifndef ENVIDR_GEO_WAVES
+#define ENVIDR_GEO_WAVES 4
+#endif
+#ifndef ENVIDR_GEO_AHEAD
+#define ENVIDR_GEO_AHEAD 2
+#endif
+#ifndef ENVIDR_GEO_XCD
+#define ENVIDR_GEO_XCD 1
+#endif
+#ifndef ENVIDR_GEO_NOMLP
+#define ENVIDR_GEO_NOMLP 0
+#endif
+#ifndef ENVIDR_GEO_NOSWEEP2
+#define ENVIDR_GEO_NOSWEEP2 0
+#endif
+#ifndef ENVIDR_GEO_NOSTORE
+#define ENVIDR_GEO_NOSTORE 0
+#endif
+#ifndef ENVIDR_GEO_JMODE
+#define ENVIDR_GEO_JMODE 2      // 0: second gather sweep (no stored Jacobian), 1: Jacobian parked in per-wave global scratch, 2: in LDS
+#endif
+#ifndef ENVIDR_GEO_IOMODE
+#define ENVIDR_GEO_IOMODE 1      // 1: MLP inputs / outputs move between lane order and tile order by half-wave swaps (registers); 0: through LDS
+#endif
+#ifndef ENVIDR_GEO_NT_FROM
+#define ENVIDR_GEO_NT_FROM 99     // hash levels >= this are gathered with the non-temporal hint
+#endif
+#ifndef ENVIDR_GEO_UNROLL_GROUPS
+#define ENVIDR_GEO_UNROLL_GROUPS 0
+#endif
+constexpr int kEvalWaves = ENVIDR_GEO_WAVES;        // waves per workgroup: two per SIMD
+constexpr int kEvalThreads = kEvalWaves * 64;
+constexpr int kSdfBlobFloats = kSdfFrags * 64;
+constexpr int kW3RowFloats = 64;                    // packed row vector of W3[0, :] (two tiles x 32)
+constexpr int kXchgFloats = (32 + 16) * 64;         // per-wave exchange area: [32 features][64 samples] + [16 outputs][64 samples]
+
+struct GeoEvalArgs {
+    const float* xyz;           // [cap,3] sample positions
+    const float* dt;            // [cap]   step the compositor uses for alpha
+    const uint32_t* range;      // device {begin, count} of the samples to evaluate, or null: [0, M)
+    const uint32_t* head;       // pipeline mode: evaluate [*begin_io, *head) and leave begin_io[1] = *head for the next round
+    uint32_t* begin_io;
+    uint32_t M;
+    // hash grid
+    const float* table;
+    uint32_t table_bytes;
+    LeanLevel lv[kLevels];
+    float bound, bound2;
+    // SDF network
+    const float* sdf_blob;
+    const float* sdf_w3r0;
+    float inv_beta, beta, density_scale;
+    float rough_bias, rough_act_scale, rough_scale;
+    // per-sample outputs (any may be null)
+    float* alpha;               // [cap]    1 - exp(-sigma dt)
+    float* sigma;               // [cap]
+    float* normal;              // [cap,3]  unit
+    float* geo;                 // [cap,12] unit
+    float* rough;               // [cap]
+    float* blend;               // [cap]    raw output 14 of the SDF network (learn_indir_blend logit)
+    float* jscratch;            // [waves in the grid][96][64] parking space of the Jacobians (L2-resident)
+};
+
+// compiler-level ordering of this wave's LDS traffic between two phases (a wave's DS operations execute in order;
+// nothing is emitted for wavefront scope)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// first SDF layer with its B operands read from the per-wave exchange area ([feature][sample], conflict-free):
+// step s of group grp: lane l supplies feature 2 s + (l >> 5) of sample 32 grp + (l & 31)
+template <int STEPS, int MT, int F0, int FRAGS, typename Src>
+__device__ __forceinline__ void pipe_layer_from_lds(Src& wp, uint32_t lane, const float* col, f32x16 (&acc)[MT]) {
+    zero_acc<MT>(acc);
+    bias_step<MT, F0, FRAGS>(wp, lane, acc);
+    float in[STEPS];
+#pragma unroll
+    for (int q = 0; q < STEPS; ++q) in[q] = col[(2 * q) * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    pipe_steps<STEPS, MT, F0 + MT, FRAGS>(wp, acc, [&](int q) { return in[q]; });
+}
+
+__global__ void __launch_bounds__(kEvalThreads, (kEvalWaves + 3) / 4) k_geo_eval(const GeoEvalArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_w[kSdfBlobFloats + kW3RowFloats];
+    __shared__ float s_x[ENVIDR_GEO_IOMODE == 0 ? kEvalWaves * kXchgFloats : 64];
+    __shared__ float s_jac[ENVIDR_GEO_JMODE == 2 ? kEvalWaves * kLevels * 6 * 64 : 64];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t begin = 0, count = a.M;
+    if (a.range) { begin = __builtin_amdgcn_readfirstlane(a.range[0]); count = min(__builtin_amdgcn_readfirstlane(a.range[1]), a.M - min(begin, a.M)); }
+    else if (a.head) {
+        begin = __builtin_amdgcn_readfirstlane(a.begin_io[0]);
+        const uint32_t end = min(__builtin_amdgcn_readfirstlane(*a.head), a.M);
+        count = end - min(begin, end);
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.begin_io[1] = end;
+    }
+    const uint32_t batches = (count + 63u) / 64u;
+#if ENVIDR_GEO_XCD
+    // XCD-aware batch order: workgroup b runs on XCD b % 8 (observed; speed only), and each XCD takes one contiguous
+    // eighth of the sample list, so image-space neighbours -- whose gathers share table rows -- meet in the same L2
+    const uint32_t xcd = blockIdx.x & 7u, in_xcd = blockIdx.x >> 3, per_xcd_blocks = (gridDim.x + 7u - xcd) >> 3;
+    const uint32_t share = (batches + 7u) / 8u;
+    const uint32_t b_lo = min(xcd * share, batches), b_hi = min(b_lo + share, batches);
+#else
+    const uint32_t in_xcd = blockIdx.x, per_xcd_blocks = gridDim.x, b_lo = 0, b_hi = batches;
+#endif
+    if (b_lo + in_xcd * kEvalWaves >= b_hi) return;          // nothing for this workgroup (most rounds of a frame are empty)
+    {
+        // the workgroup's copy of the weights: 16-byte loads, once
+        const float4* src = reinterpret_cast<const float4*>(a.sdf_blob);
+        float4* dst = reinterpret_cast<float4*>(s_w);
+        for (uint32_t i = threadIdx.x; i < kSdfBlobFloats / 4; i += kEvalThreads) dst[i] = src[i];
+        if (threadIdx.x < kW3RowFloats) s_w[kSdfBlobFloats + threadIdx.x] = a.sdf_w3r0[threadIdx.x];
+    }
+    __syncthreads();
+    WeightLdsRing<kGeoRing> wp;
+    wp.start(s_w + lane);
+    const float* w3row = s_w + kSdfBlobFloats + (lane >> 5) * 16;      // this lane half's 16 floats of a packed row-vector tile
+    float* xf = s_x + (ENVIDR_GEO_IOMODE == 0 ? wave * kXchgFloats : 0u);                              // [32][64]: features in, d sdf / d feature out
+    [[maybe_unused]] float* xo = xf + 32 * 64;                                          // [16][64]: raw outputs of the last SDF layer
+    constexpr int kSdfN = (kSdfFrags + kGeoRing - 1) / kGeoRing * kGeoRing;     // fragments per pass as the ring sees them
+
+    // Jacobian parking: 96 values per sample, [entry][lane] rows of 256 bytes in this wave's private slab (written once,
+    // read once ~30 k cycles later: it lives in the XCD's L2)
+    // (buffer addressing: one descriptor for the slab, voffset = lane * 4, the entry as an immediate / scalar offset;
+    // flat addressing makes the compiler hoist and spill a 64-bit address per 4 KiB window)
+    // per level one 16-byte and one 8-byte access per lane, both fully coalesced: [level][lane][4] then [level][lane][2]
+    const __amdgpu_buffer_rsrc_t jslab = __builtin_amdgcn_make_buffer_rsrc(
+        a.jscratch + (size_t)(blockIdx.x * kEvalWaves + wave) * (kLevels * 6 * 64), 0, kLevels * 6 * 64 * 4, 0x00020000);
+    const uint32_t lane16 = lane * 16u, lane8 = lane * 8u;
+    constexpr uint32_t kJB = kLevels * 64 * 16;      // byte offset of the 8-byte part
+    auto jstore = [&](int l, const float (&g)[3][2]) {
+        const u32x4 v4 = {__float_as_uint(g[0][0]), __float_as_uint(g[0][1]), __float_as_uint(g[1][0]), __float_as_uint(g[1][1])};
+        const u32x2 v2 = {__float_as_uint(g[2][0]), __float_as_uint(g[2][1])};
+        __builtin_amdgcn_raw_buffer_store_b128(v4, jslab, lane16, (uint32_t)(l * 1024), 0);
+        __builtin_amdgcn_raw_buffer_store_b64(v2, jslab, lane8, kJB + (uint32_t)(l * 512), 0);
+    };
+    auto jload = [&](int l, float (&g)[3][2]) {
+        const u32x4 v4 = __builtin_amdgcn_raw_buffer_load_b128(jslab, lane16, (uint32_t)(l * 1024), 0);
+        const u32x2 v2 = __builtin_amdgcn_raw_buffer_load_b64(jslab, lane8, kJB + (uint32_t)(l * 512), 0);
+        g[0][0] = __uint_as_float(v4[0]); g[0][1] = __uint_as_float(v4[1]); g[1][0] = __uint_as_float(v4[2]); g[1][1] = __uint_as_float(v4[3]);
+        g[2][0] = __uint_as_float(v2[0]); g[2][1] = __uint_as_float(v2[1]);
+    };
+    (void)jstore; (void)jload;
+    float* jac_col = s_jac + (ENVIDR_GEO_JMODE == 2 ? wave * (kLevels * 6 * 64) : 0u) + lane;     // [entry][lane]: conflict-free
+    (void)jac_col;
+    constexpr int kAhead = ENVIDR_GEO_AHEAD;           // levels whose corner gathers are in flight ahead of the one being interpolated
+    const __amdgpu_buffer_rsrc_t table = table_rsrc(a.table, a.table_bytes);
+    const uint32_t stride = per_xcd_blocks * kEvalWaves;
+
+    for (uint32_t b = b_lo + in_xcd * kEvalWaves + wave; b < b_hi; b += stride) {
+        const uint32_t sidx = b * 64u + lane;
+        const bool on = sidx < count;
+        const size_t slot = (size_t)begin + (on ? sidx : 0u);
+        float xc[3];
+        bool inside;
+        {
+            typedef float f32x3 __attribute__((ext_vector_type(3)));
+            f32x3 pv = {0.0f, 0.0f, 0.0f};
+            if (on) pv = *reinterpret_cast<const f32x3*>(a.xyz + 3 * slot);       // one 12-byte load
+            const float px = pv[0], py = pv[1], pz = pv[2];
+            // (xyz + bound) / (2 bound)  -- hashencoder/hashgrid.py:161; outside the unit cube every level contributes zeros
+            // (hashencoder.cu:124-149): evaluate at a clamped position and mask, which keeps the gathers in bounds
+            const float x01[3] = {(px + a.bound) / a.bound2, (py + a.bound) / a.bound2, (pz + a.bound) / a.bound2};
+            inside = x01[0] >= 0 && x01[0] <= 1 && x01[1] >= 0 && x01[1] <= 1 && x01[2] >= 0 && x01[2] <= 1;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) xc[d] = inside ? x01[d] : 0.5f;
+        }
+
+        // ================= phase 1: hash grid values (+ Jacobian -> parking slab) ============================
+        float feat[ENVIDR_GEO_IOMODE == 0 ? 1 : 2 * kLevels];
+        (void)feat;
+        {
+            LeanStage st[kAhead + 1];
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                (lean_prepare<(I >= ENVIDR_GEO_NT_FROM ? 2 : 0)>(a.lv[I], table, xc, st[I]), ...);
+            }(std::make_integer_sequence<int, kAhead>{});
+            __builtin_amdgcn_sched_barrier(0);
+            auto level = [&](auto lc, LeanStage& now, LeanStage& ahead) {
+                constexpr int l = decltype(lc)::value;
+                if constexpr (l + kAhead < kLevels) lean_prepare<(l + kAhead >= ENVIDR_GEO_NT_FROM ? 2 : 0)>(a.lv[l + kAhead], table, xc, ahead);
+                __builtin_amdgcn_sched_barrier(0);
+                float o[2];
+#if ENVIDR_GEO_JMODE == 1
+                float g[3][2];
+                lean_finish(now, inside ? a.lv[l].on : 0.0f, o, g);    // network.py:390-393 level mask; zeros outside the cube
+                jstore(l, g);
+#elif ENVIDR_GEO_JMODE == 2
+                float g[3][2];
+                lean_finish(now, inside ? a.lv[l].on : 0.0f, o, g);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    jac_col[((l * 3 + d) * 2 + 0) * 64] = g[d][0];
+                    jac_col[((l * 3 + d) * 2 + 1) * 64] = g[d][1];
+                }
+#else
+                lean_value(now, inside ? a.lv[l].on : 0.0f, o);
+#endif
+#if ENVIDR_GEO_IOMODE == 0
+                xf[(2 * l) * 64 + lane] = o[0];
+                xf[(2 * l + 1) * 64 + lane] = o[1];
+#else
+                feat[2 * l] = o[0]; feat[2 * l + 1] = o[1];
+#endif
+            };
+            [&]<int... L>(std::integer_sequence<int, L...>) {
+                (level(std::integral_constant<int, L>{}, st[L % (kAhead + 1)], st[(L + kAhead) % (kAhead + 1)]), ...);
+            }(std::make_integer_sequence<int, kLevels>{});
+        }
+        wave_lds_sync();
+
+        // ================= phase 2: SDF network forward + input gradient (matrix cores) ===================
+        // 32 samples ("group") at a time; activations stay in accumulator tiles between layers (mlp_mfma.hip.h); results
+        // return through the exchange area: raw outputs 0..15 -> xo, d sdf / d feature -> xf (the group's own columns)
+#if ENVIDR_GEO_IOMODE == 1
+        float inA[kLevels], inB[kLevels];
+#pragma unroll
+        for (int q = 0; q < kLevels; ++q) {
+            float e = feat[2 * q], o = feat[2 * q + 1];
+            pack_pair(e, o);
+            inA[q] = e; inB[q] = o;
+        }
+        f32x16 outA, outB, gfA, gfB;
+#endif
+#if ENVIDR_GEO_UNROLL_GROUPS
+#pragma unroll
+#else
+#pragma unroll 1
+#endif
+        for (int grp = 0; grp < (ENVIDR_GEO_NOMLP ? 0 : 2); ++grp) {
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 h1[2], h2[2], o3[1];
+            uint32_t pos1 = 0, pos2 = 0;
+#if ENVIDR_GEO_IOMODE == 0
+            const uint32_t colbase = (lane >> 5) * 64 + 32 * grp + (lane & 31);      // + feature pair row * 128
+            pipe_layer_from_lds<kLevels, 2, kSdfW1, kSdfN>(wp, lane, xf + colbase, h1);
+#else
+            float in[kLevels];
+#pragma unroll
+            for (int q = 0; q < kLevels; ++q) in[q] = grp ? inB[q] : inA[q];
+            pipe_layer_from_lanes<kLevels, 2, kSdfW1, kSdfN>(wp, lane, in, h1);
+#endif
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pos1 |= (h1[t][r] > 0 ? 1u : 0u) << (16 * t + r);
+            pipe_layer_from_tiles<2, 2, kSdfW2, kSdfN, true>(wp, lane, h1, h2);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pos2 |= (h2[t][r] > 0 ? 1u : 0u) << (16 * t + r);
+            pipe_layer_from_tiles<2, 1, kSdfW3, kSdfN, true>(wp, lane, h2, o3);
+#if ENVIDR_GEO_IOMODE == 0
+            // rows 0..15 of the output tile: registers 0..7 of both lane halves
+            const uint32_t ocol = 32 * grp + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) xo[(tile_row(r, 0) + 4 * (lane >> 5)) * 64 + ocol] = o3[0][r];
+#endif
+            // backward of sdf = o3[row 0]:  g2 = W3[0,:] * [h2 > 0];  g1 = (W2^T g2) * [h1 > 0];  gfeat = W1^T g1
+            f32x16 g2[2], g1[2], gf[1];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) g2[t][r] = (pos2 >> (16 * t + r)) & 1u ? w3row[t * 32 + r] : 0.0f;
+            pipe_layer_from_tiles<2, 2, kSdfW2t, kSdfN, false, false>(wp, lane, g2, g1);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) g1[t][r] = (pos1 >> (16 * t + r)) & 1u ? g1[t][r] : 0.0f;
+            pipe_layer_from_tiles<2, 1, kSdfW1t, kSdfN, false, false>(wp, lane, g1, gf);
+            wp.template end_pass<kSdfFrags>();
+#if ENVIDR_GEO_IOMODE == 0
+            // this group's features are consumed: its columns of xf now take d sdf / d feature
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xf[(tile_row(r, 0) + 4 * (lane >> 5)) * 64 + ocol] = gf[0][r];
+#else
+            if (grp == 0) { outA = o3[0]; gfA = gf[0]; } else { outB = o3[0]; gfB = gf[0]; }
+#endif
+        }
+        wave_lds_sync();
+#if ENVIDR_GEO_IOMODE == 1
+        float h3r[16], gfeat[32];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float p = gfA[r], q = gfB[r];
+            unpack_pair(p, q);
+            gfeat[tile_row(r, 0)] = p; gfeat[tile_row(r, 1)] = q;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {          // rows 0..15 of the output tile live in registers 0..7
+            float u = outA[r], v = outB[r];
+            unpack_pair(u, v);
+            h3r[tile_row(r, 0)] = u; h3r[tile_row(r, 1)] = v;
+        }
+#endif
+
+        // ================= phase 3: normal = J^T (d sdf / d feat) by a second gather sweep =========================
+        // The Jacobian (96 values per sample) is never stored: the corners are gathered again (L2 / Infinity-Cache hot)
+        // and contracted with the two feature gradients of their level on the fly.
+        float nrm[3] = {0, 0, 0};
+#if ENVIDR_GEO_JMODE == 2
+        {
+#pragma unroll
+            for (int l = 0; l < kLevels; ++l) {
+#if ENVIDR_GEO_IOMODE == 0
+                const float g0 = xf[(2 * l) * 64 + lane], g1 = xf[(2 * l + 1) * 64 + lane];
+#else
+                const float g0 = gfeat[2 * l], g1 = gfeat[2 * l + 1];
+#endif
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    nrm[d] += g0 * jac_col[((l * 3 + d) * 2 + 0) * 64];
+                    nrm[d] += g1 * jac_col[((l * 3 + d) * 2 + 1) * 64];
+                }
+            }
+        }
+#elif ENVIDR_GEO_JMODE == 1
+        {
+            // kernel_input_backward order: levels outer, channels inner (hashencoder.cu:346-372)
+#pragma unroll
+            for (int l = 0; l < kLevels; ++l) {
+#if ENVIDR_GEO_IOMODE == 0
+                const float g0 = xf[(2 * l) * 64 + lane], g1 = xf[(2 * l + 1) * 64 + lane];
+#else
+                const float g0 = gfeat[2 * l], g1 = gfeat[2 * l + 1];
+#endif
+                float jg[3][2];
+                jload(l, jg);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    nrm[d] += g0 * jg[d][0];
+                    nrm[d] += g1 * jg[d][1];
+                }
+            }
+        }
+#else
+        if (!ENVIDR_GEO_NOSWEEP2) {
+            // made opaque: otherwise the compiler recognises phase 1's cells, weights and gathered rows and keeps all of
+            // them alive across the matrix-core section instead of recomputing them
+            float x2[3] = {xc[0], xc[1], xc[2]};
+            asm volatile("" : "+v"(x2[0]), "+v"(x2[1]), "+v"(x2[2]));
+            LeanStage st[kAhead + 1];
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                (lean_prepare(a.lv[I], table, x2, st[I]), ...);
+            }(std::make_integer_sequence<int, kAhead>{});
+            __builtin_amdgcn_sched_barrier(0);
+            auto level2 = [&](auto lc, LeanStage& now, LeanStage& ahead) {
+                constexpr int l = decltype(lc)::value;
+                if constexpr (l + kAhead < kLevels) lean_prepare(a.lv[l + kAhead], table, x2, ahead);
+                __builtin_amdgcn_sched_barrier(0);
+                lean_contract(now, inside ? a.lv[l].on : 0.0f, xf[(2 * l) * 64 + lane], xf[(2 * l + 1) * 64 + lane], nrm);
+                // anchor: without it the optimiser sinks every level's arithmetic to the end of the sweep (its only use) and
+                // all 16 levels of gathered rows stay live until then
+                asm volatile("" : "+v"(nrm[0]), "+v"(nrm[1]), "+v"(nrm[2]));
+            };
+            [&]<int... L>(std::integer_sequence<int, L...>) {
+                (level2(std::integral_constant<int, L>{}, st[L % (kAhead + 1)], st[(L + kAhead) % (kAhead + 1)]), ...);
+            }(std::make_integer_sequence<int, kLevels>{});
+        }
+#endif
+#pragma unroll
+        for (int d = 0; d < 3; ++d) nrm[d] = nrm[d] / a.bound2;                         // d x01 / d xyz
+        normalize_n<3>(nrm, 1e-10f);                                                    // renderer.py:192
+
+        // ================= per-sample geometry terms (same statements as k_render_persistent) ===========
+        float h3[16];
+#pragma unroll
+#if ENVIDR_GEO_IOMODE == 0
+        for (int i = 0; i < 15; ++i) h3[i] = xo[i * 64 + lane];
+#else
+        for (int i = 0; i < 15; ++i) h3[i] = h3r[i];
+#endif
+        const float sdf = h3[0];
+        float geo[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) geo[i] = h3[1 + i];
+        normalize_n<12>(geo, 1e-12f);                                                   // network.py:434-435
+        const float rough = a.rough_act_scale * softplusf(h3[13] + a.rough_bias) * a.rough_scale;   // network.py:443-448
+        // Laplace density (network.py:32-37): (1/beta) (0.5 + 0.5 sign(s) expm1(-|s| / beta))
+        const float sgn = sdf > 0 ? 1.0f : (sdf < 0 ? -1.0f : 0.0f);
+        const float sigma = a.inv_beta * (0.5f + 0.5f * sgn * expm1f(-fabsf(sdf) / a.beta)) * a.density_scale;
+        if (on && (!ENVIDR_GEO_NOSTORE || sigma == 12345.0f)) {
+            if (a.alpha) a.alpha[slot] = 1.0f - expf(-sigma * a.dt[slot]);
+            if (a.sigma) a.sigma[slot] = sigma;
+            if (a.rough) a.rough[slot] = rough;
+            if (a.blend) a.blend[slot] = h3[14];
+            // wide stores: a store instruction costs texture-address cycles per instruction, not per byte
+            if (a.normal) {
+                typedef float f32x3 __attribute__((ext_vector_type(3)));
+                const f32x3 nv = {nrm[0], nrm[1], nrm[2]};
+                *reinterpret_cast<f32x3*>(a.normal + 3 * slot) = nv;
+            }
+            if (a.geo) {
+                float4* gp = reinterpret_cast<float4*>(a.geo + 12 * slot);          // 48-byte rows: 16-byte aligned
+#pragma unroll
+                for (int i = 0; i < 3; ++i) gp[i] = make_float4(geo[4 * i], geo[4 * i + 1], geo[4 * i + 2], geo[4 * i + 3]);
+            }
+        }
+        wave_lds_sync();      // the exchange area is rewritten by the next batch
+    }
+}
+
+// =====================================================================================================================
+// per-ray rounds
+// =====================================================================================================================
+struct RayState {            // 48 bytes per ray, indexed by ray id
+    float acc_t;             // composited ray time = where the marcher resumes (the reference re-derives it from the deltas)
+    float ws, depth;
+    float an[3];             // sum w * normal
+    float arough;            // sum w * roughness
+    uint32_t n_taken;        // samples composited so far
+    uint32_t chunk_begin;    // first slot of the chunk marched last round
+    uint32_t chunk_count;    // its length; bit 31: the ray ran out of samples (or reached max_steps) inside it
+    float t_first;           // round 0 only: ray time AT the first sample (first-hit search)
+    uint32_t pad;
+};
+static_assert(sizeof(RayState) == 48, "RayState layout");
+
+// counters (device uint32[kGeoCounterWords]), zeroed by the host before every frame
+constexpr uint32_t kCntSampleHead = 0, kCntRecordHead = 1, kCntOverflow = 2, kCntAlive = 8, kCntBegin = 40, kGeoCounterWords = 80;
+constexpr uint32_t kMaxRounds = 30;
+
+struct GeoRayArgs {
+    const float* rays_o; const float* rays_d;
+    uint32_t N;
+    MarchConsts mk;
+    float bound, min_near, T_thresh;
+    uint32_t max_samples;
+    uint32_t chunk;            // samples to march this round; 0: only composite (last round)
+    uint32_t round;
+    uint32_t* counters;
+    const uint32_t* alive_in;  // rounds >= 1: ids of the rays still alive
+    uint32_t* alive_out;
+    RayState* state;
+    // sample list
+    float* xyz; float* dt; float* dd;
+    uint32_t cap;
+    const float* alpha; const float* normal; const float* rough;     // written by k_geo_eval for the previous chunk
+    // records: one per composited sample
+    uint32_t* rec_ray; uint32_t* rec_idx; float* rec_w; uint32_t* rec_slot;
+    uint32_t rec_cap;
+    // per-ray outputs
+    float* depth; float* ws; float* nimg; float* rimg;
+    uint16_t* ray_cost;
+};
+
+// wave-wide exclusive prefix sum of a small per-lane count; returns the wave total in `total`
+__device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t v, uint32_t lane, uint32_t& total) {
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off);
+        if ((int)lane >= off) incl += up;
+    }
+    total = __shfl(incl, 63);
+    return incl - v;
+}
+
+// One round of the per-ray half of the geometry pass.
+//   FIRST : lane = ray id; slab test, first-hit search (empty-space skipping), rays without a sample are finished here
+//   else  : lane = entry of the alive list; the chunk evaluated by k_geo_eval since the last round is composited
+//           (raymarching.cu:996-1030 recurrence, termination tested with the pre-update transmittance), one record per
+//           composited sample is appended, finished rays write their outputs
+// then every ray still alive marches its next `chunk` samples (march_core.hip.h; the ray time is resumed from the
+// composited time after EVERY sample, as the reference loop does with one sample per iteration -- that time does not
+// depend on the densities, so marching ahead of the compositor changes nothing) into freshly allocated slots.
+template <bool FIRST>
+__global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n_in = FIRST ? a.N : __builtin_amdgcn_readfirstlane(a.counters[kCntAlive + a.round]);
+    const uint32_t wave_stride = gridDim.x * blockDim.x;
+    for (uint32_t wbase = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); wbase < n_in; wbase += wave_stride) {
+        const uint32_t i = wbase + lane;
+        const bool active = i < n_in;
+        const uint32_t ray = FIRST ? i : (active ? a.alive_in[i] : 0u);
+        RayGeom rg = {};
+        float near = 0, far = 0;
+        RayState st = {};
+        bool alive = false;          // still needs samples after this round's compositing
+        bool finish = false;         // write the ray's outputs now
+        if (active) {
+            rg = load_ray(a.rays_o, a.rays_d, ray);
+            near_far(rg, a.bound, a.min_near, near, far);
+        }
+        if constexpr (FIRST) {
+            if (active) {
+                float t = near, x, y, z, dt, t_at = 0;
+                const bool hit = march_next(a.mk, rg, far, t, x, y, z, dt, &t_at);
+                st.acc_t = near;
+                st.t_first = t_at;
+                alive = hit;
+                finish = !hit;
+            }
+        } else {
+            // ---- composite the previous chunk ------------------------------------------------------------------
+            uint32_t k = 0;              // samples of the chunk that get composited
+            bool terminated = false;
+            uint32_t cnt = 0, begin = 0;
+            bool last = false;
+            if (active) {
+                st = a.state[ray];
+                cnt = st.chunk_count & 0x7fffffffu;
+                last = (st.chunk_count >> 31) != 0;
+                begin = st.chunk_begin;
+                float ws = st.ws;
+                for (uint32_t j = 0; j < cnt; ++j) {            // pass 1: how many records does this ray append
+                    const float T = 1 - ws;
+                    ws += a.alpha[begin + j] * T;
+                    ++k;
+                    if (T < a.T_thresh) { terminated = true; break; }
+                }
+            }
+            uint32_t wave_total = 0;
+            const uint32_t my_off = wave_exclusive_scan(k, lane, wave_total);
+            uint32_t rec_base = 0;
+            if (lane == 0 && wave_total) rec_base = atomicAdd(&a.counters[kCntRecordHead], wave_total);
+            rec_base = __shfl(rec_base, 0) + my_off;
+            if (active) {
+                const bool fits = rec_base + k <= a.rec_cap;
+                if (!fits && k) a.counters[kCntOverflow] = 1u;
+                for (uint32_t j = 0; j < k; ++j) {              // pass 2: the recurrence itself + the records
+                    const uint32_t slot = begin + j;
+                    const float alpha = a.alpha[slot];
+                    const float T = 1 - st.ws;
+                    const float w = alpha * T;
+                    st.ws += w;
+                    st.acc_t = st.acc_t + a.dd[slot];
+                    st.depth += w * st.acc_t;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) st.an[d] += w * a.normal[3 * (size_t)slot + d];
+                    st.arough += w * a.rough[slot];
+                    if (fits) {
+                        const uint32_t r = rec_base + j;
+                        a.rec_ray[r] = ray; a.rec_idx[r] = st.n_taken; a.rec_w[r] = w; a.rec_slot[r] = slot;
+                    }
+                    ++st.n_taken;
+                }
+                finish = terminated || last || st.n_taken >= a.max_samples;
+                alive = !finish;
+            }
+        }
+
+        // ---- march the next chunk ------------------------------------------------------------------------------
+        // Round 0 sizes a ray's first chunk from the caller's hint when there is one (samples the ray took in an earlier
+        // render of about the same camera: exact for the frames of a fixed-camera video): the ray is then done in one
+        // round with nothing evaluated past its end.  A wrong hint costs a round or some wasted samples, never accuracy.
+        uint32_t chunk = a.chunk;
+        if constexpr (FIRST) {
+            if (alive && a.ray_cost) { const uint32_t h = a.ray_cost[ray]; if (h) chunk = min(h, 4096u); }
+        }
+        // Slots: a ray gets one contiguous run.  With a hint the run is sized by it and the ray is marched once (slots the
+        // ray turns out not to need are zero-filled: evaluated, never composited); without one the marcher first counts.
+        const bool hinted = FIRST && chunk != a.chunk;
+        uint32_t want = 0;           // slots to allocate
+        if (alive && a.chunk) {
+            if (hinted) want = min(chunk, a.max_samples - min(st.n_taken, a.max_samples));
+            else {
+                float tr = st.acc_t;
+                bool first = FIRST;
+                for (; want < chunk && st.n_taken + want < a.max_samples; ++want) {
+                    float t = first ? st.t_first : tr, x, y, z, dt;
+                    if (!march_next(a.mk, rg, far, t, x, y, z, dt)) break;
+                    tr = tr + (t - tr);
+                    first = false;
+                }
+            }
+        }
+        uint32_t wave_total = 0;
+        const uint32_t my_off = wave_exclusive_scan(want, lane, wave_total);
+        uint32_t base = 0;
+        if (lane == 0 && wave_total) base = atomicAdd(&a.counters[kCntSampleHead], wave_total);
+        base = __shfl(base, 0) + my_off;
+        if (alive && a.chunk) {
+            if (want && base + want > a.cap) { a.counters[kCntOverflow] = 2u; want = 0; }
+            float tr = st.acc_t;
+            bool first = FIRST;
+            uint32_t c = 0;
+            for (; c < want; ++c) {                              // the march, written out
+                float t = first ? st.t_first : tr, x, y, z, dt;
+                if (!march_next(a.mk, rg, far, t, x, y, z, dt)) break;
+                const float dd = t - tr;
+                const size_t slot = (size_t)base + c;
+                a.xyz[3 * slot] = x; a.xyz[3 * slot + 1] = y; a.xyz[3 * slot + 2] = z;
+                a.dt[slot] = dt;
+                a.dd[slot] = dd;
+                tr = tr + dd;
+                first = false;
+            }
+            for (uint32_t j = c; j < want; ++j) {                // only after an over-estimating hint
+                const size_t slot = (size_t)base + j;
+                a.xyz[3 * slot] = 0; a.xyz[3 * slot + 1] = 0; a.xyz[3 * slot + 2] = 0;
+                a.dt[slot] = 0; a.dd[slot] = 0;
+            }
+            st.chunk_begin = base;
+            st.chunk_count = c | ((c < chunk) ? 0x80000000u : 0u);
+            if (c == 0) { finish = true; alive = false; }       // nothing left along the ray
+        } else if (alive) {
+            finish = true; alive = false;                        // last round: whatever is left is dropped (cannot happen: the
+        }                                                        // chunk schedule covers max_steps)
+        // next round's alive list, wave by wave so that neighbouring rays stay together
+        {
+            const unsigned long long m = __ballot(alive);
+            uint32_t abase = 0;
+            if (lane == 0 && m) abase = atomicAdd(&a.counters[kCntAlive + a.round + 1], (uint32_t)__popcll(m));
+            abase = __shfl(abase, 0);
+            if (alive) {
+                a.alive_out[abase + __popcll(m & ((1ull << lane) - 1ull))] = ray;
+                a.state[ray] = st;
+            }
+        }
+        if (finish) {
+            // run_cuda epilogue for this ray (cuda_ray.py:348-362); the colour images are composited later from the records
+            const size_t id = ray;
+            a.depth[id] = st.depth;
+            a.ws[id] = st.ws;
+            if (a.nimg) {
+                const float inv = 1.0f / fmaxf(sqrtf(st.an[0] * st.an[0] + st.an[1] * st.an[1] + st.an[2] * st.an[2]), 1e-10f);
+                a.nimg[3 * id] = st.an[0] * inv; a.nimg[3 * id + 1] = st.an[1] * inv; a.nimg[3 * id + 2] = st.an[2] * inv;
+            }
+            if (a.rimg) a.rimg[id] = st.arough;
+            if (a.ray_cost) a.ray_cost[id] = (uint16_t)min(st.n_taken, 65535u);
+        }
+    }
+}
+
+int fill_eval_args(const envidr_render_desc* d, GeoEvalArgs& a, const char* who) {
+    ENVIDR_REQUIRE(d->hash_table && d->sdf_blob && d->sdf_w3_row0, "%s: null hash table / SDF weights", who);
+    ENVIDR_REQUIRE(d->num_levels == ENVIDR_MAX_LEVELS, "%s: built for 16 hash levels", who);
+    ENVIDR_REQUIRE(d->beta > 0, "%s: beta must be positive", who);
+    a.table = d->hash_table;
+    a.table_bytes = (uint32_t)d->hash_offsets[d->num_levels] * 8u;
+    const char* err = fill_lean_levels(d, a.lv);
+    ENVIDR_REQUIRE(!err, "%s: %s", who, err);
+    a.bound = d->bound; a.bound2 = 2 * d->bound;
+    a.sdf_blob = d->sdf_blob; a.sdf_w3r0 = d->sdf_w3_row0;
+    a.beta = d->beta; a.inv_beta = 1 / d->beta; a.density_scale = d->density_scale;
+    a.rough_bias = d->roughness_bias; a.rough_act_scale = d->roughness_act_scale; a.rough_scale = d->roughness_scale;
+    return ENVIDR_OK;
+}
+
+void launch_eval(const GeoEvalArgs& a, uint32_t max_samples, hipStream_t s) {
+    // one 8-wave workgroup per CU (the LDS-resident weights and the parked Jacobians fill the CU's LDS)
+    const uint32_t blocks = std::max(1u, std::min((uint32_t)device_cu_count(), ceil_div(max_samples, kEvalThreads)));
+    GeoEvalArgs b = a;
+    {
+        // parking slabs of the Jacobians: one per wave of the (persistent) grid, kept for the life of the process
+        static float* g_scratch[16] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        dev &= 15;
+        if (!g_scratch[dev]) (void)hipMalloc(&g_scratch[dev], (size_t)device_cu_count() * kEvalWaves * kLevels * 6 * 64 * sizeof(float));
+        b.jscratch = g_scratch[dev];
+    }
+    hipLaunchKernelGGL(k_geo_eval, dim3(blocks), dim3(kEvalThreads), 0, s, b);
+}
+
+
+uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+struct GeoLayout {
+    uint64_t counters, alive0, alive1, state, xyz, dt, dd, alpha, normal, geo, rough, blend, total;
+};
+GeoLayout geo_layout(uint32_t N, uint32_t cap) {
+    GeoLayout L;
+    uint64_t o = 0;
+    auto take = [&](uint64_t bytes) { const uint64_t at = o; o = align_up(o + bytes, 256); return at; };
+    L.counters = take(kGeoCounterWords * 4);
+    L.alive0 = take((uint64_t)N * 4); L.alive1 = take((uint64_t)N * 4);
+    L.state = take((uint64_t)N * sizeof(RayState));
+    L.xyz = take((uint64_t)cap * 12); L.dt = take((uint64_t)cap * 4); L.dd = take((uint64_t)cap * 4);
+    L.alpha = take((uint64_t)cap * 4); L.normal = take((uint64_t)cap * 12); L.geo = take((uint64_t)cap * 48);
+    L.rough = take((uint64_t)cap * 4); L.blend = take((uint64_t)cap * 4);
+    L.total = o;
+    return L;
+}
+
+__global__ void k_geo_finalize(const uint32_t* __restrict__ counters, uint32_t* __restrict__ rec_counter, unsigned long long* __restrict__ stats) {
+    // a frame that did not fit is reported through a record count no capacity can hold: the shading / compositing entry
+    // points then do nothing and the host, when it eventually looks, redoes the frame with larger buffers
+    *rec_counter = counters[kCntOverflow] ? 0xffffffffu : counters[kCntRecordHead];
+    if (stats) { stats[0] = counters[kCntSampleHead]; stats[1] = counters[kCntRecordHead]; stats[2] = counters[kCntOverflow]; }
+}
+
+}  // namespace
+
+extern "C" {
+
+uint64_t envidr_geometry_workspace_bytes(uint32_t N, uint32_t sample_capacity) { return geo_layout(N, sample_capacity).total; }
+
+int envidr_geometry_pass(const envidr_render_desc* d, const float* rays_o, const float* rays_d, uint32_t N,
+                         const envidr_render_out* out, envidr_geometry_export* rec, void* workspace, uint64_t workspace_bytes,
+                         uint32_t sample_capacity, envidr_stream_t stream) {
+    ENVIDR_REQUIRE(d && out && rec, "geometry_pass: null descriptor");
+    if (N == 0) return ENVIDR_OK;
+    ENVIDR_REQUIRE(rays_o && rays_d && workspace, "geometry_pass: null ray pointers / workspace");
+    ENVIDR_REQUIRE(out->depth && out->weights_sum, "geometry_pass: depth and weights_sum are required");
+    ENVIDR_REQUIRE(d->density_bitfield, "geometry_pass: null bitfield");
+    ENVIDR_REQUIRE(d->cascades >= 1 && d->grid_size >= 1 && d->max_steps >= 1, "geometry_pass: bad grid parameters");
+    ENVIDR_REQUIRE(rec->counter && rec->ray && rec->idx && rec->w && rec->slot && rec->capacity, "geometry_pass: null pointer in the record arrays");
+    ENVIDR_REQUIRE(sample_capacity >= 64, "geometry_pass: sample_capacity too small");
+    const GeoLayout L = geo_layout(N, sample_capacity);
+    ENVIDR_REQUIRE(workspace_bytes >= L.total, "geometry_pass: workspace of %llu bytes, need %llu", (unsigned long long)workspace_bytes,
+                   (unsigned long long)L.total);
+    ENVIDR_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "geometry_pass: workspace must be 256-byte aligned");
+    char* ws = reinterpret_cast<char*>(workspace);
+    hipStream_t s = as_stream(stream);
+
+    GeoEvalArgs e;
+    memset(&e, 0, sizeof(e));
+    {
+        const int rc = fill_eval_args(d, e, "geometry_pass");
+        if (rc) return rc;
+    }
+    uint32_t* counters = reinterpret_cast<uint32_t*>(ws + L.counters);
+    e.xyz = reinterpret_cast<float*>(ws + L.xyz); e.dt = reinterpret_cast<float*>(ws + L.dt);
+    e.M = sample_capacity; e.head = counters + kCntSampleHead;
+    e.alpha = reinterpret_cast<float*>(ws + L.alpha); e.normal = reinterpret_cast<float*>(ws + L.normal);
+    e.geo = reinterpret_cast<float*>(ws + L.geo); e.rough = reinterpret_cast<float*>(ws + L.rough); e.blend = reinterpret_cast<float*>(ws + L.blend);
+
+    GeoRayArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rays_o = rays_o; a.rays_d = rays_d; a.N = N;
+    a.mk = make_march_consts(d->bound, d->dt_gamma, d->max_steps, d->cascades, d->grid_size, d->density_bitfield);
+    a.bound = d->bound; a.min_near = d->min_near; a.T_thresh = d->T_thresh; a.max_samples = d->max_steps;
+    a.counters = counters;
+    a.state = reinterpret_cast<RayState*>(ws + L.state);
+    a.xyz = const_cast<float*>(e.xyz); a.dt = const_cast<float*>(e.dt); a.dd = reinterpret_cast<float*>(ws + L.dd);
+    a.cap = sample_capacity;
+    a.alpha = e.alpha; a.normal = e.normal; a.rough = e.rough;
+    a.rec_ray = rec->ray; a.rec_idx = rec->idx; a.rec_w = rec->w; a.rec_slot = const_cast<uint32_t*>(rec->slot); a.rec_cap = rec->capacity;
+    a.depth = out->depth; a.ws = out->weights_sum; a.nimg = out->normal_image; a.rimg = out->roughness_image;
+    a.ray_cost = d->ray_cost;
+    uint32_t* alive[2] = {reinterpret_cast<uint32_t*>(ws + L.alive0), reinterpret_cast<uint32_t*>(ws + L.alive1)};
+
+    // chunk schedule: 16 samples, then each round extends what a ray has so far by half (16, 8, 12, 18, 27 ...): a ray that
+    // terminates after n samples has had at most ~1.5 n evaluated, and max_steps = 1024 is covered in 12 rounds
+    uint32_t chunks[kMaxRounds], rounds = 0, covered = 0;
+    while (covered < d->max_steps && rounds < kMaxRounds - 1) {
+        chunks[rounds] = std::min(rounds == 0 ? 16u : std::max(8u, covered / 2), d->max_steps - covered);
+        covered += chunks[rounds++];
+    }
+    ENVIDR_REQUIRE(covered >= d->max_steps, "geometry_pass: max_steps %u exceeds what %u rounds cover", d->max_steps, kMaxRounds);
+
+    if (hipMemsetAsync(counters, 0, kGeoCounterWords * 4, s) != hipSuccess) return check_launch("geometry_pass memset");
+    const uint32_t ray_blocks = ceil_div(N, kBlock);
+    for (uint32_t r = 0; r <= rounds; ++r) {
+        a.round = r;
+        a.chunk = r < rounds ? chunks[r] : 0u;
+        a.alive_in = alive[(r + 1) & 1];
+        a.alive_out = alive[r & 1];
+        if (r == 0) hipLaunchKernelGGL(k_geo_rays<true>, dim3(ray_blocks), dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL(k_geo_rays<false>, dim3(std::min(ray_blocks, 1024u)), dim3(kBlock), 0, s, a);
+        {
+            const int rc = check_launch("k_geo_rays");
+            if (rc) return rc;
+        }
+        if (r < rounds) {
+            e.begin_io = counters + kCntBegin + r;
+            launch_eval(e, sample_capacity, s);
+            const int rc = check_launch("k_geo_eval");
+            if (rc) return rc;
+        }
+    }
+    hipLaunchKernelGGL(k_geo_finalize, dim3(1), dim3(1), 0, s, counters, rec->counter, reinterpret_cast<unsigned long long*>(out->stats));
+    // where the records' per-sample data lives (indexed through rec->slot)
+    rec->normal = e.normal; rec->geo_feat = e.geo; rec->roughness = e.rough; rec->blend = e.blend;
+    return check_launch("k_geo_finalize");
+}
+
+
+int envidr_geometry_eval(const envidr_render_desc* d, const float* xyz, const float* dt, uint32_t M, const uint32_t* range_dev,
+                         const envidr_geometry_samples_out* out, envidr_stream_t stream) {
+    ENVIDR_REQUIRE(d && out, "geometry_eval: null descriptor");
+    if (M == 0) return ENVIDR_OK;
+    ENVIDR_REQUIRE(xyz && (dt || !out->alpha), "geometry_eval: null sample pointers");
+    GeoEvalArgs a;
+    memset(&a, 0, sizeof(a));
+    const int rc = fill_eval_args(d, a, "geometry_eval");
+    if (rc) return rc;
+    a.xyz = xyz; a.dt = dt; a.M = M; a.range = range_dev;
+    a.alpha = out->alpha; a.sigma = out->sigma; a.normal = out->normal; a.geo = out->geo_feat; a.rough = out->roughness; a.blend = out->blend;
+    launch_eval(a, M, as_stream(stream));
+    return check_launch("k_geo_eval");
+}
+
+}  // extern "C"

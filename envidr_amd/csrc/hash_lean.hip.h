@@ -1,0 +1,205 @@
+// Lean evaluation of one smoothstep hash-grid level (value + analytic Jacobian) for the sample-parallel geometry
+// kernel (geometry_pass.hip).  Same function as hashencoder/src/hashencoder.cu:103-254 (kernel_grid, D = 3, C = 2) --
+// same cell, same smoothstep weights, same eight corner rows -- organised for the vector ALU budget of a kernel that
+// shares its SIMDs with the matrix pipe:
+//   * corner rows are gathered through ONE buffer descriptor over the whole table: 32-bit byte offsets in one VGPR
+//     each, the level's first row as the scalar offset; no 64-bit address arithmetic;
+//   * the only data-dependent control flow is one wave-uniform choice (dense or hashed level) around eight integer
+//     index computations; hashed levels must have a power-of-two size and dense levels must satisfy the
+//     conditional-subtract wrap (HashEncoder's own sizing always does; the host checks and refuses otherwise);
+//   * value and gradient come from one factorised trilinear pass (lerp along x, then y, then z; the differences the
+//     lerps need ARE the partial derivatives): ~60 vector-ALU operations per level instead of ~250 for the expanded
+//     sum over corners.  The result differs from the expanded sum by fp32 rounding only (tests/test_geometry_gpu.py).
+#pragma once
+#include "fused_common.hip.h"
+
+namespace envidr {
+
+struct LeanLevel {
+    uint32_t row0_bytes;    // first row of the level, in bytes from the table base
+    uint32_t size;          // rows
+    uint32_t m1, m2;        // dense: strides of y and z; hashed: unused
+    float scale;
+    uint32_t mask;          // hashed: size - 1
+    uint32_t hashed;
+    float on;               // 1 = level enabled, 0 = masked out (network.py:390-393)
+};
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// One level in flight: weights and the raw gathers.  The two x-neighbours of a (y, z) corner pair are fetched by ONE
+// 16-byte load whenever their rows are adjacent -- always on dense levels (rows r, r + 1), and for even cells on hashed
+// levels (the x prime is 1: rows r and r ^ 1) -- because what a gather costs on gfx950 is texture-address cycles per
+// instruction and per distinct cache line, not bytes: 6 line lookups per level on average instead of 8.
+struct LeanStage {
+    float w[3];             // smoothstep weight of the +1 corner per axis
+    float sdw[3];           // scale * d(w)/d(frac) per axis
+    u32x4 pair[4];          // rows base_j, base_j + 1 of (y, z) pair j = by | bz << 1
+    u32x2 solo[4];          // row of the x + 1 corner where it is not in `pair` (loaded only by the lanes that need it)
+    uint32_t sel;           // bit j: the x corner is the upper row of pair j; bit 4 + j: the x + 1 corner is; bit 8 + j: it is in solo[j]
+};
+
+// host: returns an error text when the table geometry is outside what the lean path handles
+inline const char* fill_lean_levels(const envidr_render_desc* d, LeanLevel (&out)[kLevels]) {
+    HashLevelK lv[kLevels];
+    memset(lv, 0, sizeof(lv));
+    const char* err = fill_hash_levels(d, lv);
+    if (err) return err;
+    for (uint32_t l = 0; l < d->num_levels; ++l) {
+        if (lv[l].size < 2) return "hash level with fewer than two rows";
+        if (lv[l].slow_mod) return "hash level with neither a power-of-two hashed size nor a dense index range below 2 * size";
+        out[l].row0_bytes = lv[l].row0 * 8u;
+        out[l].size = lv[l].size;
+        out[l].m1 = lv[l].stride1; out[l].m2 = lv[l].stride2;
+        out[l].scale = lv[l].scale;
+        out[l].mask = lv[l].size - 1u;
+        out[l].hashed = lv[l].hashed;
+        out[l].on = lv[l].enabled ? 1.0f : 0.0f;
+        if ((unsigned long long)lv[l].row0 * 8ull + (unsigned long long)lv[l].size * 8ull > 0xffffffffull) return "hash table larger than 4 GiB";
+    }
+    return nullptr;
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const float* table, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(table), 0, (int)bytes, 0x00020000);
+}
+
+// cell + weights + the gathers of one level (x in [0, 1]^3)
+template <int AUX = 0>
+__device__ __forceinline__ void lean_prepare(const LeanLevel& lv, __amdgpu_buffer_rsrc_t table, const float (&x)[3], LeanStage& st) {
+    uint32_t cell[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float p = x[d] * lv.scale + 0.0f;
+        cell[d] = (uint32_t)floorf(p);
+        p -= (float)cell[d];
+        st.sdw[d] = (6 * p * (1.0f - p)) * lv.scale;     // smoothstep' * scale
+        st.w[d] = p * p * (3.0f - 2.0f * p);             // smoothstep
+    }
+    uint32_t r0[4], r1[4], base[4];
+    if (lv.hashed) {
+        const uint32_t hy0 = cell[1] * 2654435761u, hy1 = hy0 + 2654435761u;
+        const uint32_t hz0 = cell[2] * 805459861u, hz1 = hz0 + 805459861u;
+        const uint32_t yz[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+        const uint32_t x0 = cell[0], x1 = cell[0] + 1u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r0[j] = (x0 ^ yz[j]) & lv.mask;
+            r1[j] = (x1 ^ yz[j]) & lv.mask;
+            base[j] = r0[j] & ~1u;
+        }
+    } else {
+        const uint32_t y0 = cell[1] * lv.m1, y1 = y0 + lv.m1;
+        const uint32_t z0 = cell[2] * lv.m2, z1 = z0 + lv.m2;
+        const uint32_t yz[4] = {y0 + z0, y1 + z0, y0 + z1, y1 + z1};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t i0 = cell[0] + yz[j], i1 = i0 + 1u;
+            r0[j] = min(i0, i0 - lv.size);                // idx mod size for idx < 2 size (unsigned wrap makes the minimum pick it)
+            r1[j] = min(i1, i1 - lv.size);
+            base[j] = min(r0[j], lv.size - 2u);           // the pair must not run past the level's last row
+        }
+    }
+    uint32_t sel = 0;
+    bool need = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        st.pair[j] = __builtin_amdgcn_raw_buffer_load_b128(table, base[j] * 8u, lv.row0_bytes, AUX);
+        const uint32_t o0 = r0[j] - base[j], o1 = r1[j] - base[j];     // 0 or 1 when inside the pair
+        sel |= (o0 & 1u) << j;
+        sel |= (o1 == 1u ? 1u : 0u) << (4 + j);
+        const bool out = o1 > 1u;
+        sel |= (out ? 1u : 0u) << (8 + j);
+        need |= out;
+    }
+    st.sel = sel;
+    if (need) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) st.solo[j] = __builtin_amdgcn_raw_buffer_load_b64(table, r1[j] * 8u, lv.row0_bytes, AUX);
+    }
+}
+
+// the eight corner rows of a stage, index = bx | by << 1 | bz << 2
+__device__ __forceinline__ void lean_corners(const LeanStage& st, float2 (&c)[8]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u32x4 p = st.pair[j];
+        const bool up0 = (st.sel >> j) & 1u, up1 = (st.sel >> (4 + j)) & 1u, out = (st.sel >> (8 + j)) & 1u;
+        c[2 * j].x = __uint_as_float(up0 ? p[2] : p[0]);
+        c[2 * j].y = __uint_as_float(up0 ? p[3] : p[1]);
+        const uint32_t ix = up1 ? p[2] : p[0], iy = up1 ? p[3] : p[1];
+        c[2 * j + 1].x = __uint_as_float(out ? st.solo[j][0] : ix);
+        c[2 * j + 1].y = __uint_as_float(out ? st.solo[j][1] : iy);
+    }
+}
+
+// value (2 channels) and d value / d x01 (3 x 2), multiplied by `m` (level mask x inside-the-cube mask)
+__device__ __forceinline__ void lean_finish(const LeanStage& st, float m, float (&out)[2], float (&g)[3][2]) {
+    float2 cc[8];
+    lean_corners(st, cc);
+    const float wx = st.w[0], wy = st.w[1], wz = st.w[2];
+    const float sx = st.sdw[0] * m, sy = st.sdw[1] * m, sz = st.sdw[2] * m;
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+        float c[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[i] = ch ? cc[i].y : cc[i].x;
+        float D[4], a[4];                 // x differences and x-interpolated values for the four (y, z) corners
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { D[j] = c[2 * j + 1] - c[2 * j]; a[j] = fmaf(wx, D[j], c[2 * j]); }
+        float F[2], b[2], E[2];           // y differences / y-interpolated values / y-interpolated x differences for z = 0, 1
+#pragma unroll
+        for (int z = 0; z < 2; ++z) {
+            F[z] = a[2 * z + 1] - a[2 * z];
+            b[z] = fmaf(wy, F[z], a[2 * z]);
+            E[z] = fmaf(wy, D[2 * z + 1] - D[2 * z], D[2 * z]);
+        }
+        const float G = b[1] - b[0];
+        out[ch] = fmaf(wz, G, b[0]) * m;
+        g[0][ch] = fmaf(wz, E[1] - E[0], E[0]) * sx;
+        g[1][ch] = fmaf(wz, F[1] - F[0], F[0]) * sy;
+        g[2][ch] = G * sz;
+    }
+}
+
+// value only (first sweep of a level whose Jacobian is not kept)
+__device__ __forceinline__ void lean_value(const LeanStage& st, float m, float (&out)[2]) {
+    float2 cc[8];
+    lean_corners(st, cc);
+    const float wx = st.w[0], wy = st.w[1], wz = st.w[2];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+        float a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float c0 = ch ? cc[2 * j].y : cc[2 * j].x, c1 = ch ? cc[2 * j + 1].y : cc[2 * j + 1].x; a[j] = fmaf(wx, c1 - c0, c0); }
+        const float b0 = fmaf(wy, a[1] - a[0], a[0]), b1 = fmaf(wy, a[3] - a[2], a[2]);
+        out[ch] = fmaf(wz, b1 - b0, b0) * m;
+    }
+}
+
+// second sweep: d (g0 * value_0 + g1 * value_1) / d x01 accumulated into n[3] -- the level's share of J^T g without
+// ever materialising J: the corner rows are contracted with (g0, g1) first, then one scalar trilinear gradient
+__device__ __forceinline__ void lean_contract(const LeanStage& st, float m, float g0, float g1, float (&n)[3]) {
+    float2 cc[8];
+    lean_corners(st, cc);
+    const float wx = st.w[0], wy = st.w[1], wz = st.w[2];
+    float s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = fmaf(cc[i].y, g1, cc[i].x * g0);
+    float D[4], a[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { D[j] = s[2 * j + 1] - s[2 * j]; a[j] = fmaf(wx, D[j], s[2 * j]); }
+    float F[2], b[2], E[2];
+#pragma unroll
+    for (int z = 0; z < 2; ++z) {
+        F[z] = a[2 * z + 1] - a[2 * z];
+        b[z] = fmaf(wy, F[z], a[2 * z]);
+        E[z] = fmaf(wy, D[2 * z + 1] - D[2 * z], D[2 * z]);
+    }
+    n[0] = fmaf(fmaf(wz, E[1] - E[0], E[0]), st.sdw[0] * m, n[0]);
+    n[1] = fmaf(fmaf(wz, F[1] - F[0], F[0]), st.sdw[1] * m, n[1]);
+    n[2] = fmaf(b[1] - b[0], st.sdw[2] * m, n[2]);
+}
+
+}  // namespace envidr

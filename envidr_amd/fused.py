@@ -24,7 +24,12 @@ _FP = ctypes.c_void_p
 class GeometryExport(ctypes.Structure):
     """mirror of `envidr_geometry_export`"""
     _fields_ = [("counter", _FP), ("capacity", ctypes.c_uint32), ("ray", _FP), ("idx", _FP), ("w", _FP), ("normal", _FP),
-                ("geo_feat", _FP), ("roughness", _FP)]
+                ("geo_feat", _FP), ("roughness", _FP), ("slot", _FP), ("blend", _FP)]
+
+
+class SamplesOut(ctypes.Structure):
+    """mirror of `envidr_geometry_samples_out`"""
+    _fields_ = [(n, _FP) for n in ("alpha", "sigma", "normal", "geo_feat", "roughness", "blend")]
 
 
 class RenderDesc(ctypes.Structure):
@@ -108,6 +113,13 @@ def _bind_render(lib):
     lib.envidr_composite_records.argtypes = [ctypes.POINTER(GeometryExport), _FP, _FP, _FP, _FP, _FP, ctypes.c_uint32, ctypes.c_float,
                                              ctypes.c_float, _FP, _FP, _FP, _FP]
     lib.envidr_composite_records.restype = ctypes.c_int
+    lib.envidr_geometry_eval.argtypes = [ctypes.POINTER(RenderDesc), _FP, _FP, ctypes.c_uint32, _FP, ctypes.POINTER(SamplesOut), _FP]
+    lib.envidr_geometry_eval.restype = ctypes.c_int
+    lib.envidr_geometry_workspace_bytes.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+    lib.envidr_geometry_workspace_bytes.restype = ctypes.c_uint64
+    lib.envidr_geometry_pass.argtypes = [ctypes.POINTER(RenderDesc), _FP, _FP, ctypes.c_uint32, ctypes.POINTER(RenderOut),
+                                         ctypes.POINTER(GeometryExport), _FP, ctypes.c_uint64, ctypes.c_uint32, _FP]
+    lib.envidr_geometry_pass.restype = ctypes.c_int
     lib._envidr_render_bound = True
 
 
@@ -192,6 +204,10 @@ def _shade(lib, desc, normals, dirs, geo_feat, roughness, env_rot_radian, out):
     if rc:
         raise _lib.EnvidrError(f"envidr_shade_samples failed ({rc}): {lib.envidr_last_error().decode()}")
     return res
+
+
+class FrameOverflow(_lib.EnvidrError):
+    """a frame enqueued without waiting turned out not to fit its sample / record buffers (they have been grown)"""
 
 
 @dataclass
@@ -475,6 +491,129 @@ class FusedRenderer:
             raise _lib.EnvidrError("two-phase render: record count changed between two identical geometry passes")
         res["n_records"] = M
         return res
+
+    # ---- two-phase frame on the geometry pipeline: march rounds + per-sample evaluation -> shading -> composite ----------
+    def geometry_eval(self, xyz: torch.Tensor, dt: torch.Tensor | None = None, want=("sigma", "normal", "geo_feat", "roughness")) -> dict:
+        """envidr_geometry_eval: hash grid + SDF network forward / input gradient + per-sample terms for positions [M,3]"""
+        xyz = xyz.contiguous().view(-1, 3).float()
+        M, dev = xyz.shape[0], xyz.device
+        shapes = {"alpha": (), "sigma": (), "normal": (3,), "geo_feat": (12,), "roughness": (), "blend": ()}
+        out = {k: torch.empty(M, *shapes[k], device=dev) for k in want}
+        if "alpha" in out and dt is None:
+            raise _lib.EnvidrError("geometry_eval: alpha needs the step sizes dt")
+        so = SamplesOut(**{k: v.data_ptr() for k, v in out.items()})
+        rc = self.lib.envidr_geometry_eval(ctypes.byref(self.desc), xyz.data_ptr(), None if dt is None else dt.contiguous().float().data_ptr(),
+                                           M, None, ctypes.byref(so), torch.cuda.current_stream(dev).cuda_stream)
+        if rc:
+            raise _lib.EnvidrError(f"envidr_geometry_eval failed ({rc}): {self.lib.envidr_last_error().decode()}")
+        return out
+
+    def _frame_buffers(self, N: int, dev, samples_per_ray: float) -> dict:
+        st = self.__dict__.setdefault("_frame", {})
+        cap = max(int(N * samples_per_ray), 4096)
+        if st.get("N") != N or st.get("cap", 0) < cap:
+            need = int(self.lib.envidr_geometry_workspace_bytes(N, cap))
+            st.clear()
+            st.update(N=N, cap=cap, ws=torch.empty(need, dtype=torch.uint8, device=dev), counter=torch.zeros(1, dtype=torch.int32, device=dev),
+                      ray=torch.empty(cap, dtype=torch.int32, device=dev), idx=torch.empty(cap, dtype=torch.int32, device=dev),
+                      w=torch.empty(cap, device=dev), slot=torch.empty(cap, dtype=torch.int32, device=dev),
+                      perm=torch.empty(cap, dtype=torch.int32, device=dev), cd=torch.empty(cap, 3, device=dev), cs=torch.empty(cap, 3, device=dev),
+                      cost=torch.zeros(N, dtype=torch.int16, device=dev), offsets=torch.zeros(N + 1, dtype=torch.int32, device=dev),
+                      stats=torch.zeros(3, dtype=torch.int64, device=dev), host=torch.zeros(3, dtype=torch.int64).pin_memory(),
+                      event=torch.cuda.Event(), pending=False)
+        return st
+
+    def check_frames(self) -> None:
+        """Frames are enqueued without waiting for the device.  This looks at the status words of the last one (they were
+        copied to pinned memory behind it) and raises if it did not fit its buffers -- which are then grown, so that redoing
+        the frame succeeds.  Called at the start of every frame and by anyone who needs the answer now."""
+        st = self.__dict__.get("_frame")
+        if not st or not st["pending"]:
+            return
+        st["event"].synchronize()
+        st["pending"] = False
+        samples, records, overflow = (int(v) for v in st["host"])
+        st["last"] = (samples, records)
+        if overflow:
+            N = st["N"]
+            self.__dict__["_frame_hint"] = max(2.0 * st["cap"] / N, 1.5 * max(samples, records) / N)
+            self.__dict__["_frame"] = {}
+            raise FrameOverflow(f"the frame needed more than the {st['cap']} sample / record slots it was given; buffers were grown, render it again")
+
+    def render_frame(self, rays_o: torch.Tensor, rays_d: torch.Tensor, env_rot_radian: float | None = None, out: dict | None = None,
+                     samples_per_ray_hint: float = 20.0, events: list | None = None, geometry_only: bool = False, wait: bool = True,
+                     use_cost_hint: bool = True) -> dict:
+        """One frame as: geometry pipeline (envidr_geometry_pass: march rounds + per-sample hash grid / SDF network, one record
+        per composited sample) -> shading of the records (k_shade_samples) -> per-ray composite.  Environment-MLP family.
+        The per-ray sample counts of the previous frame of these N rays (kept in the frame buffers) size each ray's first march
+        chunk (use_cost_hint; results do not depend on it).  Nothing waits for the device while the frame is enqueued; with wait=False the call does not wait at the end either
+        (video loops: check_frames() -- called by the next frame -- raises FrameOverflow if a frame did not fit).
+        `events`: four torch.cuda.Event(enable_timing=True) recorded at the pass boundaries (geometry | shading | composite)."""
+        self.check_frames()
+        rays_o = rays_o.contiguous().view(-1, 3).float()
+        rays_d = rays_d.contiguous().view(-1, 3).float()
+        N, dev = rays_o.shape[0], rays_o.device
+        res = out if out is not None else {}
+        for attempt in range(3):
+            st = self._frame_buffers(N, dev, max(samples_per_ray_hint, self.__dict__.get("_frame_hint", 0.0)))
+            cap = st["cap"]
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            for name, shape in (("depth", (N,)), ("weights_sum", (N,)), ("normal_image", (N, 3)), ("roughness_image", (N,))):
+                if name not in res or res[name].shape != shape:
+                    res[name] = torch.empty(*shape, device=dev)
+            o = RenderOut()
+            o.depth, o.weights_sum = res["depth"].data_ptr(), res["weights_sum"].data_ptr()
+            o.normal_image, o.roughness_image = res["normal_image"].data_ptr(), res["roughness_image"].data_ptr()
+            o.stats = st["stats"].data_ptr()
+            ex = GeometryExport(st["counter"].data_ptr(), cap, st["ray"].data_ptr(), st["idx"].data_ptr(), st["w"].data_ptr(), None, None, None,
+                                st["slot"].data_ptr(), None)
+            if not use_cost_hint:
+                st["cost"].zero_()
+            self.desc.ray_cost = st["cost"].data_ptr()
+            self.desc.geometry_only, self.desc.r_images, self.desc.geometry_export = 0, None, None
+            ev = events
+            if ev: ev[0].record()
+            rc = self.lib.envidr_geometry_pass(ctypes.byref(self.desc), rays_o.data_ptr(), rays_d.data_ptr(), N, ctypes.byref(o), ctypes.byref(ex),
+                                               st["ws"].data_ptr(), st["ws"].numel(), cap, stream)
+            self.desc.ray_cost = None
+            if rc:
+                raise _lib.EnvidrError(f"envidr_geometry_pass failed ({rc}): {self.lib.envidr_last_error().decode()}")
+            if ev: ev[1].record()
+            if not geometry_only:
+                _set_env_rotation(self.desc, env_rot_radian)
+                rc = self.lib.envidr_shade_records(ctypes.byref(self.desc), ctypes.byref(ex), rays_d.data_ptr(), st["cd"].data_ptr(),
+                                                   st["cs"].data_ptr(), stream)
+                if rc:
+                    raise _lib.EnvidrError(f"envidr_shade_records failed ({rc}): {self.lib.envidr_last_error().decode()}")
+            if ev: ev[2].record()
+            if not geometry_only:
+                torch.cumsum(st["cost"], 0, dtype=torch.int32, out=st["offsets"][1:])
+                for name in ("image", "diffuse_image", "specular_image"):
+                    if name not in res or res[name].shape != (N, 3):
+                        res[name] = torch.empty(N, 3, device=dev)
+                rc = self.lib.envidr_composite_records(ctypes.byref(ex), st["offsets"].data_ptr(), st["perm"].data_ptr(), st["cd"].data_ptr(),
+                                                       st["cs"].data_ptr(), res["weights_sum"].data_ptr(), N, float(self.desc.intensity_scale),
+                                                       float(self.desc.bg_color), res["image"].data_ptr(), res["diffuse_image"].data_ptr(),
+                                                       res["specular_image"].data_ptr(), stream)
+                if rc:
+                    raise _lib.EnvidrError(f"envidr_composite_records failed ({rc}): {self.lib.envidr_last_error().decode()}")
+            else:
+                res["image"] = ((1 - res["weights_sum"]) * float(self.desc.bg_color))[:, None].expand(N, 3).contiguous()
+            if ev: ev[3].record()
+            st["host"].copy_(st["stats"], non_blocking=True)
+            st["event"].record()
+            st["pending"] = True
+            res["ray_cost"] = st["cost"]
+            if not wait:
+                return res
+            try:
+                self.check_frames()
+            except FrameOverflow:
+                continue
+            res["n_records"] = st["last"][1]
+            res["n_samples"] = st["last"][0]
+            return res
+        raise _lib.EnvidrError("render_frame: the frame did not fit its buffers after two enlargements")
 
     def render_cached(self, cache: GeometryCache, env_rot_radian: float | None = None, out: dict | None = None) -> dict:
         """re-light a cached frame: envidr_shade_samples over its samples + envidr_composite_shaded; bit-identical to

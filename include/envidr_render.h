@@ -61,6 +61,10 @@ typedef struct envidr_geometry_export {
     float* normal;         /* [capacity,3]                                                                          */
     float* geo_feat;       /* [capacity,12] unit-normalised                                                         */
     float* roughness;      /* [capacity]                                                                            */
+    /* ABI 3: when `slot` is not NULL, normal / geo_feat / roughness / blend of record i live at index slot[i] of their arrays
+     * (the geometry pipeline leaves the per-sample data where the evaluation kernel wrote it and hands out indices)        */
+    const uint32_t* slot;  /* [capacity] or NULL                                                                            */
+    float* blend;          /* raw SDF-network output 14 (learn_indir_blend logit), or NULL                                  */
 } envidr_geometry_export;
 
 /* ---- scene / model description ---------------------------------------------------------------- */
@@ -210,6 +214,49 @@ int envidr_shade_records(const envidr_render_desc* desc, const envidr_geometry_e
 int envidr_composite_records(const envidr_geometry_export* records, const uint32_t* offsets, uint32_t* perm, const float* c_diffuse,
                              const float* c_specular, const float* weights_sum, uint32_t N, float intensity_scale, float bg_color,
                              float* image, float* diffuse_image, float* specular_image, envidr_stream_t stream);
+
+/* ---- geometry pipeline (envidr_amd/csrc/geometry_pass.hip) -------------------------------------------------------
+ * The per-SAMPLE half of the geometry pass as its own operator: for M sample positions, the 16-level hash grid with
+ * analytic Jacobian, the SDF network forward and input gradient, and the per-sample terms derived from them --
+ *     nerf/network.py:381-522   forward_geometry / forward_sigma   (hash grid -> SDF MLP -> Laplace density)
+ *     nerf/renderer.py:182-198  compute_normal                      (analytic instead of autograd)
+ * One lane per sample, two waves per SIMD, SDF weights resident in LDS.  Same per-sample arithmetic (same bits) as
+ * envidr_render_rays.  Uses desc->hash_*, sdf_blob, sdf_w3_row0, beta, density_scale, roughness_*, bound.
+ *   xyz   : device [M,3] positions;  dt : device [M] step sizes (only for `alpha`; may be NULL when alpha is NULL)
+ *   range : optional device uint32 {begin, count}: evaluate samples [begin, begin + count) of arrays holding M slots
+ *           (count read on the device: the host never waits for the kernel that produced the samples); NULL = [0, M)
+ * Any output pointer may be NULL. */
+typedef struct envidr_geometry_samples_out {
+    float* alpha;      /* [M]    1 - exp(-sigma dt)                                   */
+    float* sigma;      /* [M]    Laplace density * density_scale                        */
+    float* normal;     /* [M,3]  unit (eps 1e-10)                                       */
+    float* geo_feat;   /* [M,12] unit (eps 1e-12)                                       */
+    float* roughness;  /* [M]                                                           */
+    float* blend;      /* [M]    raw SDF-network output 14 (learn_indir_blend logit)    */
+} envidr_geometry_samples_out;
+
+int envidr_geometry_eval(const envidr_render_desc* desc, const float* xyz, const float* dt, uint32_t M,
+                         const uint32_t* range_dev, const envidr_geometry_samples_out* out, envidr_stream_t stream);
+
+/* The geometry half of a frame as a device-driven pipeline (two-phase frames; envidr_amd/csrc/geometry_pass.hip):
+ *     nerf/render_func/cuda_ray.py:277-346  the march -> evaluate -> composite -> compact loop, geometry part
+ * Rays march in chunks (16, 32, ... samples); each round one per-ray kernel composites the previous chunk (appending
+ * one record per composited sample) and marches the next, and one per-sample kernel (envidr_geometry_eval) evaluates
+ * the new samples.  All counts stay on the device; the call only enqueues.  Sample positions, step sizes and occupancy
+ * decisions are those of envidr_render_rays (the reference loop with one sample per iteration).
+ *   out      : depth, weights_sum (required), normal_image, roughness_image; out->stats (optional, uint64[3]):
+ *              {samples evaluated, records, overflow code}.  desc->ray_cost (uint16 [N], optional) receives the number of
+ *              composited samples per ray (what envidr_composite_records' offsets are the prefix sum of).
+ *   records  : caller-owned counter / ray / idx / w / slot arrays of `capacity` entries; on return the struct's normal /
+ *              geo_feat / roughness / blend pointers address the per-sample arrays inside the workspace.  If the frame did
+ *              not fit (samples or records), *counter is 0xffffffff: envidr_shade_records / envidr_composite_records then
+ *              do nothing and the caller redoes the frame with larger buffers.
+ *   workspace: device, 256-byte aligned, >= envidr_geometry_workspace_bytes(N, sample_capacity) bytes; may be reused by
+ *              the next frame once the records have been shaded. */
+uint64_t envidr_geometry_workspace_bytes(uint32_t N, uint32_t sample_capacity);
+int envidr_geometry_pass(const envidr_render_desc* desc, const float* rays_o, const float* rays_d, uint32_t N,
+                         const envidr_render_out* out, envidr_geometry_export* records, void* workspace,
+                         uint64_t workspace_bytes, uint32_t sample_capacity, envidr_stream_t stream);
 
 /* Composite shaded colours over cached geometry: ray r owns records offsets[r] .. offsets[r+1]-1 (sorted by (ray, idx)).
  *   image[r] = sum_i w_i (c_diffuse_i + c_specular_i) intensity_scale + (1 - weights_sum[r]) bg_color, and the optional

@@ -283,6 +283,7 @@ def render_rays(scene, rays_o: np.ndarray, rays_d: np.ndarray, opt: RenderOption
 
     step = 0
     n_samples = 0
+    ray_counts = np.zeros(N, np.int64)          # samples each ray composited (exact for the one-sample-per-iteration schedule)
     while step < opt.max_steps:
         n_alive = main["alive"].shape[0]
         if n_alive <= 0:
@@ -294,6 +295,8 @@ def render_rays(scene, rays_o: np.ndarray, rays_d: np.ndarray, opt: RenderOption
         o.call("march_rays", n_alive, n_step, main["alive"], main["t"], rays_o, rays_d, opt.bound, opt.dt_gamma, opt.max_steps,
                opt.cascades, opt.grid_size, scene.bitfield, nears, fars, xyzs, dirs, deltas, np.zeros(n_alive, F32))
         n_samples += int((deltas[:, 0] > 0).sum())
+        if n_step == 1:
+            ray_counts[main["alive"][deltas[:n_alive, 0] > 0]] += 1
         if trace is not None:
             trace.append((n_alive, n_step, M))
         s = shade_samples(scene, xyzs, dirs, opt, env_rot_radian)
@@ -313,7 +316,7 @@ def render_rays(scene, rays_o: np.ndarray, rays_d: np.ndarray, opt: RenderOption
         step += n_step
 
     res = {"image": main["image"] + (1 - main["ws"])[:, None] * opt.bg_color, "depth": main["depth"], "weights_sum": main["ws"],
-           "n_samples": n_samples}
+           "n_samples": n_samples, "ray_counts": ray_counts}
     if "normal" in extra:
         n = extra["normal"]["image"]
         n = n / np.maximum(np.linalg.norm(n, axis=-1, keepdims=True), 1e-10).astype(F32)

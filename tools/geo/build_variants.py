@@ -1,0 +1,43 @@
+"""Build experiment variants of the geometry kernel: libenvidr_amd.so re-linked with geometry_pass.hip compiled under
+different -D switches (tools/geo/variants/<name>.so; selected at run time through ENVIDR_AMD_LIB)."""
+import subprocess, sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+from envidr_amd import build as B
+
+W4 = ["-DENVIDR_GEO_WAVES=4", "-DENVIDR_GEO_JMODE=2", "-DENVIDR_GEO_IOMODE=1"]
+VARIANTS = {
+    "w4_a2": W4 + ["-DENVIDR_GEO_AHEAD=2"],
+    "w4_a4": W4 + ["-DENVIDR_GEO_AHEAD=4"],
+    "w4_a6": W4 + ["-DENVIDR_GEO_AHEAD=6"],
+    "w4_a8": W4 + ["-DENVIDR_GEO_AHEAD=8"],
+    "w4_a6_unroll": W4 + ["-DENVIDR_GEO_AHEAD=6", "-DENVIDR_GEO_UNROLL_GROUPS=1"],
+    "w4_a6_nt12": W4 + ["-DENVIDR_GEO_AHEAD=6", "-DENVIDR_GEO_NT_FROM=12"],
+    "w4_a6_nt9": W4 + ["-DENVIDR_GEO_AHEAD=6", "-DENVIDR_GEO_NT_FROM=9"],
+    "w4_a6_noxcd": W4 + ["-DENVIDR_GEO_AHEAD=6", "-DENVIDR_GEO_XCD=0"],
+    "w8_j0_nt12": ["-DENVIDR_GEO_JMODE=0", "-DENVIDR_GEO_IOMODE=0", "-DENVIDR_GEO_NT_FROM=12"],
+    "w8_j1_nt9": ["-DENVIDR_GEO_JMODE=1", "-DENVIDR_GEO_IOMODE=0", "-DENVIDR_GEO_NT_FROM=9"],
+}
+
+def main(names):
+    B.build(verbose=False)
+    out = ROOT / "tools" / "geo" / "variants"
+    out.mkdir(exist_ok=True)
+    objs = [str(o) for o in sorted((B.CSRC / "build").glob("*.o")) if o.stem != "geometry_pass"]
+    for name in names or VARIANTS:
+        flags = VARIANTS[name]
+        obj = out / f"{name}.o"
+        cmd = [B.hipcc(), *B.HIPCC_FLAGS, *flags, "-Rpass-analysis=kernel-resource-usage", "-c", str(B.CSRC / "geometry_pass.hip"), "-o", str(obj)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode:
+            print(name, "FAILED\n", r.stderr[-3000:]); continue
+        info = [l.split("remark:")[1].strip().replace("[-Rpass-analysis=kernel-resource-usage]", "") for l in r.stderr.splitlines()
+                if any(k in l for k in ("VGPRs:", "VGPRs Spill", "ScratchSize", "LDS Size"))]
+        lib = out / f"{name}.so"
+        r = subprocess.run([B.hipcc(), f"--offload-arch={B.ARCH}", "-shared", "-fPIC", "-fno-gpu-rdc", *objs, str(obj), "-o", str(lib)],
+                           capture_output=True, text=True)
+        print(name, "|", " ".join(info), "|", "link ok" if r.returncode == 0 else r.stderr[-500:])
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
