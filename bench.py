@@ -1,19 +1,18 @@
 #!/usr/bin/env python
 """Benchmark of the ENVIDR render hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: the script starts its N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Metric (BASELINE.json): rendered rays/s at 800x800, max 1024 samples/ray, plus PSNR of the GPU image
-against the CPU reference restatement on a sample of the same scene.
+Metric (BASELINE.json): rendered rays/s at 800x800, max 1024 samples/ray, plus PSNR of the GPU image against the CPU
+reference restatement of the same frame.
 
-One "step" = every rank renders ONE full 800x800 view (640 000 primary rays) of the synthetic
-toaster scene with the fused persistent kernel -- march + hash grid + SDF MLP + analytic normals +
-2x IDE + 2x environment MLP + diffuse/specular heads + compositing, all four auxiliary images on
-(normal / diffuse / specular / roughness, as the reference's toaster.ini renders them) -- and the
-finished RGB frame is gathered to rank 0 (RCCL gather over xGMI; no-op at N = 1).  Views are the
-env-rotation video frames of BASELINE config #5: view v = step * N + rank gets env rotation
-2 pi v / 200, so per-GPU work is fixed as N grows (weak scaling).  Inputs (rays, table, weights) are
+One "step" = every rank renders ONE full 800x800 view (640 000 primary rays) of the synthetic toaster scene -- march +
+hash grid + SDF MLP + analytic normals (geometry pipeline), 2x IDE + 2x environment MLP + diffuse/specular heads (shading
+pass), compositing, all four auxiliary images on (normal / diffuse / specular / roughness, as the reference's toaster.ini
+renders them) -- and the finished RGB frame is gathered to rank 0 (RCCL gather over xGMI on a side stream, overlapped with
+the next view; no-op at N = 1).  Views are the env-rotation video frames of BASELINE config #5: view v = step * N + rank
+gets env rotation 2 pi v / 200, so per-GPU work is fixed as N grows (weak scaling).  Inputs (rays, table, weights) are
 resident in HBM before the timed region.
 
 Printed by rank 0 as ONE JSON line; see DESIGN.md section "Measurement" for the roofline arithmetic.
@@ -21,9 +20,12 @@ Printed by rank 0 as ONE JSON line; see DESIGN.md section "Measurement" for the 
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,129 +38,240 @@ sys.path.insert(0, ROOT)
 H = W = 800
 FLOP_PER_SAMPLE = 650_880          # dense-layer FLOPs per shaded sample, toaster network
 FLOP_PER_SAMPLE_SHADING = 624_192  # of which in the shading pass: env MLP 305 152 x 2 + diffuse 1 728 + specular 12 160
-                                   # (the other 26 688 -- SDF network forward + input gradient -- run in the geometry pass)
+FLOP_PER_SAMPLE_GEOMETRY = 26_688  # SDF network forward 14 208 + input gradient 12 480 (geometry pass)
+FLOP_PER_SAMPLE_RELIGHT = 277_376  # neural_renderer.ini / shipped env nets: IDE 4, env hidden 160
+FLOP_PER_SAMPLE_PLAIN = 41_984     # configs[1]: no env MLP
 HASH_BYTES_PER_SAMPLE = 1024       # 16 levels x 8 corners x 8 B gathered per sample
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA dense peak
-CPU_SAMPLE_RES = 400               # cpu_baseline renders a 400x400 frame of the same scene/camera
-CPU_THREAD_CANDIDATES = (16, 32, 64)
+PEAK_HBM_GBPS = 8000.0
 
 
-def cpu_baseline(scene, env_rot: float) -> dict:
-    """the CPU restatement (oracle: C/OpenMP ops + torch CPU GEMMs, reference n_step schedule) timed
-    on the host cores on a bounded sample of the same workload"""
+def csrc_hash() -> str:
+    """identifies the kernel sources a PMC summary was collected on (there is no .git on the GPU box)"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "envidr_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".inc")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def host_cpu_info() -> dict:
+    info = {"logical_cpus": os.cpu_count()}
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        for line in out.splitlines():
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k in ("Model name", "Socket(s)", "Core(s) per socket", "Thread(s) per core"):
+                info[k] = v
+    except Exception:
+        pass
+    return info
+
+
+def cpu_baseline(scene, env_rot: float, frames: int, res: int) -> dict:
+    """the CPU restatement (oracle: C/OpenMP ops + torch CPU fp32 GEMMs, reference n_step schedule) timed on the host cores
+    on the benchmark's own frame: one warm-up (small frame: library loads, thread pools), then the median of `frames` full
+    frames.  Thread count: the best of a few candidates on a probe (all hardware threads is far from the fastest for these
+    small GEMMs on a 2 x 64-core host)."""
     from envidr_amd import scenes
     from oracle.py import render_oracle as ro
     opt = ro.RenderOptions(ide_mode="torch")
-    # thread count: all hardware threads is NOT the fastest for these small GEMMs (on the 2x64-core
-    # GPU host 256 threads run ~400x slower than 16); pick the best of a few candidates on a small probe
     probe_o, probe_d = scenes.camera_rays(96, 96)
-    best, cores = None, 1
-    for th in sorted({min(c, os.cpu_count() or 1) for c in CPU_THREAD_CANDIDATES}):
+    best, threads, tried = None, 1, {}
+    for th in sorted({min(c, os.cpu_count() or 1) for c in (16, 32, 64)}):
         torch.set_num_threads(th)
-        ro.render_rays(scene, probe_o[:256], probe_d[:256], opt, env_rot)    # warm-up (library loads, thread pools)
+        ro.render_rays(scene, probe_o[:256], probe_d[:256], opt, env_rot)    # warm-up
         t0 = time.perf_counter()
         ro.render_rays(scene, probe_o, probe_d, opt, env_rot)
-        dt = time.perf_counter() - t0
-        if best is None or dt < best:
-            best, cores = dt, th
-    torch.set_num_threads(cores)
-    rays_o, rays_d = scenes.camera_rays(CPU_SAMPLE_RES, CPU_SAMPLE_RES)
-    t0 = time.perf_counter()
-    res = ro.render_rays(scene, rays_o, rays_d, opt, env_rot)
-    dt = time.perf_counter() - t0
-    n = CPU_SAMPLE_RES * CPU_SAMPLE_RES
-    return {"value": n / dt, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"{CPU_SAMPLE_RES}x{CPU_SAMPLE_RES} frame of the same scene and camera ({n} rays, {res['n_samples']} samples, "
-                      f"{dt:.1f} s): oracle/ C+OpenMP ops + torch CPU fp32 GEMMs, reference n_step schedule, best of "
-                      f"{list(CPU_THREAD_CANDIDATES)} threads on a {os.cpu_count()}-thread host",
-            "samples_per_s": res["n_samples"] / dt, "image": res["image"]}
+        tried[th] = time.perf_counter() - t0
+        if best is None or tried[th] < best:
+            best, threads = tried[th], th
+    torch.set_num_threads(threads)
+    rays_o, rays_d = scenes.camera_rays(res, res)
+    times, out = [], None
+    for _ in range(max(frames, 1)):
+        t0 = time.perf_counter()
+        out = ro.render_rays(scene, rays_o, rays_d, opt, env_rot)
+        times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
+    n = res * res
+    return {"value": n / dt, "unit": "rays/s", "cores": threads, "kind": "port",
+            "sample": f"{res}x{res} frame of the same scene and camera ({n} rays, {out['n_samples']} samples): oracle/ C+OpenMP ops + torch "
+                      f"CPU fp32 GEMMs, reference n_step schedule; 1 warm-up, median of {len(times)} frames ({dt:.1f} s each)",
+            "frame_seconds": times, "threads_tried_probe_seconds": tried, "host": host_cpu_info(),
+            "samples_per_s": out["n_samples"] / dt, "image": out["image"]}
 
 
-def main() -> None:
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _spawned(rank: int, world: int, port: int, argv: list[str]) -> None:
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    run(argv)
+
+
+def parse(argv: list[str]):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (profiling runs)")
-    ap.add_argument("--path", choices=["two-phase", "fused"], default="two-phase",
-                    help="two-phase: geometry pass + shading pass per frame (default, faster); fused: one persistent kernel per frame")
+    ap.add_argument("--cpu-frames", type=int, default=3, help="full CPU frames timed for cpu_baseline (median)")
+    ap.add_argument("--cpu-res", type=int, default=800, help="resolution of the CPU frame (the benchmark's own: 800)")
+    ap.add_argument("--path", choices=["pipeline", "fused"], default="pipeline",
+                    help="pipeline: geometry pipeline + shading pass per frame (default); fused: one persistent kernel per frame")
     ap.add_argument("--headline-only", action="store_true", help="skip the CPU leg and the other_configs renders, so that a "
-                    "profiler sees only the headline kernel's launches")
-    args = ap.parse_args()
+                    "profiler sees only the headline kernels' launches")
+    ap.add_argument("--stub", action="store_true", help="CPU plumbing test: gloo, a stand-in renderer, tiny frames "
+                    "(tests/test_bench_cpu.py); exercises launch, view partition, overlapped gather and the JSON line")
+    return ap.parse_args(argv)
 
-    from envidr_amd import parallel, scenes
-    from envidr_amd.fused import FusedRenderer
+
+class StubRenderer:
+    """stand-in for FusedRenderer in --stub mode: the frame of view v is the constant v (so the root can check what it gathered)"""
+    def __init__(self, n):
+        self.n = n
+
+    def render_frame(self, rays_o, rays_d, env_rot, out=None, events=None, wait=True, **kw):
+        res = out if out is not None else {}
+        res["image"] = torch.full((self.n, 3), float(env_rot), dtype=torch.float32)
+        res["n_records"] = res["n_samples"] = 12 * self.n
+        return res
+
+    def check_frames(self):
+        pass
+
+
+def run(argv: list[str]) -> None:
+    args = parse(argv)
+    from envidr_amd import parallel
     import torch.distributed as dist
 
-    rank, world, local = parallel.init_from_env()
+    stub = args.stub
+    rank, world, local = parallel.init_from_env(backend="gloo" if stub else None)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-
-    scene = scenes.toaster_scene()
-    renderer = FusedRenderer.from_scene(scene, device=dev)
-    rays_o, rays_d = (torch.from_numpy(a).to(dev) for a in scenes.camera_rays(H, W))
-    N = H * W
-    out: dict = {}
-    # scheduling hint (DESIGN.md "work-list order"): samples per ray of the previous frame of this camera; orders the
-    # persistent kernel's work list longest ray first.  Order only: every frame still marches and shades every sample.
-    ray_cost = torch.zeros(N, dtype=torch.int16, device=dev)
-    gather_list = [torch.empty(N, 3, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if stub:
+        dev = torch.device("cpu")
+        n_side = 16
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        n_side = H
+    N = n_side * n_side
 
     def env_rot(view: int) -> float:
         return 2 * math.pi * (view % 200) / 200
 
-    two_phase = args.path == "two-phase"
+    if stub:
+        scene, renderer = None, StubRenderer(N)
+        rays_o = rays_d = torch.zeros(N, 3)
+    else:
+        from envidr_amd import scenes
+        from envidr_amd.fused import FusedRenderer
+        scene = scenes.toaster_scene()
+        renderer = FusedRenderer.from_scene(scene, device=dev)
+        rays_o, rays_d = (torch.from_numpy(a).to(dev) for a in scenes.camera_rays(H, W))
+    pipeline = args.path == "pipeline"
+    # two sets of output images: the gather of view i runs on a side stream while view i + 1 is rendered into the other set
+    outs = [{}, {}]
+    ray_cost = None if (stub or pipeline) else torch.zeros(N, dtype=torch.int16, device=dev)
+    gather_lists = [[torch.empty(N, 3, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None for _ in range(2)]
+    comm = torch.cuda.Stream(dev) if (world > 1 and not stub) else None
+    gather_ev = []          # (start, end) events of the gathers on the side stream
 
-    def frame(view: int, events=None):
-        if two_phase:
-            return renderer.render_two_phase(rays_o, rays_d, env_rot(view), out=out, ray_cost=ray_cost, events=events)
+    def frame(view: int, slot: int, events=None):
+        if pipeline:
+            return renderer.render_frame(rays_o, rays_d, env_rot(view) if not stub else float(view), out=outs[slot], events=events, wait=False)
         if events:
             events[0].record()
-        res = renderer.render(rays_o, rays_d, env_rot(view), extras=True, stats=True, out=out, ray_cost=ray_cost)
+        res = renderer.render(rays_o, rays_d, env_rot(view), extras=True, stats=True, out=outs[slot], ray_cost=ray_cost)
         if events:
             events[1].record()
         return res
 
-    def step(i: int) -> None:
-        res = frame(i * world + rank)
-        if world > 1:
-            dist.gather(res["image"], gather_list=gather_list, dst=0)
+    slot_sent = [None, None]     # event on the side stream: the gather that reads this output set has finished
 
-    for i in range(args.warmup):
-        step(i)
+    def step(i: int, events=None, timed=False):
+        slot = i & 1
+        if slot_sent[slot] is not None:
+            torch.cuda.current_stream(dev).wait_event(slot_sent[slot])     # (two steps ago; the gather of the last step keeps running)
+        res = frame(i * world + rank, slot, events)
+        if world > 1:
+            if comm is None:
+                dist.gather(res["image"], gather_list=gather_lists[slot], dst=0)
+            else:
+                done = torch.cuda.Event()
+                done.record()
+                with torch.cuda.stream(comm):
+                    comm.wait_event(done)
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if timed else None
+                    if ev: ev[0].record()
+                    dist.gather(res["image"], gather_list=gather_lists[slot], dst=0)
+                    if ev:
+                        ev[1].record()
+                        gather_ev.append(ev)
+                    slot_sent[slot] = torch.cuda.Event()
+                    slot_sent[slot].record()
+        return res
 
     def fence():
+        if comm is not None:
+            torch.cuda.current_stream(dev).wait_stream(comm)
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        if not stub:
+            torch.cuda.synchronize(dev)
+
+    res = None
+    for i in range(args.warmup):
+        res = step(i)
 
     # HIP events on the stream the kernels are launched on (torch's current stream), recorded at the pass boundaries
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
-    samples = 0
+    ev = None if stub else [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        res = frame((args.warmup + i) * world + rank, ev[i])
-        if world > 1:
-            dist.gather(res["image"], gather_list=gather_list, dst=0)
+        res = step(args.warmup + i, ev[i] if ev else None, timed=True)
     fence()
-    dt = time.perf_counter() - t0
-    if two_phase:
-        geometry_ms, kernel_ms, composite_ms = (float(np.mean([e[j].elapsed_time(e[j + 1]) for e in ev])) for j in range(3))
-        samples = int(res["n_records"])        # samples composited = records shaded in the last frame
+    dt_local = time.perf_counter() - t0
+    renderer.check_frames()
+    if stub and world > 1 and rank == 0:
+        last = args.warmup + args.steps - 1
+        for r in range(world):
+            assert float(gather_lists[last & 1][r][0, 0]) == float(last * world + r), "gather delivered the wrong view"
+    samples = 0 if res is None else int(res.get("n_records", 0))
+    geometry_ms = kernel_ms = composite_ms = 0.0
+    if not stub:
+        if pipeline:
+            geometry_ms, kernel_ms, composite_ms = (float(np.mean([e[j].elapsed_time(e[j + 1]) for e in ev])) for j in range(3))
+            samples = int(renderer._frame["last"][1])
+            evaluated = int(renderer._frame["last"][0])
+        else:
+            kernel_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+            samples = evaluated = int(outs[(args.warmup + args.steps - 1) & 1]["stats"][0].item())
     else:
-        kernel_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-        samples = int(out["stats"][0].item())  # samples shaded in the last frame
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        evaluated = samples
+    gather_ms = float(np.mean([a.elapsed_time(b) for a, b in gather_ev])) if gather_ev else 0.0
+    t = torch.tensor([dt_local], device=dev, dtype=torch.float64)
+    per_rank = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)] if world > 1 else [t]
     if world > 1:
+        dist.all_gather(per_rank, t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
     if rank == 0:
         rays_per_s = world * N * args.steps / dt
-        flops = samples * (FLOP_PER_SAMPLE_SHADING if two_phase else FLOP_PER_SAMPLE) / (kernel_ms * 1e-3) / 1e12
+        flops = samples * (FLOP_PER_SAMPLE_SHADING if pipeline else FLOP_PER_SAMPLE) / max(kernel_ms * 1e-3, 1e-12) / 1e12
         result = {
             "metric": "rendered rays/s at 800x800, 1024 max samples/ray", "value": rays_per_s, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -166,41 +279,68 @@ def main() -> None:
             "config": {"workload": "BASELINE configs[2]/[4] network (toaster.ini: hash L16xC2 + SDF 32-64-64-15 + IDE deg5 + env MLP "
                                    "72-256-256-256-12 x2 + diffuse/specular heads) on a synthetic shell scene, 800x800 view per GPU per "
                                    "step, env-rotation video frames sharded by view, normal/diffuse/specular/roughness images on",
-                       "rays_per_step_per_gpu": N, "samples_per_frame": samples, "samples_per_ray": samples / N,
-                       "max_steps": 1024, "T_thresh": 1e-4, "parallelism": f"views x{world} + RCCL image gather",
-                       "schedule": ("two-phase frame: geometry pass (march + hash grid + SDF network + normals, one record per "
-                                    "composited sample) -> shading pass (k_shade_samples) -> per-ray composite; every frame from scratch"
-                                    if two_phase else "one persistent kernel per frame")},
+                       "rays_per_step_per_gpu": N, "samples_per_frame": samples, "samples_evaluated_per_frame": evaluated,
+                       "samples_per_ray": samples / N, "max_steps": 1024, "T_thresh": 1e-4,
+                       "parallelism": f"views x{world} + RCCL image gather on a side stream (overlapped with the next view)",
+                       "schedule": ("geometry pipeline (device-driven march rounds + sample-parallel hash grid / SDF network, one record "
+                                    "per composited sample) -> shading pass (k_shade_samples) -> per-ray composite; every frame from "
+                                    "scratch (the previous frame's per-ray sample counts only size the march chunks)"
+                                    if pipeline else "one persistent kernel per frame")},
             "samples_per_s": world * samples * args.steps / dt,
-            "roofline": {"bound": "mfma", "achieved": flops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": flops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "k_shade_samples<5,8>" if two_phase else "k_render_persistent<5,8,0>", "kernel_ms": kernel_ms,
-                         "kernel_ms_note": ("HIP events around the shading launch (envidr_shade_records) on its stream" if two_phase else
-                                            "HIP events around one envidr_render_rays call on its stream: the persistent kernel plus "
-                                            "its two pre-pass kernels (k_first_hit + k_order_hits, about 0.5 ms)"),
-                         "algorithmic_flop_per_sample": FLOP_PER_SAMPLE_SHADING if two_phase else FLOP_PER_SAMPLE,
-                         "samples_per_launch": samples,
-                         "hbm_view": {"bound": "hbm", "achieved": samples * HASH_BYTES_PER_SAMPLE / (kernel_ms * 1e-3) / 1e9,
-                                      "peak": 8000.0, "unit": "GB/s"}},
+            "per_rank_ms_per_step": [float(x.item()) / args.steps * 1e3 for x in per_rank],
+            "gather_ms": gather_ms,
         }
-        if two_phase:
-            result["frame"] = {"geometry_ms": geometry_ms, "shading_ms": kernel_ms, "composite_ms": composite_ms,
-                               "whole_frame_mfma_TFLOPs": samples * FLOP_PER_SAMPLE / (dt / args.steps) / 1e12,
-                               "whole_frame_mfma_frac": samples * FLOP_PER_SAMPLE / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                               "hbm_record_bytes_per_sample": 80}
+        if stub:
+            result["config"]["workload"] = "STUB (CPU plumbing test)"
+            print(json.dumps(result))
+            if world > 1:
+                dist.destroy_process_group()
+            return
+        result["roofline"] = {
+            "bound": "mfma", "achieved": flops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": flops / PEAK_FP32_MFMA_TFLOPS,
+            "traffic": None, "kernel": "k_shade_samples<5,8>" if pipeline else "k_render_persistent<5,8,0>", "kernel_ms": kernel_ms,
+            "kernel_ms_note": ("HIP events around the shading launch (envidr_shade_records) on its stream" if pipeline else
+                               "HIP events around one envidr_render_rays call on its stream: the persistent kernel plus its two "
+                               "pre-pass kernels"),
+            "algorithmic_flop_per_sample": FLOP_PER_SAMPLE_SHADING if pipeline else FLOP_PER_SAMPLE, "samples_per_launch": samples,
+            "hbm_view": {"bound": "hbm", "achieved": samples * HASH_BYTES_PER_SAMPLE / (kernel_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS,
+                         "unit": "GB/s"}}
+        if pipeline:
+            frame_s = dt / args.steps
+            result["frame"] = {
+                "geometry_ms": geometry_ms, "shading_ms": kernel_ms, "composite_ms": composite_ms,
+                "whole_frame_mfma_TFLOPs": samples * FLOP_PER_SAMPLE / frame_s / 1e12,
+                "whole_frame_mfma_frac": samples * FLOP_PER_SAMPLE / frame_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                # the geometry pass is the HBM-side regime of the path: gathers + SDF network
+                "geometry_pass_roofline": {"hbm": {"achieved": evaluated * HASH_BYTES_PER_SAMPLE / (geometry_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS,
+                                                   "unit": "GB/s", "frac": evaluated * HASH_BYTES_PER_SAMPLE / (geometry_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS},
+                                           "mfma": {"achieved": evaluated * FLOP_PER_SAMPLE_GEOMETRY / (geometry_ms * 1e-3) / 1e12,
+                                                    "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                                    "frac": evaluated * FLOP_PER_SAMPLE_GEOMETRY / (geometry_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}},
+                "record_bytes_per_sample": 92}
         if world == 1 and not args.headline_only:
-            other_configs(result, scenes, FusedRenderer, rays_o, rays_d, dev, N)
+            other_configs(result, dev, rays_o, rays_d, N)
+        # HBM traffic of the dominant kernel from the PMC summary -- only if it was collected on THESE kernel sources
         prof = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        note = "no profiles/pmc_latest.json"
         if os.path.exists(prof):
             try:
-                result["roofline"]["traffic"] = json.load(open(prof)).get("hbm_bytes_per_launch")
-            except Exception:
-                pass
+                p = json.load(open(prof))
+                if p.get("csrc_sha") == csrc_hash():
+                    result["roofline"]["traffic"] = p.get("hbm_bytes_per_launch")
+                    note = f"profiles/pmc_latest.json ({p.get('tag', '?')}), FETCH_SIZE + WRITE_SIZE of {p.get('dominant_kernel', '?')} per launch"
+                else:
+                    note = (f"STALE: profiles/pmc_latest.json was collected on kernel sources {p.get('csrc_sha')}, these are {csrc_hash()} "
+                            "-- rerun tools/gpu_round.sh")
+                    print("bench.py: " + note, file=sys.stderr)
+            except Exception as e:      # noqa: BLE001
+                note = f"unreadable pmc_latest.json: {e}"
+        result["roofline"]["traffic_note"] = note
         if not args.no_cpu_baseline and not args.headline_only and world == 1:
-            cpu = cpu_baseline(scene, env_rot(0))
-            # PSNR of the GPU render vs the CPU reference restatement on the same sample
-            so, sd = (torch.from_numpy(a).to(dev) for a in scenes.camera_rays(CPU_SAMPLE_RES, CPU_SAMPLE_RES))
-            g = renderer.render(so, sd, env_rot(0), extras=False)["image"].cpu().numpy()
+            from envidr_amd import scenes
+            cpu = cpu_baseline(scene, env_rot(0), args.cpu_frames, args.cpu_res)
+            so, sd = (torch.from_numpy(a).to(dev) for a in scenes.camera_rays(args.cpu_res, args.cpu_res))
+            g = renderer.render_frame(so, sd, env_rot(0))["image"].cpu().numpy()
             ref = cpu.pop("image")
             mse = float(np.mean((g.astype(np.float64) - ref) ** 2))
             result["psnr_vs_cpu_reference_db"] = -10 * math.log10(max(mse, 1e-20))
@@ -212,40 +352,56 @@ def main() -> None:
         dist.destroy_process_group()
 
 
-def other_configs(result, scenes, FusedRenderer, rays_o, rays_d, dev, N) -> None:
-    """the other single-GPU BASELINE configurations on the same camera (parity-test configurations, not the headline)"""
-    # BASELINE configs[1] (no environment MLP; gather/latency-bound regime)
-    from envidr_amd.fused import FusedOptions
-    plain = FusedRenderer.from_scene(scenes.lego_scene(), FusedOptions(dir_sh_degree=4), device=dev)
-    pout: dict = {}
-    plain.render(rays_o, rays_d, None, extras=True, stats=True, out=pout)
+def _time(fn, reps: int, dev) -> float:
+    fn()
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
-    for _ in range(5):
-        plain.render(rays_o, rays_d, None, extras=True, stats=True, out=pout)
+    for _ in range(reps):
+        fn()
     torch.cuda.synchronize(dev)
-    pdt = (time.perf_counter() - t1) / 5
+    return (time.perf_counter() - t1) / reps
+
+
+def _both_rooflines(samples: int, seconds: float, flop_per_sample: int) -> dict:
+    hbm = samples * HASH_BYTES_PER_SAMPLE / seconds / 1e9
+    mfma = samples * flop_per_sample / seconds / 1e12
+    return {"hbm": {"achieved": hbm, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": hbm / PEAK_HBM_GBPS},
+            "mfma": {"achieved": mfma, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": mfma / PEAK_FP32_MFMA_TFLOPS}}
+
+
+def other_configs(result, dev, rays_o, rays_d, N) -> None:
+    """the other single-GPU BASELINE configurations on the same camera (parity-test configurations, not the headline)"""
+    from envidr_amd import scenes
+    from envidr_amd.fused import FusedOptions, FusedRenderer
+    oc = result.setdefault("other_configs", {})
+    # BASELINE configs[1] (no environment MLP; gather / latency-bound regime)
+    plain = FusedRenderer.from_scene(scenes.lego_scene(), FusedOptions(dir_sh_degree=4), device=dev)
+    pout: dict = {}
+    pdt = _time(lambda: plain.render(rays_o, rays_d, None, extras=True, stats=True, out=pout), 5, dev)
     psamples = int(pout["stats"][0].item())
-    result["other_configs"] = {"configs[1] hash-grid SDF + diffuse/specular MLPs (SH view dir, no env MLP), 800x800, 1 GPU": {
-        "rays_per_s": N / pdt, "ms_per_frame": pdt * 1e3, "samples_per_s": psamples / pdt,
-        "hbm_algorithmic_GBps": psamples * HASH_BYTES_PER_SAMPLE / pdt / 1e9,
-        "mfma_algorithmic_TFLOPs": psamples * 41_984 / pdt / 1e12}}
-    # the same headline frames through the single persistent kernel (the default of the drop-in renderer)
+    oc["configs[1] hash-grid SDF + diffuse/specular MLPs (SH view dir, no env MLP), 800x800, 1 GPU"] = {
+        "rays_per_s": N / pdt, "ms_per_frame": pdt * 1e3, "samples_per_s": psamples / pdt, "samples_per_frame": psamples,
+        "roofline": _both_rooflines(psamples, pdt, FLOP_PER_SAMPLE_PLAIN)}
+    # the headline frames through the single persistent kernel (envidr_render_rays)
     one = FusedRenderer.from_scene(scenes.toaster_scene(), device=dev)
     oout: dict = {}
     ocost = torch.zeros(N, dtype=torch.int16, device=dev)
-    for i in range(2):
-        one.render(rays_o, rays_d, 0.1 * i, extras=True, out=oout, ray_cost=ocost)
-    torch.cuda.synchronize(dev)
-    t1 = time.perf_counter()
-    for i in range(5):
-        one.render(rays_o, rays_d, 2 * math.pi * i / 200, extras=True, out=oout, ray_cost=ocost)
-    torch.cuda.synchronize(dev)
-    odt = (time.perf_counter() - t1) / 5
-    result.setdefault("other_configs", {})["headline workload as ONE persistent kernel per frame (envidr_render_rays), 800x800, 1 GPU"] = {
-        "rays_per_s": N / odt, "ms_per_frame": odt * 1e3}
-    # BASELINE configs[4] with the geometry cache (SURVEY.md 8f-4; NOT the headline, where every frame marches and shades
-    # from scratch): fixed camera, rotating environment: geometry once, then shading + compositing per frame
+    k = [0]
+
+    def one_frame():
+        one.render(rays_o, rays_d, 2 * math.pi * k[0] / 200, extras=True, out=oout, ray_cost=ocost)
+        k[0] += 1
+    odt = _time(one_frame, 5, dev)
+    oc["headline workload as ONE persistent kernel per frame (envidr_render_rays), 800x800, 1 GPU"] = {"rays_per_s": N / odt, "ms_per_frame": odt * 1e3}
+    # the relight variant of SURVEY 8d: IDE degree 4, env hidden 160 (shape of the shipped env_net_3.pth), kernel <4,5>
+    relight = FusedRenderer.from_scene(scenes.toaster_scene(hidden_env=160, ide_deg=4), FusedOptions(ide_degree=4), device=dev)
+    rout: dict = {}
+    rdt = _time(lambda: relight.render_frame(rays_o, rays_d, 0.3, out=rout, wait=False), 5, dev)
+    relight.check_frames()
+    rs = int(relight._frame["last"][1])
+    oc["configs[2] relight variant: IDE deg 4 + env MLP 38-160-160-160-12 x2 (shape of the shipped env nets), 800x800, 1 GPU"] = {
+        "rays_per_s": N / rdt, "ms_per_frame": rdt * 1e3, "samples_per_frame": rs, "roofline": _both_rooflines(rs, rdt, FLOP_PER_SAMPLE_RELIGHT)}
+    # BASELINE configs[4] with the geometry cache (SURVEY.md 8f-4; NOT the headline): fixed camera, rotating environment
     headline = FusedRenderer.from_scene(scenes.toaster_scene(), device=dev)
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
@@ -253,32 +409,32 @@ def other_configs(result, scenes, FusedRenderer, rays_o, rays_d, dev, N) -> None
     torch.cuda.synchronize(dev)
     build_ms = (time.perf_counter() - t1) * 1e3
     cout: dict = {}
-    headline.render_cached(cache, 0.1, out=cout)
-    torch.cuda.synchronize(dev)
-    t1 = time.perf_counter()
-    for i in range(5):
-        headline.render_cached(cache, 2 * math.pi * i / 200, out=cout)
-    torch.cuda.synchronize(dev)
-    cdt = (time.perf_counter() - t1) / 5
-    result["other_configs"]["configs[4] env-rotation video of a FIXED camera with the geometry cache (bit-identical frames), 800x800, 1 GPU"] = {
+    cdt = _time(lambda: headline.render_cached(cache, 0.1, out=cout), 5, dev)
+    oc["configs[4] env-rotation video of a FIXED camera with the geometry cache (bit-identical frames), 800x800, 1 GPU"] = {
         "rays_per_s": N / cdt, "ms_per_frame": cdt * 1e3, "cache_build_ms": build_ms, "cached_samples": cache.n_samples}
-    # BASELINE configs[3]: use_renv + indir_ref, three fused passes per frame (geometry -> reflected rays -> main pass
-    # with reflected radiance) through the NeRFRenderer.render() drop-in surface, concave (torus) scene
+    # BASELINE configs[3]: use_renv + indir_ref, three passes per frame through the NeRFRenderer.render() drop-in surface
     from envidr_amd.nerf.network import NeRFNetwork
     from envidr_amd.nerf.options import toaster_options
     iopt = toaster_options(indir_ref=True)
     imodel = NeRFNetwork.from_scene(scenes.toaster_scene(shape=scenes.torus(), seed=3), iopt, device=dev)
     ikw = dict(staged=True, bg_color=1, perturb=False, get_normal_image=True, max_steps=iopt.max_steps, T_thresh=iopt.T_thresh,
                dt_gamma=iopt.dt_gamma)
-    imodel.render(rays_o[None], rays_d[None], **ikw)
-    torch.cuda.synchronize(dev)
-    t1 = time.perf_counter()
-    for _ in range(3):
-        imodel.render(rays_o[None], rays_d[None], **ikw)
-    torch.cuda.synchronize(dev)
-    idt = (time.perf_counter() - t1) / 3
-    result["other_configs"]["configs[3] toaster network + use_renv + indir_ref (3 passes per frame), torus scene, 800x800, 1 GPU"] = {
-        "primary_rays_per_s": N / idt, "ms_per_frame": idt * 1e3}
+    idt = _time(lambda: imodel.render(rays_o[None], rays_d[None], **ikw), 3, dev)
+    direct = NeRFNetwork.from_scene(scenes.toaster_scene(shape=scenes.torus(), seed=3), toaster_options(indir_ref=False), device=dev)
+    ddt = _time(lambda: direct.render(rays_o[None], rays_d[None], **ikw), 3, dev)
+    oc["configs[3] toaster network + use_renv + indir_ref (3 passes per frame), torus scene, 800x800, 1 GPU"] = {
+        "primary_rays_per_s": N / idt, "ms_per_frame": idt * 1e3, "direct_frame_of_the_same_scene_ms": ddt * 1e3, "ratio_to_direct": idt / ddt}
+
+
+def main() -> None:
+    args = parse(sys.argv[1:])
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the driver's command line (`python bench.py --gpus N ...`) works by itself: start the N ranks here
+        import torch.multiprocessing as mp
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        mp.spawn(_spawned, args=(args.gpus, _free_port(), sys.argv[1:]), nprocs=args.gpus, join=True)
+        return
+    run(sys.argv[1:])
 
 
 if __name__ == "__main__":

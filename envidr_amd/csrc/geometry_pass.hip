@@ -98,6 +98,9 @@ constexpr int kGeoRing = ENVIDR_GEO_RING;
 #ifndef ENVIDR_GEO_NT_FROM
 #define ENVIDR_GEO_NT_FROM 99     // hash levels >= this are gathered with the non-temporal hint
 #endif
+#ifndef ENVIDR_GEO_PREFETCH
+#define ENVIDR_GEO_PREFETCH 0     // 1: the first AHEAD levels of the next batch are gathered before the matrix-core section of this one
+#endif
 #ifndef ENVIDR_GEO_UNROLL_GROUPS
 #define ENVIDR_GEO_UNROLL_GROUPS 0
 #endif
@@ -223,33 +226,49 @@ __global__ void __launch_bounds__(kEvalThreads, (kEvalWaves + 3) / 4) k_geo_eval
     const __amdgpu_buffer_rsrc_t table = table_rsrc(a.table, a.table_bytes);
     const uint32_t stride = per_xcd_blocks * kEvalWaves;
 
-    for (uint32_t b = b_lo + in_xcd * kEvalWaves + wave; b < b_hi; b += stride) {
-        const uint32_t sidx = b * 64u + lane;
-        const bool on = sidx < count;
-        const size_t slot = (size_t)begin + (on ? sidx : 0u);
-        float xc[3];
-        bool inside;
-        {
-            typedef float f32x3 __attribute__((ext_vector_type(3)));
-            f32x3 pv = {0.0f, 0.0f, 0.0f};
-            if (on) pv = *reinterpret_cast<const f32x3*>(a.xyz + 3 * slot);       // one 12-byte load
-            const float px = pv[0], py = pv[1], pz = pv[2];
-            // (xyz + bound) / (2 bound)  -- hashencoder/hashgrid.py:161; outside the unit cube every level contributes zeros
-            // (hashencoder.cu:124-149): evaluate at a clamped position and mask, which keeps the gathers in bounds
-            const float x01[3] = {(px + a.bound) / a.bound2, (py + a.bound) / a.bound2, (pz + a.bound) / a.bound2};
-            inside = x01[0] >= 0 && x01[0] <= 1 && x01[1] >= 0 && x01[1] <= 1 && x01[2] >= 0 && x01[2] <= 1;
+    struct Sample { float xc[3]; size_t slot; bool inside, on; };
+    auto load_sample = [&](uint32_t bb) {
+        Sample sm;
+        const uint32_t sidx = bb * 64u + lane;
+        sm.on = sidx < count;
+        sm.slot = (size_t)begin + (sm.on ? sidx : 0u);
+        typedef float f32x3 __attribute__((ext_vector_type(3)));
+        f32x3 pv = {0.0f, 0.0f, 0.0f};
+        if (sm.on) pv = *reinterpret_cast<const f32x3*>(a.xyz + 3 * sm.slot);       // one 12-byte load
+        // (xyz + bound) / (2 bound)  -- hashencoder/hashgrid.py:161; outside the unit cube every level contributes zeros
+        // (hashencoder.cu:124-149): evaluate at a clamped position and mask, which keeps the gathers in bounds
+        const float x01[3] = {(pv[0] + a.bound) / a.bound2, (pv[1] + a.bound) / a.bound2, (pv[2] + a.bound) / a.bound2};
+        sm.inside = x01[0] >= 0 && x01[0] <= 1 && x01[1] >= 0 && x01[1] <= 1 && x01[2] >= 0 && x01[2] <= 1;
 #pragma unroll
-            for (int d = 0; d < 3; ++d) xc[d] = inside ? x01[d] : 0.5f;
-        }
+        for (int d = 0; d < 3; ++d) sm.xc[d] = sm.inside ? x01[d] : 0.5f;
+        return sm;
+    };
+    LeanStage st[kAhead + 1];
+    auto prime = [&](const Sample& sm) {
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            (lean_prepare<(I >= ENVIDR_GEO_NT_FROM ? 2 : 0)>(a.lv[I], table, sm.xc, st[I]), ...);
+        }(std::make_integer_sequence<int, kAhead>{});
+    };
+    uint32_t b = b_lo + in_xcd * kEvalWaves + wave;
+    Sample nxt = {};
+#if ENVIDR_GEO_PREFETCH
+    if (b < b_hi) { nxt = load_sample(b); prime(nxt); }
+#endif
+    for (; b < b_hi; b += stride) {
+#if ENVIDR_GEO_PREFETCH
+        const Sample cur = nxt;
+#else
+        const Sample cur = load_sample(b);
+        prime(cur);
+#endif
+        const bool on = cur.on, inside = cur.inside;
+        const size_t slot = cur.slot;
+        const float xc[3] = {cur.xc[0], cur.xc[1], cur.xc[2]};
 
         // ================= phase 1: hash grid values (+ Jacobian -> parking slab) ============================
         float feat[ENVIDR_GEO_IOMODE == 0 ? 1 : 2 * kLevels];
         (void)feat;
         {
-            LeanStage st[kAhead + 1];
-            [&]<int... I>(std::integer_sequence<int, I...>) {
-                (lean_prepare<(I >= ENVIDR_GEO_NT_FROM ? 2 : 0)>(a.lv[I], table, xc, st[I]), ...);
-            }(std::make_integer_sequence<int, kAhead>{});
             __builtin_amdgcn_sched_barrier(0);
             auto level = [&](auto lc, LeanStage& now, LeanStage& ahead) {
                 constexpr int l = decltype(lc)::value;
@@ -283,6 +302,11 @@ __global__ void __launch_bounds__(kEvalThreads, (kEvalWaves + 3) / 4) k_geo_eval
             }(std::make_integer_sequence<int, kLevels>{});
         }
         wave_lds_sync();
+#if ENVIDR_GEO_PREFETCH
+        // every stage is free again: the next batch's first levels go out now and land under the matrix-core section
+        if (b + stride < b_hi) { nxt = load_sample(b + stride); prime(nxt); }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 
         // ================= phase 2: SDF network forward + input gradient (matrix cores) ===================
         // 32 samples ("group") at a time; activations stay in accumulator tiles between layers (mlp_mfma.hip.h); results

@@ -509,36 +509,45 @@ class FusedRenderer:
         return out
 
     def _frame_buffers(self, N: int, dev, samples_per_ray: float) -> dict:
-        st = self.__dict__.setdefault("_frame", {})
+        """workspace, record arrays, per-ray count hint and status words of the frames with N rays (a few ray counts are
+        kept: the three passes of indirect rendering alternate between theirs)"""
+        frames = self.__dict__.setdefault("_frames", {})
+        st = frames.get(N)
         cap = max(int(N * samples_per_ray), 4096)
-        if st.get("N") != N or st.get("cap", 0) < cap:
+        if st is None or st["cap"] < cap:
+            if st is None and len(frames) >= 4:
+                frames.pop(next(iter(frames)))
             need = int(self.lib.envidr_geometry_workspace_bytes(N, cap))
-            st.clear()
-            st.update(N=N, cap=cap, ws=torch.empty(need, dtype=torch.uint8, device=dev), counter=torch.zeros(1, dtype=torch.int32, device=dev),
+            st = dict(N=N, cap=cap, ws=torch.empty(need, dtype=torch.uint8, device=dev), counter=torch.zeros(1, dtype=torch.int32, device=dev),
                       ray=torch.empty(cap, dtype=torch.int32, device=dev), idx=torch.empty(cap, dtype=torch.int32, device=dev),
                       w=torch.empty(cap, device=dev), slot=torch.empty(cap, dtype=torch.int32, device=dev),
                       perm=torch.empty(cap, dtype=torch.int32, device=dev), cd=torch.empty(cap, 3, device=dev), cs=torch.empty(cap, 3, device=dev),
                       cost=torch.zeros(N, dtype=torch.int16, device=dev), offsets=torch.zeros(N + 1, dtype=torch.int32, device=dev),
                       stats=torch.zeros(3, dtype=torch.int64, device=dev), host=torch.zeros(3, dtype=torch.int64).pin_memory(),
-                      event=torch.cuda.Event(), pending=False)
+                      event=torch.cuda.Event(), pending=False, hint=samples_per_ray)
+            frames[N] = st
+        self.__dict__["_frame"] = st
         return st
 
     def check_frames(self) -> None:
-        """Frames are enqueued without waiting for the device.  This looks at the status words of the last one (they were
-        copied to pinned memory behind it) and raises if it did not fit its buffers -- which are then grown, so that redoing
-        the frame succeeds.  Called at the start of every frame and by anyone who needs the answer now."""
-        st = self.__dict__.get("_frame")
-        if not st or not st["pending"]:
-            return
-        st["event"].synchronize()
-        st["pending"] = False
-        samples, records, overflow = (int(v) for v in st["host"])
-        st["last"] = (samples, records)
-        if overflow:
-            N = st["N"]
-            self.__dict__["_frame_hint"] = max(2.0 * st["cap"] / N, 1.5 * max(samples, records) / N)
-            self.__dict__["_frame"] = {}
-            raise FrameOverflow(f"the frame needed more than the {st['cap']} sample / record slots it was given; buffers were grown, render it again")
+        """Frames are enqueued without waiting for the device.  This looks at the status words of the frames not looked at
+        yet (they were copied to pinned memory behind each frame) and raises FrameOverflow if one did not fit its buffers --
+        which are then dropped, so that redoing the frame allocates larger ones.  Called at the start of every frame and by
+        anyone who needs the answer now."""
+        overflowed = None
+        for N, st in list(self.__dict__.get("_frames", {}).items()):
+            if not st["pending"]:
+                continue
+            st["event"].synchronize()
+            st["pending"] = False
+            samples, records, overflow = (int(v) for v in st["host"])
+            st["last"] = (samples, records)
+            if overflow:
+                self.__dict__.setdefault("_frame_hints", {})[N] = max(2.0 * st["cap"] / N, 1.5 * max(samples, records) / N)
+                del self.__dict__["_frames"][N]
+                overflowed = st["cap"]
+        if overflowed is not None:
+            raise FrameOverflow(f"a frame needed more than the {overflowed} sample / record slots it was given; its buffers were dropped, render it again")
 
     def render_frame(self, rays_o: torch.Tensor, rays_d: torch.Tensor, env_rot_radian: float | None = None, out: dict | None = None,
                      samples_per_ray_hint: float = 20.0, events: list | None = None, geometry_only: bool = False, wait: bool = True,
@@ -555,7 +564,7 @@ class FusedRenderer:
         N, dev = rays_o.shape[0], rays_o.device
         res = out if out is not None else {}
         for attempt in range(3):
-            st = self._frame_buffers(N, dev, max(samples_per_ray_hint, self.__dict__.get("_frame_hint", 0.0)))
+            st = self._frame_buffers(N, dev, max(samples_per_ray_hint, self.__dict__.get("_frame_hints", {}).get(N, 0.0)))
             cap = st["cap"]
             stream = torch.cuda.current_stream(dev).cuda_stream
             for name, shape in (("depth", (N,)), ("weights_sum", (N,)), ("normal_image", (N, 3)), ("roughness_image", (N,))):

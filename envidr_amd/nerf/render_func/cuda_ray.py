@@ -1,8 +1,9 @@
 """`run_cuda`, inference branch: the reference's march -> shade -> composite -> compact loop
 (nerf/render_func/cuda_ray.py:238-359) in two forms.
 
-  * fused (default when the model supports it): ONE persistent-kernel launch for the whole ray batch
-    (envidr_amd.fused.FusedRenderer -> envidr_render_rays);
+  * fused (default when the model supports it): the geometry pipeline + record shading (envidr_amd.fused.FusedRenderer
+    .render_frame -> envidr_geometry_pass / envidr_shade_records / envidr_composite_records), or ONE persistent-kernel
+    launch for the whole ray batch (envidr_render_rays);
   * operator loop: the reference's loop structure on the HIP operators (`raymarching.march_rays`,
     model.forward_sigma / forward_color on HIP encoders + torch GEMMs, `raymarching.composite_rays`),
     with the boolean-mask compaction replaced by the device-side `compact_alive` (one 4-byte readback
@@ -49,20 +50,21 @@ def run_cuda(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, fo
         fr = self.fused_renderer()
         fr.desc.bg_color = float(bg_color)
         fr.desc.min_near = float(self.min_near)
-        # scheduling hint: per-ray sample counts of the previous render with this many rays (the frames of a video share
-        # their rays; for other rays it is merely a poor hint -- outputs never depend on it)
-        hints = self.__dict__.setdefault("_ray_cost_hints", {})
-        key = (N, bool(geometry_only), r_images is not None)
-        if key not in hints or hints[key].device != device:
-            if len(hints) > 8:
-                hints.clear()
-            hints[key] = torch.zeros(N, dtype=torch.int16, device=device)
-        # large batches of the environment-MLP family are scheduled as geometry pass + shading pass (same bits, ~5 % faster)
-        if two_phase is None:
-            two_phase = N >= 200_000
-        if two_phase and not geometry_only and r_images is None and self.use_env_net:
-            res = fr.render_two_phase(rays_o, rays_d, env_rot_radian, ray_cost=hints[key])
+        # Frames of the environment-MLP family without reflected radiance run on the geometry pipeline (march rounds +
+        # sample-parallel hash / SDF kernel -> record shading -> composite; FusedRenderer.render_frame): it keeps, per batch
+        # size, the per-ray sample counts of the previous render as a sizing hint (video frames share their rays; outputs
+        # never depend on it).  `two_phase=False` asks for the single persistent kernel instead (envidr_render_rays), which
+        # is also what the reflected-radiance pass and the no-environment family still use.
+        pipeline = (two_phase is not False) and r_images is None and self.use_env_net
+        if pipeline:
+            res = fr.render_frame(rays_o, rays_d, env_rot_radian, geometry_only=geometry_only)
         else:
+            hints = self.__dict__.setdefault("_ray_cost_hints", {})
+            key = (N, bool(geometry_only), r_images is not None)
+            if key not in hints or hints[key].device != device:
+                if len(hints) > 8:
+                    hints.clear()
+                hints[key] = torch.zeros(N, dtype=torch.int16, device=device)
             res = fr.render(rays_o, rays_d, env_rot_radian, extras=True, geometry_only=geometry_only,
                             r_images=None if r_images is None else r_images[0], ray_cost=hints[key])
         out = {"image": res["image"].view(*prefix, 3), "depth": res["depth"].view(*prefix), "weights_sum": res["weights_sum"].view(*prefix)}

@@ -1,0 +1,36 @@
+"""bench.py's multi-rank plumbing on CPU: `python bench.py --gpus 2 --stub` must start its two ranks by itself (no torchrun),
+partition the views, gather every frame to rank 0 and print ONE JSON line (gloo; a stand-in renderer)."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _run(args, env_extra=None):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_self_launch_two_ranks():
+    j = _run(["--gpus", "2", "--steps", "3", "--warmup", "2", "--stub"])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 2
+    assert len(j["per_rank_ms_per_step"]) == 2 and j["scaling"] == "weak" and j["higher_is_better"] is True
+    assert j["value"] > 0 and j["config"]["rays_per_step_per_gpu"] == 256
+
+
+def test_single_rank_and_torchrun_style_environment():
+    j = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--stub"])
+    assert j["n_gpus"] == 1 and len(j["per_rank_ms_per_step"]) == 1
+    # a rank launched by torch.distributed.run (environment already set) does not spawn again
+    j = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--stub"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert j["n_gpus"] == 1

@@ -126,12 +126,13 @@ def test_frame_that_does_not_fit_is_redone(renderer):
     import torch
     ro_, rd_ = (torch.from_numpy(a).cuda() for a in scenes.camera_rays(96, 96))
     want = {k: v.clone() for k, v in renderer.render_frame(ro_, rd_, None).items() if hasattr(v, "clone")}
-    renderer.__dict__.pop("_frame", None); renderer.__dict__.pop("_frame_hint", None)
+    renderer.__dict__.pop("_frames", None); renderer.__dict__.pop("_frame_hints", None)
     got = renderer.render_frame(ro_, rd_, None, samples_per_ray_hint=0.5)           # far too small: grown and redone inside
     torch.cuda.synchronize()
     for key in ("image", "depth", "weights_sum", "normal_image"):
         assert torch.equal(got[key], want[key]), key
-    renderer.__dict__.pop("_frame", None); renderer.__dict__.pop("_frame_hint", None)
+    assert renderer._frame["cap"] > 0.5 * 96 * 96
+    renderer.__dict__.pop("_frames", None); renderer.__dict__.pop("_frame_hints", None)
 
 
 def test_frame_edge_cases(renderer):

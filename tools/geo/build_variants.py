@@ -6,18 +6,12 @@ ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 from envidr_amd import build as B
 
-W4 = ["-DENVIDR_GEO_WAVES=4", "-DENVIDR_GEO_JMODE=2", "-DENVIDR_GEO_IOMODE=1"]
 VARIANTS = {
-    "w4_a2": W4 + ["-DENVIDR_GEO_AHEAD=2"],
-    "w4_a4": W4 + ["-DENVIDR_GEO_AHEAD=4"],
-    "w4_a6": W4 + ["-DENVIDR_GEO_AHEAD=6"],
-    "w4_a8": W4 + ["-DENVIDR_GEO_AHEAD=8"],
-    "w4_a6_unroll": W4 + ["-DENVIDR_GEO_AHEAD=6", "-DENVIDR_GEO_UNROLL_GROUPS=1"],
-    "w4_a6_nt12": W4 + ["-DENVIDR_GEO_AHEAD=6", "-DENVIDR_GEO_NT_FROM=12"],
-    "w4_a6_nt9": W4 + ["-DENVIDR_GEO_AHEAD=6", "-DENVIDR_GEO_NT_FROM=9"],
-    "w4_a6_noxcd": W4 + ["-DENVIDR_GEO_AHEAD=6", "-DENVIDR_GEO_XCD=0"],
-    "w8_j0_nt12": ["-DENVIDR_GEO_JMODE=0", "-DENVIDR_GEO_IOMODE=0", "-DENVIDR_GEO_NT_FROM=12"],
-    "w8_j1_nt9": ["-DENVIDR_GEO_JMODE=1", "-DENVIDR_GEO_IOMODE=0", "-DENVIDR_GEO_NT_FROM=9"],
+    "base": [],
+    "pf_a2": ["-DENVIDR_GEO_PREFETCH=1", "-DENVIDR_GEO_AHEAD=2"],
+    "pf_a4": ["-DENVIDR_GEO_PREFETCH=1", "-DENVIDR_GEO_AHEAD=4"],
+    "pf_a6": ["-DENVIDR_GEO_PREFETCH=1", "-DENVIDR_GEO_AHEAD=6"],
+    "pf_a8": ["-DENVIDR_GEO_PREFETCH=1", "-DENVIDR_GEO_AHEAD=8"],
 }
 
 def main(names):

@@ -7,10 +7,10 @@ TAG=${1:-r01}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 if [ "$2" != "quick" ]; then
-  timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
+  timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/smoke.log
 fi
-timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" >> $OUT/bench.err
+timeout 1500 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" >> $OUT/bench.err
 # kernel trace + stats of the same command (CPU leg skipped: it launches no kernels)
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --headline-only > $OUT/trace.log 2>&1 )
 # PMC passes, each on its own (no trace domains mixed in)
@@ -31,7 +31,7 @@ per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         name = row.get("Kernel_Name", "")
-        for key in ("shade_samples", "render_persistent", "first_hit", "order_hits", "place_records", "composite_records"):
+        for key in ("shade_samples", "render_persistent", "geo_eval", "geo_rays<true>", "geo_rays<false>", "first_hit", "order_hits", "place_records", "composite_records"):
             if key in name:
                 per_kernel[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
 summary["pmc_per_launch_mean_by_kernel"] = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in per_kernel.items()}
@@ -47,6 +47,11 @@ if "FETCH_SIZE" in p and "WRITE_SIZE" in p:
     # random reads, so both the raw and the doubled figure are kept.
     summary["hbm_bytes_per_launch"] = (p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024
     summary["hbm_bytes_per_launch_fetch_doubled"] = (2 * p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024
+import sys
+sys.path.insert(0, ".")
+import bench
+summary["csrc_sha"] = bench.csrc_hash()       # bench.py reports roofline.traffic only from a summary collected on the same kernel sources
+summary["tag"] = "$TAG"
 json.dump(summary, open(out + "/summary.json", "w"), indent=1)
 print(json.dumps(summary, indent=1)[:3000])
 PY
