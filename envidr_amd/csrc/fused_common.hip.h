@@ -21,17 +21,25 @@ struct HashLevelK {
     uint32_t hashed, andmask, enabled, slow_mod;
 };
 
-// slab test, identical arithmetic to k_near_far_from_aabb (raymarching.hip)
-__device__ __forceinline__ void near_far(const RayGeom& r, float bound, float min_near, float& near, float& far) {
-    near = (-bound - r.ox) * r.rdx; far = (bound - r.ox) * r.rdx;
+// slab test, identical arithmetic to k_near_far_from_aabb (raymarching.hip; reference raymarching.cu:91-145).
+// aabb = {xmin, ymin, zmin, xmax, ymax, zmax}: the model's aabb_infer, which a tightened marching box or a checkpoint may
+// make smaller than [-bound, bound]^3 (the marcher itself still clamps positions to the cube of half extent `bound`).
+struct Aabb { float lo[3], hi[3]; };
+__host__ __device__ inline Aabb make_aabb(const envidr_render_desc* d) {
+    Aabb b;
+    for (int i = 0; i < 3; ++i) { b.lo[i] = d->has_aabb ? d->aabb[i] : -d->bound; b.hi[i] = d->has_aabb ? d->aabb[3 + i] : d->bound; }
+    return b;
+}
+__device__ __forceinline__ void near_far(const RayGeom& r, const Aabb& box, float min_near, float& near, float& far) {
+    near = (box.lo[0] - r.ox) * r.rdx; far = (box.hi[0] - r.ox) * r.rdx;
     if (near > far) { const float c = near; near = far; far = c; }
-    float ny = (-bound - r.oy) * r.rdy, fy = (bound - r.oy) * r.rdy;
+    float ny = (box.lo[1] - r.oy) * r.rdy, fy = (box.hi[1] - r.oy) * r.rdy;
     if (ny > fy) { const float c = ny; ny = fy; fy = c; }
     bool miss = near > fy || ny > far;
     if (!miss) {
         if (ny > near) near = ny;
         if (fy < far) far = fy;
-        float nz = (-bound - r.oz) * r.rdz, fz = (bound - r.oz) * r.rdz;
+        float nz = (box.lo[2] - r.oz) * r.rdz, fz = (box.hi[2] - r.oz) * r.rdz;
         if (nz > fz) { const float c = nz; nz = fz; fz = c; }
         miss = near > fz || nz > far;
         if (!miss) {

@@ -45,6 +45,7 @@ struct RenderArgs {
     const float* rays_d;
     uint32_t N;
     MarchConsts mk;
+    Aabb box;
     float min_near, T_thresh, density_scale, bg;
     uint32_t max_samples;
     // hash grid
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(kBlock) k_first_hit(const RenderArgs a, uint32
     if (id < a.N) {
         const RayGeom rg = load_ray(a.rays_o, a.rays_d, id);
         float near, far, x, y, z, dt, t_at = 0;
-        near_far(rg, a.mk.bound, a.min_near, near, far);
+        near_far(rg, a.box, a.min_near, near, far);
         float t = near;
         hit = march_next(a.mk, rg, far, t, x, y, z, dt, &t_at);
         if (hit) {
@@ -503,7 +504,7 @@ __global__ void __launch_bounds__(kBlockThreads, (SH_DEG > 0 ? kPlainWaves : 1))
                         for (int j = 0; j < 4; ++j) rimg[j] = a.r_images[4 * (size_t)id + j];
                     }
                     float near;
-                    near_far(rg, a.mk.bound, a.min_near, near, far);
+                    near_far(rg, a.box, a.min_near, near, far);
                     t_ray = near;
                     t_resume = a.hit_t[id];
                     n_taken = 0;
@@ -1081,6 +1082,7 @@ int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const f
     memset(&a, 0, sizeof(a));
     a.rays_o = rays_o; a.rays_d = rays_d; a.N = N;
     a.mk = make_march_consts(d->bound, d->dt_gamma, d->max_steps, d->cascades, d->grid_size, d->density_bitfield);
+    a.box = make_aabb(d);
     a.min_near = d->min_near; a.T_thresh = d->T_thresh; a.density_scale = d->density_scale; a.bg = d->bg_color;
     a.max_samples = d->max_steps;
     a.table = d->hash_table;

@@ -523,7 +523,8 @@ struct GeoRayArgs {
     const float* rays_o; const float* rays_d;
     uint32_t N;
     MarchConsts mk;
-    float bound, min_near, T_thresh;
+    Aabb box;
+    float min_near, T_thresh;
     uint32_t max_samples;
     uint32_t chunk;            // samples to march this round; 0: only composite (last round)
     uint32_t round;
@@ -579,7 +580,7 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
         bool finish = false;         // write the ray's outputs now
         if (active) {
             rg = load_ray(a.rays_o, a.rays_d, ray);
-            near_far(rg, a.bound, a.min_near, near, far);
+            near_far(rg, a.box, a.min_near, near, far);
         }
         if constexpr (FIRST) {
             if (active) {
@@ -820,7 +821,7 @@ int envidr_geometry_pass(const envidr_render_desc* d, const float* rays_o, const
     memset(&a, 0, sizeof(a));
     a.rays_o = rays_o; a.rays_d = rays_d; a.N = N;
     a.mk = make_march_consts(d->bound, d->dt_gamma, d->max_steps, d->cascades, d->grid_size, d->density_bitfield);
-    a.bound = d->bound; a.min_near = d->min_near; a.T_thresh = d->T_thresh; a.max_samples = d->max_steps;
+    a.box = make_aabb(d); a.min_near = d->min_near; a.T_thresh = d->T_thresh; a.max_samples = d->max_steps;
     a.counters = counters;
     a.state = reinterpret_cast<RayState*>(ws + L.state);
     a.xyz = const_cast<float*>(e.xyz); a.dt = const_cast<float*>(e.dt); a.dd = reinterpret_cast<float*>(ws + L.dd);

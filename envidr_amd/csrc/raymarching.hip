@@ -6,6 +6,10 @@
 // runs the very same code.
 #include "march_core.hip.h"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include <float.h>
 
 using namespace envidr;
@@ -471,19 +475,28 @@ int envidr_compact_alive(uint32_t n_alive, const int32_t* rays_alive, int32_t* o
         return ENVIDR_OK;
     }
     ENVIDR_REQUIRE(rays_alive && out_alive, "compact_alive: null pointer");
-    // look-back scratch: one 8-byte slot per workgroup + a ticket, kept in a per-library buffer
-    // that grows monotonically (allocation only on growth, never in steady state).
-    static void* scratch = nullptr;
-    static size_t scratch_bytes = 0;
+    // look-back scratch: one 8-byte slot per workgroup + a ticket.  One buffer per (device, stream), grown on demand and
+    // kept: launches on different streams or devices never share ticket / prefix slots (the kernel spins on them).
+    struct Scratch { void* ptr; size_t bytes; };
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Scratch> pool;
     const uint32_t blocks = ceil_div(n_alive, kBlock);
     const size_t need = (size_t)blocks * sizeof(unsigned long long) + 16;
-    if (need > scratch_bytes) {
-        if (scratch) (void)hipFree(scratch);
-        scratch_bytes = need * 2;
-        if (hipMalloc(&scratch, scratch_bytes) != hipSuccess) {
-            scratch = nullptr; scratch_bytes = 0;
-            return check_launch("compact_alive scratch alloc");
+    void* scratch = nullptr;
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lock(mu);
+        Scratch& sc = pool[{dev, s}];
+        if (need > sc.bytes) {
+            if (sc.ptr) (void)hipFree(sc.ptr);
+            sc.bytes = need * 2;
+            if (hipMalloc(&sc.ptr, sc.bytes) != hipSuccess) {
+                sc.ptr = nullptr; sc.bytes = 0;
+                return check_launch("compact_alive scratch alloc");
+            }
         }
+        scratch = sc.ptr;
     }
     if (hipMemsetAsync(scratch, 0, need, s) != hipSuccess) return check_launch("compact_alive memset");
     int32_t* ticket = reinterpret_cast<int32_t*>(scratch);

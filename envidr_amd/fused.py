@@ -49,6 +49,7 @@ class RenderDesc(ctypes.Structure):
         ("geometry_only", ctypes.c_int32), ("r_images", _FP), ("renv_blob", _FP), ("spec2_blob", _FP),
         ("indir_roughness_thresh", ctypes.c_float), ("geometry_export", ctypes.POINTER(GeometryExport)),
         ("ray_cost", _FP), ("scratch", _FP), ("scratch_bytes", ctypes.c_uint64),
+        ("has_aabb", ctypes.c_int32), ("aabb", ctypes.c_float * 6),
     ]
 
 
@@ -374,6 +375,18 @@ class FusedRenderer:
         """scene: envidr_amd.scenes.SceneParams"""
         opt = opt or FusedOptions(bound=scene.bound, grid_size=scene.grid_size)
         return cls(scene.bitfield, scene.table, scene.offsets, scene.per_level_scale, scene.mlps, scene.beta, opt, device)
+
+    def set_aabb(self, aabb) -> None:
+        """the box rays are intersected with (NeRFRenderer.aabb_infer); None = [-bound, bound]^3"""
+        if aabb is None:
+            self.desc.has_aabb = 0
+            return
+        vals = [float(v) for v in (aabb.detach().cpu().reshape(-1).tolist() if isinstance(aabb, torch.Tensor) else np.asarray(aabb).reshape(-1))]
+        if len(vals) != 6:
+            raise _lib.EnvidrError("aabb must have six values: xmin, ymin, zmin, xmax, ymax, zmax")
+        for i, v in enumerate(vals):
+            self.desc.aabb[i] = v
+        self.desc.has_aabb = 1
 
     def set_env_rotation(self, radian: float | None) -> None:
         """w_r and the diffuse normal are multiplied by rot_theta(radian)[:3,:3] (renderer.py:160-172)."""

@@ -31,8 +31,10 @@ class _HashEncode(Function):
         inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
         B, D, C, L, S, H = ctx.dims
         grad = grad.view(B, L, C).permute(1, 0, 2).contiguous()
+        # whether the table gradient is wanted is known HERE (needs_input_grad); inside _HashEncodeBackward.forward grad
+        # mode is always off, so asking torch.is_grad_enabled() there would never produce it
         grad_inputs, grad_embeddings = _HashEncodeBackward.apply(grad, inputs, embeddings, offsets, B, D, C, L, S, H,
-                                                                 ctx.calc_grad_inputs, dy_dx)
+                                                                 ctx.calc_grad_inputs, dy_dx, bool(ctx.needs_input_grad[1]))
         return (grad_inputs if ctx.calc_grad_inputs else None), grad_embeddings, None, None, None, None
 
 
@@ -40,11 +42,10 @@ class _HashEncodeBackward(Function):
     """first backward as a Function so that autograd can differentiate it again (eikonal loss)"""
 
     @staticmethod
-    def forward(ctx, grad, inputs, embeddings, offsets, B, D, C, L, S, H, calc_grad_inputs, dy_dx):
+    def forward(ctx, grad, inputs, embeddings, offsets, B, D, C, L, S, H, calc_grad_inputs, dy_dx, need_table=True):
         grad_inputs = torch.zeros_like(inputs)
-        # the table gradient is only materialised when somebody can consume it: at inference
-        # (normals only) the reference still zero-fills and scatters into 48.8 MB every iteration
-        need_table = embeddings.requires_grad and torch.is_grad_enabled()
+        # the table gradient is only materialised when somebody consumes it (need_table = needs_input_grad of the
+        # embeddings): at inference (normals only) the reference still zero-fills and scatters into 48.8 MB every iteration
         grad_embeddings = torch.zeros_like(embeddings) if need_table else None
         _lib.call("hash_encode_backward", grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H,
                   int(calc_grad_inputs), dy_dx if calc_grad_inputs else None, grad_inputs if calc_grad_inputs else None)
@@ -61,7 +62,7 @@ class _HashEncodeBackward(Function):
         grad2_embeddings = torch.zeros_like(embeddings)
         _lib.call("hash_encode_second_backward", grad, inputs, embeddings, offsets, B, D, C, L, S, H, int(ctx.calc_grad_inputs),
                   dy_dx, grad_grad_inputs.contiguous(), grad_grad, grad2_embeddings)
-        return grad_grad, None, grad2_embeddings, None, None, None, None, None, None, None, None, None
+        return grad_grad, None, grad2_embeddings, None, None, None, None, None, None, None, None, None, None
 
 
 hash_encode = _HashEncode.apply

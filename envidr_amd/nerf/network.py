@@ -251,7 +251,7 @@ class NeRFNetwork(NeRFRenderer):
     def supports_fused(self, r_images=None, geometry_only=False, **kwargs) -> bool:
         """configurations the fused persistent kernel implements (everything else uses the operator loop)"""
         o = self.opt
-        hash_ok = o.encoding_pos == "hashgrid_diff" and o.level_dim == 2 and o.num_levels <= 16
+        hash_ok = o.encoding_pos == "hashgrid_diff" and o.level_dim == 2 and o.num_levels == 16      # the fused kernels are built for 16 levels
         net_ok = (o.num_layers == 3 and o.hidden_dim == 64 and o.geo_feat_dim == 12 and o.ensemble_mlp and o.use_roughness
                   and o.learn_indir_blend and o.mlp_bias and o.geo_feat_act == "unitNorm" and o.env_feat_act == "unitNorm")
         shade_ok = (o.use_diffuse and not o.diffuse_only and o.diffuse_with_env and o.diffuse_env_fusion == "concat"

@@ -50,6 +50,7 @@ def run_cuda(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, fo
         fr = self.fused_renderer()
         fr.desc.bg_color = float(bg_color)
         fr.desc.min_near = float(self.min_near)
+        fr.set_aabb(self.aabb_infer)               # the operator loop's near_far_from_aabb box, not just +-bound
         # Frames of the environment-MLP family without reflected radiance run on the geometry pipeline (march rounds +
         # sample-parallel hash / SDF kernel -> record shading -> composite; FusedRenderer.render_frame): it keeps, per batch
         # size, the per-ray sample counts of the previous render as a sizing hint (video frames share their rays; outputs

@@ -256,7 +256,11 @@ class NeRFRenderer(nn.Module):
         N = rays_o.shape[1]
         if batch is None or batch <= 0 or N <= batch:
             return render_func.run_cuda(self, rays_o, rays_d, fused=fused, **kw)
-        chunks = [render_func.run_cuda(self, rays_o[:, i:i + batch], rays_d[:, i:i + batch], fused=fused, **kw)
+        # per-ray inputs travel with their chunk: r_images is indexed by chunk-local ray id inside run_cuda (the reference
+        # chunks outside its three-pass block, renderer.py:416-435, so its r_images is always aligned with the chunk)
+        r_images = kw.pop("r_images", None)
+        chunks = [render_func.run_cuda(self, rays_o[:, i:i + batch], rays_d[:, i:i + batch], fused=fused,
+                                       r_images=None if r_images is None else r_images[:, i:i + batch].contiguous(), **kw)
                   for i in range(0, N, batch)]
         out = {}
         for k in chunks[0]:

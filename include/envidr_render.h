@@ -161,6 +161,12 @@ typedef struct envidr_render_desc {
      * scratch, one render at a time. */
     void* scratch;
     uint64_t scratch_bytes;
+
+    /* ABI 3: the box rays are intersected with (NeRFRenderer.aabb_infer, nerf/renderer.py:76-84; tightened by
+     * opt.marching_aabb and restored from checkpoints): {xmin, ymin, zmin, xmax, ymax, zmax}.  has_aabb = 0 means
+     * [-bound, bound]^3.  Only the ray / box intersection uses it; sample positions are still clamped to the bound cube. */
+    int32_t has_aabb;
+    float aabb[6];
 } envidr_render_desc;
 
 /* ---- per-call outputs (device pointers; any optional pointer may be NULL) --------------------- */

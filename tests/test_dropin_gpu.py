@@ -123,6 +123,57 @@ def test_encoder_modules_have_reference_surface():
     assert torch.isfinite(enc.embeddings.grad).all() and enc.embeddings.grad.abs().sum() > 0
 
 
+def test_tightened_marching_box_is_honoured_by_the_fused_paths():
+    """aabb_infer smaller than [-bound, bound]^3 (opt.marching_aabb / checkpoints): the fused paths intersect rays with the
+    SAME box as the operator loop's near_far_from_aabb (different near / far, fewer samples), not with the bound cube"""
+    import torch
+    model, opt = build_model(scenes.toaster_scene(seed=9))
+    model.aabb_infer = torch.tensor([-0.45, -0.6, -0.5, 0.55, 0.4, 0.65], dtype=torch.float32, device="cuda")
+    ro_, rd_ = scenes.camera_rays(40, 40, theta=50.0, phi=-25.0)
+    ro, rd = torch.from_numpy(ro_).cuda()[None], torch.from_numpy(rd_).cuda()[None]
+    kw = dict(staged=True, bg_color=1, perturb=False, get_normal_image=True, max_steps=opt.max_steps, T_thresh=opt.T_thresh, dt_gamma=opt.dt_gamma)
+    loop = model.render(ro, rd, fused=False, **kw)
+    full = build_model(scenes.toaster_scene(seed=9))[0].render(ro, rd, fused=False, **kw)
+    assert rel_l2(loop["image"].cpu().numpy(), full["image"].cpu().numpy()) > 1e-2          # the box matters on this view
+    for two_phase in (None, False):            # geometry pipeline, single persistent kernel
+        got = model.render(ro, rd, fused=True, two_phase=two_phase, **kw)
+        torch.cuda.synchronize()
+        for key in ("image", "depth", "weights_sum"):
+            err = rel_l2(got[key].cpu().numpy().reshape(1600, -1), loop[key].cpu().numpy().reshape(1600, -1))
+            assert err <= 3e-5, f"two_phase={two_phase} {key}: {err:.2e}"
+
+
+def test_hash_encoder_first_order_backward_reaches_the_table():
+    """`enc(x).sum().backward()` (no double backward) must fill embeddings.grad: the table gradient of a weighted sum of the
+    outputs equals the oracle's hash_encode_backward scatter (hashencoder.cu:257-343), and a plain training step would otherwise
+    silently never update the table"""
+    import torch
+    from envidr_amd.encoding import get_encoder
+    from tests.util import run_op
+    enc, _ = get_encoder("hashgrid_diff", num_levels=4, log2_hashmap_size=12)
+    enc = enc.cuda()
+    enc.embeddings.data.uniform_(-1, 1)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.rand(200, 3, device="cuda", generator=g) * 1.8 - 0.9
+    wgt = torch.rand(200, 8, device="cuda", generator=g)
+    (enc(x) * wgt).sum().backward()
+    got = enc.embeddings.grad
+    assert got is not None and torch.isfinite(got).all() and got.abs().sum() > 0
+    B, D, C, L = 200, 3, 2, 4
+    S, Hres = float(np.log2(enc.per_level_scale)), int(enc.base_resolution)
+    x01 = ((x + 1) / 2).cpu().numpy().astype(np.float32)
+    grad = wgt.view(B, L, C).permute(1, 0, 2).contiguous().cpu().numpy()
+    emb = enc.embeddings.detach().cpu().numpy()
+    want = run_op("oracle", "hash_encode_backward", grad, x01, emb, enc.offsets.cpu().numpy(), np.zeros_like(emb), B, D, C, L, S, Hres, 0,
+                  None, None)[4]
+    assert rel_l2(got.cpu().numpy(), want) <= 2e-6
+    # with the table frozen nothing is allocated or scattered (inference: normals only)
+    enc.embeddings.requires_grad_(False)
+    xi = x.clone().requires_grad_(True)
+    enc(xi).sum().backward()
+    assert xi.grad is not None and enc.embeddings.grad is got
+
+
 @pytest.mark.parametrize("fused", [True, False])
 def test_indirect_three_pass_matches_reference(fused):
     """BASELINE config #4 (use_renv + indir_ref): geometry pass -> reflected rays -> main pass with the

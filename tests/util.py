@@ -21,13 +21,19 @@ def run_op(backend: str, name: str, *args):
         work = [np.ascontiguousarray(a).copy() if (k == "p" and a is not None) else a for k, a in zip(sig, args)]
         lib.call(name, *work)
         return [w for k, w in zip(sig, work) if k == "p"]
-    assert backend == "hip"
+    assert backend in ("hip", "shim")
     import torch
     from envidr_amd import _lib
     dev = torch.device("cuda:0")
     work = [torch.from_numpy(np.ascontiguousarray(a).copy()).to(dev) if (k == "p" and a is not None) else a
             for k, a in zip(sig, args)]
-    _lib.call(name, *work)
+    if backend == "shim":
+        # through the reference-named backend modules (envidr_amd.compat): `<pkg>._ext._<pkg>.<name>(tensors...)`
+        from envidr_amd.compat.backends import EXTENSIONS, make_backend
+        pkg = next(p for p, names in EXTENSIONS.items() if name in names)
+        getattr(make_backend(pkg), name)(*[bool(a) if k == "i" else a for k, a in zip(sig, work)])
+    else:
+        _lib.call(name, *work)
     torch.cuda.synchronize()
     return [None if w is None else w.cpu().numpy() for k, w in zip(sig, work) if k == "p"]
 
