@@ -377,8 +377,9 @@ def other_configs(result, dev, rays_o, rays_d, N) -> None:
     # BASELINE configs[1] (no environment MLP; gather / latency-bound regime)
     plain = FusedRenderer.from_scene(scenes.lego_scene(), FusedOptions(dir_sh_degree=4), device=dev)
     pout: dict = {}
-    pdt = _time(lambda: plain.render(rays_o, rays_d, None, extras=True, stats=True, out=pout), 5, dev)
-    psamples = int(pout["stats"][0].item())
+    pdt = _time(lambda: plain.render_frame(rays_o, rays_d, None, out=pout, wait=False), 5, dev)
+    plain.check_frames()
+    psamples = int(plain._frame["last"][1])
     oc["configs[1] hash-grid SDF + diffuse/specular MLPs (SH view dir, no env MLP), 800x800, 1 GPU"] = {
         "rays_per_s": N / pdt, "ms_per_frame": pdt * 1e3, "samples_per_s": psamples / pdt, "samples_per_frame": psamples,
         "roofline": _both_rooflines(psamples, pdt, FLOP_PER_SAMPLE_PLAIN)}

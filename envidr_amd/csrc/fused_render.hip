@@ -357,6 +357,76 @@ __device__ __forceinline__ void shade_sample(WP& wp, const uint32_t lane, const 
 
 }
 
+// ---- reflected radiance of the sample's ray -> 12 features -> specular head again -> learnt blend (network.py:612-659,683-690).
+// `wp` must be streaming renv_blob on entry; on return it streams `after_blob`.  Shared by the persistent kernel and the
+// record-shading kernel (third pass of indirect rendering).
+template <class WP>
+__device__ __forceinline__ void shade_renv(WP& wp, const uint32_t lane, const float* renv_blob, const float* spec2_blob, const float* after_blob,
+                                           const uint32_t after_chunks, const float (&rimg)[4], const float rough, const float rough_scale,
+                                           const float indir_rough_thresh, const float blend_logit, const float (&geo)[12],
+                                           const float (&nrm)[3], const float ndot, float (&cs)[3]) {
+    constexpr uint32_t kRenvChunks = pass_chunks(kRenvFrags), kSpec2Chunks = pass_chunks(kSpec2Frags);
+    constexpr int kRenvN = ring_padded(kRenvFrags), kSpec2N = ring_padded(kSpec2Frags);
+    const float vis = rimg[3];
+    const float remap = sqrtf(rough / rough_scale / 0.75f);
+    float rin[4] = {rimg[0] * vis, rimg[1] * vis, rimg[2] * vis, remap};
+    pack_pair(rin[0], rin[1]);
+    pack_pair(rin[2], rin[3]);
+    f32x16 eA, eB;
+#pragma unroll 1
+    for (int grp = 0; grp < 2; ++grp) {
+        float in[2] = {grp ? rin[1] : rin[0], grp ? rin[3] : rin[2]};
+        f32x16 r1[2], r2[2], r3[1];
+        wp.begin_pass(renv_blob, kRenvChunks, grp == 0 ? renv_blob : spec2_blob, grp == 0 ? kRenvChunks : kSpec2Chunks);
+        pipe_layer_from_lanes<2, 2, kRenv1, kRenvN>(wp, lane, in, r1);
+        pipe_layer_from_tiles<2, 2, kRenv2, kRenvN, true>(wp, lane, r1, r2);
+        pipe_layer_from_tiles<2, 2, kRenv3, kRenvN, true>(wp, lane, r2, r1);
+        pipe_layer_from_tiles<2, 1, kRenv4, kRenvN, true>(wp, lane, r1, r3);
+        wp.template end_pass<kRenvFrags>();
+        if (grp == 0) eA = r3[0]; else eB = r3[0];
+    }
+    float e[16];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        float u = eA[r], v = eB[r];
+        unpack_pair(u, v);
+        e[tile_row(r, 0)] = u; e[tile_row(r, 1)] = v;
+    }
+    float e12[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) e12[i] = e[i];
+    normalize_n<12>(e12, 1e-12f);
+    float sin2[28];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { sin2[i] = geo[i]; sin2[15 + i] = e12[i]; }
+    sin2[12] = nrm[0]; sin2[13] = nrm[1]; sin2[14] = nrm[2]; sin2[27] = ndot;
+#pragma unroll
+    for (int s = 0; s < 14; ++s) pack_pair(sin2[2 * s], sin2[2 * s + 1]);
+    f32x16 cA, cB;
+#pragma unroll 1
+    for (int grp = 0; grp < 2; ++grp) {
+        float in_s[14];
+#pragma unroll
+        for (int s = 0; s < 14; ++s) in_s[s] = grp ? sin2[2 * s + 1] : sin2[2 * s];
+        f32x16 s1[2], s2[2], s3[1];
+        wp.begin_pass(spec2_blob, kSpec2Chunks, grp == 0 ? spec2_blob : after_blob, grp == 0 ? kSpec2Chunks : after_chunks);
+        pipe_layer_from_lanes<14, 2, kSpec2S1, kSpec2N>(wp, lane, in_s, s1);
+        pipe_layer_from_tiles<2, 2, kSpec2S2, kSpec2N, true>(wp, lane, s1, s2);
+        pipe_layer_from_tiles<2, 1, kSpec2S3, kSpec2N, true>(wp, lane, s2, s3);
+        wp.template end_pass<kSpec2Frags>();
+        if (grp == 0) cA = s3[0]; else cB = s3[0];
+    }
+    const bool masked = rough < indir_rough_thresh && vis > 0.9f;
+    const float blend = 0.98f * sigmoidf(blend_logit);                              // learn_indir_blend, network.py:443-446,630
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float p = cA[r], q = cB[r];
+        unpack_pair(p, q);
+        const float c_renv = sigmoidf(p);
+        if (masked) cs[r] = cs[r] * blend + c_renv * (1 - blend);
+    }
+}
+
 // Two network families:
 //   SH_DEG == 0: environment-MLP family (toaster.ini / neural_renderer.ini): IDE degree IDE_DEG, env hidden 32 ENV_T
 //   SH_DEG  > 0: no environment network (BASELINE configs[1]): diffuse head on geo_feat, specular head on
@@ -707,68 +777,9 @@ __global__ void __launch_bounds__(kBlockThreads, (SH_DEG > 0 ? kPlainWaves : 1))
             float env_r[12];
             shade_sample<IDE_DEG, ENV_T, SH_DEG>(wp, lane, sc, nrm, nenv, wr, vd, ndot, geo, rough, cd, cs, env_r,
                                                  [&](int i) { (void)i; ENVIDR_TICK(i); });
-            if constexpr (kEnvNet) if (renv) {
-                // ---- reflected radiance of this ray -> 12 features -> specular head again -> blend (network.py:612-659,683-690)
-                constexpr int kRenvN = ring_padded(kRenvFrags), kSpec2N = ring_padded(kSpec2Frags);
-                const float vis = rimg[3];
-                const float remap = sqrtf(rough / a.rough_scale / 0.75f);
-                float rin[4] = {rimg[0] * vis, rimg[1] * vis, rimg[2] * vis, remap};
-                pack_pair(rin[0], rin[1]);
-                pack_pair(rin[2], rin[3]);
-                f32x16 eA, eB;
-#pragma unroll 1
-                for (int grp = 0; grp < 2; ++grp) {
-                    float in[2] = {grp ? rin[1] : rin[0], grp ? rin[3] : rin[2]};
-                    f32x16 r1[2], r2[2], r3[1];
-                    wp.begin_pass(a.renv_blob, kRenvChunks, grp == 0 ? a.renv_blob : a.spec2_blob, grp == 0 ? kRenvChunks : kSpec2Chunks);
-                    pipe_layer_from_lanes<2, 2, kRenv1, kRenvN>(wp, lane, in, r1);
-                    pipe_layer_from_tiles<2, 2, kRenv2, kRenvN, true>(wp, lane, r1, r2);
-                    pipe_layer_from_tiles<2, 2, kRenv3, kRenvN, true>(wp, lane, r2, r1);
-                    pipe_layer_from_tiles<2, 1, kRenv4, kRenvN, true>(wp, lane, r1, r3);
-                    wp.template end_pass<kRenvFrags>();
-                    if (grp == 0) eA = r3[0]; else eB = r3[0];
-                }
-                float e[16];
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    float u = eA[r], v = eB[r];
-                    unpack_pair(u, v);
-                    e[tile_row(r, 0)] = u; e[tile_row(r, 1)] = v;
-                }
-                float e12[12];
-#pragma unroll
-                for (int i = 0; i < 12; ++i) e12[i] = e[i];
-                normalize_n<12>(e12, 1e-12f);
-                float sin2[28];
-#pragma unroll
-                for (int i = 0; i < 12; ++i) { sin2[i] = geo[i]; sin2[15 + i] = e12[i]; }
-                sin2[12] = nrm[0]; sin2[13] = nrm[1]; sin2[14] = nrm[2]; sin2[27] = ndot;
-#pragma unroll
-                for (int s = 0; s < 14; ++s) pack_pair(sin2[2 * s], sin2[2 * s + 1]);
-                f32x16 cA, cB;
-#pragma unroll 1
-                for (int grp = 0; grp < 2; ++grp) {
-                    float in_s[14];
-#pragma unroll
-                    for (int s = 0; s < 14; ++s) in_s[s] = grp ? sin2[2 * s + 1] : sin2[2 * s];
-                    f32x16 s1[2], s2[2], s3[1];
-                    wp.begin_pass(a.spec2_blob, kSpec2Chunks, grp == 0 ? a.spec2_blob : a.sdf_blob, grp == 0 ? kSpec2Chunks : kSdfChunks);
-                    pipe_layer_from_lanes<14, 2, kSpec2S1, kSpec2N>(wp, lane, in_s, s1);
-                    pipe_layer_from_tiles<2, 2, kSpec2S2, kSpec2N, true>(wp, lane, s1, s2);
-                    pipe_layer_from_tiles<2, 1, kSpec2S3, kSpec2N, true>(wp, lane, s2, s3);
-                    wp.template end_pass<kSpec2Frags>();
-                    if (grp == 0) cA = s3[0]; else cB = s3[0];
-                }
-                const bool masked = rough < a.indir_rough_thresh && vis > 0.9f;
-                const float blend = 0.98f * sigmoidf(h3[14]);                              // learn_indir_blend, network.py:443-446,630
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    float p = cA[r], q = cB[r];
-                    unpack_pair(p, q);
-                    const float c_renv = sigmoidf(p);
-                    if (masked) cs[r] = cs[r] * blend + c_renv * (1 - blend);
-                }
-            }
+            if constexpr (kEnvNet) if (renv)
+                shade_renv(wp, lane, a.renv_blob, a.spec2_blob, a.sdf_blob, kSdfChunks, rimg, rough, a.rough_scale, a.indir_rough_thresh,
+                           h3[14], geo, nrm, ndot, cs);
         }
         ENVIDR_TICK(6);   // heads (+ env unpack)
         {
@@ -897,6 +908,9 @@ struct ShadeArgs {
     const float* rays_d;
     const uint32_t* m_dev;
     const uint32_t* slot;       // record mode, optional: normals / geo_feat / roughness of record i live at index slot[i]
+    // reflected-radiance branch (record mode): per-ray (rgb, visibility), the learnt blend logit per sample, the two extra blobs
+    const float* r_images; const float* blend; const float* renv_blob; const float* spec2_blob;
+    float rough_scale, indir_rough_thresh;
     const float* env_blob;
     const float* head_blob;
     float kappa_diffuse, light_scale;
@@ -906,17 +920,26 @@ struct ShadeArgs {
     float* c_specular;          // [M,3]
 };
 
-template <int IDE_DEG, int ENV_T>
+// SH_DEG > 0: the no-environment family (heads only; SH-encoded view direction and normal, BASELINE configs[1]).
+// RENV: the reflected-radiance branch on top of the environment family (third pass of indirect rendering; record mode only).
+template <int IDE_DEG, int ENV_T, int SH_DEG = 0, bool RENV = false>
 __global__ void __launch_bounds__(kBlockThreads, 1) k_shade_samples(const ShadeArgs a) {
+    constexpr bool kEnvNet = SH_DEG == 0;
+    constexpr int kShDim = SH_DEG * SH_DEG;
+    constexpr int kDSteps = ((kEnvNet ? 24 : 12) + 1) / 2, kSSteps = ((kEnvNet ? 28 : 2 * kShDim + 13) + 1) / 2;
     constexpr int TERMS = ide_terms(IDE_DEG);
     constexpr int kEnvFrags = lane_layer_frags(TERMS, ENV_T, true) + 2 * tile_layer_frags(ENV_T, ENV_T, true) + tile_layer_frags(ENV_T, 1, true);
-    constexpr uint32_t kEnvChunks = pass_chunks(kEnvFrags);
+    constexpr uint32_t kEnvChunks = pass_chunks(kEnvFrags), kHeadChunks = pass_chunks(HeadLayout<kDSteps, kSSteps>::Frags);
+    constexpr uint32_t kRenvChunks = pass_chunks(kRenvFrags);
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     __shared__ __attribute__((aligned(16))) float s_weights[kSharedWeights ? 2 * kChunkFloats : 4];
     std::conditional_t<kSharedWeights, WeightPipe, WeightRing<kRingDepth>> wp;
-    wp.start(s_weights, lane, wave, a.env_blob, kEnvChunks);
-    const ShadeConsts sc = {a.env_blob, a.head_blob, a.env_blob, kEnvChunks, a.kappa_diffuse, a.light_scale};
+    // the first blob a round streams: the environment MLP, or the heads when there is none
+    const float* first_blob = kEnvNet ? a.env_blob : a.head_blob;
+    constexpr uint32_t kFirstChunks = kEnvNet ? kEnvChunks : kHeadChunks;
+    wp.start(s_weights, lane, wave, first_blob, kFirstChunks);
+    const ShadeConsts sc = {a.env_blob, a.head_blob, RENV ? a.renv_blob : first_blob, RENV ? kRenvChunks : kFirstChunks, a.kappa_diffuse, a.light_scale};
     const uint32_t waves = gridDim.x * (kBlockThreads / 64);
     // a frame whose records did not fit (count beyond the capacity) is not shaded at all: the host redoes it
     uint32_t M = a.M;
@@ -928,7 +951,8 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_shade_samples(const ShadeA
         const size_t i = on ? id : 0;
         const size_t gi = a.slot ? (size_t)a.slot[i] : i;          // where this record's geometry lives
         float nrm[3], vd[3], geo[12];
-        const float* dir = a.ray_ids ? a.rays_d + 3 * (size_t)a.ray_ids[i] : a.dirs + 3 * i;
+        const size_t ray = a.ray_ids ? (size_t)a.ray_ids[i] : 0;
+        const float* dir = a.ray_ids ? a.rays_d + 3 * ray : a.dirs + 3 * i;
 #pragma unroll
         for (int d = 0; d < 3; ++d) { nrm[d] = on ? a.normals[3 * gi + d] : 0.0f; vd[d] = on ? dir[d] : 0.0f; }
 #pragma unroll
@@ -950,7 +974,14 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_shade_samples(const ShadeA
             }
         }
         float cd[3], cs[3], env_r[12];
-        shade_sample<IDE_DEG, ENV_T, 0>(wp, lane, sc, nrm, nenv, wr, vd, ndot, geo, rough, cd, cs, env_r, [](int) {});
+        shade_sample<IDE_DEG, ENV_T, SH_DEG>(wp, lane, sc, nrm, nenv, wr, vd, ndot, geo, rough, cd, cs, env_r, [](int) {});
+        if constexpr (RENV) {
+            float rimg[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rimg[j] = on ? a.r_images[4 * ray + j] : 0.0f;
+            shade_renv(wp, lane, a.renv_blob, a.spec2_blob, first_blob, kFirstChunks, rimg, rough, a.rough_scale, a.indir_rough_thresh,
+                       a.blend[gi], geo, nrm, ndot, cs);
+        }
         if (on) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) { a.c_diffuse[3 * i + d] = cd[d]; a.c_specular[3 * i + d] = cs[d]; }
@@ -1190,18 +1221,27 @@ int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const f
 }
 
 static int launch_shade(const envidr_render_desc* d, ShadeArgs& a, envidr_stream_t stream, const char* who) {
-    ENVIDR_REQUIRE(d->env_blob && d->head_blob, "%s: null weight blob", who);
-    ENVIDR_REQUIRE(d->dir_sh_degree == 0, "%s: implemented for the environment-MLP family", who);
+    ENVIDR_REQUIRE(d->head_blob && (d->env_blob || d->dir_sh_degree), "%s: null weight blob", who);
     a.env_blob = d->env_blob; a.head_blob = d->head_blob;
     a.kappa_diffuse = d->diffuse_kappa_inv; a.light_scale = d->light_intensity_scale;
-    a.has_rot = d->has_env_rot;
+    a.has_rot = d->dir_sh_degree ? 0 : d->has_env_rot;
     for (int i = 0; i < 9; ++i) a.rot[i] = d->env_rot[i];
     const uint32_t waves_per_block = kBlockThreads / 64;
     const uint32_t blocks = std::min((uint32_t)device_cu_count() * (4 / waves_per_block), ceil_div(a.M, kBlockThreads));
     const dim3 grid(blocks), block(kBlockThreads);
     hipStream_t s = as_stream(stream);
-#define ENVIDR_LAUNCH(DEG, HT) hipLaunchKernelGGL((k_shade_samples<DEG, HT>), grid, block, 0, s, a)
-    if (d->ide_degree == 5 && d->env_hidden == 256) ENVIDR_LAUNCH(5, 8);
+    const bool renv = a.r_images != nullptr;
+#define ENVIDR_LAUNCH(DEG, HT) do { if (renv) hipLaunchKernelGGL((k_shade_samples<DEG, HT, 0, true>), grid, block, 0, s, a); \
+                                    else hipLaunchKernelGGL((k_shade_samples<DEG, HT>), grid, block, 0, s, a); } while (0)
+    if (d->dir_sh_degree == 4) {
+        ENVIDR_REQUIRE(!renv, "%s: the reflected-radiance branch belongs to the environment-MLP family", who);
+        ENVIDR_REQUIRE(a.ray_ids || a.dirs, "%s: the no-environment family needs view directions", who);
+        hipLaunchKernelGGL((k_shade_samples<4, 0, 4>), grid, block, 0, s, a);
+    } else if (d->dir_sh_degree != 0) {
+        set_error("%s: unsupported dir_sh_degree=%u (no-environment family is built for SH degree 4)", who, d->dir_sh_degree);
+        return ENVIDR_EINVAL;
+    }
+    else if (d->ide_degree == 5 && d->env_hidden == 256) ENVIDR_LAUNCH(5, 8);
     else if (d->ide_degree == 4 && d->env_hidden == 160) ENVIDR_LAUNCH(4, 5);
     else if (d->ide_degree == 5 && d->env_hidden == 128) ENVIDR_LAUNCH(5, 4);
     else if (d->ide_degree == 4 && d->env_hidden == 128) ENVIDR_LAUNCH(4, 4);
@@ -1242,6 +1282,13 @@ int envidr_shade_records(const envidr_render_desc* d, const envidr_geometry_expo
     a.geo_stride = 12; a.rough_stride = 1; a.M = rec->capacity;
     a.ray_ids = rec->ray; a.rays_d = rays_d; a.m_dev = rec->counter;
     a.slot = rec->slot;
+    if (d->r_images) {
+        // third pass of indirect rendering (network.py:612-659): per-ray reflected radiance, indexed by the records' ray ids
+        ENVIDR_REQUIRE(d->renv_blob && d->spec2_blob, "shade_records: r_images given without the renv / second specular blobs");
+        ENVIDR_REQUIRE(rec->blend, "shade_records: the reflected-radiance branch needs the records' blend logits");
+        a.r_images = d->r_images; a.blend = rec->blend; a.renv_blob = d->renv_blob; a.spec2_blob = d->spec2_blob;
+        a.rough_scale = d->roughness_scale; a.indir_rough_thresh = d->indir_roughness_thresh;
+    }
     a.c_diffuse = c_diffuse; a.c_specular = c_specular;
     return launch_shade(d, a, stream, "shade_records");
 }

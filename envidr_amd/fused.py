@@ -564,9 +564,11 @@ class FusedRenderer:
 
     def render_frame(self, rays_o: torch.Tensor, rays_d: torch.Tensor, env_rot_radian: float | None = None, out: dict | None = None,
                      samples_per_ray_hint: float = 20.0, events: list | None = None, geometry_only: bool = False, wait: bool = True,
-                     use_cost_hint: bool = True) -> dict:
+                     use_cost_hint: bool = True, r_images: torch.Tensor | None = None) -> dict:
         """One frame as: geometry pipeline (envidr_geometry_pass: march rounds + per-sample hash grid / SDF network, one record
-        per composited sample) -> shading of the records (k_shade_samples) -> per-ray composite.  Environment-MLP family.
+        per composited sample) -> shading of the records (k_shade_samples) -> per-ray composite.  Both network families
+        (environment MLP; SH heads without one); `r_images` [N,4] (reflected radiance + visibility per ray) selects the
+        reflected-radiance branch of the third pass of indirect rendering; `geometry_only` is its first pass.
         The per-ray sample counts of the previous frame of these N rays (kept in the frame buffers) size each ray's first march
         chunk (use_cost_hint; results do not depend on it).  Nothing waits for the device while the frame is enqueued; with wait=False the call does not wait at the end either
         (video loops: check_frames() -- called by the next frame -- raises FrameOverflow if a frame did not fit).
@@ -603,8 +605,16 @@ class FusedRenderer:
             if ev: ev[1].record()
             if not geometry_only:
                 _set_env_rotation(self.desc, env_rot_radian)
+                if r_images is not None:
+                    if not self.desc.renv_blob:
+                        raise _lib.EnvidrError("render_frame: r_images given but the model has no renv MLP")
+                    r_images = r_images.contiguous().view(-1, 4).float()
+                    if r_images.shape[0] != N or not r_images.is_cuda:
+                        raise _lib.EnvidrError("render_frame: r_images must be [N,4] on the GPU")
+                    self.desc.r_images = r_images.data_ptr()
                 rc = self.lib.envidr_shade_records(ctypes.byref(self.desc), ctypes.byref(ex), rays_d.data_ptr(), st["cd"].data_ptr(),
                                                    st["cs"].data_ptr(), stream)
+                self.desc.r_images = None
                 if rc:
                     raise _lib.EnvidrError(f"envidr_shade_records failed ({rc}): {self.lib.envidr_last_error().decode()}")
             if ev: ev[2].record()

@@ -51,14 +51,15 @@ def run_cuda(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, fo
         fr.desc.bg_color = float(bg_color)
         fr.desc.min_near = float(self.min_near)
         fr.set_aabb(self.aabb_infer)               # the operator loop's near_far_from_aabb box, not just +-bound
-        # Frames of the environment-MLP family without reflected radiance run on the geometry pipeline (march rounds +
-        # sample-parallel hash / SDF kernel -> record shading -> composite; FusedRenderer.render_frame): it keeps, per batch
-        # size, the per-ray sample counts of the previous render as a sizing hint (video frames share their rays; outputs
-        # never depend on it).  `two_phase=False` asks for the single persistent kernel instead (envidr_render_rays), which
-        # is also what the reflected-radiance pass and the no-environment family still use.
-        pipeline = (two_phase is not False) and r_images is None and self.use_env_net
+        # The geometry pipeline (march rounds + sample-parallel hash / SDF kernel -> record shading -> composite;
+        # FusedRenderer.render_frame) renders every fused configuration: both network families, the geometry-only first pass
+        # and the reflected-radiance third pass of indirect rendering.  It keeps, per batch size, the per-ray sample counts of
+        # the previous render as a sizing hint (video frames share their rays; outputs never depend on it).
+        # `two_phase=False` asks for the single persistent kernel instead (envidr_render_rays).
+        pipeline = two_phase is not False
         if pipeline:
-            res = fr.render_frame(rays_o, rays_d, env_rot_radian, geometry_only=geometry_only)
+            res = fr.render_frame(rays_o, rays_d, env_rot_radian, geometry_only=geometry_only,
+                                  r_images=None if r_images is None else r_images[0])
         else:
             hints = self.__dict__.setdefault("_ray_cost_hints", {})
             key = (N, bool(geometry_only), r_images is not None)

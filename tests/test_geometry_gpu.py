@@ -152,3 +152,26 @@ def test_frame_edge_cases(renderer):
     g = renderer.render_frame(torch.from_numpy(ro_).cuda(), torch.from_numpy(rd_).cuda(), geometry_only=True)
     torch.cuda.synchronize()
     assert torch.equal(g["depth"], a["depth"]) and torch.equal(g["normal_image"], a["normal_image"])
+
+
+def test_no_environment_family_on_the_pipeline():
+    """BASELINE configs[1] (SH view dir / normal into the specular head, no env MLP): geometry pipeline + heads-only record shading
+    against the reference's frame and against the oracle on the kernel's schedule"""
+    from envidr_amd.fused import FusedOptions, FusedRenderer
+    from oracle.py import render_oracle as ro
+    lego = scenes.lego_scene(seed=8)
+    r = FusedRenderer.from_scene(lego, FusedOptions(dir_sh_degree=4))
+    g = np.load(GOLD / "frame_lego_48.npz")
+    H, W = int(g["H"]), int(g["W"])
+    rays_o, rays_d = scenes.camera_rays(H, W, theta=float(g["theta"]), phi=float(g["phi"]))
+    out = _frame(r, rays_o, rays_d)
+    for key in KEYS:
+        err = rel_l2(out[key], g[key].reshape(out[key].shape))
+        assert err <= 1e-4, f"{key} vs reference frame: rel-L2 {err:.3e}"
+    rays_o, rays_d = scenes.camera_rays(40, 40, theta=15.0, phi=-60.0)
+    want = ro.render_rays(lego, rays_o, rays_d, ro.RenderOptions(), None, force_n_step=1)
+    out = _frame(r, rays_o, rays_d)
+    assert np.array_equal(out["ray_cost"].astype(np.int64), want["ray_counts"])
+    for key in KEYS:
+        err = rel_l2(out[key], want[key].reshape(out[key].shape))
+        assert err <= 2e-5, f"{key} vs oracle: rel-L2 {err:.3e}"
