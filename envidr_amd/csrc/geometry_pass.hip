@@ -542,6 +542,7 @@ struct GeoRayArgs {
     // per-ray outputs
     float* depth; float* ws; float* nimg; float* rimg;
     uint16_t* ray_cost;
+    const uint8_t* ray_mask;   // optional: rays whose byte is 0 are finished at once (round 0)
 };
 
 // wave-wide exclusive prefix sum of a small per-lane count; returns the wave total in `total`
@@ -585,7 +586,7 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
         if constexpr (FIRST) {
             if (active) {
                 float t = near, x, y, z, dt, t_at = 0;
-                const bool hit = march_next(a.mk, rg, far, t, x, y, z, dt, &t_at);
+                const bool hit = (!a.ray_mask || a.ray_mask[ray]) && march_next(a.mk, rg, far, t, x, y, z, dt, &t_at);
                 st.acc_t = near;
                 st.t_first = t_at;
                 alive = hit;
@@ -830,6 +831,7 @@ int envidr_geometry_pass(const envidr_render_desc* d, const float* rays_o, const
     a.rec_ray = rec->ray; a.rec_idx = rec->idx; a.rec_w = rec->w; a.rec_slot = const_cast<uint32_t*>(rec->slot); a.rec_cap = rec->capacity;
     a.depth = out->depth; a.ws = out->weights_sum; a.nimg = out->normal_image; a.rimg = out->roughness_image;
     a.ray_cost = d->ray_cost;
+    a.ray_mask = d->ray_mask;
     uint32_t* alive[2] = {reinterpret_cast<uint32_t*>(ws + L.alive0), reinterpret_cast<uint32_t*>(ws + L.alive1)};
 
     // chunk schedule: 16 samples, then each round extends what a ray has so far by half (16, 8, 12, 18, 27 ...): a ray that

@@ -49,7 +49,7 @@ class RenderDesc(ctypes.Structure):
         ("geometry_only", ctypes.c_int32), ("r_images", _FP), ("renv_blob", _FP), ("spec2_blob", _FP),
         ("indir_roughness_thresh", ctypes.c_float), ("geometry_export", ctypes.POINTER(GeometryExport)),
         ("ray_cost", _FP), ("scratch", _FP), ("scratch_bytes", ctypes.c_uint64),
-        ("has_aabb", ctypes.c_int32), ("aabb", ctypes.c_float * 6),
+        ("has_aabb", ctypes.c_int32), ("aabb", ctypes.c_float * 6), ("ray_mask", _FP),
     ]
 
 
@@ -535,7 +535,7 @@ class FusedRenderer:
                       ray=torch.empty(cap, dtype=torch.int32, device=dev), idx=torch.empty(cap, dtype=torch.int32, device=dev),
                       w=torch.empty(cap, device=dev), slot=torch.empty(cap, dtype=torch.int32, device=dev),
                       perm=torch.empty(cap, dtype=torch.int32, device=dev), cd=torch.empty(cap, 3, device=dev), cs=torch.empty(cap, 3, device=dev),
-                      cost=torch.zeros(N, dtype=torch.int16, device=dev), offsets=torch.zeros(N + 1, dtype=torch.int32, device=dev),
+                      cost=torch.zeros(N, dtype=torch.int16, device=dev), costs={}, offsets=torch.zeros(N + 1, dtype=torch.int32, device=dev),
                       stats=torch.zeros(3, dtype=torch.int64, device=dev), host=torch.zeros(3, dtype=torch.int64).pin_memory(),
                       event=torch.cuda.Event(), pending=False, hint=samples_per_ray)
             frames[N] = st
@@ -564,11 +564,14 @@ class FusedRenderer:
 
     def render_frame(self, rays_o: torch.Tensor, rays_d: torch.Tensor, env_rot_radian: float | None = None, out: dict | None = None,
                      samples_per_ray_hint: float = 20.0, events: list | None = None, geometry_only: bool = False, wait: bool = True,
-                     use_cost_hint: bool = True, r_images: torch.Tensor | None = None) -> dict:
+                     use_cost_hint: bool = True, r_images: torch.Tensor | None = None, ray_mask: torch.Tensor | None = None,
+                     tag: str = "") -> dict:
         """One frame as: geometry pipeline (envidr_geometry_pass: march rounds + per-sample hash grid / SDF network, one record
         per composited sample) -> shading of the records (k_shade_samples) -> per-ray composite.  Both network families
         (environment MLP; SH heads without one); `r_images` [N,4] (reflected radiance + visibility per ray) selects the
-        reflected-radiance branch of the third pass of indirect rendering; `geometry_only` is its first pass.
+        reflected-radiance branch of the third pass of indirect rendering; `geometry_only` is its first pass.  `ray_mask`
+        (bool / uint8 [N]): rays with 0 are not rendered (background, zero weight).  `tag` separates the per-ray count hints
+        of different uses of the same N rays (the three passes of an indirect frame march different rays).
         The per-ray sample counts of the previous frame of these N rays (kept in the frame buffers) size each ray's first march
         chunk (use_cost_hint; results do not depend on it).  Nothing waits for the device while the frame is enqueued; with wait=False the call does not wait at the end either
         (video loops: check_frames() -- called by the next frame -- raises FrameOverflow if a frame did not fit).
@@ -591,15 +594,24 @@ class FusedRenderer:
             o.stats = st["stats"].data_ptr()
             ex = GeometryExport(st["counter"].data_ptr(), cap, st["ray"].data_ptr(), st["idx"].data_ptr(), st["w"].data_ptr(), None, None, None,
                                 st["slot"].data_ptr(), None)
+            if tag not in st["costs"]:
+                st["costs"][tag] = torch.zeros(N, dtype=torch.int16, device=dev)
+            st["cost"] = st["costs"][tag]
             if not use_cost_hint:
                 st["cost"].zero_()
             self.desc.ray_cost = st["cost"].data_ptr()
+            if ray_mask is not None:
+                ray_mask = ray_mask.reshape(-1).to(torch.uint8).contiguous()
+                if ray_mask.shape[0] != N or not ray_mask.is_cuda:
+                    raise _lib.EnvidrError("render_frame: ray_mask must be [N] on the GPU")
+            self.desc.ray_mask = None if ray_mask is None else ray_mask.data_ptr()
             self.desc.geometry_only, self.desc.r_images, self.desc.geometry_export = 0, None, None
             ev = events
             if ev: ev[0].record()
             rc = self.lib.envidr_geometry_pass(ctypes.byref(self.desc), rays_o.data_ptr(), rays_d.data_ptr(), N, ctypes.byref(o), ctypes.byref(ex),
                                                st["ws"].data_ptr(), st["ws"].numel(), cap, stream)
             self.desc.ray_cost = None
+            self.desc.ray_mask = None
             if rc:
                 raise _lib.EnvidrError(f"envidr_geometry_pass failed ({rc}): {self.lib.envidr_last_error().decode()}")
             if ev: ev[1].record()

@@ -270,9 +270,58 @@ class NeRFRenderer(nn.Module):
                 out[k] = torch.cat([c[k] for c in chunks], 0 if k in ("diffuse_image", "specular_image", "roughness_image") else 1)
         return out
 
+    def _render_indirect_masked(self, rays_o, rays_d, get_normal_image, use_specular_color, env_net_index, env_rot_radian, **kwargs):
+        """The same three passes on the fused geometry pipeline, with ray MASKS instead of boolean-mask gathers: every pass runs
+        over all N rays (masked-out rays cost a byte load), r_images is indexed by ray id directly, and nothing between the
+        passes needs a count on the host -- no nonzero, no masked_scatter, no synchronisation (the reference gathers the
+        selected rays, renderer.py:455-470,490-512, which costs three host round trips per frame)."""
+        dt = 2 * SQRT3 / self.opt.indir_max_steps
+        geo = self._run(rays_o, rays_d, get_normal_image=get_normal_image, main_pass=False, geometry_only=True,
+                        env_rot_radian=env_rot_radian, fused=True, frame_tag="indirect-geometry", **kwargs)
+        normals = geo["normal_image"]                       # [1,N,3]
+        depth = geo["depth"] - dt                           # [1,N]
+        ws = geo["weights_sum"]
+        ref_mask = (depth != 0) & (ws > 0.9)
+        ray_mask = (depth != 0) & (ws > 0.3)
+        ref_o = rays_o + depth[..., None] * rays_d
+        ref_d = reflect_dir(-rays_d, normals)
+        saved_bg, saved_near = kwargs.get("bg_color"), self.min_near
+        bg = 0 if saved_bg is None else saved_bg
+        self.min_near = dt * 2
+        kw2 = dict(kwargs, bg_color=0, max_steps=self.opt.indir_max_steps, early_stop_steps=self.opt.indir_early_stop_steps,
+                   force_all_rays=True)
+        try:
+            ref = self._run(ref_o, ref_d, get_normal_image=get_normal_image, use_specular_color=use_specular_color,
+                            env_net_index=env_net_index, main_pass=False, bg_sphere=False, env_rot_radian=env_rot_radian, fused=True,
+                            ray_mask=ref_mask, frame_tag="indirect-reflected", **kw2)
+        finally:
+            self.min_near = saved_near
+        # reflected radiance + visibility per primary ray; zero where no reflected ray was traced (the reference's new_zeros +
+        # masked_scatter, renderer.py:483-486)
+        r_images = torch.cat([ref["image"], ref["weights_sum"][..., None]], -1) * ref_mask[..., None]
+        kw3 = dict(kwargs, bg_color=0)
+        res = self._run(rays_o, rays_d, get_normal_image=get_normal_image, use_specular_color=use_specular_color,
+                        env_net_index=env_net_index, main_pass=True, r_images=r_images, bg_sphere=False, env_rot_radian=env_rot_radian,
+                        fused=True, ray_mask=ray_mask, frame_tag="indirect-main", **kw3)
+        res["normal_image"] = normals
+        res["depth"] = depth
+        for k in ("specular_image", "diffuse_image", "roughness_image"):
+            if k in res and res[k] is not None:
+                res[k] = res[k].reshape(1, -1, res[k].shape[-1])
+        wsum = res["weights_sum"][..., None]
+        res["image"] = (torch.zeros_like(normals) + bg) * (1 - wsum) + res["image"]
+        if get_normal_image:
+            res["normal_image"] = res["normal_image"] * wsum + (1 - wsum)
+        return res
+
     def _render_indirect(self, rays_o, rays_d, get_normal_image, use_specular_color, env_net_index, env_rot_radian, fused, **kwargs):
         """three passes (reference renderer.py:437-513): geometry only -> reflected rays -> main pass
         with the reflected radiance fed to the renv branch."""
+        batch = self.opt.max_ray_batch_cuda
+        if (fused and kwargs.get("two_phase") is not False and (batch is None or batch <= 0 or rays_o.shape[1] <= batch)
+                and not torch.is_tensor(kwargs.get("bg_color")) and not kwargs.get("perturb")
+                and self.supports_fused(geometry_only=True) and self.supports_fused(r_images=rays_o.new_zeros(1, 1, 4))):
+            return self._render_indirect_masked(rays_o, rays_d, get_normal_image, use_specular_color, env_net_index, env_rot_radian, **kwargs)
         dt = 2 * SQRT3 / self.opt.indir_max_steps
         geo = self._run(rays_o, rays_d, get_normal_image=get_normal_image, main_pass=False, geometry_only=True,
                         env_rot_radian=env_rot_radian, fused=fused, **kwargs)

@@ -167,6 +167,11 @@ typedef struct envidr_render_desc {
      * [-bound, bound]^3.  Only the ray / box intersection uses it; sample positions are still clamped to the bound cube. */
     int32_t has_aabb;
     float aabb[6];
+
+    /* ABI 3, geometry pipeline: optional device uint8 [N]; rays whose byte is 0 are not rendered (weights_sum = depth = 0,
+     * image = background): the three passes of indirect rendering (renderer.py:439-513) then run over the SAME N rays
+     * with masks instead of boolean-mask gathers, host-side counts and scatters between them. */
+    const uint8_t* ray_mask;
 } envidr_render_desc;
 
 /* ---- per-call outputs (device pointers; any optional pointer may be NULL) --------------------- */
