@@ -536,7 +536,8 @@ class FusedRenderer:
                       w=torch.empty(cap, device=dev), slot=torch.empty(cap, dtype=torch.int32, device=dev),
                       perm=torch.empty(cap, dtype=torch.int32, device=dev), cd=torch.empty(cap, 3, device=dev), cs=torch.empty(cap, 3, device=dev),
                       cost=torch.zeros(N, dtype=torch.int16, device=dev), costs={}, offsets=torch.zeros(N + 1, dtype=torch.int32, device=dev),
-                      stats=torch.zeros(3, dtype=torch.int64, device=dev), host=torch.zeros(3, dtype=torch.int64).pin_memory(),
+                      stats=torch.zeros(3, dtype=torch.int64, device=dev), worst=torch.zeros(3, dtype=torch.int64, device=dev),
+                      host=torch.zeros(6, dtype=torch.int64).pin_memory(),
                       event=torch.cuda.Event(), pending=False, hint=samples_per_ray)
             frames[N] = st
         self.__dict__["_frame"] = st
@@ -553,8 +554,10 @@ class FusedRenderer:
                 continue
             st["event"].synchronize()
             st["pending"] = False
-            samples, records, overflow = (int(v) for v in st["host"])
+            samples, records, _, w_samples, w_records, overflow = (int(v) for v in st["host"])
             st["last"] = (samples, records)
+            st["worst"].zero_()
+            samples, records = max(samples, w_samples), max(records, w_records)
             if overflow:
                 self.__dict__.setdefault("_frame_hints", {})[N] = max(2.0 * st["cap"] / N, 1.5 * max(samples, records) / N)
                 del self.__dict__["_frames"][N]
@@ -644,7 +647,11 @@ class FusedRenderer:
             else:
                 res["image"] = ((1 - res["weights_sum"]) * float(self.desc.bg_color))[:, None].expand(N, 3).contiguous()
             if ev: ev[3].record()
-            st["host"].copy_(st["stats"], non_blocking=True)
+            # status of this frame + the worst since the last look (several frames may be in flight: the three passes of an
+            # indirect frame, a video loop)
+            torch.maximum(st["worst"], st["stats"], out=st["worst"])
+            st["host"][:3].copy_(st["stats"], non_blocking=True)
+            st["host"][3:].copy_(st["worst"], non_blocking=True)
             st["event"].record()
             st["pending"] = True
             res["ray_cost"] = st["cost"]

@@ -30,7 +30,7 @@ def _state(N, nears, device):
 def run_cuda(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024,
              T_thresh=1e-4, get_normal_image=False, use_specular_color=True, early_stop_steps=-1, ray_depth=None,
              main_pass=True, r_images=None, geometry_only=False, grad_ray=False, bg_sphere=True, env_rot_radian=None,
-             fused=True, two_phase=None, ray_mask=None, frame_tag="", **kwargs):
+             fused=True, two_phase=None, ray_mask=None, frame_tag="", wait=True, **kwargs):
     self = model
     if self.training:
         raise NotImplementedError("run_cuda training branch is out of scope (operators are in envidr_amd.raymarching)")
@@ -59,7 +59,7 @@ def run_cuda(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, fo
         pipeline = two_phase is not False
         if pipeline:
             res = fr.render_frame(rays_o, rays_d, env_rot_radian, geometry_only=geometry_only,
-                                  r_images=None if r_images is None else r_images[0], ray_mask=ray_mask, tag=frame_tag)
+                                  r_images=None if r_images is None else r_images[0], ray_mask=ray_mask, tag=frame_tag, wait=wait)
         else:
             if ray_mask is not None:
                 raise NotImplementedError("ray_mask is a feature of the geometry pipeline (two_phase)")

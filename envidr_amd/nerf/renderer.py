@@ -275,7 +275,21 @@ class NeRFRenderer(nn.Module):
         over all N rays (masked-out rays cost a byte load), r_images is indexed by ray id directly, and nothing between the
         passes needs a count on the host -- no nonzero, no masked_scatter, no synchronisation (the reference gathers the
         selected rays, renderer.py:455-470,490-512, which costs three host round trips per frame)."""
+        from ..fused import FrameOverflow
+        for attempt in range(3):
+            try:
+                # the three passes are enqueued back to back; whether they fitted their buffers is looked at once, at the end
+                res = self._indirect_passes(rays_o, rays_d, get_normal_image, use_specular_color, env_net_index, env_rot_radian, **kwargs)
+                self.fused_renderer().check_frames()
+                return res
+            except FrameOverflow:
+                if attempt == 2:
+                    raise
+        raise AssertionError("unreachable")
+
+    def _indirect_passes(self, rays_o, rays_d, get_normal_image, use_specular_color, env_net_index, env_rot_radian, **kwargs):
         dt = 2 * SQRT3 / self.opt.indir_max_steps
+        kwargs = dict(kwargs, wait=False)
         geo = self._run(rays_o, rays_d, get_normal_image=get_normal_image, main_pass=False, geometry_only=True,
                         env_rot_radian=env_rot_radian, fused=True, frame_tag="indirect-geometry", **kwargs)
         normals = geo["normal_image"]                       # [1,N,3]
