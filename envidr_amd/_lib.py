@@ -21,6 +21,7 @@ LIB_PATH = Path(os.environ.get("ENVIDR_AMD_LIB", _PKG / "libenvidr_amd.so"))
 SIGNATURES: dict[str, str] = {
     # raymarching (include/envidr_amd.h, reference raymarching.h:7-18)
     "near_far_from_aabb": "pppufpp",
+    "get_rays": "pffffuuupp",
     "sph_from_ray": "ppfup",
     "morton3D": "pup",
     "morton3D_invert": "pup",

@@ -395,6 +395,27 @@ __global__ void __launch_bounds__(kBlock) k_composite_train_bwd(
     }
 }
 
+// ---- ray generation (reference nerf/utils.py:109-209, full-image branch :193-207) -----------------------------------------
+// One lane per (camera, pixel): pixel centre (+0.5), camera-space direction ((i - cx) / fx, (j - cy) / fy, 1) normalised, rotated by
+// the camera-to-world pose; the origin is the pose's translation.  fp32 throughout, the reference's operation order.
+__global__ void __launch_bounds__(kBlock) k_get_rays(const float* __restrict__ poses, float fx, float fy, float cx, float cy, uint32_t H,
+                                                     uint32_t W, uint32_t B, float* __restrict__ rays_o, float* __restrict__ rays_d) {
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per = (size_t)H * W;
+    if (id >= per * B) return;
+    const uint32_t b = (uint32_t)(id / per), pix = (uint32_t)(id % per);
+    const float i = (float)(pix % W) + 0.5f, j = (float)(pix / W) + 0.5f;
+    const float xs = (i - cx) / fx * 1.0f, ys = (j - cy) / fy * 1.0f, zs = 1.0f;
+    const float inv = sqrtf(xs * xs + ys * ys + zs * zs);
+    const float dx = xs / inv, dy = ys / inv, dz = zs / inv;
+    const float* P = poses + 16 * (size_t)b;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        rays_d[3 * id + k] = dx * P[4 * k] + dy * P[4 * k + 1] + dz * P[4 * k + 2];
+        rays_o[3 * id + k] = P[4 * k + 3];
+    }
+}
+
 // =============================================================================================
 // C-ABI launchers
 // =============================================================================================
@@ -412,6 +433,14 @@ int envidr_near_far_from_aabb(const float* rays_o, const float* rays_d, const fl
                               float min_near, float* nears, float* fars, envidr_stream_t stream) {
     ENVIDR_REQUIRE(N == 0 || (rays_o && rays_d && aabb && nears && fars), "near_far_from_aabb: null pointer");
     LAUNCH_1D(k_near_far_from_aabb, N, stream, rays_o, rays_d, aabb, N, min_near, nears, fars);
+}
+
+int envidr_get_rays(const float* poses, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, uint32_t B, float* rays_o,
+                    float* rays_d, envidr_stream_t stream) {
+    ENVIDR_REQUIRE(B == 0 || H == 0 || W == 0 || (poses && rays_o && rays_d), "get_rays: null pointer");
+    const unsigned long long n = (unsigned long long)H * W * B;
+    ENVIDR_REQUIRE(n < (1ull << 32), "get_rays: too many rays for one call");
+    LAUNCH_1D(k_get_rays, (uint32_t)n, stream, poses, fx, fy, cx, cy, H, W, B, rays_o, rays_d);
 }
 
 int envidr_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords,

@@ -46,6 +46,12 @@ int envidr_near_far_from_aabb(const float* rays_o, const float* rays_d, const fl
                               uint32_t N, float min_near, float* nears, float* fars,
                               envidr_stream_t stream);
 
+/* utils.get_rays, full-image branch (nerf/utils.py:109-209, :193-207): pixel centres at +0.5 -> unit camera directions ->
+ * rotated by the camera-to-world pose; origins = the pose's translation.  poses: device [B,4,4] row-major; outputs device
+ * [B, H*W, 3], pixels row-major.  (The reference computes this with torch ops; here it is one launch.) */
+int envidr_get_rays(const float* poses, float fx, float fy, float cx, float cy, uint32_t H, uint32_t W, uint32_t B,
+                    float* rays_o, float* rays_d, envidr_stream_t stream);
+
 /* raymarching.cu:201 sph_from_ray -- far hit with sphere(radius) -> (theta,phi) in [-1,1]^2. */
 int envidr_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N,
                         float* coords, envidr_stream_t stream);

@@ -82,9 +82,22 @@ def test_render_entry_points_validate_their_descriptor():
     d.env_blob = d.head_blob = p
     assert lib.envidr_shade_samples(ctypes.byref(d), p, p, p, 7, p, 1, 4, p, p, None) == -1
     assert b"geo_feat_stride" in lib.envidr_last_error()
-    d.dir_sh_degree = 4
+    d.dir_sh_degree = 3
     assert lib.envidr_shade_samples(ctypes.byref(d), p, p, p, 12, p, 1, 4, p, p, None) == -1
-    assert b"environment-MLP family" in lib.envidr_last_error()
+    assert b"unsupported dir_sh_degree" in lib.envidr_last_error()
+    # geometry pipeline entry points
+    d = fused.RenderDesc()
+    ex = fused.GeometryExport()
+    assert lib.envidr_geometry_pass(ctypes.byref(d), None, None, 0, ctypes.byref(o), ctypes.byref(ex), None, 0, 0, None) == 0      # N = 0
+    assert lib.envidr_geometry_pass(None, None, None, 8, ctypes.byref(o), ctypes.byref(ex), None, 0, 0, None) == -1
+    assert b"null descriptor" in lib.envidr_last_error()
+    assert lib.envidr_geometry_pass(ctypes.byref(d), p, p, 8, ctypes.byref(o), ctypes.byref(ex), None, 0, 0, None) == -1
+    assert b"workspace" in lib.envidr_last_error()
+    assert lib.envidr_geometry_workspace_bytes(640000, 16_000_000) > 16_000_000 * 92
+    so = fused.SamplesOut()
+    assert lib.envidr_geometry_eval(ctypes.byref(d), None, None, 0, None, ctypes.byref(so), None) == 0                              # M = 0
+    assert lib.envidr_geometry_eval(ctypes.byref(d), None, None, 4, None, ctypes.byref(so), None) == -1
+    assert b"null sample pointers" in lib.envidr_last_error()
 
 
 def _tile_row(r, h):

@@ -95,6 +95,28 @@ def test_every_reference_backend_function_is_covered_and_checks_its_arguments():
         _backend.near_far_from_aabb(xc, xc, torch.zeros(6, device="cuda"), 4, 0.2, torch.zeros(4, device="cuda"), torch.zeros(4, device="cuda"))
 
 
+def test_get_rays_on_the_device_matches_the_reference():
+    """SURVEY.md 8 a1 on the GPU: envidr_get_rays (one launch) against the rays the reference's own get_rays produced
+    (tests/golden/get_rays.npz, nerf/utils.py:193-207), and at the benchmark's 800x800 against the host generator"""
+    import torch
+    from pathlib import Path
+    from envidr_amd import scenes
+    from envidr_amd.nerf.utils import get_rays
+    g = np.load(Path(__file__).parent / "golden" / "get_rays.npz")
+    H, W = int(g["H"]), int(g["W"])
+    r = get_rays(torch.from_numpy(g["poses"]).cuda(), g["intrinsics"], H, W, -1)
+    torch.cuda.synchronize()
+    assert r["rays_d"].shape == (2, H * W, 3) and r["rays_d"].is_cuda
+    assert np.allclose(r["rays_d"].cpu().numpy(), g["rays_d"], atol=1e-6, rtol=0)
+    assert np.array_equal(r["rays_o"].cpu().numpy(), g["rays_o"])
+    pose = scenes.nerf_matrix_to_ngp(scenes.pose_spherical(30.0, -20.0, 4.0), scale=0.65)
+    intr = scenes.intrinsics_for(800, 800)
+    big = get_rays(torch.from_numpy(pose[None].astype(np.float32)).cuda(), intr, 800, 800, -1)
+    ro, rd = scenes.camera_rays(800, 800)
+    assert np.allclose(big["rays_d"][0].cpu().numpy(), rd, atol=1e-6, rtol=0) and np.array_equal(big["rays_o"][0].cpu().numpy(), ro)
+    assert torch.allclose(big["rays_d"].norm(dim=-1), torch.ones(1, 640000, device="cuda"), atol=1e-6)
+
+
 def test_compact_alive_matches_boolean_mask():
     rng = np.random.default_rng(3)
     for n in (1, 63, 64, 65, 255, 256, 257, 1000, 70000):
