@@ -121,7 +121,14 @@ class NeRFNetwork(NeRFRenderer):
                         nn.init.zeros_(lin.bias)
         if opt.use_diffuse and opt.mlp_bias:
             self.color_net[-1].bias.data -= np.log(3)      # lower specular at initialisation
+        # background model on the sphere of radius bg_radius (reference network.py:343-367): 2-D hash grid of the sphere
+        # coordinates + SH(4) of the view direction -> bias-free MLP -> rgb
         self.bg_net = None
+        if self.bg_radius > 0:
+            self.num_layers_bg, self.hidden_dim_bg = num_layers_bg, hidden_dim_bg
+            self.encoder_bg, self.in_dim_bg = get_encoder(encoding_bg, input_dim=2, num_levels=4, log2_hashmap_size=19, desired_resolution=2048)
+            self.encoder_dir_bg, self.in_dim_dir_bg = get_encoder("sphere_harmonics", degree=4)
+            self.bg_net = _mlp([self.in_dim_bg + self.in_dim_dir_bg] + [hidden_dim_bg] * (num_layers_bg - 1) + [3], bias=False)
         self.roughness = opt.default_roughness
         self.blend_weight = None
         self.metallic = 1.0
@@ -236,6 +243,12 @@ class NeRFNetwork(NeRFRenderer):
         sdf, sigma, geo_feat, _, _ = self.forward_sigma(x)
         return sdf, sigma, self.forward_color(geo_feat, d, normal, w_r, n_dot_w_o)
 
+    def background(self, x, d):
+        """rgb of the background sphere: x [N,2] sphere coordinates in [-1,1] (raymarching.sph_from_ray), d [N,3] view
+        directions (reference network.py:727-742)"""
+        h = torch.cat([self.encoder_dir_bg(d), self.encoder_bg(x)], dim=-1)
+        return torch.sigmoid(_run_mlp(self.bg_net, h)) if self.opt.color_act == "sigmoid" else _run_mlp(self.bg_net, h)
+
     def color(self, x, d, mask=None, geo_feat=None, normal=None, w_r=None, n_dot_w_o=None, **kwargs):
         """rgb of the samples selected by `mask` (all when None), zeros elsewhere (reference network.py:745-770)"""
         if mask is None:
@@ -269,7 +282,7 @@ class NeRFNetwork(NeRFRenderer):
         # reflected-radiance branch of the main indirect pass: renv MLP 4-64-64-64-12 with the learnt blend
         renv_ok = r_images is None or (shade_ok and o.use_renv and self.renv_net is not None and o.learn_indir_blend
                                        and not o.indir_only and not o.train_renv and r_images.shape[-1] == 4)
-        return bool(hash_ok and net_ok and (shade_ok or plain_ok) and renv_ok and self.bg_radius <= 0 and not self.training)
+        return bool(hash_ok and net_ok and (shade_ok or plain_ok) and renv_ok and not self.training)
 
     def _build_fused(self):
         from ..fused import FusedOptions, FusedRenderer

@@ -39,16 +39,26 @@ def run_cuda(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, fo
     rays_d = rays_d.contiguous().view(-1, 3)
     N, device = rays_o.shape[0], rays_o.device
     opt = self.opt
-    if bg_color is None:
+    sphere_bg = None
+    if self.bg_radius > 0 and bg_sphere:
+        # background model (reference cuda_ray.py:56-60): where the ray leaves the sphere of radius bg_radius -> 2-D grid
+        # encoding + SH of the view direction -> bg MLP; blended with (1 - weights_sum) like any background colour
+        with torch.no_grad():
+            sph = raymarching.sph_from_ray(rays_o, rays_d, self.bg_radius)
+            sphere_bg = self.background(sph, rays_d)
+        bg_color = sphere_bg
+    elif bg_color is None:
         bg_color = 1
     visual = list(opt.visual_items) if opt.use_diffuse else []
 
     # ---------------- fused persistent kernel ----------------
-    scalar_bg = not torch.is_tensor(bg_color)
+    # a per-ray background (the sphere model) is blended after the fused render: it runs with background 0
+    tensor_bg = bg_color if (torch.is_tensor(bg_color) and bg_color.dim() == 2 and bg_color.shape[0] == N) else None
+    scalar_bg = tensor_bg is not None or not torch.is_tensor(bg_color)
     if (fused and ray_depth is None and not perturb and scalar_bg and max_steps == opt.max_steps and T_thresh == opt.T_thresh
             and dt_gamma == opt.dt_gamma and self.supports_fused(r_images=r_images, geometry_only=geometry_only)):
         fr = self.fused_renderer()
-        fr.desc.bg_color = float(bg_color)
+        fr.desc.bg_color = 0.0 if tensor_bg is not None else float(bg_color)
         fr.desc.min_near = float(self.min_near)
         fr.set_aabb(self.aabb_infer)               # the operator loop's near_far_from_aabb box, not just +-bound
         # The geometry pipeline (march rounds + sample-parallel hash / SDF kernel -> record shading -> composite;
@@ -71,7 +81,10 @@ def run_cuda(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, fo
                 hints[key] = torch.zeros(N, dtype=torch.int16, device=device)
             res = fr.render(rays_o, rays_d, env_rot_radian, extras=True, geometry_only=geometry_only,
                             r_images=None if r_images is None else r_images[0], ray_cost=hints[key])
-        out = {"image": res["image"].view(*prefix, 3), "depth": res["depth"].view(*prefix), "weights_sum": res["weights_sum"].view(*prefix)}
+        image = res["image"] if tensor_bg is None else res["image"] + (1 - res["weights_sum"])[:, None] * tensor_bg
+        out = {"image": image.view(*prefix, 3), "depth": res["depth"].view(*prefix), "weights_sum": res["weights_sum"].view(*prefix)}
+        if sphere_bg is not None:
+            out["sphere_bg"] = sphere_bg
         if geometry_only:
             out["image"] = None
             out["normal_image"] = res["normal_image"].view(*prefix, 3)
@@ -156,6 +169,8 @@ def run_cuda(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, fo
         step += n_step
 
     results = {"depth": main["depth"].view(*prefix), "weights_sum": main["ws"].view(*prefix)}
+    if sphere_bg is not None:
+        results["sphere_bg"] = sphere_bg
     if geometry_only:
         results["image"] = None
         results["normal_image"] = F.normalize(main["image"], dim=-1, eps=1e-10).view(*prefix, 3)

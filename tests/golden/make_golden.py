@@ -138,7 +138,9 @@ def install_reference():
                       "composite_rays"])
     he = _RefBackend(["hash_encode_forward", "hash_encode_backward", "hash_encode_second_backward"])
     sh = _RefBackend(["sh_encode_forward", "sh_encode_backward"])
-    for pkg, name, backend in [("raymarching", "_raymarching", rm), ("hashencoder", "_hashencoder", he), ("shencoder", "_shencoder", sh)]:
+    ge = _RefBackend(["grid_encode_forward", "grid_encode_backward"])
+    for pkg, name, backend in [("raymarching", "_raymarching", rm), ("hashencoder", "_hashencoder", he), ("shencoder", "_shencoder", sh),
+                               ("gridencoder", "_gridencoder", ge)]:
         ext = types.ModuleType(f"{pkg}._ext")
         setattr(ext, name, backend)
         sys.modules[f"{pkg}._ext"] = ext
@@ -241,6 +243,33 @@ def golden_frame(model, opt, tag, H, W, env_rot=None, theta=30.0, phi=-20.0, ext
                         trace=np.array(trace, np.int32), **(extra or {}))
     print(f"[golden] frame_{tag}: {H}x{W}, {len(trace)} loop iterations, {sum(t[3] for t in trace)} samples, "
           f"hit fraction {float((res['weights_sum'] > 0).float().mean()):.3f}, mean rgb {res['image'].mean(dim=(0, 1)).tolist()}")
+
+
+def golden_background():
+    """run_cuda's background-sphere branch (cuda_ray.py:56-62, network.py:343-367,727-742): toaster.ini + `--bg_radius 3`.
+    The background model's parameters (2-D hash grid table, bias-free MLP) are the reference's own seeded initialisation
+    scaled up so that the background is not flat; they are stored in the fixture as the test's input data."""
+    scene = scenes.toaster_scene(seed=6)
+    model, opt = build_reference_model(scene, extra_argv=["--bg_radius", "3"])
+    assert model.bg_radius == 3 and model.bg_net is not None
+    g = torch.Generator().manual_seed(17)
+    with torch.no_grad():
+        model.encoder_bg.embeddings.data = (torch.rand(model.encoder_bg.embeddings.shape, generator=g) * 2 - 1) * 0.5
+        for lin in model.bg_net:
+            lin.weight.data = (torch.rand(lin.weight.shape, generator=g) * 2 - 1) * (6.0 / lin.weight.shape[1]) ** 0.5
+    extra = {"bg_table": model.encoder_bg.embeddings.detach().numpy().astype(F), "bg_offsets": model.encoder_bg.offsets.numpy(),
+             "bg_radius": np.float32(3.0)}
+    for i, lin in enumerate(model.bg_net):
+        extra[f"bg_w{i}"] = lin.weight.detach().numpy().astype(F)
+    H = W = 40
+    ro, rd = scenes.camera_rays(H, W, theta=300.0, phi=-15.0)
+    res = model.render(torch.from_numpy(ro)[None], torch.from_numpy(rd)[None], staged=True, bg_color=None, perturb=False,
+                       get_normal_image=True, env_rot_radian=None, **vars(opt))
+    g2 = lambda t: t.detach().numpy().astype(F).reshape(H * W, -1).squeeze(-1) if t.numel() == H * W else t.detach().numpy().astype(F).reshape(H * W, -1)
+    np.savez_compressed(OUT / "frame_toaster_bg_40.npz", H=H, W=W, theta=300.0, phi=-15.0, image=g2(res["image"]), depth=g2(res["depth"]),
+                        weights_sum=g2(res["weights_sum"]), sphere_bg=g2(res["sphere_bg"]), **extra)
+    print(f"[golden] frame_toaster_bg_40: sphere_bg mean {res['sphere_bg'].mean(0).tolist()}, std {float(res['sphere_bg'].std()):.3f}, "
+          f"hit fraction {float((res['weights_sum'] > 0).float().mean()):.3f}")
 
 
 def golden_relight():
@@ -436,6 +465,7 @@ def main():
     assert opt4.indir_ref and opt4.use_renv
     golden_frame(model4, opt4, "toaster_indir_40", 40, 40, theta=40.0, phi=-50.0)
     golden_relight()
+    golden_background()
     golden_grid()
     golden_demo()
     # BASELINE configs[1]: no environment network, SH-encoded view direction and normal

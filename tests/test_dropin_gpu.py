@@ -143,6 +143,30 @@ def test_tightened_marching_box_is_honoured_by_the_fused_paths():
             assert err <= 3e-5, f"two_phase={two_phase} {key}: {err:.2e}"
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_background_sphere_branch_matches_reference(fused):
+    """bg_radius > 0: sph_from_ray + 2-D grid_encode + sh_encode -> background MLP, blended with (1 - weights_sum); against the
+    reference's own render of the same model (cuda_ray.py:56-62, network.py:343-367,727-742)"""
+    import torch
+    g = np.load(GOLD / "frame_toaster_bg_40.npz")
+    model, opt = build_model(scenes.toaster_scene(seed=6), bg_radius=float(g["bg_radius"]))
+    assert model.bg_net is not None and tuple(model.encoder_bg.embeddings.shape) == g["bg_table"].shape
+    with torch.no_grad():
+        model.encoder_bg.embeddings.data = torch.from_numpy(g["bg_table"]).cuda()
+        for i, lin in enumerate(model.bg_net):
+            lin.weight.data = torch.from_numpy(g[f"bg_w{i}"]).cuda()
+    H, W = int(g["H"]), int(g["W"])
+    ro_, rd_ = scenes.camera_rays(H, W, theta=float(g["theta"]), phi=float(g["phi"]))
+    res = model.render(torch.from_numpy(ro_).cuda()[None], torch.from_numpy(rd_).cuda()[None], staged=True, bg_color=None, perturb=False,
+                       get_normal_image=True, fused=fused, max_steps=opt.max_steps, T_thresh=opt.T_thresh, dt_gamma=opt.dt_gamma)
+    torch.cuda.synchronize()
+    assert model.supports_fused()
+    assert np.abs(res["sphere_bg"].cpu().numpy() - g["sphere_bg"]).max() <= 1e-5
+    for key in ("image", "depth", "weights_sum"):
+        err = rel_l2(res[key].cpu().numpy().reshape(H * W, -1), g[key].reshape(H * W, -1))
+        assert err <= 1e-4, f"{key}: rel-L2 {err:.3e}"
+
+
 def test_hash_encoder_first_order_backward_reaches_the_table():
     """`enc(x).sum().backward()` (no double backward) must fill embeddings.grad: the table gradient of a weighted sum of the
     outputs equals the oracle's hash_encode_backward scatter (hashencoder.cu:257-343), and a plain training step would otherwise

@@ -151,6 +151,33 @@ def test_ide_oracle_vs_reference_fp32():
         assert mat.dtype == np.float32
 
 
+def test_background_sphere_matches_reference():
+    """run_cuda's background-sphere branch (cuda_ray.py:56-62, network.py:727-742): the oracle's sph_from_ray + 2-D grid_encode
+    + sh_encode operators and a plain fp32 MLP reproduce the `sphere_bg` the reference rendered (fixture frame_toaster_bg_40)"""
+    from oracle import clib
+    g = np.load(GOLD / "frame_toaster_bg_40.npz")
+    H, W = int(g["H"]), int(g["W"])
+    ro, rd = scenes.camera_rays(H, W, theta=float(g["theta"]), phi=float(g["phi"]))
+    N = H * W
+    o = clib.oracle()
+    sph = np.zeros((N, 2), np.float32)
+    o.call("sph_from_ray", ro, rd, float(g["bg_radius"]), N, sph)
+    offsets = g["bg_offsets"].astype(np.int32)
+    L, C = offsets.shape[0] - 1, 2
+    pls = float(np.exp2(np.log2(2048 / 16) / (L - 1)))
+    x01 = ((sph + 1) / 2).astype(np.float32)                       # GridEncoder.forward: (inputs + bound) / (2 bound), bound 1
+    enc = np.zeros((L, N, C), np.float32)
+    o.call("grid_encode_forward", x01, g["bg_table"], offsets, enc, N, 2, C, L, float(np.log2(pls)), 16, None, 0, 0)
+    enc = enc.transpose(1, 0, 2).reshape(N, L * C)
+    shd = np.zeros((N, 16), np.float32)
+    o.call("sh_encode_forward", rd, shd, N, 3, 4, None)
+    h = np.concatenate([shd, enc], -1)
+    h = np.maximum(h @ g["bg_w0"].T, 0) @ g["bg_w1"].T
+    bg = 1 / (1 + np.exp(-h.astype(np.float64)))
+    assert np.abs(bg - g["sphere_bg"]).max() <= 2e-6
+    assert g["sphere_bg"].std() > 0.02                             # not a flat background
+
+
 def test_get_rays_matches_reference():
     """both ray generators (torch, used by the drop-in surface; numpy, used by scenes / bench) against the
     reference's get_rays on a non-square image"""
