@@ -101,6 +101,9 @@ constexpr int kGeoRing = ENVIDR_GEO_RING;
 #ifndef ENVIDR_GEO_PREFETCH
 #define ENVIDR_GEO_PREFETCH 0     // 1: the first AHEAD levels of the next batch are gathered before the matrix-core section of this one
 #endif
+#ifndef ENVIDR_GEO_KERNEL32
+#define ENVIDR_GEO_KERNEL32 1      // 1: k_geo_eval32 (32 samples per wave, two waves per SIMD), 0: k_geo_eval (64, one per SIMD)
+#endif
 #ifndef ENVIDR_GEO_UNROLL_GROUPS
 #define ENVIDR_GEO_UNROLL_GROUPS 0
 #endif
@@ -500,6 +503,209 @@ __global__ void __launch_bounds__(kEvalThreads, (kEvalWaves + 3) / 4) k_geo_eval
 }
 
 // =====================================================================================================================
+// k_geo_eval32: the same evaluation with 32 samples per wave and the 16 hash levels split between the two lane halves
+// =====================================================================================================================
+// Lane (s, h) -- sample s = lane & 31 of the batch, half h = lane >> 5 -- evaluates the eight levels 2 i + h.  What this
+// buys: the Jacobian a wave parks is 48 values per lane (12 KiB per wave), so EIGHT waves -- two per SIMD -- fit beside the
+// LDS-resident weights, and one wave's gather phase (fabric-bound) overlaps its SIMD partner's matrix-core phase; the
+// matrix-core section of a wave is one 32-sample group; all 64 lanes gather.  The half-wave exchange the MFMA operand
+// packing needs anyway (v_permlane32_swap) also brings a level's two channels together for the first layer and hands
+// every lane the feature gradients of its own levels afterwards.
+constexpr int kE32Waves = 8;
+constexpr int kE32Threads = kE32Waves * 64;
+constexpr int kE32Steps = kLevels / 2;            // level pairs: step i covers level 2 i (lower lanes) and 2 i + 1 (upper lanes)
+
+__global__ void __launch_bounds__(kE32Threads, 2) k_geo_eval32(const GeoEvalArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_w[kSdfBlobFloats + kW3RowFloats];
+    __shared__ __attribute__((aligned(16))) LeanLevel s_lv[kLevels];
+    __shared__ float s_jac[kE32Waves * kE32Steps * 6 * 64];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t half = lane >> 5, sl = lane & 31u;
+    uint32_t begin = 0, count = a.M;
+    if (a.range) { begin = __builtin_amdgcn_readfirstlane(a.range[0]); count = min(__builtin_amdgcn_readfirstlane(a.range[1]), a.M - min(begin, a.M)); }
+    else if (a.head) {
+        begin = __builtin_amdgcn_readfirstlane(a.begin_io[0]);
+        const uint32_t end = min(__builtin_amdgcn_readfirstlane(*a.head), a.M);
+        count = end - min(begin, end);
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.begin_io[1] = end;
+    }
+    const uint32_t batches = (count + 31u) / 32u;
+#if ENVIDR_GEO_XCD
+    const uint32_t xcd = blockIdx.x & 7u, in_xcd = blockIdx.x >> 3, per_xcd_blocks = (gridDim.x + 7u - xcd) >> 3;
+    const uint32_t share = (batches + 7u) / 8u;
+    const uint32_t b_lo = min(xcd * share, batches), b_hi = min(b_lo + share, batches);
+#else
+    const uint32_t in_xcd = blockIdx.x, per_xcd_blocks = gridDim.x, b_lo = 0, b_hi = batches;
+#endif
+    if (b_lo + in_xcd * kE32Waves >= b_hi) return;
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.sdf_blob);
+        float4* dst = reinterpret_cast<float4*>(s_w);
+        for (uint32_t i = threadIdx.x; i < kSdfBlobFloats / 4; i += kE32Threads) dst[i] = src[i];
+        if (threadIdx.x < kW3RowFloats) s_w[kSdfBlobFloats + threadIdx.x] = a.sdf_w3r0[threadIdx.x];
+        if (threadIdx.x < kLevels) s_lv[threadIdx.x] = a.lv[threadIdx.x];
+    }
+    __syncthreads();
+    WeightLdsRing<kGeoRing> wp;
+    wp.start(s_w + lane);
+    const float* w3row = s_w + kSdfBlobFloats + half * 16;
+    float* jac_col = s_jac + wave * (kE32Steps * 6 * 64) + lane;
+    constexpr int kSdfN = (kSdfFrags + kGeoRing - 1) / kGeoRing * kGeoRing;
+    constexpr int kAhead = ENVIDR_GEO_AHEAD;
+    const __amdgpu_buffer_rsrc_t table = table_rsrc(a.table, a.table_bytes);
+    const uint32_t stride = per_xcd_blocks * kE32Waves;
+
+    for (uint32_t b = b_lo + in_xcd * kE32Waves + wave; b < b_hi; b += stride) {
+        const uint32_t sidx = b * 32u + sl;
+        const bool on = sidx < count;
+        const size_t slot = (size_t)begin + (on ? sidx : 0u);
+        float xc[3];
+        bool inside;
+        {
+            typedef float f32x3 __attribute__((ext_vector_type(3)));
+            f32x3 pv = {0.0f, 0.0f, 0.0f};
+            if (on) pv = *reinterpret_cast<const f32x3*>(a.xyz + 3 * slot);
+            const float x01[3] = {(pv[0] + a.bound) / a.bound2, (pv[1] + a.bound) / a.bound2, (pv[2] + a.bound) / a.bound2};
+            inside = x01[0] >= 0 && x01[0] <= 1 && x01[1] >= 0 && x01[1] <= 1 && x01[2] >= 0 && x01[2] <= 1;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) xc[d] = inside ? x01[d] : 0.5f;
+        }
+
+        // ================= phase 1: this lane's eight levels: values + Jacobian -> LDS ============================
+        float f0[kE32Steps], f1[kE32Steps];
+        {
+            LeanStage st[kAhead + 1];
+            LeanLevel lvs[kAhead + 1];
+            auto prep = [&](int i, LeanStage& stg, LeanLevel& lv) {
+                lv = s_lv[2 * i + half];                                       // per-lane level constants (two distinct rows: broadcast)
+                lean_prepare<0, true>(lv, table, xc, stg);
+            };
+            [&]<int... I>(std::integer_sequence<int, I...>) { (prep(I, st[I], lvs[I]), ...); }(std::make_integer_sequence<int, kAhead>{});
+            __builtin_amdgcn_sched_barrier(0);
+            auto step = [&](auto ic, LeanStage& now, LeanLevel& lvnow, LeanStage& ahead, LeanLevel& lvahead) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i + kAhead < kE32Steps) prep(i + kAhead, ahead, lvahead);
+                __builtin_amdgcn_sched_barrier(0);
+                float o[2], g[3][2];
+                lean_finish(now, inside ? lvnow.on : 0.0f, o, g);
+                f0[i] = o[0]; f1[i] = o[1];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    jac_col[((i * 3 + d) * 2 + 0) * 64] = g[d][0];
+                    jac_col[((i * 3 + d) * 2 + 1) * 64] = g[d][1];
+                }
+            };
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                (step(std::integral_constant<int, I>{}, st[I % (kAhead + 1)], lvs[I % (kAhead + 1)], st[(I + kAhead) % (kAhead + 1)],
+                      lvs[(I + kAhead) % (kAhead + 1)]), ...);
+            }(std::make_integer_sequence<int, kE32Steps>{});
+        }
+        // first-layer operands: step q = level q takes (channel 0 | channel 1) of the 32 samples in the (lower | upper) lanes
+        float in[kLevels];
+#pragma unroll
+        for (int i = 0; i < kE32Steps; ++i) {
+            float u = f0[i], v = f1[i];
+            swap_halves(u, v);               // u = [ch0 | ch1] of level 2 i,  v = [ch0 | ch1] of level 2 i + 1
+            in[2 * i] = u; in[2 * i + 1] = v;
+        }
+
+        // ================= phase 2: SDF network forward + input gradient: one 32-sample group ===================
+        f32x16 o3[1], gf[1];
+        {
+            f32x16 h1[2], h2[2];
+            uint32_t pos1 = 0, pos2 = 0;
+            pipe_layer_from_lanes<kLevels, 2, kSdfW1, kSdfN>(wp, lane, in, h1);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pos1 |= (h1[t][r] > 0 ? 1u : 0u) << (16 * t + r);
+            pipe_layer_from_tiles<2, 2, kSdfW2, kSdfN, true>(wp, lane, h1, h2);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pos2 |= (h2[t][r] > 0 ? 1u : 0u) << (16 * t + r);
+            pipe_layer_from_tiles<2, 1, kSdfW3, kSdfN, true>(wp, lane, h2, o3);
+            f32x16 g2[2], g1[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) g2[t][r] = (pos2 >> (16 * t + r)) & 1u ? w3row[t * 32 + r] : 0.0f;
+            pipe_layer_from_tiles<2, 2, kSdfW2t, kSdfN, false, false>(wp, lane, g2, g1);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) g1[t][r] = (pos1 >> (16 * t + r)) & 1u ? g1[t][r] : 0.0f;
+            pipe_layer_from_tiles<2, 1, kSdfW1t, kSdfN, false, false>(wp, lane, g1, gf);
+            wp.template end_pass<kSdfFrags>();
+        }
+
+        // ================= phase 3: every lane gets d sdf / d (its own levels' features); normal = J^T g ===================
+        // register r of the gradient tile holds feature (r & 3) + 8 (r >> 2) + 4 h: per quad of registers one exchange per
+        // channel hands both halves the gradients of their levels 2 i + h for i = 2 k and 2 k + 1
+        float g0[kE32Steps], g1c[kE32Steps];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float u = gf[0][4 * k], v = gf[0][4 * k + 2];
+            swap_halves(u, v);
+            g0[2 * k] = u; g0[2 * k + 1] = v;
+            float p = gf[0][4 * k + 1], q = gf[0][4 * k + 3];
+            swap_halves(p, q);
+            g1c[2 * k] = p; g1c[2 * k + 1] = q;
+        }
+        float part[3] = {0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < kE32Steps; ++i)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                part[d] += g0[i] * jac_col[((i * 3 + d) * 2 + 0) * 64];
+                part[d] += g1c[i] * jac_col[((i * 3 + d) * 2 + 1) * 64];
+            }
+        float nrm[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float lo = part[d], hi = part[d];
+            swap_halves(lo, hi);             // lo = the lower half's sum in every lane, hi = the upper half's
+            nrm[d] = (lo + hi) / a.bound2;                                              // even levels + odd levels; d x01 / d xyz
+        }
+        normalize_n<3>(nrm, 1e-10f);                                                    // renderer.py:192
+        // raw outputs 0..15 of the last layer: rows 0-3, 8-11 in the lower lanes' registers 0..7, rows 4-7, 12-15 in the upper lanes'
+        float h3[16];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float lo = o3[0][r], hi = o3[0][r];
+            swap_halves(lo, hi);
+            h3[tile_row(r, 0)] = lo; h3[tile_row(r, 1)] = hi;
+        }
+        const float sdf = h3[0];
+        float geo[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) geo[i] = h3[1 + i];
+        normalize_n<12>(geo, 1e-12f);                                                   // network.py:434-435
+        const float rough = a.rough_act_scale * softplusf(h3[13] + a.rough_bias) * a.rough_scale;   // network.py:443-448
+        const float sgn = sdf > 0 ? 1.0f : (sdf < 0 ? -1.0f : 0.0f);
+        const float sigma = a.inv_beta * (0.5f + 0.5f * sgn * expm1f(-fabsf(sdf) / a.beta)) * a.density_scale;
+        if (on && half == 0) {
+            if (a.alpha) a.alpha[slot] = 1.0f - expf(-sigma * a.dt[slot]);
+            if (a.sigma) a.sigma[slot] = sigma;
+            if (a.rough) a.rough[slot] = rough;
+            if (a.blend) a.blend[slot] = h3[14];
+            if (a.normal) {
+                typedef float f32x3 __attribute__((ext_vector_type(3)));
+                const f32x3 nv = {nrm[0], nrm[1], nrm[2]};
+                *reinterpret_cast<f32x3*>(a.normal + 3 * slot) = nv;
+            }
+            if (a.geo) {
+                float4* gp = reinterpret_cast<float4*>(a.geo + 12 * slot);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) gp[i] = make_float4(geo[4 * i], geo[4 * i + 1], geo[4 * i + 2], geo[4 * i + 3]);
+            }
+        }
+        wave_lds_sync();      // the parked Jacobian is rewritten by the next batch
+    }
+}
+
+// =====================================================================================================================
 // per-ray rounds
 // =====================================================================================================================
 struct RayState {            // 48 bytes per ray, indexed by ray id
@@ -752,7 +958,13 @@ void launch_eval(const GeoEvalArgs& a, uint32_t max_samples, hipStream_t s) {
         if (!g_scratch[dev]) (void)hipMalloc(&g_scratch[dev], (size_t)device_cu_count() * kEvalWaves * kLevels * 6 * 64 * sizeof(float));
         b.jscratch = g_scratch[dev];
     }
+#if ENVIDR_GEO_KERNEL32
+    const uint32_t blocks32 = std::max(1u, std::min((uint32_t)device_cu_count(), ceil_div(max_samples, kE32Waves * 32u)));
+    hipLaunchKernelGGL(k_geo_eval32, dim3(blocks32), dim3(kE32Threads), 0, s, b);
+    (void)blocks;
+#else
     hipLaunchKernelGGL(k_geo_eval, dim3(blocks), dim3(kEvalThreads), 0, s, b);
+#endif
 }
 
 

@@ -66,7 +66,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const float* table,
 }
 
 // cell + weights + the gathers of one level (x in [0, 1]^3)
-template <int AUX = 0>
+// LANE_LEVEL: the level differs between lanes (its constants live in vector registers): the level's first row then goes
+// into the per-lane offset instead of the scalar offset of the buffer instruction
+template <int AUX = 0, bool LANE_LEVEL = false>
 __device__ __forceinline__ void lean_prepare(const LeanLevel& lv, __amdgpu_buffer_rsrc_t table, const float (&x)[3], LeanStage& st) {
     uint32_t cell[3];
 #pragma unroll
@@ -105,7 +107,7 @@ __device__ __forceinline__ void lean_prepare(const LeanLevel& lv, __amdgpu_buffe
     bool need = false;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        st.pair[j] = __builtin_amdgcn_raw_buffer_load_b128(table, base[j] * 8u, lv.row0_bytes, AUX);
+        st.pair[j] = __builtin_amdgcn_raw_buffer_load_b128(table, base[j] * 8u + (LANE_LEVEL ? lv.row0_bytes : 0u), LANE_LEVEL ? 0u : lv.row0_bytes, AUX);
         const uint32_t o0 = r0[j] - base[j], o1 = r1[j] - base[j];     // 0 or 1 when inside the pair
         sel |= (o0 & 1u) << j;
         sel |= (o1 == 1u ? 1u : 0u) << (4 + j);
@@ -116,7 +118,8 @@ __device__ __forceinline__ void lean_prepare(const LeanLevel& lv, __amdgpu_buffe
     st.sel = sel;
     if (need) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) st.solo[j] = __builtin_amdgcn_raw_buffer_load_b64(table, r1[j] * 8u, lv.row0_bytes, AUX);
+        for (int j = 0; j < 4; ++j)
+            st.solo[j] = __builtin_amdgcn_raw_buffer_load_b64(table, r1[j] * 8u + (LANE_LEVEL ? lv.row0_bytes : 0u), LANE_LEVEL ? 0u : lv.row0_bytes, AUX);
     }
 }
 

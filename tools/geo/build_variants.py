@@ -7,11 +7,10 @@ sys.path.insert(0, str(ROOT))
 from envidr_amd import build as B
 
 VARIANTS = {
-    "base": [],
-    "pf_a2": ["-DENVIDR_GEO_PREFETCH=1", "-DENVIDR_GEO_AHEAD=2"],
-    "pf_a4": ["-DENVIDR_GEO_PREFETCH=1", "-DENVIDR_GEO_AHEAD=4"],
-    "pf_a6": ["-DENVIDR_GEO_PREFETCH=1", "-DENVIDR_GEO_AHEAD=6"],
-    "pf_a8": ["-DENVIDR_GEO_PREFETCH=1", "-DENVIDR_GEO_AHEAD=8"],
+    "k32": [],
+    "k32_a1": ["-DENVIDR_GEO_AHEAD=1"],
+    "k32_a3": ["-DENVIDR_GEO_AHEAD=3"],
+    "k64": ["-DENVIDR_GEO_KERNEL32=0"],
 }
 
 def main(names):
