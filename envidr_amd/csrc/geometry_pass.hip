@@ -3,18 +3,20 @@
 // The geometry half of a frame -- march -> hash grid -> SDF network forward + input gradient -> density, normal,
 // geometry feature, roughness -> compositing weights -- as a device-driven sequence of two kinds of launches:
 //
-//   k_geo_rays   one lane per ray still alive: composites the samples its ray got evaluated in the previous round
-//                (reference recurrence, raymarching.cu:996-1030), finishes rays that terminated or left the scene,
-//                and marches the next chunk of samples of the others (march_core.hip.h, the standalone operator's
-//                bit-exact code) into a compact sample list.  Chunks grow geometrically (16, 32, 64 ...): a ray that
-//                terminates early wastes at most the rest of its current chunk, a ray that never does is done in a
-//                handful of rounds.  No host round trip: counts and the alive list live on the device, the host
-//                enqueues a fixed number of rounds.
-//   k_geo_eval   one lane per SAMPLE of the round's list, nothing per ray: 16-level hash gathers with analytic
-//                Jacobian, SDF network forward and backward on the matrix cores, per-sample geometry terms.  Every
-//                lane has work every round; two waves per SIMD (one in its gather / interpolation phase while the
-//                other owns the matrix pipe); the SDF weights are read from HBM once per workgroup and stay in LDS;
-//                the Jacobian of a sample is held half in registers, half in LDS until the backward pass needs it.
+//   k_geo_rays   one wave per block of 64 neighbouring rays, lane = ray: composites the samples its rays got evaluated
+//                in the previous round (reference recurrence, raymarching.cu:996-1030), finishes rays that terminated
+//                or left the scene, and marches the next chunk of samples of the others (march_core.hip.h, the
+//                standalone operator's bit-exact code) into a compact sample list, laid out sample-major per block so
+//                that every access of the wave is contiguous (see "Memory layout of the rounds").  The first chunk is
+//                sized from the caller's per-ray hint when there is one, else 16; later chunks extend what a ray has by
+//                half (8, 12, 18, 27 ...).  No host round trip: counts and the list of live blocks stay on the device,
+//                the host enqueues a fixed number of rounds.
+//   k_geo_eval32 one lane per (sample, half of the hash levels) of the round's list, nothing per ray: 16-level hash
+//                gathers with analytic Jacobian, SDF network forward and backward on the matrix cores, per-sample
+//                geometry terms.  32 samples per wave, two waves per SIMD (one in its gather / interpolation phase
+//                while the other owns the matrix pipe); the SDF weights are read from HBM once per workgroup and stay
+//                in LDS, and so does the Jacobian of a batch until the backward pass has produced the feature gradients.
+//                (k_geo_eval is the earlier 64-samples-per-wave form, one wave per SIMD; kept for A/B measurements.)
 //
 // Sample positions are those of the reference loop with one sample per ray per iteration (the marcher is resumed
 // from the composited ray time after every sample, which does not depend on the densities), i.e. exactly the samples
@@ -708,18 +710,27 @@ __global__ void __launch_bounds__(kE32Threads, 2) k_geo_eval32(const GeoEvalArgs
 // =====================================================================================================================
 // per-ray rounds
 // =====================================================================================================================
-struct RayState {            // 48 bytes per ray, indexed by ray id
+// Memory layout of the rounds.  A *block* is the 64 rays 64 b .. 64 b + 63 -- one wave, lane = ray -- for the whole pass:
+// rays, hints, per-ray outputs and the per-ray state (structure of arrays) are then read and written by consecutive lanes
+// at consecutive addresses.  The chunk a block marches in a round occupies one contiguous run of sample slots, laid out
+// SAMPLE-major: first every ray's sample 0, then every ray's sample 1 (of the rays that have one) ...:
+//     slot(lane, c) = base + sum_{c' < c} popcount(M_c') + popcount(M_c & lanes below),   M_c = lanes with more than c samples
+// so that at every step of the march (and of the compositing a round later, which rebuilds the same masks from the
+// per-ray counts) the lanes of a wave touch one contiguous piece of every sample array.  With one run per ray instead,
+// each lane access is its own 64-byte line request, and both per-ray kernels ran at the chip's line-request rate
+// (~80 G lines/s: 0.8 and 1.0 ms per frame) rather than at anything to do with their arithmetic.
+// Records are appended the same way (sample-major within the block), which also makes the shading kernel's reads through
+// rec->slot and the final compositor's reads through perm[] nearly sequential.
+// Blocks are never re-packed: the list a round consumes is the ids of the blocks that still have a live ray.
+enum RayField : int { kFAccT = 0, kFWs, kFDepth, kFAn0, kFAn1, kFAn2, kFRough, kFTaken, kFChunk, kStateFields };
+struct RayState {
     float acc_t;             // composited ray time = where the marcher resumes (the reference re-derives it from the deltas)
     float ws, depth;
     float an[3];             // sum w * normal
     float arough;            // sum w * roughness
     uint32_t n_taken;        // samples composited so far
-    uint32_t chunk_begin;    // first slot of the chunk marched last round
-    uint32_t chunk_count;    // its length; bit 31: the ray ran out of samples (or reached max_steps) inside it
-    float t_first;           // round 0 only: ray time AT the first sample (first-hit search)
-    uint32_t pad;
+    uint32_t chunk_count;    // samples marched last round (0: the ray is finished); bit 31: the ray ran out of samples inside it
 };
-static_assert(sizeof(RayState) == 48, "RayState layout");
 
 // counters (device uint32[kGeoCounterWords]), zeroed by the host before every frame
 constexpr uint32_t kCntSampleHead = 0, kCntRecordHead = 1, kCntOverflow = 2, kCntAlive = 8, kCntBegin = 40, kGeoCounterWords = 80;
@@ -735,9 +746,11 @@ struct GeoRayArgs {
     uint32_t chunk;            // samples to march this round; 0: only composite (last round)
     uint32_t round;
     uint32_t* counters;
-    const uint32_t* alive_in;  // rounds >= 1: ids of the rays still alive
+    const uint32_t* alive_in;  // rounds >= 1: ids of the blocks that still have a live ray
     uint32_t* alive_out;
-    RayState* state;
+    uint32_t* block_base;      // [blocks] first slot of the chunk the block marched last
+    uint32_t* state;           // [kStateFields][n_pad] (floats and counts)
+    uint32_t n_pad;
     // sample list
     float* xyz; float* dt; float* dd;
     uint32_t cap;
@@ -751,97 +764,119 @@ struct GeoRayArgs {
     const uint8_t* ray_mask;   // optional: rays whose byte is 0 are finished at once (round 0)
 };
 
-// wave-wide exclusive prefix sum of a small per-lane count; returns the wave total in `total`
-__device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t v, uint32_t lane, uint32_t& total) {
-    uint32_t incl = v;
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t up = __shfl_up(incl, off);
-        if ((int)lane >= off) incl += up;
-    }
-    total = __shfl(incl, 63);
-    return incl - v;
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
 }
 
-// One round of the per-ray half of the geometry pass.
-//   FIRST : lane = ray id; slab test, first-hit search (empty-space skipping), rays without a sample are finished here
-//   else  : lane = entry of the alive list; the chunk evaluated by k_geo_eval since the last round is composited
-//           (raymarching.cu:996-1030 recurrence, termination tested with the pre-update transmittance), one record per
-//           composited sample is appended, finished rays write their outputs
+// One round of the per-ray half of the geometry pass; one wave per block.
+//   FIRST : slab test, first-hit search (empty-space skipping); rays without a sample are finished here
+//   else  : the chunk evaluated by k_geo_eval since the last round is composited (raymarching.cu:996-1030 recurrence,
+//           termination tested with the pre-update transmittance), one record per composited sample is appended,
+//           finished rays write their outputs
 // then every ray still alive marches its next `chunk` samples (march_core.hip.h; the ray time is resumed from the
 // composited time after EVERY sample, as the reference loop does with one sample per iteration -- that time does not
 // depend on the densities, so marching ahead of the compositor changes nothing) into freshly allocated slots.
 template <bool FIRST>
 __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t n_in = FIRST ? a.N : __builtin_amdgcn_readfirstlane(a.counters[kCntAlive + a.round]);
-    const uint32_t wave_stride = gridDim.x * blockDim.x;
-    for (uint32_t wbase = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); wbase < n_in; wbase += wave_stride) {
-        const uint32_t i = wbase + lane;
-        const bool active = i < n_in;
-        const uint32_t ray = FIRST ? i : (active ? a.alive_in[i] : 0u);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t n_in = FIRST ? (a.N + 63u) / 64u : __builtin_amdgcn_readfirstlane(a.counters[kCntAlive + a.round]);
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t bi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; bi < n_in; bi += n_waves) {
+        const uint32_t blk = FIRST ? bi : __builtin_amdgcn_readfirstlane(a.alive_in[bi]);
+        const uint32_t ray = blk * 64u + lane;
+        const bool in_range = ray < a.N;
+        uint32_t* const sp = a.state + ray;
         RayGeom rg = {};
-        float near = 0, far = 0;
+        float near = 0, far = 0, t_first = 0;
         RayState st = {};
         bool alive = false;          // still needs samples after this round's compositing
         bool finish = false;         // write the ray's outputs now
-        if (active) {
-            rg = load_ray(a.rays_o, a.rays_d, ray);
-            near_far(rg, a.box, a.min_near, near, far);
-        }
         if constexpr (FIRST) {
-            if (active) {
-                float t = near, x, y, z, dt, t_at = 0;
-                const bool hit = (!a.ray_mask || a.ray_mask[ray]) && march_next(a.mk, rg, far, t, x, y, z, dt, &t_at);
+            if (in_range) {
+                rg = load_ray(a.rays_o, a.rays_d, ray);
+                near_far(rg, a.box, a.min_near, near, far);
+                float t = near, x, y, z, dt;
+                const bool hit = (!a.ray_mask || a.ray_mask[ray]) && march_next(a.mk, rg, far, t, x, y, z, dt, &t_first);
                 st.acc_t = near;
-                st.t_first = t_at;
                 alive = hit;
                 finish = !hit;
             }
         } else {
             // ---- composite the previous chunk ------------------------------------------------------------------
+            uint32_t cnt = 0;
+            bool last = false;
+            if (in_range) {
+                const uint32_t cc = sp[kFChunk * (size_t)a.n_pad];
+                cnt = cc & 0x7fffffffu;
+                last = (cc >> 31) != 0;
+            }
+            const bool active = cnt != 0;
+            if (active) {
+                rg = load_ray(a.rays_o, a.rays_d, ray);
+                near_far(rg, a.box, a.min_near, near, far);
+                st.acc_t = __uint_as_float(sp[kFAccT * (size_t)a.n_pad]);
+                st.ws = __uint_as_float(sp[kFWs * (size_t)a.n_pad]);
+                st.depth = __uint_as_float(sp[kFDepth * (size_t)a.n_pad]);
+                st.an[0] = __uint_as_float(sp[kFAn0 * (size_t)a.n_pad]);
+                st.an[1] = __uint_as_float(sp[kFAn1 * (size_t)a.n_pad]);
+                st.an[2] = __uint_as_float(sp[kFAn2 * (size_t)a.n_pad]);
+                st.arough = __uint_as_float(sp[kFRough * (size_t)a.n_pad]);
+                st.n_taken = sp[kFTaken * (size_t)a.n_pad];
+            }
+            const uint32_t base = __builtin_amdgcn_readfirstlane(a.block_base[blk]);
             uint32_t k = 0;              // samples of the chunk that get composited
             bool terminated = false;
-            uint32_t cnt = 0, begin = 0;
-            bool last = false;
-            if (active) {
-                st = a.state[ray];
-                cnt = st.chunk_count & 0x7fffffffu;
-                last = (st.chunk_count >> 31) != 0;
-                begin = st.chunk_begin;
-                float ws = st.ws;
-                for (uint32_t j = 0; j < cnt; ++j) {            // pass 1: how many records does this ray append
-                    const float T = 1 - ws;
-                    ws += a.alpha[begin + j] * T;
-                    ++k;
-                    if (T < a.T_thresh) { terminated = true; break; }
+            {
+                float ws = st.ws;        // pass 1: how many records does each ray append
+                bool going = active;
+                uint32_t off = 0;
+                for (uint32_t c = 0;; ++c) {
+                    const unsigned long long m = __ballot(c < cnt);
+                    if (!__ballot(going && c < cnt)) break;
+                    const uint32_t slot = base + off + (uint32_t)__popcll(m & below);
+                    off += (uint32_t)__popcll(m);
+                    if (going && c < cnt) {
+                        const float T = 1 - ws;
+                        ws += a.alpha[slot] * T;
+                        ++k;
+                        if (T < a.T_thresh) { terminated = true; going = false; }
+                    }
                 }
             }
-            uint32_t wave_total = 0;
-            const uint32_t my_off = wave_exclusive_scan(k, lane, wave_total);
+            const uint32_t wave_records = wave_sum(k);
             uint32_t rec_base = 0;
-            if (lane == 0 && wave_total) rec_base = atomicAdd(&a.counters[kCntRecordHead], wave_total);
-            rec_base = __shfl(rec_base, 0) + my_off;
-            if (active) {
-                const bool fits = rec_base + k <= a.rec_cap;
-                if (!fits && k) a.counters[kCntOverflow] = 1u;
-                for (uint32_t j = 0; j < k; ++j) {              // pass 2: the recurrence itself + the records
-                    const uint32_t slot = begin + j;
-                    const float alpha = a.alpha[slot];
-                    const float T = 1 - st.ws;
-                    const float w = alpha * T;
-                    st.ws += w;
-                    st.acc_t = st.acc_t + a.dd[slot];
-                    st.depth += w * st.acc_t;
+            if (lane == 0 && wave_records) rec_base = atomicAdd(&a.counters[kCntRecordHead], wave_records);
+            rec_base = __builtin_amdgcn_readfirstlane(rec_base);
+            const bool fits = rec_base + wave_records <= a.rec_cap;
+            if (!fits && lane == 0) a.counters[kCntOverflow] = 1u;
+            {
+                uint32_t off = 0, roff = 0;
+                for (uint32_t c = 0;; ++c) {                    // pass 2: the recurrence itself + the records
+                    const unsigned long long m = __ballot(c < cnt), mk = __ballot(c < k);
+                    if (!mk) break;
+                    const uint32_t slot = base + off + (uint32_t)__popcll(m & below);
+                    const uint32_t r = rec_base + roff + (uint32_t)__popcll(mk & below);
+                    off += (uint32_t)__popcll(m);
+                    roff += (uint32_t)__popcll(mk);
+                    if (c < k) {
+                        const float alpha = a.alpha[slot];
+                        const float T = 1 - st.ws;
+                        const float w = alpha * T;
+                        st.ws += w;
+                        st.acc_t = st.acc_t + a.dd[slot];
+                        st.depth += w * st.acc_t;
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) st.an[d] += w * a.normal[3 * (size_t)slot + d];
-                    st.arough += w * a.rough[slot];
-                    if (fits) {
-                        const uint32_t r = rec_base + j;
-                        a.rec_ray[r] = ray; a.rec_idx[r] = st.n_taken; a.rec_w[r] = w; a.rec_slot[r] = slot;
+                        for (int d = 0; d < 3; ++d) st.an[d] += w * a.normal[3 * (size_t)slot + d];
+                        st.arough += w * a.rough[slot];
+                        if (fits) { a.rec_ray[r] = ray; a.rec_idx[r] = st.n_taken; a.rec_w[r] = w; a.rec_slot[r] = slot; }
+                        ++st.n_taken;
                     }
-                    ++st.n_taken;
                 }
+            }
+            if (active) {
                 finish = terminated || last || st.n_taken >= a.max_samples;
                 alive = !finish;
             }
@@ -855,8 +890,8 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
         if constexpr (FIRST) {
             if (alive && a.ray_cost) { const uint32_t h = a.ray_cost[ray]; if (h) chunk = min(h, 4096u); }
         }
-        // Slots: a ray gets one contiguous run.  With a hint the run is sized by it and the ray is marched once (slots the
-        // ray turns out not to need are zero-filled: evaluated, never composited); without one the marcher first counts.
+        // With a hint the ray's slots are sized by it and the ray is marched once (slots the ray turns out not to need
+        // are zero-filled: evaluated, never composited); without one the marcher first counts.
         const bool hinted = FIRST && chunk != a.chunk;
         uint32_t want = 0;           // slots to allocate
         if (alive && a.chunk) {
@@ -865,54 +900,74 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
                 float tr = st.acc_t;
                 bool first = FIRST;
                 for (; want < chunk && st.n_taken + want < a.max_samples; ++want) {
-                    float t = first ? st.t_first : tr, x, y, z, dt;
+                    float t = first ? t_first : tr, x, y, z, dt;
                     if (!march_next(a.mk, rg, far, t, x, y, z, dt)) break;
                     tr = tr + (t - tr);
                     first = false;
                 }
             }
         }
-        uint32_t wave_total = 0;
-        const uint32_t my_off = wave_exclusive_scan(want, lane, wave_total);
+        const uint32_t wave_slots = wave_sum(want);
         uint32_t base = 0;
-        if (lane == 0 && wave_total) base = atomicAdd(&a.counters[kCntSampleHead], wave_total);
-        base = __shfl(base, 0) + my_off;
-        if (alive && a.chunk) {
-            if (want && base + want > a.cap) { a.counters[kCntOverflow] = 2u; want = 0; }
+        if (lane == 0 && wave_slots) base = atomicAdd(&a.counters[kCntSampleHead], wave_slots);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (wave_slots && base + wave_slots > a.cap) {
+            if (lane == 0) a.counters[kCntOverflow] = 2u;
+            want = 0;
+        }
+        uint32_t marched = 0;
+        {
             float tr = st.acc_t;
-            bool first = FIRST;
-            uint32_t c = 0;
-            for (; c < want; ++c) {                              // the march, written out
-                float t = first ? st.t_first : tr, x, y, z, dt;
-                if (!march_next(a.mk, rg, far, t, x, y, z, dt)) break;
-                const float dd = t - tr;
-                const size_t slot = (size_t)base + c;
-                a.xyz[3 * slot] = x; a.xyz[3 * slot + 1] = y; a.xyz[3 * slot + 2] = z;
-                a.dt[slot] = dt;
-                a.dd[slot] = dd;
-                tr = tr + dd;
-                first = false;
+            bool first = FIRST, ended = false;
+            uint32_t off = 0;
+            for (uint32_t c = 0;; ++c) {                         // the march, written out sample-major
+                const unsigned long long m = __ballot(c < want);
+                if (!m) break;
+                const size_t slot = (size_t)base + off + (uint32_t)__popcll(m & below);
+                off += (uint32_t)__popcll(m);
+                if (c < want) {
+                    float x = 0, y = 0, z = 0, dt = 0, dd = 0;
+                    if (!ended) {
+                        float t = first ? t_first : tr;
+                        if (march_next(a.mk, rg, far, t, x, y, z, dt)) {
+                            dd = t - tr;
+                            tr = tr + dd;
+                            first = false;
+                            ++marched;
+                        } else {
+                            ended = true;                        // only after an over-estimating hint: the rest is zero-filled
+                            x = y = z = dt = 0;
+                        }
+                    }
+                    a.xyz[3 * slot] = x; a.xyz[3 * slot + 1] = y; a.xyz[3 * slot + 2] = z;
+                    a.dt[slot] = dt;
+                    a.dd[slot] = dd;
+                }
             }
-            for (uint32_t j = c; j < want; ++j) {                // only after an over-estimating hint
-                const size_t slot = (size_t)base + j;
-                a.xyz[3 * slot] = 0; a.xyz[3 * slot + 1] = 0; a.xyz[3 * slot + 2] = 0;
-                a.dt[slot] = 0; a.dd[slot] = 0;
-            }
-            st.chunk_begin = base;
-            st.chunk_count = c | ((c < chunk) ? 0x80000000u : 0u);
-            if (c == 0) { finish = true; alive = false; }       // nothing left along the ray
-        } else if (alive) {
-            finish = true; alive = false;                        // last round: whatever is left is dropped (cannot happen: the
-        }                                                        // chunk schedule covers max_steps)
-        // next round's alive list, wave by wave so that neighbouring rays stay together
+        }
+        if (alive) {
+            st.chunk_count = marched | ((marched < chunk) ? 0x80000000u : 0u);
+            if (marched == 0) { finish = true; alive = false; }   // nothing left along the ray (or the last round: cannot
+        }                                                         // leave anything, the chunk schedule covers max_steps)
+        // next round's block list + the per-ray state of the blocks on it
         {
             const unsigned long long m = __ballot(alive);
-            uint32_t abase = 0;
-            if (lane == 0 && m) abase = atomicAdd(&a.counters[kCntAlive + a.round + 1], (uint32_t)__popcll(m));
-            abase = __shfl(abase, 0);
-            if (alive) {
-                a.alive_out[abase + __popcll(m & ((1ull << lane) - 1ull))] = ray;
-                a.state[ray] = st;
+            if (m) {
+                if (lane == 0) {
+                    a.alive_out[atomicAdd(&a.counters[kCntAlive + a.round + 1], 1u)] = blk;
+                    a.block_base[blk] = base;
+                }
+                if (in_range) sp[kFChunk * (size_t)a.n_pad] = alive ? st.chunk_count : 0u;
+                if (alive) {
+                    sp[kFAccT * (size_t)a.n_pad] = __float_as_uint(st.acc_t);
+                    sp[kFWs * (size_t)a.n_pad] = __float_as_uint(st.ws);
+                    sp[kFDepth * (size_t)a.n_pad] = __float_as_uint(st.depth);
+                    sp[kFAn0 * (size_t)a.n_pad] = __float_as_uint(st.an[0]);
+                    sp[kFAn1 * (size_t)a.n_pad] = __float_as_uint(st.an[1]);
+                    sp[kFAn2 * (size_t)a.n_pad] = __float_as_uint(st.an[2]);
+                    sp[kFRough * (size_t)a.n_pad] = __float_as_uint(st.arough);
+                    sp[kFTaken * (size_t)a.n_pad] = st.n_taken;
+                }
             }
         }
         if (finish) {
@@ -971,15 +1026,18 @@ void launch_eval(const GeoEvalArgs& a, uint32_t max_samples, hipStream_t s) {
 uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
 struct GeoLayout {
-    uint64_t counters, alive0, alive1, state, xyz, dt, dd, alpha, normal, geo, rough, blend, total;
+    uint64_t counters, alive0, alive1, block_base, state, xyz, dt, dd, alpha, normal, geo, rough, blend, total;
+    uint32_t n_pad;
 };
 GeoLayout geo_layout(uint32_t N, uint32_t cap) {
     GeoLayout L;
     uint64_t o = 0;
     auto take = [&](uint64_t bytes) { const uint64_t at = o; o = align_up(o + bytes, 256); return at; };
     L.counters = take(kGeoCounterWords * 4);
-    L.alive0 = take((uint64_t)N * 4); L.alive1 = take((uint64_t)N * 4);
-    L.state = take((uint64_t)N * sizeof(RayState));
+    const uint64_t blocks = ((uint64_t)N + 63) / 64;
+    L.n_pad = (uint32_t)(blocks * 64);
+    L.alive0 = take(blocks * 4); L.alive1 = take(blocks * 4); L.block_base = take(blocks * 4);
+    L.state = take((uint64_t)kStateFields * L.n_pad * 4);
     L.xyz = take((uint64_t)cap * 12); L.dt = take((uint64_t)cap * 4); L.dd = take((uint64_t)cap * 4);
     L.alpha = take((uint64_t)cap * 4); L.normal = take((uint64_t)cap * 12); L.geo = take((uint64_t)cap * 48);
     L.rough = take((uint64_t)cap * 4); L.blend = take((uint64_t)cap * 4);
@@ -1036,7 +1094,8 @@ int envidr_geometry_pass(const envidr_render_desc* d, const float* rays_o, const
     a.mk = make_march_consts(d->bound, d->dt_gamma, d->max_steps, d->cascades, d->grid_size, d->density_bitfield);
     a.box = make_aabb(d); a.min_near = d->min_near; a.T_thresh = d->T_thresh; a.max_samples = d->max_steps;
     a.counters = counters;
-    a.state = reinterpret_cast<RayState*>(ws + L.state);
+    a.state = reinterpret_cast<uint32_t*>(ws + L.state); a.n_pad = L.n_pad;
+    a.block_base = reinterpret_cast<uint32_t*>(ws + L.block_base);
     a.xyz = const_cast<float*>(e.xyz); a.dt = const_cast<float*>(e.dt); a.dd = reinterpret_cast<float*>(ws + L.dd);
     a.cap = sample_capacity;
     a.alpha = e.alpha; a.normal = e.normal; a.rough = e.rough;
