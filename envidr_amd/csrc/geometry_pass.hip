@@ -103,6 +103,9 @@ constexpr int kGeoRing = ENVIDR_GEO_RING;
 #ifndef ENVIDR_GEO_PREFETCH
 #define ENVIDR_GEO_PREFETCH 0     // 1: the first AHEAD levels of the next batch are gathered before the matrix-core section of this one
 #endif
+#ifndef ENVIDR_GEO_RAYS_DEBUG
+#define ENVIDR_GEO_RAYS_DEBUG 0
+#endif
 #ifndef ENVIDR_GEO_KERNEL32
 #define ENVIDR_GEO_KERNEL32 1      // 1: k_geo_eval32 (32 samples per wave, two waves per SIMD), 0: k_geo_eval (64, one per SIMD)
 #endif
@@ -762,7 +765,32 @@ struct GeoRayArgs {
     float* depth; float* ws; float* nimg; float* rimg;
     uint16_t* ray_cost;
     const uint8_t* ray_mask;   // optional: rays whose byte is 0 are finished at once (round 0)
+    const uint8_t* linear_grid; // one-cascade fast marcher (march_core.hip.h): the bitfield in linear cell order, or null
+    uint32_t log2H;
 };
+
+// MODE 0: any grid (march_next), 1: one cascade, power-of-two grid, linear bitfield copy, 2: the same with dt_gamma == 0
+template <int MODE>
+__device__ __forceinline__ bool geo_march(const GeoRayArgs& a, const RayGeom& r, float far, float& t, float& x, float& y, float& z, float& dt,
+                                          float* t_at = nullptr) {
+    if constexpr (MODE == 0) return march_next(a.mk, r, far, t, x, y, z, dt, t_at);
+    else return march_next_c1<MODE == 2>(a.mk, a.linear_grid, a.log2H, r, far, t, x, y, z, dt, t_at);
+}
+
+// linear_grid bit (x + H y + H^2 z) = Morton-ordered bitfield bit morton(x, y, z); one thread per output byte
+__global__ void __launch_bounds__(kBlock) k_linearize_bitfield(const uint8_t* __restrict__ grid, uint8_t* __restrict__ linear_grid, uint32_t log2H) {
+    const uint32_t byte = blockIdx.x * blockDim.x + threadIdx.x;
+    if (byte >= (1u << (3 * log2H)) / 8u) return;
+    const uint32_t mask = (1u << log2H) - 1u;
+    uint32_t v = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) {
+        const uint32_t cell = byte * 8u + j;
+        const uint32_t m = morton_encode(cell & mask, (cell >> log2H) & mask, cell >> (2 * log2H));
+        v |= ((grid[m >> 3] >> (m & 7)) & 1u) << j;
+    }
+    linear_grid[byte] = (uint8_t)v;
+}
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
@@ -778,9 +806,14 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // then every ray still alive marches its next `chunk` samples (march_core.hip.h; the ray time is resumed from the
 // composited time after EVERY sample, as the reference loop does with one sample per iteration -- that time does not
 // depend on the densities, so marching ahead of the compositor changes nothing) into freshly allocated slots.
-template <bool FIRST>
+constexpr uint32_t kTimeCache = 32;      // chunks up to this many samples (the first five rounds) are marched once
+
+template <bool FIRST, int MODE>
 __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
+    // ray times of the samples the counting pass found (un-hinted chunks), so that the write pass does not march again
+    __shared__ float s_time[kBlock / 64][kTimeCache][64];
     const uint32_t lane = threadIdx.x & 63;
+    float* const t_cache = &s_time[threadIdx.x >> 6][0][lane];
     const unsigned long long below = (1ull << lane) - 1ull;
     const uint32_t n_in = FIRST ? (a.N + 63u) / 64u : __builtin_amdgcn_readfirstlane(a.counters[kCntAlive + a.round]);
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -799,9 +832,17 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
                 rg = load_ray(a.rays_o, a.rays_d, ray);
                 near_far(rg, a.box, a.min_near, near, far);
                 float t = near, x, y, z, dt;
-                const bool hit = (!a.ray_mask || a.ray_mask[ray]) && march_next(a.mk, rg, far, t, x, y, z, dt, &t_first);
+#if ENVIDR_GEO_RAYS_DEBUG == 1
+                const bool hit = false;
+#else
+                const bool hit = (!a.ray_mask || a.ray_mask[ray]) && geo_march<MODE>(a, rg, far, t, x, y, z, dt, &t_first);
+#endif
                 st.acc_t = near;
+#if ENVIDR_GEO_RAYS_DEBUG == 2
+                alive = false; if (hit) st.depth = t_first;
+#else
                 alive = hit;
+#endif
                 finish = !hit;
             }
         } else {
@@ -900,8 +941,9 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
                 float tr = st.acc_t;
                 bool first = FIRST;
                 for (; want < chunk && st.n_taken + want < a.max_samples; ++want) {
-                    float t = first ? t_first : tr, x, y, z, dt;
-                    if (!march_next(a.mk, rg, far, t, x, y, z, dt)) break;
+                    float t = first ? t_first : tr, x, y, z, dt, t_at;
+                    if (!geo_march<MODE>(a, rg, far, t, x, y, z, dt, &t_at)) break;
+                    if (want < kTimeCache) t_cache[want * 64] = t_at;      // the write pass below restarts from these
                     tr = tr + (t - tr);
                     first = false;
                 }
@@ -917,6 +959,7 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
         }
         uint32_t marched = 0;
         {
+            const bool cached = !hinted && a.chunk <= kTimeCache;
             float tr = st.acc_t;
             bool first = FIRST, ended = false;
             uint32_t off = 0;
@@ -927,9 +970,21 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
                 off += (uint32_t)__popcll(m);
                 if (c < want) {
                     float x = 0, y = 0, z = 0, dt = 0, dd = 0;
-                    if (!ended) {
+                    if (cached) {
+                        // the counting pass found this sample at ray time t_at: position, step and ray-time bookkeeping are
+                        // the marcher's own statements for an occupied cell
+                        const float t_at = t_cache[c * 64];
+                        x = clampf(rg.ox + t_at * rg.dx, -a.mk.bound, a.mk.bound);
+                        y = clampf(rg.oy + t_at * rg.dy, -a.mk.bound, a.mk.bound);
+                        z = clampf(rg.oz + t_at * rg.dz, -a.mk.bound, a.mk.bound);
+                        dt = step_size(a.mk, t_at);
+                        const float t = t_at + dt;
+                        dd = t - tr;
+                        tr = tr + dd;
+                        ++marched;
+                    } else if (!ended) {
                         float t = first ? t_first : tr;
-                        if (march_next(a.mk, rg, far, t, x, y, z, dt)) {
+                        if (geo_march<MODE>(a, rg, far, t, x, y, z, dt)) {
                             dd = t - tr;
                             tr = tr + dd;
                             first = false;
@@ -1026,9 +1081,10 @@ void launch_eval(const GeoEvalArgs& a, uint32_t max_samples, hipStream_t s) {
 uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
 struct GeoLayout {
-    uint64_t counters, alive0, alive1, block_base, state, xyz, dt, dd, alpha, normal, geo, rough, blend, total;
+    uint64_t counters, alive0, alive1, block_base, state, linear_grid, xyz, dt, dd, alpha, normal, geo, rough, blend, total;
     uint32_t n_pad;
 };
+constexpr uint64_t kLinearGridBytes = 256ull * 256 * 256 / 8;        // the largest grid the fast marcher takes
 GeoLayout geo_layout(uint32_t N, uint32_t cap) {
     GeoLayout L;
     uint64_t o = 0;
@@ -1038,6 +1094,7 @@ GeoLayout geo_layout(uint32_t N, uint32_t cap) {
     L.n_pad = (uint32_t)(blocks * 64);
     L.alive0 = take(blocks * 4); L.alive1 = take(blocks * 4); L.block_base = take(blocks * 4);
     L.state = take((uint64_t)kStateFields * L.n_pad * 4);
+    L.linear_grid = take(kLinearGridBytes);
     L.xyz = take((uint64_t)cap * 12); L.dt = take((uint64_t)cap * 4); L.dd = take((uint64_t)cap * 4);
     L.alpha = take((uint64_t)cap * 4); L.normal = take((uint64_t)cap * 12); L.geo = take((uint64_t)cap * 48);
     L.rough = take((uint64_t)cap * 4); L.blend = take((uint64_t)cap * 4);
@@ -1115,14 +1172,33 @@ int envidr_geometry_pass(const envidr_render_desc* d, const float* rays_o, const
     ENVIDR_REQUIRE(covered >= d->max_steps, "geometry_pass: max_steps %u exceeds what %u rounds cover", d->max_steps, kMaxRounds);
 
     if (hipMemsetAsync(counters, 0, kGeoCounterWords * 4, s) != hipSuccess) return check_launch("geometry_pass memset");
+    // one cascade on a power-of-two grid (every scene of the reference): the marcher reads a linear-order copy of the bitfield
+    int mode = 0;
+    if (d->cascades == 1 && (d->grid_size & (d->grid_size - 1)) == 0 && d->grid_size >= 2 && d->grid_size <= 256) {
+        uint32_t log2H = 0;
+        while ((1u << log2H) < d->grid_size) ++log2H;
+        uint8_t* lin = reinterpret_cast<uint8_t*>(ws + L.linear_grid);
+        const uint32_t bytes = (1u << (3 * log2H)) / 8u;
+        hipLaunchKernelGGL(k_linearize_bitfield, dim3(ceil_div(bytes, kBlock)), dim3(kBlock), 0, s, d->density_bitfield, lin, log2H);
+        a.linear_grid = lin; a.log2H = log2H;
+        mode = d->dt_gamma == 0 ? 2 : 1;
+    }
     const uint32_t ray_blocks = ceil_div(N, kBlock);
     for (uint32_t r = 0; r <= rounds; ++r) {
         a.round = r;
         a.chunk = r < rounds ? chunks[r] : 0u;
         a.alive_in = alive[(r + 1) & 1];
         a.alive_out = alive[r & 1];
-        if (r == 0) hipLaunchKernelGGL(k_geo_rays<true>, dim3(ray_blocks), dim3(kBlock), 0, s, a);
-        else hipLaunchKernelGGL(k_geo_rays<false>, dim3(std::min(ray_blocks, 1024u)), dim3(kBlock), 0, s, a);
+        const dim3 grid(r == 0 ? ray_blocks : std::min(ray_blocks, 1024u));
+        if (r == 0) {
+            if (mode == 2) hipLaunchKernelGGL((k_geo_rays<true, 2>), grid, dim3(kBlock), 0, s, a);
+            else if (mode == 1) hipLaunchKernelGGL((k_geo_rays<true, 1>), grid, dim3(kBlock), 0, s, a);
+            else hipLaunchKernelGGL((k_geo_rays<true, 0>), grid, dim3(kBlock), 0, s, a);
+        } else {
+            if (mode == 2) hipLaunchKernelGGL((k_geo_rays<false, 2>), grid, dim3(kBlock), 0, s, a);
+            else if (mode == 1) hipLaunchKernelGGL((k_geo_rays<false, 1>), grid, dim3(kBlock), 0, s, a);
+            else hipLaunchKernelGGL((k_geo_rays<false, 0>), grid, dim3(kBlock), 0, s, a);
+        }
         {
             const int rc = check_launch("k_geo_rays");
             if (rc) return rc;

@@ -150,6 +150,48 @@ __device__ __forceinline__ bool march_next(const MarchConsts& k, const RayGeom& 
     return k.H_pow2 ? march_next_impl<true>(k, r, far, t, x, y, z, dt, t_at) : march_next_impl<false>(k, r, far, t, x, y, z, dt, t_at);
 }
 
+// The same marcher for the geometry every scene of the reference has -- ONE cascade (bound <= 1: every level clamp gives 0,
+// mip_bound = bound, 1 / mip_bound = 1 / bound) on a power-of-two grid of at most 256^3 cells -- reading a copy of the
+// bitfield in x-fastest LINEAR cell order (k_linearize_bitfield) instead of Morton order.  Every float operation that
+// produces t, the position, dt or the voxel coordinates is the statement of march_next_impl<true>, so the samples are the
+// same bits; what is gone is the arithmetic whose result is a constant here (two frexp level clamps, the scalbn pair, the
+// float bit index) and the 3 x 10-operation bit interleave.  These kernels are VALU-issue bound (a ray that misses the
+// object walks ~200 empty cells), so the instruction count per cell is their run time.
+// GAMMA0: dt_gamma == 0, the step is one constant (clampf(t * 0, dt_min, dt_max) for any finite t).
+__device__ __forceinline__ bool march_fast_ok(const MarchConsts& k) { return k.cascades == 1.0f && k.H_pow2 && k.H <= 256u; }
+
+template <bool GAMMA0>
+__device__ __forceinline__ bool march_next_c1(const MarchConsts& k, const uint8_t* __restrict__ linear_grid, uint32_t log2H, const RayGeom& r,
+                                              float far, float& t, float& x, float& y, float& z, float& dt, float* t_at) {
+    const float dtc = step_size(k, 0.0f);
+    while (t < far) {
+        x = clampf(r.ox + t * r.dx, -k.bound, k.bound);
+        y = clampf(r.oy + t * r.dy, -k.bound, k.bound);
+        z = clampf(r.oz + t * r.dz, -k.bound, k.bound);
+        dt = GAMMA0 ? dtc : step_size(k, t);
+        const int nx = voxel_coord<true>(k, x, k.rbound);
+        const int ny = voxel_coord<true>(k, y, k.rbound);
+        const int nz = voxel_coord<true>(k, z, k.rbound);
+        const uint32_t bit = (uint32_t)nx | ((uint32_t)ny << log2H) | ((uint32_t)nz << (2 * log2H));
+        const bool occupied = linear_grid[bit >> 3] & (1u << (bit & 7));
+        if (occupied) {
+            if (t_at) *t_at = t;
+            t += dt;
+            return true;
+        }
+        const float tx = exit_time(k, nx, r.dx, r.rdx, x, k.bound);
+        const float ty = exit_time(k, ny, r.dy, r.rdy, y, k.bound);
+        const float tz = exit_time(k, nz, r.dz, r.rdz, z, k.bound);
+        const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+        if constexpr (GAMMA0) {
+            do { t += dtc; } while (t < tt);
+        } else {
+            do { t += step_size(k, t); } while (t < tt);
+        }
+    }
+    return false;
+}
+
 // One compositing update (reference raymarching.cu:996-1030, inference form: transmittance is
 // re-derived from the running weight sum, termination is tested with the pre-update T).
 struct Accum {

@@ -11,6 +11,8 @@ VARIANTS = {
     "k32_a1": ["-DENVIDR_GEO_AHEAD=1"],
     "k32_a3": ["-DENVIDR_GEO_AHEAD=3"],
     "k64": ["-DENVIDR_GEO_KERNEL32=0"],
+    "rays_dbg1": ["-DENVIDR_GEO_RAYS_DEBUG=1"],
+    "rays_dbg2": ["-DENVIDR_GEO_RAYS_DEBUG=2"],
 }
 
 def main(names):
