@@ -15,5 +15,5 @@ void set_error(const char* fmt, ...) {
 
 extern "C" {
 const char* envidr_last_error(void) { return envidr::g_error; }
-int envidr_abi_version(void) { return 3; }   // 3: geometry pipeline (envidr_geometry_pass / _eval), envidr_geometry_export grew (slot, blend)
+int envidr_abi_version(void) { return 4; }   // 4: split-precision shading mode (descriptor grew: env_split_blob / env_split_bias / env_features)
 }

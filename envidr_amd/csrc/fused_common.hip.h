@@ -194,6 +194,35 @@ constexpr int kSdfW1 = 0, kSdfW2 = kSdfW1 + lane_layer_frags(16, 2, true), kSdfW
               kSdfW2t = kSdfW3 + tile_layer_frags(2, 1, true), kSdfW1t = kSdfW2t + tile_layer_frags(2, 2, false),
               kSdfFrags = kSdfW1t + tile_layer_frags(2, 1, false);
 
+// arguments of the shade-only kernels (fused_render.hip k_shade_samples, shade_split.hip k_env_split)
+struct ShadeArgs {
+    const float* normals;       // [M,3] unit
+    const float* dirs;          // [M,3] unit view directions (camera -> sample)
+    const float* geo_feat;      // [M,12] (stride 12) or one shared [12] (stride 0), already unit-normalised
+    const float* roughness;     // [M] (stride 1) or one shared value (stride 0): the IDE kappa_inv of the reflected direction
+    uint32_t geo_stride, rough_stride, M;
+    // record mode (two-phase frames): the view direction of record i is rays_d[ray_ids[i]] and the number of records is
+    // read on the device (min(*m_dev, M)), so the host never waits for the geometry pass
+    const uint32_t* ray_ids;
+    const float* rays_d;
+    const uint32_t* m_dev;
+    const uint32_t* slot;       // record mode, optional: normals / geo_feat / roughness of record i live at index slot[i]
+    // reflected-radiance branch (record mode): per-ray (rgb, visibility), the learnt blend logit per sample, the two extra blobs
+    const float* r_images; const float* blend; const float* renv_blob; const float* spec2_blob;
+    float rough_scale, indir_rough_thresh;
+    const float* env_blob;
+    const float* head_blob;
+    float kappa_diffuse, light_scale;
+    int has_rot;
+    float rot[9];
+    float* c_diffuse;           // [M,3]
+    float* c_specular;          // [M,3]
+    // split-precision mode (shade_split.hip): the environment features of sample i, [M,24] = env(normal) | env(reflection),
+    // written by k_env_split and consumed by the PRE_ENV instantiation of k_shade_samples
+    float* env_pre;
+};
+
 int device_cu_count();   // fused_render.hip
+int launch_env_split(const envidr_render_desc* d, const ShadeArgs& a, hipStream_t s, const char* who);   // shade_split.hip
 
 }  // namespace envidr

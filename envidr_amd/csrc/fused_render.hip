@@ -233,10 +233,13 @@ struct ShadeConsts {
     float kappa_diffuse, light_scale;
 };
 
-template <int IDE_DEG, int ENV_T, int SH_DEG, class WP, class Tick>
+// PRE_ENV: the environment features were computed beforehand (split-precision mode, shade_split.hip): env_pre points at this
+// lane's 24 floats env(normal) | env(reflection) and `wp` streams head_blob on entry.
+template <int IDE_DEG, int ENV_T, int SH_DEG, bool PRE_ENV = false, class WP, class Tick>
 __device__ __forceinline__ void shade_sample(WP& wp, const uint32_t lane, const ShadeConsts c, const float (&nrm)[3],
                                              const float (&nenv)[3], const float (&wr)[3], const float (&vd)[3], const float ndot,
-                                             const float (&geo)[12], const float rough, float (&cd)[3], float (&cs)[3], float (&env_r)[12], Tick&& tick) {
+                                             const float (&geo)[12], const float rough, float (&cd)[3], float (&cs)[3], float (&env_r)[12], Tick&& tick,
+                                             const float* env_pre = nullptr) {
     constexpr bool kEnvNet = SH_DEG == 0;
     constexpr int kShDim = SH_DEG * SH_DEG;
     constexpr int kDiffIn = kEnvNet ? 24 : 12, kSpecIn = kEnvNet ? 28 : 2 * kShDim + 13;
@@ -251,7 +254,16 @@ __device__ __forceinline__ void shade_sample(WP& wp, const uint32_t lane, const 
     constexpr int kEnvN = ring_padded(kEnvFrags), kHeadN = ring_padded(kHeadFrags);
     // ================= environment MLP on IDE(normal) and IDE(reflection) =====================
     float env_n[12];
-    if constexpr (kEnvNet)
+    if constexpr (kEnvNet && PRE_ENV) {
+        const float4* ep = reinterpret_cast<const float4*>(env_pre);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float4 u = ep[q], v = ep[3 + q];
+            env_n[4 * q] = u.x; env_n[4 * q + 1] = u.y; env_n[4 * q + 2] = u.z; env_n[4 * q + 3] = u.w;
+            env_r[4 * q] = v.x; env_r[4 * q + 1] = v.y; env_r[4 * q + 2] = v.z; env_r[4 * q + 3] = v.w;
+        }
+    }
+    if constexpr (kEnvNet && !PRE_ENV)
 #pragma unroll 1
     for (int enc = 0; enc < 2; ++enc) {
         const float vx = enc ? wr[0] : nenv[0], vy = enc ? wr[1] : nenv[1], vz = enc ? wr[2] : nenv[2];
@@ -896,33 +908,10 @@ __global__ void __launch_bounds__(kBlockThreads, (SH_DEG > 0 ? kPlainWaves : 1))
 // Shade-only kernel: the shading half of the loop for samples whose geometry is already known
 // (surface rendering as in demo.ipynb cell 17, re-lighting / env rotation of cached geometry).
 // ------------------------------------------------------------------------------------------
-struct ShadeArgs {
-    const float* normals;       // [M,3] unit
-    const float* dirs;          // [M,3] unit view directions (camera -> sample)
-    const float* geo_feat;      // [M,12] (stride 12) or one shared [12] (stride 0), already unit-normalised
-    const float* roughness;     // [M] (stride 1) or one shared value (stride 0): the IDE kappa_inv of the reflected direction
-    uint32_t geo_stride, rough_stride, M;
-    // record mode (two-phase frames): the view direction of record i is rays_d[ray_ids[i]] and the number of records is
-    // read on the device (min(*m_dev, M)), so the host never waits for the geometry pass
-    const uint32_t* ray_ids;
-    const float* rays_d;
-    const uint32_t* m_dev;
-    const uint32_t* slot;       // record mode, optional: normals / geo_feat / roughness of record i live at index slot[i]
-    // reflected-radiance branch (record mode): per-ray (rgb, visibility), the learnt blend logit per sample, the two extra blobs
-    const float* r_images; const float* blend; const float* renv_blob; const float* spec2_blob;
-    float rough_scale, indir_rough_thresh;
-    const float* env_blob;
-    const float* head_blob;
-    float kappa_diffuse, light_scale;
-    int has_rot;
-    float rot[9];
-    float* c_diffuse;           // [M,3]
-    float* c_specular;          // [M,3]
-};
 
 // SH_DEG > 0: the no-environment family (heads only; SH-encoded view direction and normal, BASELINE configs[1]).
 // RENV: the reflected-radiance branch on top of the environment family (third pass of indirect rendering; record mode only).
-template <int IDE_DEG, int ENV_T, int SH_DEG = 0, bool RENV = false>
+template <int IDE_DEG, int ENV_T, int SH_DEG = 0, bool RENV = false, bool PRE_ENV = false>
 __global__ void __launch_bounds__(kBlockThreads, 1) k_shade_samples(const ShadeArgs a) {
     constexpr bool kEnvNet = SH_DEG == 0;
     constexpr int kShDim = SH_DEG * SH_DEG;
@@ -936,8 +925,8 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_shade_samples(const ShadeA
     __shared__ __attribute__((aligned(16))) float s_weights[kSharedWeights ? 2 * kChunkFloats : 4];
     std::conditional_t<kSharedWeights, WeightPipe, WeightRing<kRingDepth>> wp;
     // the first blob a round streams: the environment MLP, or the heads when there is none
-    const float* first_blob = kEnvNet ? a.env_blob : a.head_blob;
-    constexpr uint32_t kFirstChunks = kEnvNet ? kEnvChunks : kHeadChunks;
+    const float* first_blob = (kEnvNet && !PRE_ENV) ? a.env_blob : a.head_blob;
+    constexpr uint32_t kFirstChunks = (kEnvNet && !PRE_ENV) ? kEnvChunks : kHeadChunks;
     wp.start(s_weights, lane, wave, first_blob, kFirstChunks);
     const ShadeConsts sc = {a.env_blob, a.head_blob, RENV ? a.renv_blob : first_blob, RENV ? kRenvChunks : kFirstChunks, a.kappa_diffuse, a.light_scale};
     const uint32_t waves = gridDim.x * (kBlockThreads / 64);
@@ -974,7 +963,8 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_shade_samples(const ShadeA
             }
         }
         float cd[3], cs[3], env_r[12];
-        shade_sample<IDE_DEG, ENV_T, SH_DEG>(wp, lane, sc, nrm, nenv, wr, vd, ndot, geo, rough, cd, cs, env_r, [](int) {});
+        shade_sample<IDE_DEG, ENV_T, SH_DEG, PRE_ENV>(wp, lane, sc, nrm, nenv, wr, vd, ndot, geo, rough, cd, cs, env_r, [](int) {},
+                                                      PRE_ENV ? a.env_pre + 24 * i : nullptr);
         if constexpr (RENV) {
             float rimg[4];
 #pragma unroll
@@ -1231,7 +1221,16 @@ static int launch_shade(const envidr_render_desc* d, ShadeArgs& a, envidr_stream
     const dim3 grid(blocks), block(kBlockThreads);
     hipStream_t s = as_stream(stream);
     const bool renv = a.r_images != nullptr;
+    // split-precision mode: the environment features come from the fp16-pair kernel (shade_split.hip), the heads stay fp32
+    const bool split = d->env_split_blob != nullptr && !d->dir_sh_degree;
+    if (split) {
+        ENVIDR_REQUIRE(!renv, "%s: split precision does not cover the reflected-radiance branch", who);
+        a.env_pre = d->env_features;
+        const int rc = launch_env_split(d, a, s, who);
+        if (rc) return rc;
+    }
 #define ENVIDR_LAUNCH(DEG, HT) do { if (renv) hipLaunchKernelGGL((k_shade_samples<DEG, HT, 0, true>), grid, block, 0, s, a); \
+                                    else if (split) hipLaunchKernelGGL((k_shade_samples<DEG, HT, 0, false, true>), grid, block, 0, s, a); \
                                     else hipLaunchKernelGGL((k_shade_samples<DEG, HT>), grid, block, 0, s, a); } while (0)
     if (d->dir_sh_degree == 4) {
         ENVIDR_REQUIRE(!renv, "%s: the reflected-radiance branch belongs to the environment-MLP family", who);

@@ -1,0 +1,215 @@
+// Split-precision dense layers on the fp16 matrix cores of gfx950 (v_mfma_f32_32x32x16_f16, 16x the fp32 MFMA rate).
+//
+// NOT the default path and never the headline number: the fp32 kernels (mlp_mfma.hip.h) are.  This is the optional
+// "split" shading mode (FusedOptions.env_precision = "f16x2"), reported separately by bench.py with its own error
+// against the same goldens.
+//
+// Every fp32 operand is carried as two halves,  v = hi + lo * 2^-11  with  hi = fp16(v),  lo = fp16((v - hi) * 2^11)
+// (22 significand bits; the 2^11 keeps `lo` in fp16's normal range whenever `hi` is), and a product is three MFMAs into
+// two fp32 accumulators:
+//     main += a_hi * b_hi            corr += a_hi * b_lo + a_lo * b_hi            result = main + corr * 2^-11
+// The dropped a_lo * b_lo term is 2^-22 relative; products of halves are exact in the fp32 accumulation.  Three 8-pass
+// MFMAs (96 cycles) replace the eight 16-pass fp32 MFMAs (512 cycles) that cover the same 16 x 32 x 32 block.
+//
+// Layout conventions follow mlp_mfma.hip.h: weights are the A operand, activations the B operand, a 32 x 32 output tile
+// of layer n is consumed as the B operand of layer n + 1 from the registers it was accumulated in:
+//   A fragment (one 16-deep reduction step, one 32-row output tile) = 64 lanes x 8 halves (16 B per lane, 1 KiB);
+//     lane (m = lane & 31, h = lane >> 5), slot i  <->  W[32 t + m][ k(step, h, i) ]
+//   k(step, h, i):  lane order  16 step + 8 h + i               (layer input = per-item feature registers)
+//                   tile order  32 (step / 2) + tile_row(8 (step & 1) + i, h)      (layer input = accumulator tiles)
+//   (v_mfma_f32_32x32x16_f16 multiplies slot (h, i) of A with slot (h, i) of B whatever k the hardware calls it:
+//    tools/probe/mfma_f16_probe.hip checks exactly this and the D register -> row map on the device.)
+// Output tiles are accumulated kSplitGroup at a time (two accumulators each), so a layer's blob is ordered
+//   [group of tiles][step][tile in group][hi fragment, lo fragment]
+// and the four waves of a workgroup -- one per SIMD, each with its own 32 items -- consume it in lock step through a
+// double-buffered LDS ring (SplitWeightPipe): 1 KiB per MFMA per wave from L2 would be 5x what L2 delivers.
+#pragma once
+#include "mlp_mfma.hip.h"
+
+#include <cstring>
+
+namespace envidr {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+constexpr float kSplitScale = 2048.0f, kSplitInv = 1.0f / 2048.0f;
+constexpr float kSplitMaxAct = 60000.0f;          // activations are clamped here before the fp16 split (fp16 max 65504)
+#ifndef ENVIDR_SPLIT_GROUP
+#define ENVIDR_SPLIT_GROUP 2
+#endif
+constexpr int kSplitGroup = ENVIDR_SPLIT_GROUP;
+
+enum SplitOrder : int { kSplitLaneOrder = 0, kSplitTileOrder = 1 };
+__host__ __device__ constexpr int split_k(SplitOrder o, int s, int h, int i) {
+    return o == kSplitLaneOrder ? 16 * s + 8 * h + i : 32 * (s >> 1) + tile_row(8 * (s & 1) + i, h);
+}
+constexpr uint32_t split_steps_for(SplitOrder o, uint32_t k_in) { return o == kSplitLaneOrder ? (k_in + 15) / 16 : round_up(k_in, 32) / 16; }
+constexpr int split_layer_frags(int steps, int mt) { return steps * mt * 2; }        // fragments of 1 KiB
+constexpr int kSplitFragHalves = 64 * 8;
+
+// ---- host side: fp32 -> (hi, lo) fp16 pairs, fragment order ---------------------------------------------------------
+inline uint16_t f32_to_f16_rne(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u, ax = x & 0x7fffffffu;
+    if (ax > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);
+    if (ax >= 0x47800000u) return (uint16_t)(sign | 0x7c00u);                     // >= 65536
+    if (ax < 0x33000001u) return (uint16_t)sign;                                  // <= 2^-25: rounds to zero (tie to even)
+    const int e = (int)(ax >> 23) - 127;
+    const uint32_t m = (ax & 0x7fffffu) | 0x800000u;
+    const int shift = e >= -14 ? 13 : -e - 1;
+    uint32_t q = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (q & 1u))) ++q;
+    const uint32_t out = e >= -14 ? ((uint32_t)(e + 15) << 10) + (q - 0x400u) : q;   // a rounding carry walks into the exponent
+    return (uint16_t)(sign | out);
+}
+inline float f16_bits_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
+    uint32_t x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else {
+            int k = 0;
+            uint32_t mm = m;
+            while (!(mm & 0x400u)) { mm <<= 1; ++k; }
+            x = sign | ((uint32_t)(127 - 15 - k + 1) << 23) | ((mm & 0x3ffu) << 13);
+        }
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112u) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &x, 4);
+    return f;
+}
+
+// dst: split_layer_frags(steps, mt) * kSplitFragHalves halves.  W is [m_out, k_in] row-major.
+inline void pack_split_weight(const float* W, uint32_t m_out, uint32_t k_in, SplitOrder order, uint32_t group, uint16_t* dst) {
+    const uint32_t steps = split_steps_for(order, k_in), mt = round_up(m_out, 32) / 32;
+    size_t frag = 0;
+    for (uint32_t t0 = 0; t0 < mt; t0 += group)
+        for (uint32_t s = 0; s < steps; ++s)
+            for (uint32_t t = t0; t < std::min(mt, t0 + group); ++t, frag += 2)
+                for (uint32_t lane = 0; lane < 64; ++lane)
+                    for (uint32_t i = 0; i < 8; ++i) {
+                        const uint32_t m = 32 * t + (lane & 31u), k = (uint32_t)split_k(order, (int)s, (int)(lane >> 5), (int)i);
+                        const float w = (m < m_out && k < k_in) ? W[(size_t)m * k_in + k] : 0.0f;
+                        const uint16_t hi = f32_to_f16_rne(w);
+                        const uint16_t lo = f32_to_f16_rne((w - f16_bits_to_f32(hi)) * kSplitScale);
+                        dst[frag * kSplitFragHalves + lane * 8 + i] = hi;
+                        dst[(frag + 1) * kSplitFragHalves + lane * 8 + i] = lo;
+                    }
+}
+
+// ---- device side ------------------------------------------------------------------------------------------------------
+constexpr int kSplitChunkFrags = 16;
+constexpr uint32_t kSplitChunkBytes = kSplitChunkFrags * 1024u;       // 16 KiB, two of them in LDS
+constexpr int split_pass_chunks(int frags) { return (frags + kSplitChunkFrags - 1) / kSplitChunkFrags; }
+
+// WeightPipe (mlp_mfma.hip.h) for 1-KiB fragments: see there for the protocol
+struct SplitWeightPipe {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4* lds;                 // workgroup base of u32x4[2][1024]
+    uint32_t lane, wave, slot;
+    const u32x4* frag;          // this lane's column of the chunk being consumed
+    u32x4 stage[4];
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t chunks;            // chunks in the (only) pass: the stream wraps around to chunk 0
+    uint32_t local;
+
+    __device__ __forceinline__ uint32_t voff() const { return (wave * 256u + lane) * 16u; }
+    __device__ __forceinline__ void load_stage(uint32_t chunk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stage[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff(), chunk * kSplitChunkBytes + (uint32_t)i * 1024u, 0);
+    }
+    __device__ __forceinline__ void store_stage(uint32_t to_slot) {
+        u32x4* dst = lds + to_slot * 1024u + wave * 256u + lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i * 64] = stage[i];
+    }
+    __device__ __forceinline__ void start(void* lds_base, uint32_t lane_, uint32_t wave_, const void* blob, uint32_t chunks_) {
+        lds = reinterpret_cast<u32x4*>(lds_base); lane = lane_; wave = wave_; chunks = chunks_;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(blob), 0, (int)(chunks_ * kSplitChunkBytes), 0x00020000);
+        load_stage(0);
+        store_stage(1);
+        load_stage(chunks_ > 1 ? 1 : 0);
+        slot = 0;
+        local = 0xffffffffu;
+        frag = lds + lane;
+    }
+    __device__ __forceinline__ void begin_pass() { local = 0xffffffffu; }
+    __device__ __forceinline__ void boundary() {
+        __syncthreads();
+        ++local;
+        slot ^= 1u;
+        store_stage(slot ^ 1u);
+        uint32_t ahead = local + 2;
+        if (ahead >= chunks) ahead -= chunks;                  // the next pass streams the same blob again
+        if (ahead >= chunks) ahead -= chunks;
+        load_stage(ahead);
+        frag = lds + slot * 1024u + lane;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <int I>
+    __device__ __forceinline__ half8 take() {
+        if constexpr (I % kSplitChunkFrags == 0) boundary();
+        return __builtin_bit_cast(half8, frag[(I % kSplitChunkFrags) * 64]);
+    }
+};
+
+// v -> (hi, lo)
+__device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)((v - (float)hi) * kSplitScale);
+}
+
+// reduction steps S .. NSTEPS-1 of one group of GT output tiles whose first fragment (of step 0) is FG
+template <int S, int NSTEPS, int GT, int FG, class Pipe>
+__device__ __forceinline__ void split_steps(Pipe& wp, const half8 (&xh)[NSTEPS], const half8 (&xl)[NSTEPS], f32x16 (&mainacc)[GT], f32x16 (&corr)[GT]) {
+    if constexpr (S < NSTEPS) {
+        half8 ah[GT], al[GT];
+        [&]<int... T>(std::integer_sequence<int, T...>) {
+            ((ah[T] = wp.template take<FG + (S * GT + T) * 2>(), al[T] = wp.template take<FG + (S * GT + T) * 2 + 1>()), ...);
+            ((mainacc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[T], xh[S], mainacc[T], 0, 0, 0)), ...);
+            ((corr[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[T], xl[S], corr[T], 0, 0, 0)), ...);
+            ((corr[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[T], xh[S], corr[T], 0, 0, 0)), ...);
+        }(std::make_integer_sequence<int, GT>{});
+        split_steps<S + 1, NSTEPS, GT, FG>(wp, xh, xl, mainacc, corr);
+    }
+}
+
+// One layer.  xh / xl: the B operands (NSTEPS reduction steps of 16), F0: index of the layer's first fragment in the pass,
+// emit(t, acc): called once per finished output tile t with main + corr * 2^-11 (no bias).
+template <int NSTEPS, int MT, int F0, int T0 = 0, class Pipe, class Emit>
+__device__ __forceinline__ void split_layer(Pipe& wp, const half8 (&xh)[NSTEPS], const half8 (&xl)[NSTEPS], Emit&& emit) {
+    if constexpr (T0 < MT) {
+        constexpr int G = kSplitGroup, GT = (MT - T0) < G ? (MT - T0) : G, FG = F0 + 2 * NSTEPS * T0;
+        f32x16 mainacc[GT], corr[GT];
+#pragma unroll
+        for (int t = 0; t < GT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { mainacc[t][r] = 0.0f; corr[t][r] = 0.0f; }
+        split_steps<0, NSTEPS, GT, FG>(wp, xh, xl, mainacc, corr);
+        [&]<int... T>(std::integer_sequence<int, T...>) {
+            ([&] {
+                f32x16 v;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = mainacc[T][r] + corr[T][r] * kSplitInv;
+                emit(std::integral_constant<int, T0 + T>{}, v);
+            }(), ...);
+        }(std::make_integer_sequence<int, GT>{});
+        split_layer<NSTEPS, MT, F0, T0 + G>(wp, xh, xl, emit);
+    }
+}
+
+// accumulator tile (+ bias, ReLU) -> the two reduction steps of the next layer it forms (tile order)
+__device__ __forceinline__ void split_tile_to_steps(const f32x16& v, const f32x16& bias, half8& h0, half8& l0, half8& h1, half8& l1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float a = __builtin_amdgcn_fmed3f(v[i] + bias[i], 0.0f, kSplitMaxAct);            // ReLU (+ fp16 range clamp)
+        const float b = __builtin_amdgcn_fmed3f(v[8 + i] + bias[8 + i], 0.0f, kSplitMaxAct);
+        _Float16 hi, lo;
+        split_f16(a, hi, lo); h0[i] = hi; l0[i] = lo;
+        split_f16(b, hi, lo); h1[i] = hi; l1[i] = lo;
+    }
+}
+
+}  // namespace envidr

@@ -50,6 +50,7 @@ class RenderDesc(ctypes.Structure):
         ("indir_roughness_thresh", ctypes.c_float), ("geometry_export", ctypes.POINTER(GeometryExport)),
         ("ray_cost", _FP), ("scratch", _FP), ("scratch_bytes", ctypes.c_uint64),
         ("has_aabb", ctypes.c_int32), ("aabb", ctypes.c_float * 6), ("ray_mask", _FP),
+        ("env_split_blob", _FP), ("env_split_bias", _FP), ("env_features", _FP),
     ]
 
 
@@ -83,6 +84,9 @@ class FusedOptions:
     diffuse_kappa_inv: float = 0.64
     light_intensity_scale: float = 1.0
     intensity_scale: float = 1.0
+    # arithmetic of the environment MLP: "fp32" (default, what every headline number uses) or "f16x2" -- fp16 matrix cores
+    # with every operand carried as a (hi, lo) fp16 pair, fp32 accumulation (csrc/mlp_split.hip.h); the heads stay fp32
+    env_precision: str = "fp32"
 
 
 def _bind_render(lib):
@@ -98,6 +102,12 @@ def _bind_render(lib):
     lib.envidr_packed_layer_floats.restype = ctypes.c_uint32
     lib.envidr_pack_layer.argtypes = [_FP, _FP, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, _FP]
     lib.envidr_pack_layer.restype = ctypes.c_int
+    lib.envidr_split_layer_halves.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
+    lib.envidr_split_layer_halves.restype = ctypes.c_uint32
+    lib.envidr_split_chunk_bytes.restype = ctypes.c_uint32
+    lib.envidr_split_group.restype = ctypes.c_uint32
+    lib.envidr_pack_layer_split.argtypes = [_FP, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, _FP]
+    lib.envidr_pack_layer_split.restype = ctypes.c_int
     lib.envidr_pack_rowvec.argtypes = [_FP, ctypes.c_uint32, _FP]
     lib.envidr_pack_rowvec.restype = ctypes.c_int
     lib.envidr_render_rays.argtypes = [ctypes.POINTER(RenderDesc), _FP, _FP, ctypes.c_uint32, ctypes.POINTER(RenderOut), _FP, _FP]
@@ -157,6 +167,26 @@ def pack_layer(W, bias, k_order: int, transpose: bool = False) -> np.ndarray:
     if rc:
         raise _lib.EnvidrError(lib.envidr_last_error().decode())
     return dst
+
+
+def pack_env_split(env) -> tuple[np.ndarray, np.ndarray]:
+    """the four environment-MLP layers for the split-precision mode: (uint16 blob of (hi, lo) fp16 fragments in consumption
+    order, zero-padded to whole LDS chunks; float32 biases as packed row-vector tiles)"""
+    lib = _lib.load()
+    _bind_render(lib)
+    parts, biases = [], []
+    for i, (W, b) in enumerate(env):
+        W = _np32(W)
+        order = 0 if i == 0 else 1
+        dst = np.empty(lib.envidr_split_layer_halves(order, W.shape[1], W.shape[0]), np.uint16)
+        rc = lib.envidr_pack_layer_split(W.ctypes.data, W.shape[0], W.shape[1], order, dst.ctypes.data)
+        if rc:
+            raise _lib.EnvidrError(lib.envidr_last_error().decode())
+        parts.append(dst)
+        biases.append(pack_rowvec(b))
+    flat = np.concatenate(parts)
+    chunk = lib.envidr_split_chunk_bytes() // 2
+    return np.concatenate([flat, np.zeros((-flat.size) % chunk, np.uint16)]), np.concatenate(biases)
 
 
 def pack_rowvec(v) -> np.ndarray:
@@ -369,6 +399,29 @@ class FusedRenderer:
         d.has_env_rot = 0
         self.desc = d
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._env_layers = env
+        self._split = None            # (blob tensor, bias tensor) of the split-precision mode, packed on first use
+        self._env_feat = None
+        if self.opt.env_precision not in ("fp32", "f16x2"):
+            raise _lib.EnvidrError(f"env_precision must be 'fp32' or 'f16x2', not {self.opt.env_precision!r}")
+
+    def _set_precision(self, precision: str | None, records: int) -> None:
+        """point the descriptor at the split-precision weights + a feature scratch of `records` rows, or clear them"""
+        precision = precision or self.opt.env_precision
+        d = self.desc
+        if precision == "fp32":
+            d.env_split_blob = d.env_split_bias = d.env_features = None
+            return
+        if precision != "f16x2":
+            raise _lib.EnvidrError(f"env_precision must be 'fp32' or 'f16x2', not {precision!r}")
+        if self._env_layers is None:
+            raise _lib.EnvidrError("split precision belongs to the environment-MLP family")
+        if self._split is None:
+            blob, bias = pack_env_split(self._env_layers)
+            self._split = (torch.from_numpy(blob.view(np.int16)).to(self.device), torch.from_numpy(bias).to(self.device))
+        if self._env_feat is None or self._env_feat.shape[0] < records:
+            self._env_feat = torch.empty(max(records, 1), 24, device=self.device)
+        d.env_split_blob, d.env_split_bias, d.env_features = self._split[0].data_ptr(), self._split[1].data_ptr(), self._env_feat.data_ptr()
 
     @classmethod
     def from_scene(cls, scene, opt: FusedOptions | None = None, device="cuda"):
@@ -392,9 +445,14 @@ class FusedRenderer:
         """w_r and the diffuse normal are multiplied by rot_theta(radian)[:3,:3] (renderer.py:160-172)."""
         _set_env_rotation(self.desc, radian)
 
-    def shade(self, normals, dirs, geo_feat, roughness, env_rot_radian: float | None = None, out: dict | None = None) -> dict:
+    def shade(self, normals, dirs, geo_feat, roughness, env_rot_radian: float | None = None, out: dict | None = None,
+              env_precision: str | None = None) -> dict:
         """shading only, for samples with known geometry (envidr_shade_samples); environment-MLP family"""
-        return _shade(self.lib, self.desc, normals, dirs, geo_feat, roughness, env_rot_radian, out)
+        self._set_precision(env_precision, int(normals.numel() // 3))
+        try:
+            return _shade(self.lib, self.desc, normals, dirs, geo_feat, roughness, env_rot_radian, out)
+        finally:
+            self._set_precision("fp32", 0)
 
     # ---- geometry cache: march / hash / SDF once per camera, shading per environment -----------------
     def cache_geometry(self, rays_o: torch.Tensor, rays_d: torch.Tensor, samples_per_ray_hint: float = 16.0) -> GeometryCache:
@@ -568,7 +626,7 @@ class FusedRenderer:
     def render_frame(self, rays_o: torch.Tensor, rays_d: torch.Tensor, env_rot_radian: float | None = None, out: dict | None = None,
                      samples_per_ray_hint: float = 20.0, events: list | None = None, geometry_only: bool = False, wait: bool = True,
                      use_cost_hint: bool = True, r_images: torch.Tensor | None = None, ray_mask: torch.Tensor | None = None,
-                     tag: str = "") -> dict:
+                     tag: str = "", env_precision: str | None = None) -> dict:
         """One frame as: geometry pipeline (envidr_geometry_pass: march rounds + per-sample hash grid / SDF network, one record
         per composited sample) -> shading of the records (k_shade_samples) -> per-ray composite.  Both network families
         (environment MLP; SH heads without one); `r_images` [N,4] (reflected radiance + visibility per ray) selects the
@@ -578,7 +636,8 @@ class FusedRenderer:
         The per-ray sample counts of the previous frame of these N rays (kept in the frame buffers) size each ray's first march
         chunk (use_cost_hint; results do not depend on it).  Nothing waits for the device while the frame is enqueued; with wait=False the call does not wait at the end either
         (video loops: check_frames() -- called by the next frame -- raises FrameOverflow if a frame did not fit).
-        `events`: four torch.cuda.Event(enable_timing=True) recorded at the pass boundaries (geometry | shading | composite)."""
+        `events`: four torch.cuda.Event(enable_timing=True) recorded at the pass boundaries (geometry | shading | composite).
+        `env_precision`: "fp32" / "f16x2" for this frame (default: FusedOptions.env_precision)."""
         self.check_frames()
         rays_o = rays_o.contiguous().view(-1, 3).float()
         rays_d = rays_d.contiguous().view(-1, 3).float()
@@ -627,9 +686,11 @@ class FusedRenderer:
                     if r_images.shape[0] != N or not r_images.is_cuda:
                         raise _lib.EnvidrError("render_frame: r_images must be [N,4] on the GPU")
                     self.desc.r_images = r_images.data_ptr()
+                self._set_precision("fp32" if r_images is not None or self._env_layers is None else env_precision, st["cap"])
                 rc = self.lib.envidr_shade_records(ctypes.byref(self.desc), ctypes.byref(ex), rays_d.data_ptr(), st["cd"].data_ptr(),
                                                    st["cs"].data_ptr(), stream)
                 self.desc.r_images = None
+                self._set_precision("fp32", 0)
                 if rc:
                     raise _lib.EnvidrError(f"envidr_shade_records failed ({rc}): {self.lib.envidr_last_error().decode()}")
             if ev: ev[2].record()

@@ -45,6 +45,13 @@ int envidr_pack_linear(const float* W_host, uint32_t m_out, uint32_t k_in, int t
 uint32_t envidr_packed_layer_floats(int k_order, uint32_t k_in, uint32_t m_out, int with_bias);
 int envidr_pack_layer(const float* W_host, const float* bias_host, uint32_t m_out, uint32_t k_in, int transpose,
                       int k_order, float* dst_host);
+/* split-precision weight packing (host): W [m_out, k_in] row-major -> (hi, lo) fp16 fragments; k_order as envidr_pack_layer.
+ * dst holds envidr_split_layer_halves(k_order, k_in, m_out) uint16. */
+uint32_t envidr_split_layer_halves(int k_order, uint32_t k_in, uint32_t m_out);
+uint32_t envidr_split_chunk_bytes(void);
+uint32_t envidr_split_group(void);
+int envidr_pack_layer_split(const float* W_host, uint32_t m_out, uint32_t k_in, int k_order, uint16_t* dst_host);
+
 int envidr_pack_rowvec(const float* v_host, uint32_t m_out, float* dst_host);
 
 /* ---- geometry cache ----------------------------------------------------------
@@ -172,6 +179,18 @@ typedef struct envidr_render_desc {
      * image = background): the three passes of indirect rendering (renderer.py:439-513) then run over the SAME N rays
      * with masks instead of boolean-mask gathers, host-side counts and scatters between them. */
     const uint8_t* ray_mask;
+
+    /* ABI 4, optional split-precision shading mode (NOT the default, never what bench.py's headline runs): when
+     * env_split_blob is set, envidr_shade_samples / envidr_shade_records evaluate the environment MLP on the fp16 matrix
+     * cores with every operand carried as a (hi, lo) fp16 pair -- 22-bit significands, fp32 accumulation
+     * (envidr_amd/csrc/mlp_split.hip.h) -- and only the heads in fp32.
+     *   env_split_blob  device: the four layers packed by envidr_pack_layer_split in consumption order, zero-padded to a
+     *                   multiple of envidr_split_chunk_bytes()
+     *   env_split_bias  device float: the four biases as envidr_pack_rowvec tiles, concatenated
+     *   env_features    device float [capacity, 24] scratch the mode writes env(normal) | env(reflection) into */
+    const void* env_split_blob;
+    const float* env_split_bias;
+    float* env_features;
 } envidr_render_desc;
 
 /* ---- per-call outputs (device pointers; any optional pointer may be NULL) --------------------- */
