@@ -100,30 +100,36 @@ inline void pack_split_weight(const float* W, uint32_t m_out, uint32_t k_in, Spl
 }
 
 // ---- device side ------------------------------------------------------------------------------------------------------
-constexpr int kSplitChunkFrags = 16;
-constexpr uint32_t kSplitChunkBytes = kSplitChunkFrags * 1024u;       // 16 KiB, two of them in LDS
+#ifndef ENVIDR_SPLIT_CHUNK_FRAGS
+#define ENVIDR_SPLIT_CHUNK_FRAGS 32
+#endif
+constexpr int kSplitChunkFrags = ENVIDR_SPLIT_CHUNK_FRAGS;            // a chunk must outlast the L2 round trip of its successor's
+constexpr uint32_t kSplitChunkBytes = kSplitChunkFrags * 1024u;       // prefetch: 32 KiB = 48 MFMAs = 1536 cycles; two of them in LDS
+constexpr int kSplitStage = kSplitChunkFrags / 4;                     // 16-byte registers per lane holding a quarter chunk in flight
 constexpr int split_pass_chunks(int frags) { return (frags + kSplitChunkFrags - 1) / kSplitChunkFrags; }
 
 // WeightPipe (mlp_mfma.hip.h) for 1-KiB fragments: see there for the protocol
 struct SplitWeightPipe {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    u32x4* lds;                 // workgroup base of u32x4[2][1024]
+    u32x4* lds;                 // workgroup base of u32x4[2][kSplitChunkFrags * 64]
     uint32_t lane, wave, slot;
     const u32x4* frag;          // this lane's column of the chunk being consumed
-    u32x4 stage[4];
+    u32x4 stage[kSplitStage];
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t chunks;            // chunks in the (only) pass: the stream wraps around to chunk 0
     uint32_t local;
 
-    __device__ __forceinline__ uint32_t voff() const { return (wave * 256u + lane) * 16u; }
+    // wave w moves fragments [w * kSplitStage, (w + 1) * kSplitStage) of every chunk
+    __device__ __forceinline__ uint32_t voff() const { return (wave * (kSplitStage * 64u) + lane) * 16u; }
     __device__ __forceinline__ void load_stage(uint32_t chunk) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) stage[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff(), chunk * kSplitChunkBytes + (uint32_t)i * 1024u, 0);
+        for (int i = 0; i < kSplitStage; ++i)
+            stage[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff(), chunk * kSplitChunkBytes + (uint32_t)i * 1024u, 0);
     }
     __device__ __forceinline__ void store_stage(uint32_t to_slot) {
-        u32x4* dst = lds + to_slot * 1024u + wave * 256u + lane;
+        u32x4* dst = lds + to_slot * (kSplitChunkFrags * 64u) + wave * (kSplitStage * 64u) + lane;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dst[i * 64] = stage[i];
+        for (int i = 0; i < kSplitStage; ++i) dst[i * 64] = stage[i];
     }
     __device__ __forceinline__ void start(void* lds_base, uint32_t lane_, uint32_t wave_, const void* blob, uint32_t chunks_) {
         lds = reinterpret_cast<u32x4*>(lds_base); lane = lane_; wave = wave_; chunks = chunks_;
@@ -135,17 +141,17 @@ struct SplitWeightPipe {
         local = 0xffffffffu;
         frag = lds + lane;
     }
-    __device__ __forceinline__ void begin_pass() { local = 0xffffffffu; }
     __device__ __forceinline__ void boundary() {
         __syncthreads();
         ++local;
+        if (local == chunks) local = 0;                        // the next pass streams the same blob again
         slot ^= 1u;
         store_stage(slot ^ 1u);
         uint32_t ahead = local + 2;
-        if (ahead >= chunks) ahead -= chunks;                  // the next pass streams the same blob again
+        if (ahead >= chunks) ahead -= chunks;
         if (ahead >= chunks) ahead -= chunks;
         load_stage(ahead);
-        frag = lds + slot * 1024u + lane;
+        frag = lds + slot * (kSplitChunkFrags * 64u) + lane;
         __builtin_amdgcn_sched_barrier(0);
     }
     template <int I>
@@ -155,31 +161,62 @@ struct SplitWeightPipe {
     }
 };
 
+// Fragments are read from LDS PF ahead of the MFMAs that consume them, through a register ring (fragment I of a pass sits
+// in ring[I % PF]; taking it re-issues the read of fragment I + PF, rolling over into the next pass at the end): left to
+// the compiler, the four ds_read_b128 of a step are issued right in front of its MFMAs and every step waits out the LDS
+// latency (measured: 80 k instead of 30 k cycles per pass).  FRAGS must be a multiple of PF (end_pass pads).
+#ifndef ENVIDR_SPLIT_AHEAD
+#define ENVIDR_SPLIT_AHEAD 8
+#endif
+template <int PF>
+struct SplitFragRing {
+    SplitWeightPipe pipe;
+    half8 ring[PF];
+    __device__ __forceinline__ void start(void* lds_base, uint32_t lane, uint32_t wave, const void* blob, uint32_t chunks) {
+        pipe.start(lds_base, lane, wave, blob, chunks);
+        [&]<int... I>(std::integer_sequence<int, I...>) { ((ring[I] = pipe.template take<I>()), ...); }(std::make_integer_sequence<int, PF>{});
+    }
+    template <int I, int FRAGS>
+    __device__ __forceinline__ half8 take() {
+        static_assert(FRAGS % PF == 0, "pad the pass to a multiple of the ring depth");
+        const half8 v = ring[I % PF];
+        if constexpr (I + PF < FRAGS) ring[I % PF] = pipe.template take<I + PF>();
+        else ring[I % PF] = pipe.template take<I + PF - FRAGS>();
+        return v;
+    }
+    // dummy takes up to the padded length (keeps ring slot = index % PF valid in the next pass)
+    template <int USED, int FRAGS, int I = USED>
+    __device__ __forceinline__ void end_pass() {
+        if constexpr (I < FRAGS) { (void)take<I, FRAGS>(); end_pass<USED, FRAGS, I + 1>(); }
+    }
+};
+
 // v -> (hi, lo)
 __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
     hi = (_Float16)v;
     lo = (_Float16)((v - (float)hi) * kSplitScale);
 }
 
-// reduction steps S .. NSTEPS-1 of one group of GT output tiles whose first fragment (of step 0) is FG
-template <int S, int NSTEPS, int GT, int FG, class Pipe>
-__device__ __forceinline__ void split_steps(Pipe& wp, const half8 (&xh)[NSTEPS], const half8 (&xl)[NSTEPS], f32x16 (&mainacc)[GT], f32x16 (&corr)[GT]) {
+// reduction steps S .. NSTEPS-1 of one group of GT output tiles whose first fragment (of step 0) is FG; FRAGS: padded pass length
+template <int S, int NSTEPS, int GT, int FG, int FRAGS, class Ring>
+__device__ __forceinline__ void split_steps(Ring& wp, const half8 (&xh)[NSTEPS], const half8 (&xl)[NSTEPS], f32x16 (&mainacc)[GT], f32x16 (&corr)[GT]) {
     if constexpr (S < NSTEPS) {
         half8 ah[GT], al[GT];
         [&]<int... T>(std::integer_sequence<int, T...>) {
-            ((ah[T] = wp.template take<FG + (S * GT + T) * 2>(), al[T] = wp.template take<FG + (S * GT + T) * 2 + 1>()), ...);
+            ((ah[T] = wp.template take<FG + (S * GT + T) * 2, FRAGS>(), al[T] = wp.template take<FG + (S * GT + T) * 2 + 1, FRAGS>()), ...);
+            __builtin_amdgcn_sched_barrier(0);            // the reads issued above are for a LATER step: keep them ahead of these MFMAs
             ((mainacc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[T], xh[S], mainacc[T], 0, 0, 0)), ...);
             ((corr[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[T], xl[S], corr[T], 0, 0, 0)), ...);
             ((corr[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[T], xh[S], corr[T], 0, 0, 0)), ...);
         }(std::make_integer_sequence<int, GT>{});
-        split_steps<S + 1, NSTEPS, GT, FG>(wp, xh, xl, mainacc, corr);
+        split_steps<S + 1, NSTEPS, GT, FG, FRAGS>(wp, xh, xl, mainacc, corr);
     }
 }
 
 // One layer.  xh / xl: the B operands (NSTEPS reduction steps of 16), F0: index of the layer's first fragment in the pass,
 // emit(t, acc): called once per finished output tile t with main + corr * 2^-11 (no bias).
-template <int NSTEPS, int MT, int F0, int T0 = 0, class Pipe, class Emit>
-__device__ __forceinline__ void split_layer(Pipe& wp, const half8 (&xh)[NSTEPS], const half8 (&xl)[NSTEPS], Emit&& emit) {
+template <int NSTEPS, int MT, int F0, int FRAGS, int T0 = 0, class Ring, class Emit>
+__device__ __forceinline__ void split_layer(Ring& wp, const half8 (&xh)[NSTEPS], const half8 (&xl)[NSTEPS], Emit&& emit) {
     if constexpr (T0 < MT) {
         constexpr int G = kSplitGroup, GT = (MT - T0) < G ? (MT - T0) : G, FG = F0 + 2 * NSTEPS * T0;
         f32x16 mainacc[GT], corr[GT];
@@ -187,16 +224,16 @@ __device__ __forceinline__ void split_layer(Pipe& wp, const half8 (&xh)[NSTEPS],
         for (int t = 0; t < GT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { mainacc[t][r] = 0.0f; corr[t][r] = 0.0f; }
-        split_steps<0, NSTEPS, GT, FG>(wp, xh, xl, mainacc, corr);
+        split_steps<0, NSTEPS, GT, FG, FRAGS>(wp, xh, xl, mainacc, corr);
         [&]<int... T>(std::integer_sequence<int, T...>) {
             ([&] {
                 f32x16 v;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = mainacc[T][r] + corr[T][r] * kSplitInv;
+                for (int r = 0; r < 16; ++r) v[r] = __builtin_fmaf(corr[T][r], kSplitInv, mainacc[T][r]);
                 emit(std::integral_constant<int, T0 + T>{}, v);
             }(), ...);
         }(std::make_integer_sequence<int, GT>{});
-        split_layer<NSTEPS, MT, F0, T0 + G>(wp, xh, xl, emit);
+        split_layer<NSTEPS, MT, F0, FRAGS, T0 + G>(wp, xh, xl, emit);
     }
 }
 

@@ -22,7 +22,8 @@ struct EnvSplitLayout {
     static constexpr int TERMS = ide_terms(IDE_DEG), K1 = 2 * TERMS, S1 = (K1 + 15) / 16, SH = 2 * ENV_T;
     static constexpr int F1 = 0, F2 = F1 + split_layer_frags(S1, ENV_T), F3 = F2 + split_layer_frags(SH, ENV_T),
                          F4 = F3 + split_layer_frags(SH, ENV_T), Frags = F4 + split_layer_frags(SH, 1);
-    static constexpr int Chunks = split_pass_chunks(Frags);
+    static constexpr int Padded = (Frags + ENVIDR_SPLIT_AHEAD - 1) / ENVIDR_SPLIT_AHEAD * ENVIDR_SPLIT_AHEAD;   // ring-aligned pass length
+    static constexpr int Chunks = split_pass_chunks(Padded);
     static constexpr int BiasTiles = 3 * ENV_T + 1;
 };
 
@@ -31,13 +32,14 @@ __global__ void __launch_bounds__(kSplitThreads, 1) k_env_split(const ShadeArgs 
     using L = EnvSplitLayout<IDE_DEG, ENV_T>;
     constexpr int TERMS = L::TERMS, S1 = L::S1, SH = L::SH;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    __shared__ u32x4 s_w[2 * 1024];
+    __shared__ u32x4 s_w[2 * kSplitChunkFrags * 64];
     __shared__ __attribute__((aligned(16))) float s_bias[L::BiasTiles * 32];
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (uint32_t i = threadIdx.x; i < (uint32_t)L::BiasTiles * 32; i += kSplitThreads) s_bias[i] = bias[i];
-    SplitWeightPipe wp;
-    wp.start(s_w, lane, wave, blob, L::Chunks);        // its first boundary() is also the barrier that publishes s_bias
+    __syncthreads();
+    SplitFragRing<ENVIDR_SPLIT_AHEAD> wp;
+    wp.start(s_w, lane, wave, blob, L::Chunks);
     const float* bias_lane = s_bias + (lane >> 5) * 16;
     auto bias_tile = [&](int tile) {
         f32x16 b;
@@ -104,25 +106,25 @@ __global__ void __launch_bounds__(kSplitThreads, 1) k_env_split(const ShadeArgs 
 #pragma unroll
             for (int j = 0; j < S1; ++j) { xh[j] = grp ? inh[1][j] : inh[0][j]; xl[j] = grp ? inl[1][j] : inl[0][j]; }
             half8 ph[SH], pl[SH], qh[SH], ql[SH];
-            wp.begin_pass();
-            split_layer<S1, ENV_T, L::F1>(wp, xh, xl, [&](auto tc, const f32x16& v) {
+            split_layer<S1, ENV_T, L::F1, L::Padded>(wp, xh, xl, [&](auto tc, const f32x16& v) {
                 constexpr int t = decltype(tc)::value;
                 split_tile_to_steps(v, bias_tile(t), ph[2 * t], pl[2 * t], ph[2 * t + 1], pl[2 * t + 1]);
             });
-            split_layer<SH, ENV_T, L::F2>(wp, ph, pl, [&](auto tc, const f32x16& v) {
+            split_layer<SH, ENV_T, L::F2, L::Padded>(wp, ph, pl, [&](auto tc, const f32x16& v) {
                 constexpr int t = decltype(tc)::value;
                 split_tile_to_steps(v, bias_tile(ENV_T + t), qh[2 * t], ql[2 * t], qh[2 * t + 1], ql[2 * t + 1]);
             });
-            split_layer<SH, ENV_T, L::F3>(wp, qh, ql, [&](auto tc, const f32x16& v) {
+            split_layer<SH, ENV_T, L::F3, L::Padded>(wp, qh, ql, [&](auto tc, const f32x16& v) {
                 constexpr int t = decltype(tc)::value;
                 split_tile_to_steps(v, bias_tile(2 * ENV_T + t), ph[2 * t], pl[2 * t], ph[2 * t + 1], pl[2 * t + 1]);
             });
             f32x16 o;
-            split_layer<SH, 1, L::F4>(wp, ph, pl, [&](auto, const f32x16& v) {
+            split_layer<SH, 1, L::F4, L::Padded>(wp, ph, pl, [&](auto, const f32x16& v) {
                 const f32x16 b = bias_tile(3 * ENV_T);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[r] = v[r] + b[r];
             });
+            wp.template end_pass<L::Frags, L::Padded>();
             if (grp == 0) outA = o; else outB = o;
         }
         float e[16];

@@ -33,5 +33,14 @@ int main() {
             worst = fmax(worst, fabs(want - hD[lane * 16 + r]));
         }
     printf("mfma_f32_32x32x16_f16 layout check: max |diff| = %g (%s)\n", worst, worst < 1e-3 ? "ok" : "MISMATCH");
+    // subnormal fp16 inputs: A = 2^-20 and 3 * 2^-24 (both below fp16's smallest normal 2^-14), B = 1024: flushed -> 0
+    for (int i = 0; i < 512; ++i) { hA[i] = 0; hB[i] = 0; }
+    for (int m = 0; m < 32; ++m) { hA[m * 8 + 0] = ldexpf(1.0f, -20); hA[m * 8 + 1] = 3 * ldexpf(1.0f, -24); }
+    for (int n = 0; n < 32; ++n) { hB[n * 8 + 0] = 1024.0f; hB[n * 8 + 1] = 1024.0f; }
+    hipMemcpy(dA, hA, sizeof(hA), hipMemcpyHostToDevice); hipMemcpy(dB, hB, sizeof(hB), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+    hipMemcpy(hD, dD, sizeof(hD), hipMemcpyDeviceToHost);
+    const double want_sub = 1024.0 * (ldexp(1.0, -20) + 3 * ldexp(1.0, -24));
+    printf("subnormal fp16 operands: D[0][0] = %.9g, exact %.9g (%s)\n", hD[0], want_sub, fabs(hD[0] - want_sub) < 1e-9 ? "honoured" : "FLUSHED");
     return worst < 1e-3 ? 0 : 1;
 }
