@@ -4,12 +4,15 @@
 // "split" shading mode (FusedOptions.env_precision = "f16x2"), reported separately by bench.py with its own error
 // against the same goldens.
 //
-// Every fp32 operand is carried as two halves,  v = hi + lo * 2^-11  with  hi = fp16(v),  lo = fp16((v - hi) * 2^11)
-// (22 significand bits; the 2^11 keeps `lo` in fp16's normal range whenever `hi` is), and a product is three MFMAs into
-// two fp32 accumulators:
-//     main += a_hi * b_hi            corr += a_hi * b_lo + a_lo * b_hi            result = main + corr * 2^-11
+// Every fp32 operand is carried as two halves,  v = hi + lo  with  hi = fp16(v),  lo = fp16(v - hi)  (up to 22 significand
+// bits: `lo` is a subnormal half for |v| < 2^-3 or so, i.e. an absolute resolution of 2^-25 there -- the fp16 MFMAs of
+// gfx950 honour subnormal operands, tools/probe/mfma_f16_probe.hip checks that on the device), and a product is three
+// MFMAs into ONE fp32 accumulator that starts at the bias:
+//     acc = bias;   acc += a_hi * b_hi + a_hi * b_lo + a_lo * b_hi
 // The dropped a_lo * b_lo term is 2^-22 relative; products of halves are exact in the fp32 accumulation.  Three 8-pass
 // MFMAs (96 cycles) replace the eight 16-pass fp32 MFMAs (512 cycles) that cover the same 16 x 32 x 32 block.
+// (Two MFMAs on the same accumulator are two apart in the stream: 36 instead of 33 cycles per MFMA,
+// tools/probe/mfma_dep_probe.hip.)
 //
 // Layout conventions follow mlp_mfma.hip.h: weights are the A operand, activations the B operand, a 32 x 32 output tile
 // of layer n is consumed as the B operand of layer n + 1 from the registers it was accumulated in:
@@ -31,7 +34,6 @@
 namespace envidr {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-constexpr float kSplitScale = 2048.0f, kSplitInv = 1.0f / 2048.0f;
 constexpr float kSplitMaxAct = 60000.0f;          // activations are clamped here before the fp16 split (fp16 max 65504)
 #ifndef ENVIDR_SPLIT_GROUP
 #define ENVIDR_SPLIT_GROUP 2
@@ -93,13 +95,16 @@ inline void pack_split_weight(const float* W, uint32_t m_out, uint32_t k_in, Spl
                         const uint32_t m = 32 * t + (lane & 31u), k = (uint32_t)split_k(order, (int)s, (int)(lane >> 5), (int)i);
                         const float w = (m < m_out && k < k_in) ? W[(size_t)m * k_in + k] : 0.0f;
                         const uint16_t hi = f32_to_f16_rne(w);
-                        const uint16_t lo = f32_to_f16_rne((w - f16_bits_to_f32(hi)) * kSplitScale);
+                        const uint16_t lo = f32_to_f16_rne(w - f16_bits_to_f32(hi));
                         dst[frag * kSplitFragHalves + lane * 8 + i] = hi;
                         dst[(frag + 1) * kSplitFragHalves + lane * 8 + i] = lo;
                     }
 }
 
 // ---- device side ------------------------------------------------------------------------------------------------------
+#ifndef ENVIDR_SPLIT_DEBUG
+#define ENVIDR_SPLIT_DEBUG 0
+#endif
 #ifndef ENVIDR_SPLIT_CHUNK_FRAGS
 #define ENVIDR_SPLIT_CHUNK_FRAGS 32
 #endif
@@ -142,15 +147,20 @@ struct SplitWeightPipe {
         frag = lds + lane;
     }
     __device__ __forceinline__ void boundary() {
+#if ENVIDR_SPLIT_DEBUG == 2
+        slot ^= 1u; frag = lds + slot * (kSplitChunkFrags * 64u) + lane; return;          // timing experiment: no barrier, no streaming
+#endif
         __syncthreads();
         ++local;
         if (local == chunks) local = 0;                        // the next pass streams the same blob again
         slot ^= 1u;
+#if ENVIDR_SPLIT_DEBUG != 1                                    // (1: timing experiment, barriers but no streaming)
         store_stage(slot ^ 1u);
         uint32_t ahead = local + 2;
         if (ahead >= chunks) ahead -= chunks;
         if (ahead >= chunks) ahead -= chunks;
         load_stage(ahead);
+#endif
         frag = lds + slot * (kSplitChunkFrags * 64u) + lane;
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -194,55 +204,46 @@ struct SplitFragRing {
 // v -> (hi, lo)
 __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
     hi = (_Float16)v;
-    lo = (_Float16)((v - (float)hi) * kSplitScale);
+    lo = (_Float16)(v - (float)hi);
 }
 
 // reduction steps S .. NSTEPS-1 of one group of GT output tiles whose first fragment (of step 0) is FG; FRAGS: padded pass length
 template <int S, int NSTEPS, int GT, int FG, int FRAGS, class Ring>
-__device__ __forceinline__ void split_steps(Ring& wp, const half8 (&xh)[NSTEPS], const half8 (&xl)[NSTEPS], f32x16 (&mainacc)[GT], f32x16 (&corr)[GT]) {
+__device__ __forceinline__ void split_steps(Ring& wp, const half8 (&xh)[NSTEPS], const half8 (&xl)[NSTEPS], f32x16 (&acc)[GT]) {
     if constexpr (S < NSTEPS) {
         half8 ah[GT], al[GT];
         [&]<int... T>(std::integer_sequence<int, T...>) {
             ((ah[T] = wp.template take<FG + (S * GT + T) * 2, FRAGS>(), al[T] = wp.template take<FG + (S * GT + T) * 2 + 1, FRAGS>()), ...);
             __builtin_amdgcn_sched_barrier(0);            // the reads issued above are for a LATER step: keep them ahead of these MFMAs
-            ((mainacc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[T], xh[S], mainacc[T], 0, 0, 0)), ...);
-            ((corr[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[T], xl[S], corr[T], 0, 0, 0)), ...);
-            ((corr[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[T], xh[S], corr[T], 0, 0, 0)), ...);
+            ((acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[T], xh[S], acc[T], 0, 0, 0)), ...);
+            ((acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[T], xl[S], acc[T], 0, 0, 0)), ...);
+            ((acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[T], xh[S], acc[T], 0, 0, 0)), ...);
         }(std::make_integer_sequence<int, GT>{});
-        split_steps<S + 1, NSTEPS, GT, FG, FRAGS>(wp, xh, xl, mainacc, corr);
+        split_steps<S + 1, NSTEPS, GT, FG, FRAGS>(wp, xh, xl, acc);
     }
 }
 
 // One layer.  xh / xl: the B operands (NSTEPS reduction steps of 16), F0: index of the layer's first fragment in the pass,
-// emit(t, acc): called once per finished output tile t with main + corr * 2^-11 (no bias).
-template <int NSTEPS, int MT, int F0, int FRAGS, int T0 = 0, class Ring, class Emit>
-__device__ __forceinline__ void split_layer(Ring& wp, const half8 (&xh)[NSTEPS], const half8 (&xl)[NSTEPS], Emit&& emit) {
+// bias(t): the f32x16 the accumulator of output tile t starts from, emit(t, acc): called once per finished output tile.
+template <int NSTEPS, int MT, int F0, int FRAGS, int T0 = 0, class Ring, class Bias, class Emit>
+__device__ __forceinline__ void split_layer(Ring& wp, const half8 (&xh)[NSTEPS], const half8 (&xl)[NSTEPS], Bias&& bias, Emit&& emit) {
     if constexpr (T0 < MT) {
         constexpr int G = kSplitGroup, GT = (MT - T0) < G ? (MT - T0) : G, FG = F0 + 2 * NSTEPS * T0;
-        f32x16 mainacc[GT], corr[GT];
+        f32x16 acc[GT];
 #pragma unroll
-        for (int t = 0; t < GT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { mainacc[t][r] = 0.0f; corr[t][r] = 0.0f; }
-        split_steps<0, NSTEPS, GT, FG, FRAGS>(wp, xh, xl, mainacc, corr);
-        [&]<int... T>(std::integer_sequence<int, T...>) {
-            ([&] {
-                f32x16 v;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = __builtin_fmaf(corr[T][r], kSplitInv, mainacc[T][r]);
-                emit(std::integral_constant<int, T0 + T>{}, v);
-            }(), ...);
-        }(std::make_integer_sequence<int, GT>{});
-        split_layer<NSTEPS, MT, F0, FRAGS, T0 + G>(wp, xh, xl, emit);
+        for (int t = 0; t < GT; ++t) acc[t] = bias(T0 + t);
+        split_steps<0, NSTEPS, GT, FG, FRAGS>(wp, xh, xl, acc);
+        [&]<int... T>(std::integer_sequence<int, T...>) { (emit(std::integral_constant<int, T0 + T>{}, acc[T]), ...); }(std::make_integer_sequence<int, GT>{});
+        split_layer<NSTEPS, MT, F0, FRAGS, T0 + G>(wp, xh, xl, bias, emit);
     }
 }
 
-// accumulator tile (+ bias, ReLU) -> the two reduction steps of the next layer it forms (tile order)
-__device__ __forceinline__ void split_tile_to_steps(const f32x16& v, const f32x16& bias, half8& h0, half8& l0, half8& h1, half8& l1) {
+// accumulator tile (bias included) -> ReLU -> the two reduction steps of the next layer it forms (tile order)
+__device__ __forceinline__ void split_tile_to_steps(const f32x16& v, half8& h0, half8& l0, half8& h1, half8& l1) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const float a = __builtin_amdgcn_fmed3f(v[i] + bias[i], 0.0f, kSplitMaxAct);            // ReLU (+ fp16 range clamp)
-        const float b = __builtin_amdgcn_fmed3f(v[8 + i] + bias[8 + i], 0.0f, kSplitMaxAct);
+        const float a = __builtin_amdgcn_fmed3f(v[i], 0.0f, kSplitMaxAct);            // ReLU (+ fp16 range clamp)
+        const float b = __builtin_amdgcn_fmed3f(v[8 + i], 0.0f, kSplitMaxAct);
         _Float16 hi, lo;
         split_f16(a, hi, lo); h0[i] = hi; l0[i] = lo;
         split_f16(b, hi, lo); h1[i] = hi; l1[i] = lo;

@@ -1,7 +1,7 @@
 // Split-precision environment MLP (optional shading mode, never the default / headline path): the two evaluations of
 // the environment network per sample -- IDE(rotated normal, kappa_diffuse) and IDE(reflected direction, roughness),
 // network.py:524-541,586-600 -- on the fp16 matrix cores with every operand carried as a (hi, lo) fp16 pair
-// (mlp_split.hip.h: 22-bit significands, fp32 accumulation).  The kernel writes the 2 x 12 normalised environment
+// (mlp_split.hip.h: up to 22-bit significands, fp32 accumulation).  The kernel writes the 2 x 12 normalised environment
 // features of every sample; the heads then run in fp32 in k_shade_samples' PRE_ENV instantiation.
 //
 // One workgroup = 4 waves (one per SIMD) sharing the weight stream through LDS; one wave = 32 samples = 64 items:
@@ -106,24 +106,20 @@ __global__ void __launch_bounds__(kSplitThreads, 1) k_env_split(const ShadeArgs 
 #pragma unroll
             for (int j = 0; j < S1; ++j) { xh[j] = grp ? inh[1][j] : inh[0][j]; xl[j] = grp ? inl[1][j] : inl[0][j]; }
             half8 ph[SH], pl[SH], qh[SH], ql[SH];
-            split_layer<S1, ENV_T, L::F1, L::Padded>(wp, xh, xl, [&](auto tc, const f32x16& v) {
+            split_layer<S1, ENV_T, L::F1, L::Padded>(wp, xh, xl, [&](int t) { return bias_tile(t); }, [&](auto tc, const f32x16& v) {
                 constexpr int t = decltype(tc)::value;
-                split_tile_to_steps(v, bias_tile(t), ph[2 * t], pl[2 * t], ph[2 * t + 1], pl[2 * t + 1]);
+                split_tile_to_steps(v, ph[2 * t], pl[2 * t], ph[2 * t + 1], pl[2 * t + 1]);
             });
-            split_layer<SH, ENV_T, L::F2, L::Padded>(wp, ph, pl, [&](auto tc, const f32x16& v) {
+            split_layer<SH, ENV_T, L::F2, L::Padded>(wp, ph, pl, [&](int t) { return bias_tile(ENV_T + t); }, [&](auto tc, const f32x16& v) {
                 constexpr int t = decltype(tc)::value;
-                split_tile_to_steps(v, bias_tile(ENV_T + t), qh[2 * t], ql[2 * t], qh[2 * t + 1], ql[2 * t + 1]);
+                split_tile_to_steps(v, qh[2 * t], ql[2 * t], qh[2 * t + 1], ql[2 * t + 1]);
             });
-            split_layer<SH, ENV_T, L::F3, L::Padded>(wp, qh, ql, [&](auto tc, const f32x16& v) {
+            split_layer<SH, ENV_T, L::F3, L::Padded>(wp, qh, ql, [&](int t) { return bias_tile(2 * ENV_T + t); }, [&](auto tc, const f32x16& v) {
                 constexpr int t = decltype(tc)::value;
-                split_tile_to_steps(v, bias_tile(2 * ENV_T + t), ph[2 * t], pl[2 * t], ph[2 * t + 1], pl[2 * t + 1]);
+                split_tile_to_steps(v, ph[2 * t], pl[2 * t], ph[2 * t + 1], pl[2 * t + 1]);
             });
             f32x16 o;
-            split_layer<SH, 1, L::F4, L::Padded>(wp, ph, pl, [&](auto, const f32x16& v) {
-                const f32x16 b = bias_tile(3 * ENV_T);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[r] = v[r] + b[r];
-            });
+            split_layer<SH, 1, L::F4, L::Padded>(wp, ph, pl, [&](int) { return bias_tile(3 * ENV_T); }, [&](auto, const f32x16& v) { o = v; });
             wp.template end_pass<L::Frags, L::Padded>();
             if (grp == 0) outA = o; else outB = o;
         }

@@ -15,15 +15,25 @@ VARIANTS = {
     "rays_dbg2": ["-DENVIDR_GEO_RAYS_DEBUG=2"],
 }
 
+SPLIT_VARIANTS = {
+    "split": [],
+    "split_nostream": ["-DENVIDR_SPLIT_DEBUG=1"],
+    "split_nobarrier": ["-DENVIDR_SPLIT_DEBUG=2"],
+    "split_noconv": ["-DENVIDR_SPLIT_DEBUG=3"],
+    "split_g4": ["-DENVIDR_SPLIT_GROUP=4"],
+    "split_pf4": ["-DENVIDR_SPLIT_AHEAD=4"],
+}
+
 def main(names):
     B.build(verbose=False)
     out = ROOT / "tools" / "geo" / "variants"
     out.mkdir(exist_ok=True)
-    objs = [str(o) for o in sorted((B.CSRC / "build").glob("*.o")) if o.stem != "geometry_pass"]
     for name in names or VARIANTS:
-        flags = VARIANTS[name]
+        src = "shade_split" if name in SPLIT_VARIANTS else "geometry_pass"
+        objs = [str(o) for o in sorted((B.CSRC / "build").glob("*.o")) if o.stem != src]
+        flags = SPLIT_VARIANTS[name] if name in SPLIT_VARIANTS else VARIANTS[name]
         obj = out / f"{name}.o"
-        cmd = [B.hipcc(), *B.HIPCC_FLAGS, *flags, "-Rpass-analysis=kernel-resource-usage", "-c", str(B.CSRC / "geometry_pass.hip"), "-o", str(obj)]
+        cmd = [B.hipcc(), *B.HIPCC_FLAGS, *flags, "-Rpass-analysis=kernel-resource-usage", "-c", str(B.CSRC / f"{src}.hip"), "-o", str(obj)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             print(name, "FAILED\n", r.stderr[-3000:]); continue

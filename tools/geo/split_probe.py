@@ -1,0 +1,18 @@
+"""time of the split-precision environment kernel + fp32 heads on one 800x800 frame's records (run on the GPU box)"""
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+import torch
+from envidr_amd import scenes
+from envidr_amd.fused import FusedRenderer
+dev = torch.device("cuda:0")
+r = FusedRenderer.from_scene(scenes.toaster_scene(), device=dev)
+ro, rd = (torch.from_numpy(a).to(dev) for a in scenes.camera_rays(800, 800))
+out = {}
+for i in range(3):
+    r.render_frame(ro, rd, 0.1, out=out, env_precision="f16x2")
+ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(5)]
+for i in range(5):
+    r.render_frame(ro, rd, 0.1, out=out, events=ev[i], wait=False, env_precision="f16x2")
+r.check_frames(); torch.cuda.synchronize()
+print(f"shading (split env + fp32 heads) {sum(e[1].elapsed_time(e[2]) for e in ev)/5:.2f} ms")
