@@ -413,6 +413,17 @@ def other_configs(result, dev, rays_o, rays_d, N) -> None:
     cdt = _time(lambda: headline.render_cached(cache, 0.1, out=cout), 5, dev)
     oc["configs[4] env-rotation video of a FIXED camera with the geometry cache (bit-identical frames), 800x800, 1 GPU"] = {
         "rays_per_s": N / cdt, "ms_per_frame": cdt * 1e3, "cache_build_ms": build_ms, "cached_samples": cache.n_samples}
+    # split-precision shading mode (env MLP on the fp16 matrix cores with (hi, lo) operand pairs, heads fp32): reported here
+    # only, NEVER the headline (whose dtype is f32 throughout); error measured against the fp32 frame of the same view
+    ref = {k_: v.clone() for k_, v in headline.render_frame(rays_o, rays_d, 0.1, out={}).items() if k_ in ("image", "specular_image")}
+    sout: dict = {}
+    sdt = _time(lambda: headline.render_frame(rays_o, rays_d, 0.1, out=sout, wait=False, env_precision="f16x2"), 5, dev)
+    headline.check_frames()
+    split = headline.render_frame(rays_o, rays_d, 0.1, out=sout, env_precision="f16x2")
+    srel = {k_: float(torch.linalg.norm(split[k_] - ref[k_]) / torch.linalg.norm(ref[k_])) for k_ in ref}
+    oc["headline workload in the optional split-precision shading mode (env MLP: fp16 MFMA on (hi, lo) pairs; NOT f32, not comparable to value), 800x800, 1 GPU"] = {
+        "rays_per_s": N / sdt, "ms_per_frame": sdt * 1e3, "dtype": "f16x2 pairs (env MLP) + f32 (everything else)",
+        "rel_l2_vs_f32_frame": srel, "parity_tests": "tests/test_split_gpu.py: <= 1e-4 rel-L2 vs the reference's chains and frames"}
     # BASELINE configs[3]: use_renv + indir_ref, three passes per frame through the NeRFRenderer.render() drop-in surface
     from envidr_amd.nerf.network import NeRFNetwork
     from envidr_amd.nerf.options import toaster_options
