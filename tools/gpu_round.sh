@@ -31,7 +31,7 @@ per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         name = row.get("Kernel_Name", "")
-        for key in ("shade_samples", "render_persistent", "geo_eval", "geo_rays<true>", "geo_rays<false>", "first_hit", "order_hits", "place_records", "composite_records"):
+        for key in ("shade_samples", "render_persistent", "geo_eval", "geo_rays<true", "geo_rays<false", "env_split", "first_hit", "order_hits", "place_records", "composite_records"):
             if key in name:
                 per_kernel[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
 summary["pmc_per_launch_mean_by_kernel"] = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in per_kernel.items()}
