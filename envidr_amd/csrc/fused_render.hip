@@ -1216,11 +1216,15 @@ static int launch_shade(const envidr_render_desc* d, ShadeArgs& a, envidr_stream
     a.kappa_diffuse = d->diffuse_kappa_inv; a.light_scale = d->light_intensity_scale;
     a.has_rot = d->dir_sh_degree ? 0 : d->has_env_rot;
     for (int i = 0; i < 9; ++i) a.rot[i] = d->env_rot[i];
-    const uint32_t waves_per_block = kBlockThreads / 64;
-    const uint32_t blocks = std::min((uint32_t)device_cu_count() * (4 / waves_per_block), ceil_div(a.M, kBlockThreads));
-    const dim3 grid(blocks), block(kBlockThreads);
     hipStream_t s = as_stream(stream);
     const bool renv = a.r_images != nullptr;
+    // the heads-only instantiations (no environment MLP in the kernel: the SH family, and the split-precision mode whose
+    // environment features are computed beforehand) need 216 registers: two waves per SIMD, which they want -- they are
+    // latency-, not MFMA-bound
+    const bool heads_only = d->dir_sh_degree != 0 || (d->env_split_blob != nullptr && !renv);
+    const uint32_t waves_per_block = kBlockThreads / 64;
+    const uint32_t blocks = std::min((uint32_t)device_cu_count() * ((heads_only ? 8 : 4) / waves_per_block), ceil_div(a.M, kBlockThreads));
+    const dim3 grid(blocks), block(kBlockThreads);
     // split-precision mode: the environment features come from the fp16-pair kernel (shade_split.hip), the heads stay fp32
     const bool split = d->env_split_blob != nullptr && !d->dir_sh_degree;
     if (split) {
