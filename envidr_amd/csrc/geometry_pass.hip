@@ -1162,11 +1162,15 @@ int envidr_geometry_pass(const envidr_render_desc* d, const float* rays_o, const
     a.ray_mask = d->ray_mask;
     uint32_t* alive[2] = {reinterpret_cast<uint32_t*>(ws + L.alive0), reinterpret_cast<uint32_t*>(ws + L.alive1)};
 
-    // chunk schedule: 16 samples, then each round extends what a ray has so far by half (16, 8, 12, 18, 27 ...): a ray that
-    // terminates after n samples has had at most ~1.5 n evaluated, and max_steps = 1024 is covered in 12 rounds
+    // chunk schedule: 16 samples, then each round extends what a ray has so far by half (16, 8, 12, 18, 27, 40 ...): a ray
+    // that terminates after n samples has had at most ~1.5 n evaluated.  A ray still alive after six rounds (121 samples)
+    // is crossing something thin or translucent and is given all that is left in one go (the counting pass allocates only
+    // what it can actually march): 7 rounds instead of 12 cover max_steps = 1024, and a frame whose rays are all done after
+    // the first round or two -- the hinted frames of a video -- pays for fewer empty launches.
     uint32_t chunks[kMaxRounds], rounds = 0, covered = 0;
     while (covered < d->max_steps && rounds < kMaxRounds - 1) {
-        chunks[rounds] = std::min(rounds == 0 ? 16u : std::max(8u, covered / 2), d->max_steps - covered);
+        const uint32_t grow = rounds == 0 ? 16u : std::max(8u, covered / 2);
+        chunks[rounds] = std::min(rounds >= 6 ? d->max_steps : grow, d->max_steps - covered);
         covered += chunks[rounds++];
     }
     ENVIDR_REQUIRE(covered >= d->max_steps, "geometry_pass: max_steps %u exceeds what %u rounds cover", d->max_steps, kMaxRounds);

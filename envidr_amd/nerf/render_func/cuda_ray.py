@@ -112,13 +112,17 @@ def run_cuda(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, fo
         extra["specular"] = _state(N, nears, device)
     count = torch.zeros(1, dtype=torch.int32, device=device)
 
-    def compact(st):
-        # device-side order-preserving compaction into the state's spare buffer (ping-pong); the
-        # survivor count (4 bytes) is the only thing read back to size the next iteration
-        raymarching.compact_alive(st["alive"], st["spare"], count)
+    def compact(states):
+        # device-side order-preserving compaction of every composited stream into its spare buffer (ping-pong).  All
+        # streams composite the same densities and deltas, and a ray dies on its transmittance alone, so their alive lists
+        # are identical: ONE survivor count (4 bytes) is read back per iteration to size the next one (the reference
+        # re-derives each list with its own boolean mask + host sync, cuda_ray.py:326-341)
+        for st in states:
+            raymarching.compact_alive(st["alive"], st["spare"], count)
         n = int(count.item())
-        st["buf"], st["spare"] = st["spare"], st["buf"]
-        st["alive"] = st["buf"][:n]
+        for st in states:
+            st["buf"], st["spare"] = st["spare"], st["buf"]
+            st["alive"] = st["buf"][:n]
 
     def composite(st, n_alive, n_step, sigmas, colors, deltas, accum=True):
         raymarching.composite_rays(n_alive, n_step, st["alive"], st["t"], sigmas, colors, deltas, st["ws"], st["depth"], st["image"],
@@ -154,18 +158,15 @@ def run_cuda(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, fo
             composite(main, n_alive, n_step, sigmas, rgbs, deltas)
             if "diffuse" in extra:
                 composite(extra["diffuse"], n_alive, n_step, sigmas, self.c_diffuse, deltas)
-                compact(extra["diffuse"])
             if "specular" in extra:
                 accum = True
                 if torch.is_tensor(roughness):
                     deltas[..., 1:] = roughness.detach()       # roughness rides in the depth slot (reference :329-333)
                     accum = False
                 composite(extra["specular"], n_alive, n_step, sigmas, self.c_specular, deltas, accum)
-                compact(extra["specular"])
             if "normal" in extra:
                 composite(extra["normal"], n_alive, n_step, sigmas, normals, deltas)
-                compact(extra["normal"])
-        compact(main)
+        compact([main, *extra.values()])
         step += n_step
 
     results = {"depth": main["depth"].view(*prefix), "weights_sum": main["ws"].view(*prefix)}
