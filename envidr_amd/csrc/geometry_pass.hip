@@ -736,7 +736,9 @@ struct RayState {
 };
 
 // counters (device uint32[kGeoCounterWords]), zeroed by the host before every frame
-constexpr uint32_t kCntSampleHead = 0, kCntRecordHead = 1, kCntOverflow = 2, kCntAlive = 8, kCntBegin = 40, kGeoCounterWords = 80;
+constexpr uint32_t kCntSampleHead = 0, kCntRecordHead = 1, kCntOverflow = 2, kCntAlive = 8, kCntBegin = 40, kCntOcc = 72, kGeoCounterWords = 80;
+// kCntOcc + 0..2: max over occupied cells of (H - 1 - coordinate) (i.e. the minimum, as a maximum: the words start at zero),
+// kCntOcc + 3..5: max coordinate; written by k_linearize_bitfield
 constexpr uint32_t kMaxRounds = 30;
 
 struct GeoRayArgs {
@@ -767,7 +769,31 @@ struct GeoRayArgs {
     const uint8_t* ray_mask;   // optional: rays whose byte is 0 are finished at once (round 0)
     const uint8_t* linear_grid; // one-cascade fast marcher (march_core.hip.h): the bitfield in linear cell order, or null
     uint32_t log2H;
+    uint32_t occ_clip;          // ray_range(): clip rays to the box of the occupied cells
 };
+
+// [near, far) of a ray: the slab test against the model's box (near_far: the reference's arithmetic), with `far` pulled in to
+// where the ray leaves the bounding box of the OCCUPIED cells, grown by a cell on every side (a ray that misses that box
+// gets an empty range).  Beyond that point the marcher can only skip empty cells until it runs out at `far`, so the
+// samples are the same; what goes away is that walk -- ~200 cells for every ray that misses the object, the longest
+// lanes of the first round.  Only with the linear bitfield copy (its kernel reduces the box) and a model box inside the cube.
+__device__ __forceinline__ void ray_range(const GeoRayArgs& a, const RayGeom& rg, float& near, float& far) {
+    near_far(rg, a.box, a.min_near, near, far);
+    if (a.occ_clip) {
+        const uint32_t H1 = (1u << a.log2H) - 1u;
+        const float cs = 2.0f * a.mk.bound / (float)(H1 + 1u);
+        Aabb ob;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int lo = (int)H1 - (int)a.counters[kCntOcc + d], hi = (int)a.counters[kCntOcc + 3 + d];
+            ob.lo[d] = -a.mk.bound + (float)(lo - 1) * cs;
+            ob.hi[d] = -a.mk.bound + (float)(hi + 2) * cs;
+        }
+        float n2, f2;
+        near_far(rg, ob, 0.0f, n2, f2);
+        far = n2 == FLT_MAX ? 0.0f : fminf(far, f2);
+    }
+}
 
 // MODE 0: any grid (march_next), 1: one cascade, power-of-two grid, linear bitfield copy, 2: the same with dt_gamma == 0
 template <int MODE>
@@ -775,6 +801,12 @@ __device__ __forceinline__ bool geo_march(const GeoRayArgs& a, const RayGeom& r,
                                           float* t_at = nullptr) {
     if constexpr (MODE == 0) return march_next(a.mk, r, far, t, x, y, z, dt, t_at);
     else return march_next_c1<MODE == 2>(a.mk, a.linear_grid, a.log2H, r, far, t, x, y, z, dt, t_at);
+}
+
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
+    return v;
 }
 
 // linear_grid bit (x + H y + H^2 z) = Morton-ordered bitfield bit morton(x, y, z); one thread per output byte
@@ -790,6 +822,48 @@ __global__ void __launch_bounds__(kBlock) k_linearize_bitfield(const uint8_t* __
         v |= ((grid[m >> 3] >> (m & 7)) & 1u) << j;
     }
     linear_grid[byte] = (uint8_t)v;
+}
+
+// bounding box of the occupied cells -> counters[kCntOcc ..] (all six as maxima, see there).  A few waves, each over a
+// contiguous slice of the linear grid and ONE atomic per bound per wave: thousands of waves taking same-address atomics at
+// once (the reduction fused into the kernel above) cost 30 us.
+constexpr uint32_t kOccBoxWaves = 64;
+__global__ void __launch_bounds__(64) k_occupied_box(const uint8_t* __restrict__ linear_grid, uint32_t log2H, uint32_t* __restrict__ counters) {
+    const uint32_t bytes = (1u << (3 * log2H)) / 8u, mask = (1u << log2H) - 1u;
+    const uint32_t per_wave = (bytes + kOccBoxWaves - 1) / kOccBoxWaves;
+    const uint32_t lo = blockIdx.x * per_wave, hi = min(bytes, lo + per_wave);
+    uint32_t b[6] = {0, 0, 0, 0, 0, 0};
+    auto take = [&](uint32_t byte, uint32_t v) {
+        if (!v) return;
+        // the eight cells of a byte share y and z (H >= 8): x from the lowest / highest set bit
+        const uint32_t cell = byte * 8u, x0 = cell & mask, y = (cell >> log2H) & mask, z = cell >> (2 * log2H);
+        b[0] = max(b[0], mask - (x0 + (uint32_t)__builtin_ctz(v))); b[1] = max(b[1], mask - y); b[2] = max(b[2], mask - z);
+        b[3] = max(b[3], x0 + 31u - (uint32_t)__builtin_clz(v)); b[4] = max(b[4], y); b[5] = max(b[5], z);
+    };
+    // 16 bytes per lane per load, all of a lane's loads in flight together (the grid is 64-byte granular for H >= 8)
+    for (uint32_t base = lo + threadIdx.x * 16u; base < hi; base += 64u * 16u * 4u) {
+        uint4 w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t at = base + (uint32_t)k * 64u * 16u;
+            w[k] = at + 16u <= hi ? *reinterpret_cast<const uint4*>(linear_grid + at) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t at = base + (uint32_t)k * 64u * 16u;
+            const uint32_t words[4] = {w[k].x, w[k].y, w[k].z, w[k].w};
+            if (!(words[0] | words[1] | words[2] | words[3])) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) take(at + 4u * q + j, (words[q] >> (8 * j)) & 0xffu);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const uint32_t m = wave_max(b[q]);
+        if (threadIdx.x == 0 && m) atomicMax(&counters[kCntOcc + q], m);
+    }
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -830,7 +904,7 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
         if constexpr (FIRST) {
             if (in_range) {
                 rg = load_ray(a.rays_o, a.rays_d, ray);
-                near_far(rg, a.box, a.min_near, near, far);
+                ray_range(a, rg, near, far);
                 float t = near, x, y, z, dt;
 #if ENVIDR_GEO_RAYS_DEBUG == 1
                 const bool hit = false;
@@ -857,7 +931,7 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
             const bool active = cnt != 0;
             if (active) {
                 rg = load_ray(a.rays_o, a.rays_d, ray);
-                near_far(rg, a.box, a.min_near, near, far);
+                ray_range(a, rg, near, far);
                 st.acc_t = __uint_as_float(sp[kFAccT * (size_t)a.n_pad]);
                 st.ws = __uint_as_float(sp[kFWs * (size_t)a.n_pad]);
                 st.depth = __uint_as_float(sp[kFDepth * (size_t)a.n_pad]);
@@ -1178,13 +1252,17 @@ int envidr_geometry_pass(const envidr_render_desc* d, const float* rays_o, const
     if (hipMemsetAsync(counters, 0, kGeoCounterWords * 4, s) != hipSuccess) return check_launch("geometry_pass memset");
     // one cascade on a power-of-two grid (every scene of the reference): the marcher reads a linear-order copy of the bitfield
     int mode = 0;
-    if (d->cascades == 1 && (d->grid_size & (d->grid_size - 1)) == 0 && d->grid_size >= 2 && d->grid_size <= 256) {
+    if (d->cascades == 1 && (d->grid_size & (d->grid_size - 1)) == 0 && d->grid_size >= 8 && d->grid_size <= 256) {
         uint32_t log2H = 0;
         while ((1u << log2H) < d->grid_size) ++log2H;
         uint8_t* lin = reinterpret_cast<uint8_t*>(ws + L.linear_grid);
         const uint32_t bytes = (1u << (3 * log2H)) / 8u;
         hipLaunchKernelGGL(k_linearize_bitfield, dim3(ceil_div(bytes, kBlock)), dim3(kBlock), 0, s, d->density_bitfield, lin, log2H);
         a.linear_grid = lin; a.log2H = log2H;
+        a.occ_clip = 1;
+        for (int i = 0; i < 3; ++i)
+            if (a.box.lo[i] < -d->bound || a.box.hi[i] > d->bound) a.occ_clip = 0;       // positions outside the cube are clamped INTO boundary cells
+        if (a.occ_clip) hipLaunchKernelGGL(k_occupied_box, dim3(kOccBoxWaves), dim3(64), 0, s, lin, log2H, counters);
         mode = d->dt_gamma == 0 ? 2 : 1;
     }
     const uint32_t ray_blocks = ceil_div(N, kBlock);
