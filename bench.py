@@ -41,6 +41,7 @@ FLOP_PER_SAMPLE_SHADING = 624_192  # of which in the shading pass: env MLP 305 1
 FLOP_PER_SAMPLE_GEOMETRY = 26_688  # SDF network forward 14 208 + input gradient 12 480 (geometry pass)
 FLOP_PER_SAMPLE_RELIGHT = 277_376  # neural_renderer.ini / shipped env nets: IDE 4, env hidden 160
 FLOP_PER_SAMPLE_PLAIN = 41_984     # configs[1]: no env MLP
+FLOP_PER_SAMPLE_RENV = 30_592      # third pass of indirect rendering: renv MLP 4-64-64-64-12 (18 432) + the specular head again (12 160)
 HASH_BYTES_PER_SAMPLE = 1024       # 16 levels x 8 corners x 8 B gathered per sample
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 PEAK_HBM_GBPS = 8000.0
@@ -432,10 +433,26 @@ def other_configs(result, dev, rays_o, rays_d, N) -> None:
     ikw = dict(staged=True, bg_color=1, perturb=False, get_normal_image=True, max_steps=iopt.max_steps, T_thresh=iopt.T_thresh,
                dt_gamma=iopt.dt_gamma)
     idt = _time(lambda: imodel.render(rays_o[None], rays_d[None], **ikw), 3, dev)
+    ifr = imodel.fused_renderer()
+    ifr.frame_log = {}
+    imodel.render(rays_o[None], rays_d[None], **ikw)
+    torch.cuda.synchronize(dev)
+    ilog = {t: [int(v) for v in x.tolist()] for t, x in ifr.frame_log.items()}
+    ifr.frame_log = None
+    # algorithmic work of the three passes: geometry (SDF forward + input gradient) on every evaluated sample, full shading on
+    # the records of the reflected and main passes, the reflected-radiance MLP + second specular head on the main pass's
+    iflop = (sum(v[0] for v in ilog.values()) * FLOP_PER_SAMPLE_GEOMETRY + (ilog.get("indirect-reflected", [0, 0])[1] + ilog.get("indirect-main", [0, 0])[1]) * FLOP_PER_SAMPLE_SHADING
+             + ilog.get("indirect-main", [0, 0])[1] * FLOP_PER_SAMPLE_RENV)
+    isamples = sum(v[0] for v in ilog.values())
     direct = NeRFNetwork.from_scene(scenes.toaster_scene(shape=scenes.torus(), seed=3), toaster_options(indir_ref=False), device=dev)
     ddt = _time(lambda: direct.render(rays_o[None], rays_d[None], **ikw), 3, dev)
     oc["configs[3] toaster network + use_renv + indir_ref (3 passes per frame), torus scene, 800x800, 1 GPU"] = {
-        "primary_rays_per_s": N / idt, "ms_per_frame": idt * 1e3, "direct_frame_of_the_same_scene_ms": ddt * 1e3, "ratio_to_direct": idt / ddt}
+        "primary_rays_per_s": N / idt, "ms_per_frame": idt * 1e3, "direct_frame_of_the_same_scene_ms": ddt * 1e3, "ratio_to_direct": idt / ddt,
+        "samples_evaluated_and_records_per_pass": {t: v[:2] for t, v in ilog.items()},
+        "roofline": {"hbm": {"achieved": isamples * HASH_BYTES_PER_SAMPLE / idt / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                             "frac": isamples * HASH_BYTES_PER_SAMPLE / idt / 1e9 / PEAK_HBM_GBPS},
+                     "mfma": {"achieved": iflop / idt / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                              "frac": iflop / idt / 1e12 / PEAK_FP32_MFMA_TFLOPS}}}
 
 
 def main() -> None:

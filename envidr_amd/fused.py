@@ -715,6 +715,8 @@ class FusedRenderer:
             st["host"][3:].copy_(st["worst"], non_blocking=True)
             st["event"].record()
             st["pending"] = True
+            if self.__dict__.get("frame_log") is not None:       # measurement hook: (samples evaluated, records, overflow) per tag, on the device
+                self.frame_log[tag] = st["stats"].clone()
             res["ray_cost"] = st["cost"]
             if not wait:
                 return res
