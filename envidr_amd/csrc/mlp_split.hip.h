@@ -105,6 +105,9 @@ inline void pack_split_weight(const float* W, uint32_t m_out, uint32_t k_in, Spl
 #ifndef ENVIDR_SPLIT_DEBUG
 #define ENVIDR_SPLIT_DEBUG 0
 #endif
+#ifndef ENVIDR_SPLIT_PIN
+#define ENVIDR_SPLIT_PIN 1        // 2: a scheduling barrier after every MFMA + filler piece, 1: one per reduction step, 0: none
+#endif
 #ifndef ENVIDR_SPLIT_CHUNK_FRAGS
 #define ENVIDR_SPLIT_CHUNK_FRAGS 32
 #endif
@@ -113,61 +116,76 @@ constexpr uint32_t kSplitChunkBytes = kSplitChunkFrags * 1024u;       // prefetc
 constexpr int kSplitStage = kSplitChunkFrags / 4;                     // 16-byte registers per lane holding a quarter chunk in flight
 constexpr int split_pass_chunks(int frags) { return (frags + kSplitChunkFrags - 1) / kSplitChunkFrags; }
 
-// WeightPipe (mlp_mfma.hip.h) for 1-KiB fragments: see there for the protocol
+// WeightPipe (mlp_mfma.hip.h) for 1-KiB fragments, with one difference: the staged copy global -> registers -> LDS of the
+// NEXT chunk is not done in one burst at the chunk boundary but one 1-KiB piece per wave every four fragments.  LDS takes
+// writes at 64 B/clk: the 32 KiB of a chunk written at once kept it busy for ~500 cycles, and the fragment reads of the
+// chunk just started queued behind them (the boundaries cost ~740 cycles each, a quarter of the kernel).
 struct SplitWeightPipe {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     u32x4* lds;                 // workgroup base of u32x4[2][kSplitChunkFrags * 64]
     uint32_t lane, wave, slot;
     const u32x4* frag;          // this lane's column of the chunk being consumed
-    u32x4 stage[kSplitStage];
+    u32x4 stage[kSplitStage];   // this wave's quarter of the next chunk (landed) / of the one after (in flight)
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t chunks;            // chunks in the (only) pass: the stream wraps around to chunk 0
     uint32_t local;
+    uint32_t ahead_off;         // byte offset of the chunk whose loads are issued during the current chunk
 
     // wave w moves fragments [w * kSplitStage, (w + 1) * kSplitStage) of every chunk
     __device__ __forceinline__ uint32_t voff() const { return (wave * (kSplitStage * 64u) + lane) * 16u; }
-    __device__ __forceinline__ void load_stage(uint32_t chunk) {
-#pragma unroll
-        for (int i = 0; i < kSplitStage; ++i)
-            stage[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff(), chunk * kSplitChunkBytes + (uint32_t)i * 1024u, 0);
+    template <int I>
+    __device__ __forceinline__ void load_piece(uint32_t chunk_off) {
+        stage[I] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff(), chunk_off + (uint32_t)I * 1024u, 0);
     }
-    __device__ __forceinline__ void store_stage(uint32_t to_slot) {
+    template <int I>
+    __device__ __forceinline__ void store_piece(uint32_t to_slot) {
         u32x4* dst = lds + to_slot * (kSplitChunkFrags * 64u) + wave * (kSplitStage * 64u) + lane;
-#pragma unroll
-        for (int i = 0; i < kSplitStage; ++i) dst[i * 64] = stage[i];
+        dst[I * 64] = stage[I];
     }
     __device__ __forceinline__ void start(void* lds_base, uint32_t lane_, uint32_t wave_, const void* blob, uint32_t chunks_) {
         lds = reinterpret_cast<u32x4*>(lds_base); lane = lane_; wave = wave_; chunks = chunks_;
         rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(blob), 0, (int)(chunks_ * kSplitChunkBytes), 0x00020000);
-        load_stage(0);
-        store_stage(1);
-        load_stage(chunks_ > 1 ? 1 : 0);
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            (load_piece<I>(0), ...);
+            (store_piece<I>(1), ...);                          // chunk 0 -> slot 1 (the first boundary flips to it)
+            (load_piece<I>(chunks_ > 1 ? kSplitChunkBytes : 0u), ...);        // chunk 1 staged
+        }(std::make_integer_sequence<int, kSplitStage>{});
         slot = 0;
         local = 0xffffffffu;
+        ahead_off = 0;
         frag = lds + lane;
     }
     __device__ __forceinline__ void boundary() {
 #if ENVIDR_SPLIT_DEBUG == 2
         slot ^= 1u; frag = lds + slot * (kSplitChunkFrags * 64u) + lane; return;          // timing experiment: no barrier, no streaming
 #endif
-        __syncthreads();
+        __syncthreads();                                       // everybody is done reading the other slot, and done writing this one
         ++local;
         if (local == chunks) local = 0;                        // the next pass streams the same blob again
         slot ^= 1u;
-#if ENVIDR_SPLIT_DEBUG != 1                                    // (1: timing experiment, barriers but no streaming)
-        store_stage(slot ^ 1u);
         uint32_t ahead = local + 2;
         if (ahead >= chunks) ahead -= chunks;
         if (ahead >= chunks) ahead -= chunks;
-        load_stage(ahead);
-#endif
+        ahead_off = ahead * kSplitChunkBytes;
         frag = lds + slot * (kSplitChunkFrags * 64u) + lane;
         __builtin_amdgcn_sched_barrier(0);
     }
     template <int I>
     __device__ __forceinline__ half8 take() {
-        if constexpr (I % kSplitChunkFrags == 0) boundary();
-        return __builtin_bit_cast(half8, frag[(I % kSplitChunkFrags) * 64]);
+        constexpr int c = I % kSplitChunkFrags;
+        if constexpr (c == 0) boundary();
+#if ENVIDR_SPLIT_DEBUG != 1 && ENVIDR_SPLIT_DEBUG != 2         // (timing experiments without the streaming)
+        // piece c / 4 of the staged chunk (local + 1) goes to the other slot, and its register is refilled from chunk local + 2
+        if constexpr (c % 4 == 1 && c / 4 < kSplitStage) {
+#if ENVIDR_SPLIT_DEBUG != 4                                     // (4: loads only, 5: LDS writes only -- timing experiments)
+            store_piece<c / 4>(slot ^ 1u);
+#endif
+#if ENVIDR_SPLIT_DEBUG != 5
+            load_piece<c / 4>(ahead_off);
+#endif
+        }
+#endif
+        return __builtin_bit_cast(half8, frag[c * 64]);
     }
 };
 
@@ -247,6 +265,91 @@ __device__ __forceinline__ void split_tile_to_steps(const f32x16& v, half8& h0, 
         _Float16 hi, lo;
         split_f16(a, hi, lo); h0[i] = hi; l0[i] = lo;
         split_f16(b, hi, lo); h1[i] = hi; l1[i] = lo;
+    }
+}
+
+// accumulator registers 2 J, 2 J + 1 of a tile (bias included) -> ReLU -> their two slots of the reduction step (h, l) they belong to
+template <int J>
+__device__ __forceinline__ void split_pair_to_step(const f32x16& v, half8& h, half8& l) {
+    constexpr int r = 2 * J;
+    const float a = __builtin_amdgcn_fmed3f(v[r], 0.0f, kSplitMaxAct), b = __builtin_amdgcn_fmed3f(v[r + 1], 0.0f, kSplitMaxAct);
+    _Float16 hi, lo;
+    split_f16(a, hi, lo); h[r % 8] = hi; l[r % 8] = lo;
+    split_f16(b, hi, lo); h[(r + 1) % 8] = hi; l[(r + 1) % 8] = lo;
+}
+
+// ---- the same layers with the conversion epilogue of a tile group slipped into the MFMA gaps of the NEXT group ------------
+// A wave's own vector-ALU instructions hide under its MFMAs only if they sit between them in program order (one wave per
+// SIMD: there is nobody else to fill the gaps), and the epilogue -- accumulator read, ReLU, fp16 split of every value: ~5
+// instructions per activation, a third as many cycles as the MFMAs of the pass -- came after a group's last MFMA.  Here the
+// accumulators of a finished group are *pending*: a Drain object converts them a few values at a time after each MFMA of the
+// group that follows (two accumulator sets alternate), also across a layer boundary: the last group of layer n feeds only the
+// LAST reduction steps of layer n + 1, so it is drained during the steps before those.
+struct NoFiller {
+    static constexpr int kDeadline = 0;
+    template <int P, int NP> __device__ __forceinline__ void piece() const {}
+};
+
+// GT pending tiles, first of them tile T0 of its layer; sink(tile, j, acc) converts accumulator registers 2 j, 2 j + 1 of
+// that tile; DEADLINE: the consuming group must be done draining before this reduction step (0 = any step will do)
+template <int GT, int T0, int DEADLINE, class Sink>
+struct Drain {
+    static constexpr int kDeadline = DEADLINE;
+    static constexpr int kPairs = GT * 8;
+    const f32x16* acc;
+    Sink* sink;
+    template <int P, int NP>
+    __device__ __forceinline__ void piece() const {
+        constexpr int lo = kPairs * P / NP, hi = kPairs * (P + 1) / NP;
+        [&]<int... Q>(std::integer_sequence<int, Q...>) {
+            ((*sink)(std::integral_constant<int, T0 + (lo + Q) / 8>{}, std::integral_constant<int, (lo + Q) % 8>{}, acc[(lo + Q) / 8]), ...);
+        }(std::make_integer_sequence<int, hi - lo>{});
+    }
+};
+
+template <int S, int NSTEPS, int GT, int FG, int FRAGS, class Ring, class Filler>
+__device__ __forceinline__ void split_steps_filled(Ring& wp, const half8 (&xh)[NSTEPS], const half8 (&xl)[NSTEPS], f32x16* acc, const Filler& fill) {
+    if constexpr (S < NSTEPS) {
+        half8 ah[GT], al[GT];
+        [&]<int... T>(std::integer_sequence<int, T...>) {
+            ((ah[T] = wp.template take<FG + (S * GT + T) * 2, FRAGS>(), al[T] = wp.template take<FG + (S * GT + T) * 2 + 1, FRAGS>()), ...);
+        }(std::make_integer_sequence<int, GT>{});
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int GAPS = 3 * GT;
+        constexpr int ACT = Filler::kDeadline == 0 ? NSTEPS : (Filler::kDeadline < NSTEPS ? Filler::kDeadline : NSTEPS);
+        [&]<int... Q>(std::integer_sequence<int, Q...>) {
+            ([&] {
+                constexpr int kind = Q / GT, t = Q % GT;          // 0: a_hi b_hi, 1: a_hi b_lo, 2: a_lo b_hi
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kind == 2 ? al[t] : ah[t], kind == 1 ? xl[S] : xh[S], acc[t], 0, 0, 0);
+                if constexpr (S < ACT) fill.template piece<S * GAPS + Q, ACT * GAPS>();
+#if ENVIDR_SPLIT_PIN == 2
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }(), ...);
+        }(std::make_integer_sequence<int, GAPS>{});
+#if ENVIDR_SPLIT_PIN == 1
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        split_steps_filled<S + 1, NSTEPS, GT, FG, FRAGS>(wp, xh, xl, acc, fill);
+    }
+}
+
+// One layer, pipelined.  `cur` / `other`: the two accumulator sets (kSplitGroup tiles each); group 0 accumulates into `cur`
+// while `first` (the pending work handed over by the caller: the previous layer's last group, or NoFiller) drains; group g + 1
+// drains group g through `sink`.  Returns, through `done(acc, T0 of the last group, GT of it)`, the set that holds the
+// layer's last group, still to be drained by whoever comes next.
+template <int NSTEPS, int MT, int F0, int FRAGS, int T0 = 0, class Ring, class Bias, class Sink, class First, class Then>
+__device__ __forceinline__ void split_layer_piped(Ring& wp, const half8 (&xh)[NSTEPS], const half8 (&xl)[NSTEPS], Bias&& bias, Sink& sink,
+                                                  f32x16* cur, f32x16* other, const First& first, Then&& then) {
+    constexpr int G = kSplitGroup, GT = (MT - T0) < G ? (MT - T0) : G, FG = F0 + 2 * NSTEPS * T0;
+#pragma unroll
+    for (int t = 0; t < GT; ++t) cur[t] = bias(T0 + t);
+    split_steps_filled<0, NSTEPS, GT, FG, FRAGS>(wp, xh, xl, cur, first);
+    if constexpr (T0 + G < MT) {
+        const Drain<GT, T0, 0, Sink> pending{cur, &sink};
+        split_layer_piped<NSTEPS, MT, F0, FRAGS, T0 + G>(wp, xh, xl, bias, sink, other, cur, pending, then);
+    } else {
+        then(cur, other, std::integral_constant<int, T0>{}, std::integral_constant<int, GT>{});
     }
 }
 

@@ -15,6 +15,9 @@ using namespace envidr;
 
 namespace {
 
+#ifndef ENVIDR_SPLIT_PIPED
+#define ENVIDR_SPLIT_PIPED 1
+#endif
 constexpr uint32_t kSplitThreads = 256;
 
 template <int IDE_DEG, int ENV_T>
@@ -22,7 +25,10 @@ struct EnvSplitLayout {
     static constexpr int TERMS = ide_terms(IDE_DEG), K1 = 2 * TERMS, S1 = (K1 + 15) / 16, SH = 2 * ENV_T;
     static constexpr int F1 = 0, F2 = F1 + split_layer_frags(S1, ENV_T), F3 = F2 + split_layer_frags(SH, ENV_T),
                          F4 = F3 + split_layer_frags(SH, ENV_T), Frags = F4 + split_layer_frags(SH, 1);
-    static constexpr int Padded = (Frags + ENVIDR_SPLIT_AHEAD - 1) / ENVIDR_SPLIT_AHEAD * ENVIDR_SPLIT_AHEAD;   // ring-aligned pass length
+    // pass length in fragments: whole LDS chunks (the staging of the next chunk is driven by the takes of the current one) and a
+    // multiple of the ring depth
+    static_assert(kSplitChunkFrags % ENVIDR_SPLIT_AHEAD == 0, "ring depth must divide the chunk");
+    static constexpr int Padded = (Frags + kSplitChunkFrags - 1) / kSplitChunkFrags * kSplitChunkFrags;
     static constexpr int Chunks = split_pass_chunks(Padded);
     static constexpr int BiasTiles = 3 * ENV_T + 1;
 };
@@ -106,6 +112,33 @@ __global__ void __launch_bounds__(kSplitThreads, 1) k_env_split(const ShadeArgs 
 #pragma unroll
             for (int j = 0; j < S1; ++j) { xh[j] = grp ? inh[1][j] : inh[0][j]; xl[j] = grp ? inl[1][j] : inl[0][j]; }
             half8 ph[SH], pl[SH], qh[SH], ql[SH];
+#if ENVIDR_SPLIT_PIPED
+            // every tile group's fp16 conversion runs in the MFMA gaps of the group after it (mlp_split.hip.h, "pending")
+            f32x16 accA[kSplitGroup], accB[kSplitGroup], o;
+            auto sink_p = [&](auto tc, auto jc, const f32x16& v) {
+                constexpr int t = decltype(tc)::value, j = decltype(jc)::value;
+                split_pair_to_step<j>(v, ph[2 * t + (j >= 4)], pl[2 * t + (j >= 4)]);
+            };
+            auto sink_q = [&](auto tc, auto jc, const f32x16& v) {
+                constexpr int t = decltype(tc)::value, j = decltype(jc)::value;
+                split_pair_to_step<j>(v, qh[2 * t + (j >= 4)], ql[2 * t + (j >= 4)]);
+            };
+            auto sink_none = [&](auto, auto, const f32x16&) {};
+            split_layer_piped<S1, ENV_T, L::F1, L::Padded>(wp, xh, xl, [&](int t) { return bias_tile(t); }, sink_p, accA, accB, NoFiller{},
+              [&](f32x16* c1, f32x16* o1, auto t0, auto gt) {
+                const Drain<decltype(gt)::value, decltype(t0)::value, 2 * decltype(t0)::value, decltype(sink_p)> pend1{c1, &sink_p};
+                split_layer_piped<SH, ENV_T, L::F2, L::Padded>(wp, ph, pl, [&](int t) { return bias_tile(ENV_T + t); }, sink_q, o1, c1, pend1,
+                  [&](f32x16* c2, f32x16* o2, auto t0b, auto gtb) {
+                    const Drain<decltype(gtb)::value, decltype(t0b)::value, 2 * decltype(t0b)::value, decltype(sink_q)> pend2{c2, &sink_q};
+                    split_layer_piped<SH, ENV_T, L::F3, L::Padded>(wp, qh, ql, [&](int t) { return bias_tile(2 * ENV_T + t); }, sink_p, o2, c2, pend2,
+                      [&](f32x16* c3, f32x16* o3, auto t0c, auto gtc) {
+                        const Drain<decltype(gtc)::value, decltype(t0c)::value, 2 * decltype(t0c)::value, decltype(sink_p)> pend3{c3, &sink_p};
+                        split_layer_piped<SH, 1, L::F4, L::Padded>(wp, ph, pl, [&](int) { return bias_tile(3 * ENV_T); }, sink_none, o3, c3, pend3,
+                          [&](f32x16* c4, f32x16*, auto, auto) { o = c4[0]; });
+                      });
+                  });
+              });
+#else
             split_layer<S1, ENV_T, L::F1, L::Padded>(wp, xh, xl, [&](int t) { return bias_tile(t); }, [&](auto tc, const f32x16& v) {
                 constexpr int t = decltype(tc)::value;
                 split_tile_to_steps(v, ph[2 * t], pl[2 * t], ph[2 * t + 1], pl[2 * t + 1]);
@@ -120,6 +153,7 @@ __global__ void __launch_bounds__(kSplitThreads, 1) k_env_split(const ShadeArgs 
             });
             f32x16 o;
             split_layer<SH, 1, L::F4, L::Padded>(wp, ph, pl, [&](int) { return bias_tile(3 * ENV_T); }, [&](auto, const f32x16& v) { o = v; });
+#endif
             wp.template end_pass<L::Frags, L::Padded>();
             if (grp == 0) outA = o; else outB = o;
         }

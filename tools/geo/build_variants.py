@@ -20,7 +20,13 @@ SPLIT_VARIANTS = {
     "split_nostream": ["-DENVIDR_SPLIT_DEBUG=1"],
     "split_nobarrier": ["-DENVIDR_SPLIT_DEBUG=2"],
     "split_noconv": ["-DENVIDR_SPLIT_DEBUG=3"],
+    "split_loadsonly": ["-DENVIDR_SPLIT_DEBUG=4"],
+    "split_writesonly": ["-DENVIDR_SPLIT_DEBUG=5"],
     "split_g4": ["-DENVIDR_SPLIT_GROUP=4"],
+    "split_pin0": ["-DENVIDR_SPLIT_PIN=0"],
+    "split_pin1": ["-DENVIDR_SPLIT_PIN=1"],
+    "split_pin2": ["-DENVIDR_SPLIT_PIN=2"],
+    "split_unpiped": ["-DENVIDR_SPLIT_PIPED=0"],
     "split_pf4": ["-DENVIDR_SPLIT_AHEAD=4"],
 }
 
