@@ -28,6 +28,8 @@
 #include "fused_common.hip.h"
 #include "sh_core.hip.h"
 
+#include <map>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -1141,8 +1143,7 @@ int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const f
     a.ray_counter = ray_counter;
 
     hipStream_t s = as_stream(stream);
-    // work-list scratch: the caller's (desc->scratch: one per in-flight render, so that renders on different streams may
-    // overlap) or the library's own (grows monotonically; one render at a time)
+    // work-list scratch: the caller's (desc->scratch) or the library's own (grows monotonically)
     uint32_t* hit_ids; float* hit_t; uint32_t* counters;
     if (d->scratch) {
         ENVIDR_REQUIRE(d->scratch_bytes >= envidr_render_scratch_bytes(N), "render_rays: scratch of %llu bytes, need %llu",
@@ -1151,21 +1152,27 @@ int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const f
         hit_ids = counters + kScratchCounterWords;
         hit_t = reinterpret_cast<float*>(hit_ids + N);
     } else {
-        static uint32_t* g_hit_ids = nullptr;
-        static float* g_hit_t = nullptr;
-        static uint32_t* g_counters = nullptr;
-        static uint32_t g_cap = 0;
-        if (N > g_cap || !g_counters) {
-            if (g_hit_ids) (void)hipFree(g_hit_ids);
-            if (g_hit_t) (void)hipFree(g_hit_t);
-            if (!g_counters && hipMalloc(&g_counters, kScratchCounterWords * 4) != hipSuccess) return check_launch("render_rays counters alloc");
-            g_cap = N + N / 4;
-            if (hipMalloc(&g_hit_ids, (size_t)g_cap * 4) != hipSuccess || hipMalloc(&g_hit_t, (size_t)g_cap * 4) != hipSuccess) {
-                g_hit_ids = nullptr; g_hit_t = nullptr; g_cap = 0;
+        // one set per (device, stream), under a lock: renders enqueued on different streams or devices never share a work
+        // list (a render on the SAME stream may: stream order serialises them)
+        struct WorkScratch { uint32_t* hit_ids = nullptr; float* hit_t = nullptr; uint32_t* counters = nullptr; uint32_t cap = 0; };
+        static std::mutex g_mu;
+        static std::map<std::pair<int, hipStream_t>, WorkScratch> g_sets;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lock(g_mu);
+        WorkScratch& w = g_sets[{dev, s}];
+        if (N > w.cap || !w.counters) {
+            if (w.hit_ids) (void)hipFree(w.hit_ids);
+            if (w.hit_t) (void)hipFree(w.hit_t);
+            w.hit_ids = nullptr; w.hit_t = nullptr;
+            if (!w.counters && hipMalloc(&w.counters, kScratchCounterWords * 4) != hipSuccess) return check_launch("render_rays counters alloc");
+            w.cap = N + N / 4;
+            if (hipMalloc(&w.hit_ids, (size_t)w.cap * 4) != hipSuccess || hipMalloc(&w.hit_t, (size_t)w.cap * 4) != hipSuccess) {
+                w.hit_ids = nullptr; w.hit_t = nullptr; w.cap = 0;
                 return check_launch("render_rays work-list alloc");
             }
         }
-        hit_ids = g_hit_ids; hit_t = g_hit_t; counters = g_counters;
+        hit_ids = w.hit_ids; hit_t = w.hit_t; counters = w.counters;
     }
     (void)ray_counter;   // kept in the ABI for callers that manage their own queue word; the library uses its own pair
     a.ray_counter = counters;

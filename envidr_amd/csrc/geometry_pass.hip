@@ -1133,8 +1133,9 @@ void launch_eval(const GeoEvalArgs& a, uint32_t max_samples, hipStream_t s) {
     // one 8-wave workgroup per CU (the LDS-resident weights and the parked Jacobians fill the CU's LDS)
     const uint32_t blocks = std::max(1u, std::min((uint32_t)device_cu_count(), ceil_div(max_samples, kEvalThreads)));
     GeoEvalArgs b = a;
+#if !ENVIDR_GEO_KERNEL32 && ENVIDR_GEO_JMODE == 1
     {
-        // parking slabs of the Jacobians: one per wave of the (persistent) grid, kept for the life of the process
+        // experiment (k_geo_eval with the Jacobians parked in global memory): one slab per wave of the persistent grid
         static float* g_scratch[16] = {};
         int dev = 0;
         (void)hipGetDevice(&dev);
@@ -1142,6 +1143,7 @@ void launch_eval(const GeoEvalArgs& a, uint32_t max_samples, hipStream_t s) {
         if (!g_scratch[dev]) (void)hipMalloc(&g_scratch[dev], (size_t)device_cu_count() * kEvalWaves * kLevels * 6 * 64 * sizeof(float));
         b.jscratch = g_scratch[dev];
     }
+#endif
 #if ENVIDR_GEO_KERNEL32
     const uint32_t blocks32 = std::max(1u, std::min((uint32_t)device_cu_count(), ceil_div(max_samples, kE32Waves * 32u)));
     hipLaunchKernelGGL(k_geo_eval32, dim3(blocks32), dim3(kE32Threads), 0, s, b);
