@@ -15,5 +15,5 @@ void set_error(const char* fmt, ...) {
 
 extern "C" {
 const char* envidr_last_error(void) { return envidr::g_error; }
-int envidr_abi_version(void) { return 4; }   // 4: split-precision shading mode (descriptor grew: env_split_blob / env_split_bias / env_features)
+int envidr_abi_version(void) { return 5; }   // 5: sdf_geo_blob (16-column geometry kernel); 4: split-precision shading mode
 }

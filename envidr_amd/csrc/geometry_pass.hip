@@ -106,6 +106,9 @@ constexpr int kGeoRing = ENVIDR_GEO_RING;
 #ifndef ENVIDR_GEO_RAYS_DEBUG
 #define ENVIDR_GEO_RAYS_DEBUG 0
 #endif
+#ifndef ENVIDR_GEO_KERNEL16
+#define ENVIDR_GEO_KERNEL16 1      // 1: k_geo_eval16 (16 samples per wave, 16-column MFMAs) when the descriptor carries its weight packing
+#endif
 #ifndef ENVIDR_GEO_KERNEL32
 #define ENVIDR_GEO_KERNEL32 1      // 1: k_geo_eval32 (32 samples per wave, two waves per SIMD), 0: k_geo_eval (64, one per SIMD)
 #endif
@@ -133,6 +136,7 @@ struct GeoEvalArgs {
     // SDF network
     const float* sdf_blob;
     const float* sdf_w3r0;
+    const float* sdf_e16_blob;  // k_geo_eval16's packing of the same network (geo_eval16.hip.h), or null
     float inv_beta, beta, density_scale;
     float rough_bias, rough_act_scale, rough_scale;
     // per-sample outputs (any may be null)
@@ -710,6 +714,10 @@ __global__ void __launch_bounds__(kE32Threads, 2) k_geo_eval32(const GeoEvalArgs
     }
 }
 
+}  // namespace
+#include "geo_eval16.hip.h"
+namespace {
+
 // =====================================================================================================================
 // per-ray rounds
 // =====================================================================================================================
@@ -1124,6 +1132,7 @@ int fill_eval_args(const envidr_render_desc* d, GeoEvalArgs& a, const char* who)
     ENVIDR_REQUIRE(!err, "%s: %s", who, err);
     a.bound = d->bound; a.bound2 = 2 * d->bound;
     a.sdf_blob = d->sdf_blob; a.sdf_w3r0 = d->sdf_w3_row0;
+    a.sdf_e16_blob = ENVIDR_GEO_KERNEL16 ? d->sdf_geo_blob : nullptr;
     a.beta = d->beta; a.inv_beta = 1 / d->beta; a.density_scale = d->density_scale;
     a.rough_bias = d->roughness_bias; a.rough_act_scale = d->roughness_act_scale; a.rough_scale = d->roughness_scale;
     return ENVIDR_OK;
@@ -1144,6 +1153,11 @@ void launch_eval(const GeoEvalArgs& a, uint32_t max_samples, hipStream_t s) {
         b.jscratch = g_scratch[dev];
     }
 #endif
+    if (b.sdf_e16_blob) {
+        const uint32_t blocks16 = std::max(1u, std::min((uint32_t)device_cu_count(), ceil_div(max_samples, kE16Waves * 16u)));
+        hipLaunchKernelGGL(k_geo_eval16, dim3(blocks16), dim3(kE16Threads), 0, s, b);
+        return;
+    }
 #if ENVIDR_GEO_KERNEL32
     const uint32_t blocks32 = std::max(1u, std::min((uint32_t)device_cu_count(), ceil_div(max_samples, kE32Waves * 32u)));
     hipLaunchKernelGGL(k_geo_eval32, dim3(blocks32), dim3(kE32Threads), 0, s, b);
@@ -1300,6 +1314,14 @@ int envidr_geometry_pass(const envidr_render_desc* d, const float* rays_o, const
     return check_launch("k_geo_finalize");
 }
 
+
+uint32_t envidr_sdf_geometry_floats(void) { return (uint32_t)(kE16BlobFloats + kE16W3Row); }
+
+int envidr_pack_sdf_geometry(const float* W1, const float* b1, const float* W2, const float* b2, const float* W3, const float* b3, float* dst_host) {
+    ENVIDR_REQUIRE(W1 && b1 && W2 && b2 && W3 && b3 && dst_host, "pack_sdf_geometry: null pointer");
+    pack_sdf_e16(W1, b1, W2, b2, W3, b3, dst_host);
+    return ENVIDR_OK;
+}
 
 int envidr_geometry_eval(const envidr_render_desc* d, const float* xyz, const float* dt, uint32_t M, const uint32_t* range_dev,
                          const envidr_geometry_samples_out* out, envidr_stream_t stream) {

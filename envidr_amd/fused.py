@@ -51,6 +51,7 @@ class RenderDesc(ctypes.Structure):
         ("ray_cost", _FP), ("scratch", _FP), ("scratch_bytes", ctypes.c_uint64),
         ("has_aabb", ctypes.c_int32), ("aabb", ctypes.c_float * 6), ("ray_mask", _FP),
         ("env_split_blob", _FP), ("env_split_bias", _FP), ("env_features", _FP),
+        ("sdf_geo_blob", _FP),
     ]
 
 
@@ -87,6 +88,9 @@ class FusedOptions:
     # arithmetic of the environment MLP: "fp32" (default, what every headline number uses) or "f16x2" -- fp16 matrix cores
     # with every operand carried as a (hi, lo) fp16 pair, fp32 accumulation (csrc/mlp_split.hip.h); the heads stay fp32
     env_precision: str = "fp32"
+    # per-sample geometry kernel: "32" = k_geo_eval32 (32 samples per wave, two waves per SIMD: the default, and the faster),
+    # "16" = k_geo_eval16 (16-column MFMAs, three waves per SIMD; kept as a measured alternative, csrc/geo_eval16.hip.h)
+    geometry_kernel: str = "32"
 
 
 def _bind_render(lib):
@@ -102,6 +106,9 @@ def _bind_render(lib):
     lib.envidr_packed_layer_floats.restype = ctypes.c_uint32
     lib.envidr_pack_layer.argtypes = [_FP, _FP, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, _FP]
     lib.envidr_pack_layer.restype = ctypes.c_int
+    lib.envidr_sdf_geometry_floats.restype = ctypes.c_uint32
+    lib.envidr_pack_sdf_geometry.argtypes = [_FP] * 7
+    lib.envidr_pack_sdf_geometry.restype = ctypes.c_int
     lib.envidr_split_layer_halves.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
     lib.envidr_split_layer_halves.restype = ctypes.c_uint32
     lib.envidr_split_chunk_bytes.restype = ctypes.c_uint32
@@ -164,6 +171,23 @@ def pack_layer(W, bias, k_order: int, transpose: bool = False) -> np.ndarray:
     b = None if bias is None else _np32(bias).reshape(-1)
     dst = np.empty(lib.envidr_packed_layer_floats(k_order, K, M, int(b is not None)), np.float32)
     rc = lib.envidr_pack_layer(W.ctypes.data, None if b is None else b.ctypes.data, m_out, k_in, int(transpose), k_order, dst.ctypes.data)
+    if rc:
+        raise _lib.EnvidrError(lib.envidr_last_error().decode())
+    return dst
+
+
+def pack_sdf_geometry(sdf) -> np.ndarray:
+    """the SDF network 2L -> 64 -> 64 -> 15 for the 16-column geometry kernel (csrc/geo_eval16.hip.h)"""
+    lib = _lib.load()
+    _bind_render(lib)
+    arrs = []
+    for W, b in sdf:
+        arrs += [_np32(W), _np32(b).reshape(-1)]
+    if arrs[0].shape != (64, 32) or arrs[2].shape != (64, 64) or arrs[4].shape[1] != 64 or arrs[4].shape[0] < 15:
+        raise _lib.EnvidrError("pack_sdf_geometry expects the SDF network 32 -> 64 -> 64 -> 15")
+    arrs[4], arrs[5] = np.ascontiguousarray(arrs[4][:15]), np.ascontiguousarray(arrs[5][:15])
+    dst = np.empty(lib.envidr_sdf_geometry_floats(), np.float32)
+    rc = lib.envidr_pack_sdf_geometry(*[a.ctypes.data for a in arrs], dst.ctypes.data)
     if rc:
         raise _lib.EnvidrError(lib.envidr_last_error().decode())
     return dst
@@ -390,6 +414,10 @@ class FusedRenderer:
             d.spec2_blob = blob([L(spc[0], 0), L(spc[1], 1), L(spc[2], 1)])
         d.indir_roughness_thresh = self.opt.indir_roughness_thresh
         d.sdf_w3_row0 = up(pack_rowvec(_np32(sdf[2][0])[0])).data_ptr()
+        if self.opt.geometry_kernel not in ("32", "16"):
+            raise _lib.EnvidrError(f"geometry_kernel must be '32' or '16', not {self.opt.geometry_kernel!r}")
+        if self.opt.geometry_kernel == "16":
+            d.sdf_geo_blob = up(pack_sdf_geometry(sdf)).data_ptr()
         d.beta = float(min(max(beta, self.opt.beta_min), self.opt.beta_max))     # LaplaceDensity.get_beta clamp
         d.roughness_bias, d.roughness_act_scale = self.opt.roughness_bias, self.opt.roughness_act_scale
         d.roughness_scale = self.opt.roughness_scale

@@ -45,6 +45,13 @@ int envidr_pack_linear(const float* W_host, uint32_t m_out, uint32_t k_in, int t
 uint32_t envidr_packed_layer_floats(int k_order, uint32_t k_in, uint32_t m_out, int with_bias);
 int envidr_pack_layer(const float* W_host, const float* bias_host, uint32_t m_out, uint32_t k_in, int transpose,
                       int k_order, float* dst_host);
+/* The SDF network 32 -> 64 -> 64 -> 15 (weights [out, in] row-major + biases) for the 16-column geometry kernel: forward layers,
+ * the two transposed layers of the input gradient and row 0 of W3, rows / reduction order permuted as
+ * envidr_amd/csrc/geo_eval16.hip.h describes.  dst holds envidr_sdf_geometry_floats() floats. */
+uint32_t envidr_sdf_geometry_floats(void);
+int envidr_pack_sdf_geometry(const float* W1, const float* b1, const float* W2, const float* b2, const float* W3, const float* b3,
+                             float* dst_host);
+
 /* split-precision weight packing (host): W [m_out, k_in] row-major -> (hi, lo) fp16 fragments; k_order as envidr_pack_layer.
  * dst holds envidr_split_layer_halves(k_order, k_in, m_out) uint16. */
 uint32_t envidr_split_layer_halves(int k_order, uint32_t k_in, uint32_t m_out);
@@ -191,6 +198,11 @@ typedef struct envidr_render_desc {
     const void* env_split_blob;
     const float* env_split_bias;
     float* env_features;
+
+    /* ABI 5, optional: the SDF network packed for the 16-column geometry kernel (envidr_pack_sdf_geometry; device,
+     * envidr_sdf_geometry_floats() floats).  With it the geometry entry points run k_geo_eval16 (16 samples per wave, three
+     * waves per SIMD); without it k_geo_eval32 on sdf_blob.  Same results up to fp32 summation order. */
+    const float* sdf_geo_blob;
 } envidr_render_desc;
 
 /* ---- per-call outputs (device pointers; any optional pointer may be NULL) --------------------- */

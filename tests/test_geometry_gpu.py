@@ -35,6 +35,30 @@ def _frame(renderer, rays_o, rays_d, env_rot=None, **kw):
     return out
 
 
+@pytest.fixture(scope="module")
+def renderer16(scene):
+    """the same scene on the alternative 16-column geometry kernel (k_geo_eval16)"""
+    from envidr_amd.fused import FusedOptions, FusedRenderer
+    return FusedRenderer.from_scene(scene, FusedOptions(bound=scene.bound, grid_size=scene.grid_size, geometry_kernel="16"))
+
+
+def test_sixteen_column_geometry_kernel_agrees(renderer, renderer16):
+    """k_geo_eval16 against k_geo_eval32 on a frame: same integer trace, images within fp32 summation order (the few samples
+    on a ReLU kink of the SDF network may flip: bounded like the other cross-implementation checks)"""
+    rays_o, rays_d = scenes.camera_rays(96, 96, theta=70.0, phi=25.0)
+    a, b = _frame(renderer, rays_o, rays_d, 0.2), _frame(renderer16, rays_o, rays_d, 0.2)
+    assert np.array_equal(a["ray_cost"], b["ray_cost"]) and a["n_records"] == b["n_records"]
+    for key in KEYS:
+        err = rel_l2(b[key], a[key])
+        assert err <= (5e-4 if key == "normal_image" else 2e-4), f"{key}: rel-L2 {err:.3e}"
+    g = np.load(GOLD / "frame_toaster_48.npz")
+    rays_o, rays_d = scenes.camera_rays(int(g["H"]), int(g["W"]), theta=float(g["theta"]), phi=float(g["phi"]))
+    out = _frame(renderer16, rays_o, rays_d, None if np.isnan(g["env_rot"]) else float(g["env_rot"]))
+    for key in KEYS:
+        err = rel_l2(out[key], g[key].reshape(out[key].shape))
+        assert err <= 1e-4, f"{key}: rel-L2 {err:.3e}"
+
+
 def test_geometry_eval_matches_the_oracle_per_sample(scene, renderer):
     """envidr_geometry_eval (hash grid + SDF network forward / backward + density, normal, roughness) against the CPU
     oracle's per-sample chain (hash operator + torch fp32 layers + autograd normal) on points in and around the shell"""

@@ -70,3 +70,37 @@ def test_pack_env_split_pads_to_whole_chunks(lib):
 def test_split_packer_rejects_null(lib):
     assert lib.envidr_pack_layer_split(None, 4, 4, 0, None) != 0
     assert b"pack_layer_split" in lib.envidr_last_error()
+
+
+def test_sdf_geometry_packer_layout(lib):
+    """envidr_pack_sdf_geometry (the 16-column geometry kernel's weights) against the layout its header describes"""
+    from envidr_amd.fused import pack_sdf_geometry
+    rng = np.random.default_rng(3)
+    W1, b1 = rng.normal(size=(64, 32)).astype(np.float32), rng.normal(size=64).astype(np.float32)
+    W2, b2 = rng.normal(size=(64, 64)).astype(np.float32), rng.normal(size=64).astype(np.float32)
+    W3, b3 = rng.normal(size=(15, 64)).astype(np.float32), rng.normal(size=15).astype(np.float32)
+    blob = pack_sdf_geometry([(W1, b1), (W2, b2), (W3, b3)])
+    assert blob.size == lib.envidr_sdf_geometry_floats() and blob.size % 64 == 0
+    frag = blob[:-64].reshape(-1, 64)
+    assert np.array_equal(blob[-64:], W3[0])
+    L1, L2, L3, B2, B1 = 0, 36, 36 + 68, 36 + 68 + 17, 36 + 68 + 17 + 64
+    w3_row = lambda q, r: ({0: 0, 1: 13, 2: 14, 3: -1}[q] if r == 0 else 1 + 3 * q + (r - 1))
+    for lane in (0, 5, 17, 38, 63):
+        m, kq = lane & 15, lane >> 4
+        for T in range(4):
+            assert frag[L1 + T, lane] == (b1[16 * T + m] if kq == 0 else 0)
+            for s in range(8):
+                assert frag[L1 + (1 + s) * 4 + T, lane] == W1[16 * T + m, 2 * (4 * (s >> 1) + kq) + (s & 1)]
+            for s in range(16):
+                k = 16 * (s >> 2) + 4 * kq + (s & 3)
+                assert frag[L2 + (1 + s) * 4 + T, lane] == W2[16 * T + m, k]
+                assert frag[B2 + s * 4 + T, lane] == W2[k, 16 * T + m]
+        row = w3_row(m >> 2, m & 3)
+        assert frag[L3, lane] == (b3[row] if kq == 0 and row >= 0 else 0)
+        for s in range(16):
+            k = 16 * (s >> 2) + 4 * kq + (s & 3)
+            assert frag[L3 + 1 + s, lane] == (W3[row, k] if row >= 0 else 0)
+            for T in range(2):
+                q, r = m >> 2, m & 3
+                assert frag[B1 + s * 2 + T, lane] == W1[k, 2 * (4 * (2 * T + (r >> 1)) + q) + (r & 1)]
+    assert np.all(frag[217:] == 0)

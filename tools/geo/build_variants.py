@@ -10,7 +10,13 @@ VARIANTS = {
     "k32": [],
     "k32_a1": ["-DENVIDR_GEO_AHEAD=1"],
     "k32_a3": ["-DENVIDR_GEO_AHEAD=3"],
-    "k64": ["-DENVIDR_GEO_KERNEL32=0"],
+    "k64": ["-DENVIDR_GEO_KERNEL32=0", "-DENVIDR_GEO_KERNEL16=0"],
+    "k32only": ["-DENVIDR_GEO_KERNEL16=0"],
+    "k16": [],
+    "k16_a1": ["-DENVIDR_GEO_AHEAD=1"],
+    "k16_a3": ["-DENVIDR_GEO_AHEAD=3"],
+    "k16_w16_a1": ["-DENVIDR_GEO_E16_WAVES=16", "-DENVIDR_GEO_AHEAD=1"],
+    "k16_w8": ["-DENVIDR_GEO_E16_WAVES=8"],
     "rays_dbg1": ["-DENVIDR_GEO_RAYS_DEBUG=1"],
     "rays_dbg2": ["-DENVIDR_GEO_RAYS_DEBUG=2"],
 }
