@@ -629,15 +629,18 @@ class FusedRenderer:
         self.__dict__["_frame"] = st
         return st
 
-    def check_frames(self) -> None:
+    def check_frames(self, block: bool = True) -> None:
         """Frames are enqueued without waiting for the device.  This looks at the status words of the frames not looked at
         yet (they were copied to pinned memory behind each frame) and raises FrameOverflow if one did not fit its buffers --
-        which are then dropped, so that redoing the frame allocates larger ones.  Called at the start of every frame and by
-        anyone who needs the answer now."""
+        which are then dropped, so that redoing the frame allocates larger ones.  Called (block=False: only frames the device
+        has finished, so that the host can enqueue a frame ahead of the device) at the start of every frame, and with
+        block=True by anyone who needs the answer now."""
         overflowed = None
         for N, st in list(self.__dict__.get("_frames", {}).items()):
             if not st["pending"]:
                 continue
+            if not block and not st["event"].query():
+                continue                                   # still running: its (sticky) status is looked at later
             st["event"].synchronize()
             st["pending"] = False
             samples, records, _, w_samples, w_records, overflow = (int(v) for v in st["host"])
@@ -666,7 +669,7 @@ class FusedRenderer:
         (video loops: check_frames() -- called by the next frame -- raises FrameOverflow if a frame did not fit).
         `events`: four torch.cuda.Event(enable_timing=True) recorded at the pass boundaries (geometry | shading | composite).
         `env_precision`: "fp32" / "f16x2" for this frame (default: FusedOptions.env_precision)."""
-        self.check_frames()
+        self.check_frames(block=False)
         rays_o = rays_o.contiguous().view(-1, 3).float()
         rays_d = rays_d.contiguous().view(-1, 3).float()
         N, dev = rays_o.shape[0], rays_o.device
