@@ -147,6 +147,19 @@ def test_full_size_counts_equal_the_persistent_kernel(renderer):
         assert err <= (5e-4 if key == "normal_image" else 2e-4 if key.endswith("_image") else 5e-5), f"{key}: {err:.2e}"
 
 
+def test_rays_are_independent_of_their_batch(renderer):
+    """a ray's pixels do not depend on which other rays share its frame (blocks of 64 rays, sample-major slots, the per-ray
+    hint): a sub-range rendered alone -- unaligned to the 64-ray blocks -- is bit-identical to the same rays inside the frame"""
+    import torch
+    ro_, rd_ = (torch.from_numpy(a).cuda() for a in scenes.camera_rays(400, 400, theta=80.0, phi=40.0))
+    full = {k: v.clone() for k, v in renderer.render_frame(ro_, rd_, 0.4).items() if hasattr(v, "clone")}
+    lo, hi = 30011, 101003
+    part = renderer.render_frame(ro_[lo:hi].contiguous(), rd_[lo:hi].contiguous(), 0.4)
+    torch.cuda.synchronize()
+    for key in ("image", "depth", "weights_sum", "diffuse_image", "specular_image", "roughness_image", "ray_cost"):
+        assert torch.equal(full[key][lo:hi], part[key]), key
+
+
 def test_frame_that_does_not_fit_is_redone(renderer):
     import torch
     ro_, rd_ = (torch.from_numpy(a).cuda() for a in scenes.camera_rays(96, 96))
