@@ -838,8 +838,8 @@ __global__ void __launch_bounds__(kBlock) k_linearize_bitfield(const uint8_t* __
 constexpr uint32_t kOccBoxWaves = 64;
 __global__ void __launch_bounds__(64) k_occupied_box(const uint8_t* __restrict__ linear_grid, uint32_t log2H, uint32_t* __restrict__ counters) {
     const uint32_t bytes = (1u << (3 * log2H)) / 8u, mask = (1u << log2H) - 1u;
-    const uint32_t per_wave = (bytes + kOccBoxWaves - 1) / kOccBoxWaves;
-    const uint32_t lo = blockIdx.x * per_wave, hi = min(bytes, lo + per_wave);
+    const uint32_t per_wave = ((bytes + kOccBoxWaves - 1) / kOccBoxWaves + 15u) & ~15u;       // whole 16-byte loads (bytes is a multiple of 64)
+    const uint32_t lo = min(bytes, blockIdx.x * per_wave), hi = min(bytes, lo + per_wave);
     uint32_t b[6] = {0, 0, 0, 0, 0, 0};
     auto take = [&](uint32_t byte, uint32_t v) {
         if (!v) return;

@@ -160,6 +160,27 @@ def test_rays_are_independent_of_their_batch(renderer):
         assert torch.equal(full[key][lo:hi], part[key]), key
 
 
+@pytest.mark.parametrize("grid", [8, 16, 32])
+def test_small_occupancy_grids(grid):
+    """the one-cascade marcher + the occupied-box clipping on small grids (their bitfields are a few 16-byte loads): same
+    per-ray counts as the general marcher of the single-kernel renderer, same images"""
+    import dataclasses
+    import torch
+    from envidr_amd.fused import FusedOptions, FusedRenderer
+    base = scenes.toaster_scene()
+    small = dataclasses.replace(base, bitfield=scenes.occupancy_bitfield(scenes.shell(0.5, 0.12), H=grid), grid_size=grid)
+    r = FusedRenderer.from_scene(small, FusedOptions(bound=small.bound, grid_size=grid))
+    ro_, rd_ = (torch.from_numpy(a).cuda() for a in scenes.camera_rays(96, 96, theta=60.0, phi=15.0))
+    cost = torch.zeros(ro_.shape[0], dtype=torch.int16, device="cuda")
+    one = {k: v.clone() for k, v in r.render(ro_, rd_, 0.2, extras=True, ray_cost=cost).items()}
+    res = r.render_frame(ro_, rd_, 0.2)
+    torch.cuda.synchronize()
+    assert int(res["ray_cost"].sum()) > 1000
+    assert torch.equal(res["ray_cost"].to(torch.int32), cost.to(torch.int32))
+    for key in ("image", "depth", "weights_sum"):
+        assert rel_l2(res[key].cpu().numpy(), one[key].cpu().numpy()) <= 2e-4, key
+
+
 def test_frame_that_does_not_fit_is_redone(renderer):
     import torch
     ro_, rd_ = (torch.from_numpy(a).cuda() for a in scenes.camera_rays(96, 96))
