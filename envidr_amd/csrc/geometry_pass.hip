@@ -733,7 +733,7 @@ namespace {
 // Records are appended the same way (sample-major within the block), which also makes the shading kernel's reads through
 // rec->slot and the final compositor's reads through perm[] nearly sequential.
 // Blocks are never re-packed: the list a round consumes is the ids of the blocks that still have a live ray.
-enum RayField : int { kFAccT = 0, kFWs, kFDepth, kFAn0, kFAn1, kFAn2, kFRough, kFTaken, kFChunk, kStateFields };
+enum RayField : int { kFAccT = 0, kFWs, kFDepth, kFAn0, kFAn1, kFAn2, kFRough, kFTaken, kFChunk, kFAlloc, kStateFields };
 struct RayState {
     float acc_t;             // composited ray time = where the marcher resumes (the reference re-derives it from the deltas)
     float ws, depth;
@@ -742,6 +742,8 @@ struct RayState {
     uint32_t n_taken;        // samples composited so far
     uint32_t chunk_count;    // samples marched last round (0: the ray is finished); bit 31: the ray ran out of samples inside it
 };
+// (state field kFAlloc: the slots a ray was GIVEN for its chunk, >= chunk_count -- an over-estimating hint leaves zero-filled
+//  slots -- kept for every lane of a live block: the sample-major slot layout of the block is defined by these counts)
 
 // counters (device uint32[kGeoCounterWords]), zeroed by the host before every frame
 constexpr uint32_t kCntSampleHead = 0, kCntRecordHead = 1, kCntOverflow = 2, kCntAlive = 8, kCntBegin = 40, kCntOcc = 72, kGeoCounterWords = 80;
@@ -929,12 +931,13 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
             }
         } else {
             // ---- composite the previous chunk ------------------------------------------------------------------
-            uint32_t cnt = 0;
+            uint32_t cnt = 0, alloc = 0;
             bool last = false;
             if (in_range) {
                 const uint32_t cc = sp[kFChunk * (size_t)a.n_pad];
                 cnt = cc & 0x7fffffffu;
                 last = (cc >> 31) != 0;
+                alloc = sp[kFAlloc * (size_t)a.n_pad];
             }
             const bool active = cnt != 0;
             if (active) {
@@ -957,7 +960,7 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
                 bool going = active;
                 uint32_t off = 0;
                 for (uint32_t c = 0;; ++c) {
-                    const unsigned long long m = __ballot(c < cnt);
+                    const unsigned long long m = __ballot(c < alloc);
                     if (!__ballot(going && c < cnt)) break;
                     const uint32_t slot = base + off + (uint32_t)__popcll(m & below);
                     off += (uint32_t)__popcll(m);
@@ -978,7 +981,7 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
             {
                 uint32_t off = 0, roff = 0;
                 for (uint32_t c = 0;; ++c) {                    // pass 2: the recurrence itself + the records
-                    const unsigned long long m = __ballot(c < cnt), mk = __ballot(c < k);
+                    const unsigned long long m = __ballot(c < alloc), mk = __ballot(c < k);
                     if (!mk) break;
                     const uint32_t slot = base + off + (uint32_t)__popcll(m & below);
                     const uint32_t r = rec_base + roff + (uint32_t)__popcll(mk & below);
@@ -1094,7 +1097,10 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
                     a.alive_out[atomicAdd(&a.counters[kCntAlive + a.round + 1], 1u)] = blk;
                     a.block_base[blk] = base;
                 }
-                if (in_range) sp[kFChunk * (size_t)a.n_pad] = alive ? st.chunk_count : 0u;
+                if (in_range) {
+                    sp[kFChunk * (size_t)a.n_pad] = alive ? st.chunk_count : 0u;
+                    sp[kFAlloc * (size_t)a.n_pad] = want;            // every lane's share of the block's slot layout, alive or not
+                }
                 if (alive) {
                     sp[kFAccT * (size_t)a.n_pad] = __float_as_uint(st.acc_t);
                     sp[kFWs * (size_t)a.n_pad] = __float_as_uint(st.ws);

@@ -147,6 +147,35 @@ def test_full_size_counts_equal_the_persistent_kernel(renderer):
         assert err <= (5e-4 if key == "normal_image" else 2e-4 if key.endswith("_image") else 5e-5), f"{key}: {err:.2e}"
 
 
+def test_frames_do_not_depend_on_the_hint(renderer):
+    """the per-ray count hint only sizes allocations: exact, absent, over-estimating (zero-filled slots inside the blocks'
+    sample-major layout), under-estimating (extra rounds) and garbage hints all give the same frame, bit for bit"""
+    import torch
+    ro_, rd_ = (torch.from_numpy(a).cuda() for a in scenes.camera_rays(160, 160, theta=65.0, phi=35.0))
+    N = ro_.shape[0]
+    keys = ("image", "depth", "weights_sum", "normal_image", "diffuse_image", "specular_image", "roughness_image")
+    want = {k: v.clone() for k, v in renderer.render_frame(ro_, rd_, 0.3, use_cost_hint=False).items() if k in keys or k == "ray_cost"}
+    exact = want["ray_cost"].clone()
+    st = renderer._frames[N]
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    hints = {
+        "exact": exact,
+        "over": (exact.to(torch.int32) + torch.randint(0, 40, (N,), device="cuda", generator=gen, dtype=torch.int32)).to(exact.dtype),
+        "under": (exact.to(torch.int32) // 2).to(exact.dtype),
+        "garbage": torch.randint(0, 200, (N,), device="cuda", generator=gen, dtype=torch.int32).to(exact.dtype),
+        "over on rays that miss": torch.full_like(exact, 25),
+    }
+    for name, h in hints.items():
+        st["cost"].copy_(h)
+        for tag in list(st.get("costs", {})):
+            st["costs"][tag].copy_(h)
+        got = renderer.render_frame(ro_, rd_, 0.3, use_cost_hint=True)
+        torch.cuda.synchronize()
+        assert torch.equal(got["ray_cost"], exact), name
+        for k in keys:
+            assert torch.equal(got[k], want[k]), (name, k)
+
+
 def test_rays_are_independent_of_their_batch(renderer):
     """a ray's pixels do not depend on which other rays share its frame (blocks of 64 rays, sample-major slots, the per-ray
     hint): a sub-range rendered alone -- unaligned to the 64-ray blocks -- is bit-identical to the same rays inside the frame"""
