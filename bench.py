@@ -321,7 +321,9 @@ def run(argv: list[str]) -> None:
                 "geometry_pass_bound_note": ("neither roofline binds this stage: its hash sweep is bound by the rate at which L2 misses come back "
                                              "(~15 missed 64-B lines per sample of the 48.8 MB table, 55-65 G random lines/s measured with "
                                              "tools/probe/gather_probe.hip => ~1.95 ms per frame) and its SDF network costs ~1.5 ms of fp32 "
-                                             "MFMA time; kernels with 2, 3 and 4 waves per SIMD all land at 2.75-3.0 ms (DESIGN.md 3.1)"),
+                                             "MFMA time; kernels with 2, 3 and 4 waves per SIMD all land at 2.75-3.0 ms (DESIGN.md 3.1).  The evaluation "
+                                             "kernel alone moves its 1 024 algorithmic bytes per sample at ~2.9 TB/s against the 3.5 TB/s this chip "
+                                             "delivers for random 64-byte lines from a table that size"),
                 "record_bytes_per_sample": 92}
         if world == 1 and not args.headline_only:
             other_configs(result, dev, rays_o, rays_d, N)
