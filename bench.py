@@ -3,6 +3,8 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: the script starts its N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus 1 --force-dist                        (one rank through the N > 1 code path: RCCL world of 1)
+    python bench.py --gpus N --scaling strong                    (ONE frame per step, its 8x8-pixel tiles interleaved over the ranks)
 
 Metric (BASELINE.json): rendered rays/s at 800x800, max 1024 samples/ray, plus PSNR of the GPU image against the CPU
 reference restatement of the same frame.
@@ -14,6 +16,11 @@ renders them) -- and the finished RGB frame is gathered to rank 0 (RCCL gather o
 the next view; no-op at N = 1).  Views are the env-rotation video frames of BASELINE config #5: view v = step * N + rank
 gets env rotation 2 pi v / 200, so per-GPU work is fixed as N grows (weak scaling).  Inputs (rays, table, weights) are
 resident in HBM before the timed region.
+
+The headline step renders the same camera every time, so the per-ray sample counts the pipeline keeps from the previous
+frame are an EXACT hint (the frame is then one march round, nothing evaluated that is not composited).  Two more legs say
+what that is worth (JSON keys `cold_frame`, `moving_camera`): every frame un-hinted, and a camera that moves 2 degrees per
+step with `envidr_get_rays` inside the timed region and the previous pose's counts as the hint.
 
 Printed by rank 0 as ONE JSON line; see DESIGN.md section "Measurement" for the roofline arithmetic.
 """
@@ -74,17 +81,19 @@ def host_cpu_info() -> dict:
 
 def cpu_baseline(scene, env_rot: float, frames: int, res: int) -> dict:
     """the CPU restatement (oracle: C/OpenMP ops + torch CPU fp32 GEMMs, reference n_step schedule) timed on the host cores
-    on the benchmark's own frame: one warm-up (small frame: library loads, thread pools), then the median of `frames` full
-    frames.  Thread count: the best of a few candidates on a probe (all hardware threads is far from the fastest for these
-    small GEMMs on a 2 x 64-core host)."""
+    on the benchmark's own frame.  Thread count: every candidate in {16, 32, 64, all hardware threads} renders a 400x400 frame
+    of the SAME scene and camera once (160 000 rays: the first loop iterations are 160 k-row GEMMs, the regime of the full
+    frame -- a 96x96 probe is not), after a small warm-up; the fastest is used.  Then the median of `frames` full frames."""
     from envidr_amd import scenes
     from oracle.py import render_oracle as ro
     opt = ro.RenderOptions(ide_mode="torch")
-    probe_o, probe_d = scenes.camera_rays(96, 96)
+    probe_res = min(400, res)
+    probe_o, probe_d = scenes.camera_rays(probe_res, probe_res)
     best, threads, tried = None, 1, {}
-    for th in sorted({min(c, os.cpu_count() or 1) for c in (16, 32, 64)}):
+    ncpu = os.cpu_count() or 1
+    for th in sorted({min(c, ncpu) for c in (16, 32, 64, ncpu)}):
         torch.set_num_threads(th)
-        ro.render_rays(scene, probe_o[:256], probe_d[:256], opt, env_rot)    # warm-up
+        ro.render_rays(scene, probe_o[:256], probe_d[:256], opt, env_rot)    # warm-up (library loads, thread pools)
         t0 = time.perf_counter()
         ro.render_rays(scene, probe_o, probe_d, opt, env_rot)
         tried[th] = time.perf_counter() - t0
@@ -101,8 +110,10 @@ def cpu_baseline(scene, env_rot: float, frames: int, res: int) -> dict:
     n = res * res
     return {"value": n / dt, "unit": "rays/s", "cores": threads, "kind": "port",
             "sample": f"{res}x{res} frame of the same scene and camera ({n} rays, {out['n_samples']} samples): oracle/ C+OpenMP ops + torch "
-                      f"CPU fp32 GEMMs, reference n_step schedule; 1 warm-up, median of {len(times)} frames ({dt:.1f} s each)",
-            "frame_seconds": times, "threads_tried_probe_seconds": tried, "host": host_cpu_info(),
+                      f"CPU fp32 GEMMs, reference n_step schedule; median of {len(times)} frames ({dt:.1f} s each) at the fastest of the "
+                      f"thread counts tried on a {probe_res}x{probe_res} frame of the same scene",
+            "frame_seconds": times, "threads_tried_seconds_on_probe_frame": tried, "probe_frame": f"{probe_res}x{probe_res}",
+            "ide_mode": "torch (the reference's fp32 complex-power formulation, ide_encoder.py:98-130)", "host": host_cpu_info(),
             "samples_per_s": out["n_samples"] / dt, "image": out["image"]}
 
 
@@ -132,6 +143,11 @@ def parse(argv: list[str]):
                     help="pipeline: geometry pipeline + shading pass per frame (default); fused: one persistent kernel per frame")
     ap.add_argument("--headline-only", action="store_true", help="skip the CPU leg and the other_configs renders, so that a "
                     "profiler sees only the headline kernels' launches")
+    ap.add_argument("--force-dist", action="store_true", help="run a single rank through the N > 1 code path: process group of one "
+                    "(RCCL on the GPU), gather on the side stream, slot events, barrier -- the branch the multi-GPU run takes")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak: one full view per rank per step (default); "
+                    "strong: ONE view per step, its 8x8-pixel tiles interleaved over the ranks, gathered and assembled on rank 0")
+    ap.add_argument("--cold", action="store_true", help="headline frames without the per-ray hint (profiling the cold frame)")
     ap.add_argument("--stub", action="store_true", help="CPU plumbing test: gloo, a stand-in renderer, tiny frames "
                     "(tests/test_bench_cpu.py); exercises launch, view partition, overlapped gather and the JSON line")
     return ap.parse_args(argv)
@@ -139,17 +155,35 @@ def parse(argv: list[str]):
 
 class StubRenderer:
     """stand-in for FusedRenderer in --stub mode: the frame of view v is the constant v (so the root can check what it gathered)"""
-    def __init__(self, n):
-        self.n = n
 
     def render_frame(self, rays_o, rays_d, env_rot, out=None, events=None, wait=True, **kw):
+        n = rays_o.shape[0]
         res = out if out is not None else {}
-        res["image"] = torch.full((self.n, 3), float(env_rot), dtype=torch.float32)
-        res["n_records"] = res["n_samples"] = 12 * self.n
+        # strong scaling: every pixel carries its own ray id as well, so the assembled frame can be checked pixel by pixel
+        res["image"] = torch.stack([torch.full((n,), float(env_rot)), rays_o[:, 0], rays_d[:, 0]], -1)
+        res["n_records"] = res["n_samples"] = 12 * n
         return res
 
     def check_frames(self):
         pass
+
+
+def load_scene(rank: int, world: int, dist_on: bool, dev):
+    """The synthetic scene on every rank.  Rank 0 generates it (table 48.8 MB + bitfield: seconds of host time); with more than
+    one rank the two big arrays are broadcast (RCCL over xGMI: "model state replicated, broadcast once at load")
+    instead of every rank generating its own copy; the MLP weights (< 1 MB, milliseconds) are generated from the seed everywhere."""
+    import torch.distributed as dist
+    from envidr_amd import scenes
+    if not dist_on or world == 1:
+        return scenes.toaster_scene()
+    sc = scenes.toaster_scene(arrays=(rank == 0))
+    rows = int(sc.offsets[-1])
+    table = torch.from_numpy(sc.table).to(dev) if rank == 0 else torch.empty(rows, 2, dtype=torch.float32, device=dev)
+    bitfield = torch.from_numpy(sc.bitfield).to(dev) if rank == 0 else torch.empty(sc.cascades * sc.grid_size ** 3 // 8, dtype=torch.uint8, device=dev)
+    dist.broadcast(table, src=0)
+    dist.broadcast(bitfield, src=0)
+    sc.table, sc.bitfield = table, bitfield
+    return sc
 
 
 def run(argv: list[str]) -> None:
@@ -158,9 +192,11 @@ def run(argv: list[str]) -> None:
     import torch.distributed as dist
 
     stub = args.stub
-    rank, world, local = parallel.init_from_env(backend="gloo" if stub else None)
+    rank, world, local = parallel.init_from_env(backend="gloo" if stub else None, force=args.force_dist)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist_on = world > 1 or args.force_dist         # the collective code path (a world of one with --force-dist)
+    strong = args.scaling == "strong"
     if stub:
         dev = torch.device("cpu")
         n_side = 16
@@ -168,31 +204,43 @@ def run(argv: list[str]) -> None:
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
         n_side = H
-    N = n_side * n_side
+    N_frame = n_side * n_side
 
     def env_rot(view: int) -> float:
         return 2 * math.pi * (view % 200) / 200
 
     if stub:
-        scene, renderer = None, StubRenderer(N)
-        rays_o = rays_d = torch.zeros(N, 3)
+        scene, renderer = None, StubRenderer()
+        rays_o = torch.arange(N_frame, dtype=torch.float32)[:, None].expand(N_frame, 3).contiguous()
+        rays_d = rays_o * 2
     else:
         from envidr_amd import scenes
         from envidr_amd.fused import FusedRenderer
-        scene = scenes.toaster_scene()
+        scene = load_scene(rank, world, dist_on, dev)
         renderer = FusedRenderer.from_scene(scene, device=dev)
         rays_o, rays_d = (torch.from_numpy(a).to(dev) for a in scenes.camera_rays(H, W))
+    # strong scaling: this rank's interleaved 8x8-pixel tiles of THE frame; weak: the whole frame (its own view)
+    sizes = parallel.shard_sizes(n_side, n_side, world) if strong else [N_frame] * world
+    if strong:
+        mine = parallel.tile_shard(n_side, n_side, rank, world).to(dev)
+        rays_o, rays_d = rays_o[mine].contiguous(), rays_d[mine].contiguous()
+        place = torch.cat([parallel.tile_shard(n_side, n_side, r, world) for r in range(world)]).to(dev) if rank == 0 else None
+    N = rays_o.shape[0]                          # rays this rank renders per step
+    n_max = max(sizes)
     pipeline = args.path == "pipeline"
     # two sets of output images: the gather of view i runs on a side stream while view i + 1 is rendered into the other set
     outs = [{}, {}]
     ray_cost = None if (stub or pipeline) else torch.zeros(N, dtype=torch.int16, device=dev)
-    gather_lists = [[torch.empty(N, 3, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None for _ in range(2)]
-    comm = torch.cuda.Stream(dev) if (world > 1 and not stub) else None
+    gather_lists = [[torch.empty(n_max, 3, device=dev) for _ in range(world)] if (dist_on and rank == 0) else None for _ in range(2)]
+    send_pad = [torch.zeros(n_max, 3, device=dev) for _ in range(2)] if (dist_on and N != n_max) else None    # ragged shards: padded sends
+    frames = [torch.empty(N_frame, 3, device=dev) for _ in range(2)] if (strong and rank == 0) else None
+    comm = torch.cuda.Stream(dev) if (dist_on and not stub) else None
     gather_ev = []          # (start, end) events of the gathers on the side stream
 
     def frame(view: int, slot: int, events=None):
         if pipeline:
-            return renderer.render_frame(rays_o, rays_d, env_rot(view) if not stub else float(view), out=outs[slot], events=events, wait=False)
+            return renderer.render_frame(rays_o, rays_d, env_rot(view) if not stub else float(view), out=outs[slot], events=events, wait=False,
+                                         use_cost_hint=not args.cold)
         if events:
             events[0].record()
         res = renderer.render(rays_o, rays_d, env_rot(view), extras=True, stats=True, out=outs[slot], ray_cost=ray_cost)
@@ -202,25 +250,36 @@ def run(argv: list[str]) -> None:
 
     slot_sent = [None, None]     # event on the side stream: the gather that reads this output set has finished
 
+    def deliver(res, slot, timed):
+        """the finished image -> rank 0 (+ assembly of the tile shards there); runs on the side stream when there is one"""
+        img = res["image"]
+        if send_pad is not None:
+            send_pad[slot][:N].copy_(img)
+            img = send_pad[slot]
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if (timed and comm is not None) else None
+        if ev: ev[0].record()
+        dist.gather(img, gather_list=gather_lists[slot], dst=0)
+        if strong and rank == 0:
+            # un-permutation of the tiles: one indexed copy over the concatenated shards
+            frames[slot][place] = torch.cat([g[:n] for g, n in zip(gather_lists[slot], sizes)])
+        if ev:
+            ev[1].record()
+            gather_ev.append(ev)
+
     def step(i: int, events=None, timed=False):
         slot = i & 1
         if slot_sent[slot] is not None:
             torch.cuda.current_stream(dev).wait_event(slot_sent[slot])     # (two steps ago; the gather of the last step keeps running)
-        res = frame(i * world + rank, slot, events)
-        if world > 1:
+        res = frame(i if strong else i * world + rank, slot, events)
+        if dist_on:
             if comm is None:
-                dist.gather(res["image"], gather_list=gather_lists[slot], dst=0)
+                deliver(res, slot, timed)
             else:
                 done = torch.cuda.Event()
                 done.record()
                 with torch.cuda.stream(comm):
                     comm.wait_event(done)
-                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if timed else None
-                    if ev: ev[0].record()
-                    dist.gather(res["image"], gather_list=gather_lists[slot], dst=0)
-                    if ev:
-                        ev[1].record()
-                        gather_ev.append(ev)
+                    deliver(res, slot, timed)
                     slot_sent[slot] = torch.cuda.Event()
                     slot_sent[slot].record()
         return res
@@ -228,7 +287,7 @@ def run(argv: list[str]) -> None:
     def fence():
         if comm is not None:
             torch.cuda.current_stream(dev).wait_stream(comm)
-        if world > 1:
+        if dist_on:
             dist.barrier()
         if not stub:
             torch.cuda.synchronize(dev)
@@ -246,10 +305,22 @@ def run(argv: list[str]) -> None:
     fence()
     dt_local = time.perf_counter() - t0
     renderer.check_frames()
-    if stub and world > 1 and rank == 0:
-        last = args.warmup + args.steps - 1
-        for r in range(world):
-            assert float(gather_lists[last & 1][r][0, 0]) == float(last * world + r), "gather delivered the wrong view"
+    last = args.warmup + args.steps - 1
+    delivered_ok = None
+    if dist_on and rank == 0 and args.steps > 0:
+        # what arrived is what was rendered: the last step's gathered image(s) against the senders' own
+        if stub:
+            for r in range(world):
+                want_view = float(last if strong else last * world + r)
+                assert float(gather_lists[last & 1][r][0, 0]) == want_view, "gather delivered the wrong view"
+            if strong:
+                ids = torch.arange(N_frame, dtype=torch.float32)
+                assert torch.equal(frames[last & 1][:, 1], ids) and torch.equal(frames[last & 1][:, 2], 2 * ids), "tiles assembled in the wrong place"
+            delivered_ok = True
+        elif strong:
+            delivered_ok = bool(torch.equal(frames[last & 1][place[:N]], outs[last & 1]["image"]))
+        else:
+            delivered_ok = bool(torch.equal(gather_lists[last & 1][0][:N], outs[last & 1]["image"]))
     samples = 0 if res is None else int(res.get("n_records", 0))
     geometry_ms = kernel_ms = composite_ms = 0.0
     if not stub:
@@ -259,42 +330,58 @@ def run(argv: list[str]) -> None:
             evaluated = int(renderer._frame["last"][0])
         else:
             kernel_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-            samples = evaluated = int(outs[(args.warmup + args.steps - 1) & 1]["stats"][0].item())
+            samples = evaluated = int(outs[last & 1]["stats"][0].item())
     else:
         evaluated = samples
     gather_ms = float(np.mean([a.elapsed_time(b) for a, b in gather_ev])) if gather_ev else 0.0
     t = torch.tensor([dt_local], device=dev, dtype=torch.float64)
-    per_rank = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)] if world > 1 else [t]
-    if world > 1:
+    per_rank = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)] if dist_on else [t]
+    if dist_on:
         dist.all_gather(per_rank, t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
     if rank == 0:
-        rays_per_s = world * N * args.steps / dt
+        rays_per_step = N_frame if strong else world * N_frame
+        rays_per_s = rays_per_step * args.steps / dt
         flops = samples * (FLOP_PER_SAMPLE_SHADING if pipeline else FLOP_PER_SAMPLE) / max(kernel_ms * 1e-3, 1e-12) / 1e12
+        if strong:
+            par = (f"ONE 800x800 view per step, its 8x8-pixel tiles interleaved over {world} rank(s) (parallel.tile_shard), RCCL gather of the "
+                   "shards + one indexed copy into the frame on rank 0, on a side stream (overlapped with the next view)")
+        else:
+            par = f"views x{world} + RCCL image gather on a side stream (overlapped with the next view)"
+        if args.force_dist and world == 1:
+            par += "; --force-dist: a process group of ONE rank through the same gather / event / barrier code"
         result = {
             "metric": "rendered rays/s at 800x800, 1024 max samples/ray", "value": rays_per_s, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]/[4] network (toaster.ini: hash L16xC2 + SDF 32-64-64-15 + IDE deg5 + env MLP "
-                                   "72-256-256-256-12 x2 + diffuse/specular heads) on a synthetic shell scene, 800x800 view per GPU per "
-                                   "step, env-rotation video frames sharded by view, normal/diffuse/specular/roughness images on",
+                                   "72-256-256-256-12 x2 + diffuse/specular heads) on a synthetic shell scene, 800x800 view per "
+                                   + ("step, sharded by 8x8-pixel tiles" if strong else "GPU per step, env-rotation video frames sharded by view")
+                                   + ", normal/diffuse/specular/roughness images on",
                        "rays_per_step_per_gpu": N, "samples_per_frame": samples, "samples_evaluated_per_frame": evaluated,
-                       "samples_per_ray": samples / N, "max_steps": 1024, "T_thresh": 1e-4,
-                       "parallelism": f"views x{world} + RCCL image gather on a side stream (overlapped with the next view)",
+                       "samples_per_ray": samples / max(N, 1), "max_steps": 1024, "T_thresh": 1e-4, "parallelism": par,
                        "schedule": ("geometry pipeline (device-driven march rounds + sample-parallel hash grid / SDF network, one record "
-                                    "per composited sample) -> shading pass (k_shade_samples) -> per-ray composite; every frame from "
-                                    "scratch (the previous frame's per-ray sample counts only size the march chunks)"
+                                    "per composited sample) -> shading pass (k_shade_samples) -> per-ray composite; every frame marches, "
+                                    "evaluates and shades from scratch.  "
+                                    + ("NO per-ray hint (--cold): 16 samples first, then chunks predicted per ray from its transmittance."
+                                       if args.cold else
+                                       "The camera is fixed (env-rotation video), so the per-ray sample counts kept from the previous frame "
+                                       "are an EXACT hint: one march round, samples_evaluated == samples_composited.  See cold_frame / "
+                                       "moving_camera for frames without that help.")
                                     if pipeline else "one persistent kernel per frame")},
-            "samples_per_s": world * samples * args.steps / dt,
+            "samples_per_s": (1 if strong else world) * samples * args.steps / dt,
             "per_rank_ms_per_step": [float(x.item()) / args.steps * 1e3 for x in per_rank],
             "gather_ms": gather_ms,
         }
+        if dist_on:
+            result["dist"] = {"backend": dist.get_backend(), "world": world, "force_dist": bool(args.force_dist), "gathered_equals_rendered": delivered_ok,
+                              "scene": "none (stub)" if stub else ("generated on rank 0, table + bitfield broadcast" if world > 1 else "generated locally")}
         if stub:
             result["config"]["workload"] = "STUB (CPU plumbing test)"
             print(json.dumps(result))
-            if world > 1:
+            if dist_on:
                 dist.destroy_process_group()
             return
         result["roofline"] = {
@@ -307,7 +394,7 @@ def run(argv: list[str]) -> None:
             "hbm_view": {"bound": "hbm", "achieved": samples * HASH_BYTES_PER_SAMPLE / (kernel_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS,
                          "unit": "GB/s"}}
         if pipeline:
-            frame_s = dt / args.steps
+            frame_s = float(per_rank[0].item()) / args.steps         # rank 0's own frame time (its shard in strong mode)
             result["frame"] = {
                 "geometry_ms": geometry_ms, "shading_ms": kernel_ms, "composite_ms": composite_ms,
                 "whole_frame_mfma_TFLOPs": samples * FLOP_PER_SAMPLE / frame_s / 1e12,
@@ -319,13 +406,14 @@ def run(argv: list[str]) -> None:
                                                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                                     "frac": evaluated * FLOP_PER_SAMPLE_GEOMETRY / (geometry_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}},
                 "geometry_pass_bound_note": ("neither roofline binds this stage: its hash sweep is bound by the rate at which L2 misses come back "
-                                             "(~15 missed 64-B lines per sample of the 48.8 MB table, 55-65 G random lines/s measured with "
-                                             "tools/probe/gather_probe.hip => ~1.95 ms per frame) and its SDF network costs ~1.5 ms of fp32 "
-                                             "MFMA time; kernels with 2, 3 and 4 waves per SIMD all land at 2.75-3.0 ms (DESIGN.md 3.1).  The evaluation "
-                                             "kernel alone moves its 1 024 algorithmic bytes per sample at ~2.9 TB/s against the 3.5 TB/s this chip "
-                                             "delivers for random 64-byte lines from a table that size"),
+                                             "(~12-15 missed 64-B lines per sample of the 48.8 MB table, 55-65 G random lines/s measured with "
+                                             "tools/probe/gather_probe.hip, profiles/r02_gather_probe.txt => ~1.95 ms per frame) and its SDF network "
+                                             "costs ~1.5 ms of fp32 MFMA time; kernels with 2, 3 and 4 waves per SIMD all land at 2.75-3.0 ms "
+                                             "(DESIGN.md 3.1)"),
                 "record_bytes_per_sample": 92}
-        if world == 1 and not args.headline_only:
+        if world == 1 and not strong and not args.headline_only and pipeline:
+            context_legs(result, renderer, dev, args.steps, N_frame)
+        if world == 1 and not strong and not args.headline_only:
             other_configs(result, dev, rays_o, rays_d, N)
         # HBM traffic of the dominant kernel from the PMC summary -- only if it was collected on THESE kernel sources
         prof = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -343,7 +431,7 @@ def run(argv: list[str]) -> None:
             except Exception as e:      # noqa: BLE001
                 note = f"unreadable pmc_latest.json: {e}"
         result["roofline"]["traffic_note"] = note
-        if not args.no_cpu_baseline and not args.headline_only and world == 1:
+        if not args.no_cpu_baseline and not args.headline_only and world == 1 and not strong:
             from envidr_amd import scenes
             cpu = cpu_baseline(scene, env_rot(0), args.cpu_frames, args.cpu_res)
             so, sd = (torch.from_numpy(a).to(dev) for a in scenes.camera_rays(args.cpu_res, args.cpu_res))
@@ -352,11 +440,63 @@ def run(argv: list[str]) -> None:
             mse = float(np.mean((g.astype(np.float64) - ref) ** 2))
             result["psnr_vs_cpu_reference_db"] = -10 * math.log10(max(mse, 1e-20))
             result["rel_l2_vs_cpu_reference"] = float(np.linalg.norm(g.astype(np.float64) - ref) / np.linalg.norm(ref))
+            result["rel_l2_note"] = ("GPU side: IDE as fp64 Horner on the reference's fp32 coefficient table (csrc/ide_encoder.hip); CPU side: "
+                                     "ide_mode='torch', the reference's fp32 complex-power formulation, whose own l = 16 terms carry ~1e-2 of "
+                                     "rounding noise (DESIGN.md 4.4) -- most of this figure; with ide_mode='exact' on the CPU the two sides "
+                                     "agree to ~1e-7 (tests/test_geometry_gpu.py::test_integer_trace_is_the_oracles)")
             result["cpu_baseline"] = cpu
             result["speedup_vs_cpu_baseline"] = rays_per_s / cpu["value"]
         print(json.dumps(result))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
+
+
+def context_legs(result, renderer, dev, steps: int, N: int) -> None:
+    """the headline workload WITHOUT the exact per-ray hint its fixed camera provides: (a) every frame cold, (b) a camera that
+    moves 2 degrees per step, rays generated on the device inside the timed region, hint = the previous pose's counts"""
+    from envidr_amd import scenes
+    from envidr_amd.nerf.utils import get_rays
+    steps = max(steps, 4)
+
+    def leg(make_rays, use_hint: bool, warm: int) -> dict:
+        out: dict = {}
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
+        log = []
+        renderer.frame_log = {}
+        for i in range(warm):
+            o, d = make_rays(i)
+            renderer.render_frame(o, d, 0.1, out=out, wait=False, use_cost_hint=use_hint)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            o, d = make_rays(warm + i)
+            renderer.render_frame(o, d, 0.1, out=out, events=ev[i], wait=False, use_cost_hint=use_hint)
+            log.append(renderer.frame_log[""])
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+        renderer.check_frames()
+        renderer.frame_log = None
+        stats = torch.stack(log).cpu().numpy()
+        geo, shade, comp = (float(np.mean([e[j].elapsed_time(e[j + 1]) for e in ev])) for j in range(3))
+        return {"ms_per_frame": dt * 1e3, "rays_per_s": N / dt, "geometry_ms": geo, "shading_ms": shade, "composite_ms": comp,
+                "samples_evaluated_per_frame": float(stats[:, 0].mean()), "samples_composited_per_frame": float(stats[:, 1].mean()),
+                "evaluated_over_composited": float(stats[:, 0].sum() / max(stats[:, 1].sum(), 1)), "frames": steps}
+
+    fixed = tuple(torch.from_numpy(a).to(dev) for a in scenes.camera_rays(H, W))
+    result["cold_frame"] = dict(leg(lambda i: fixed, False, 1),
+                                note="use_cost_hint=False every frame: 16 samples per ray first, then per-ray predicted chunks")
+    # moving camera: theta advances 2 degrees per step; poses uploaded once, rays by envidr_get_rays INSIDE the timed region
+    n_pose = steps + 2
+    poses = torch.from_numpy(np.stack([scenes.nerf_matrix_to_ngp(scenes.pose_spherical(30.0 + 2.0 * i, -20.0, 4.0), scale=0.65)
+                                       for i in range(n_pose)]).astype(np.float32)).to(dev)
+    intr = scenes.intrinsics_for(H, W)
+
+    def moving(i):
+        r = get_rays(poses[i % n_pose:i % n_pose + 1], intr, H, W)
+        return r["rays_o"][0], r["rays_d"][0]
+    result["moving_camera"] = dict(leg(moving, True, 2),
+                                   note="camera orbit advanced 2 degrees per frame; envidr_get_rays inside the timed region; the per-ray hint is "
+                                        "the previous pose's sample counts (wrong for rays near silhouettes: extra rounds / zero-filled slots)")
 
 
 def _time(fn, reps: int, dev) -> float:

@@ -37,10 +37,7 @@ using namespace envidr;
 
 namespace {
 
-#ifndef ENVIDR_MAX_GROUP
-#define ENVIDR_MAX_GROUP 8
-#endif
-constexpr uint32_t kMaxGroup = ENVIDR_MAX_GROUP;   // largest number of lanes (consecutive samples) per ray in tail mode
+constexpr uint32_t kMaxGroup = 8;   // largest number of lanes (consecutive samples) per ray in tail mode
 
 struct RenderArgs {
     const float* rays_o;
@@ -88,10 +85,7 @@ struct RenderArgs {
 
 // cost buckets of the optional scheduling hint: 256 buckets of 2^kCostShift samples (coarse buckets keep image-space
 // neighbours, whose hash gathers share cache lines, together)
-#ifndef ENVIDR_COST_SHIFT
-#define ENVIDR_COST_SHIFT 4
-#endif
-constexpr uint32_t kCostShift = ENVIDR_COST_SHIFT;
+constexpr uint32_t kCostShift = 4;
 constexpr uint32_t kCostBuckets = 256, kCostBase = 4;      // counters: [0] queue head, [1] hits, [4..] bucket counts, then bucket cursors
 constexpr uint32_t kScratchCounterWords = kCostBase + 2 * kCostBuckets;
 __device__ __forceinline__ uint32_t cost_bucket(uint32_t cost) { return min(cost >> kCostShift, kCostBuckets - 1); }
@@ -194,27 +188,12 @@ struct HeadLayout {
                          Frags = S3 + tile_layer_frags(2, 1, true);
 };
 
-// Weight delivery: 0 = every wave streams the blobs from L2 through its own register ring (single-wave
-// workgroups), 1 = the four waves of a 256-thread workgroup share one LDS stream.  Measured at fp32:
-// the ring is faster (the per-chunk barrier of the shared stream costs more than the 4x L2 traffic it
-// saves); the shared stream is what a faster MFMA mode needs.
-#ifndef ENVIDR_SHARED_WEIGHTS
-#define ENVIDR_SHARED_WEIGHTS 0
-#endif
-constexpr bool kSharedWeights = ENVIDR_SHARED_WEIGHTS != 0;
-#ifndef ENVIDR_RING_DEPTH
-#define ENVIDR_RING_DEPTH 32
-#endif
-constexpr int kRingDepth = ENVIDR_RING_DEPTH;
-#ifndef ENVIDR_HASH_AHEAD
-#define ENVIDR_HASH_AHEAD 2
-#endif
-constexpr int kHashAhead = ENVIDR_HASH_AHEAD;     // hash levels whose corner gathers are in flight ahead of the one being interpolated
-#ifndef ENVIDR_PLAIN_WAVES
-#define ENVIDR_PLAIN_WAVES 1
-#endif
-constexpr int kPlainWaves = ENVIDR_PLAIN_WAVES;   // waves per SIMD the no-environment family is built for (it is latency-, not MFMA-bound)
-constexpr uint32_t kBlockThreads = kSharedWeights ? 256 : 64;
+// Weight delivery: every wave streams the pass blobs from L2 through its own register ring (WeightRing, mlp_mfma.hip.h),
+// single-wave workgroups.  (A 4-wave LDS-shared stream was measured in round 1 and was slower at the fp32 MFMA rate -- its
+// per-chunk barriers cost more than the 4x L2 traffic it saves)
+constexpr int kRingDepth = 32;
+constexpr int kHashAhead = 2;         // hash levels whose corner gathers are in flight ahead of the one being interpolated
+constexpr uint32_t kBlockThreads = 64;
 constexpr int ring_padded(int frags) { return (frags + kRingDepth - 1) / kRingDepth * kRingDepth; }
 
 // reflected-radiance branch (network.py:612-659): renv MLP 4 -> 64 -> 64 -> 64 -> 12, then the specular head again
@@ -448,7 +427,7 @@ __device__ __forceinline__ void shade_renv(WP& wp, const uint32_t lane, const fl
 // GEOM: geometry-only launches (first pass of indirect rendering, geometry pass of a two-phase frame) get their own
 // instantiation without any shading code
 template <int IDE_DEG, int ENV_T, int SH_DEG, bool GEOM = false>
-__global__ void __launch_bounds__(kBlockThreads, (SH_DEG > 0 ? kPlainWaves : 1)) k_render_persistent(const RenderArgs a) {
+__global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const RenderArgs a) {
     constexpr bool kEnvNet = SH_DEG == 0;
     constexpr int kShDim = SH_DEG * SH_DEG;
     constexpr int kDiffIn = kEnvNet ? 24 : 12, kSpecIn = kEnvNet ? 28 : 2 * kShDim + 13;
@@ -462,14 +441,13 @@ __global__ void __launch_bounds__(kBlockThreads, (SH_DEG > 0 ? kPlainWaves : 1))
     constexpr uint32_t kSdfChunks = pass_chunks(kSdfFrags), kEnvChunks = pass_chunks(kEnvFrags), kHeadChunks = pass_chunks(kHeadFrags);
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    __shared__ __attribute__((aligned(16))) float s_weights[kSharedWeights ? 2 * kChunkFloats : 4];
-    __shared__ float s_jac[(kSharedWeights ? 4 : 1) * kLevels * 6 * 64];
+    __shared__ float s_jac[kLevels * 6 * 64];
     // per-ray state that is only touched by march and blend, parked here while a sample is shaded (it would
     // otherwise sit in -- or be spilled from -- registers the 256-wide layers need)
     constexpr int kParked = 26;
-    __shared__ float s_park[(kSharedWeights ? 4 : 1) * kParked * 64];
-    std::conditional_t<kSharedWeights, WeightPipe, WeightRing<kRingDepth>> wp;
-    wp.start(s_weights, lane, wave, a.sdf_blob, kSdfChunks);
+    __shared__ float s_park[kParked * 64];
+    WeightRing<kRingDepth> wp;
+    wp.start(lane, a.sdf_blob, kSdfChunks);
     // fragments per pass as the weight source sees them (the ring pads every pass to a multiple of its depth)
     constexpr int kSdfN = ring_padded(kSdfFrags), kEnvN = ring_padded(kEnvFrags), kHeadN = ring_padded(kHeadFrags);
 
@@ -484,14 +462,6 @@ __global__ void __launch_bounds__(kBlockThreads, (SH_DEG > 0 ? kPlainWaves : 1))
     float an[3] = {0, 0, 0}, ad[3] = {0, 0, 0}, as[3] = {0, 0, 0}, arough = 0;
     float rimg[4] = {0, 0, 0, 0};      // this ray's reflected radiance (rgb, visibility) when a.r_images is given
     unsigned long long n_samples = 0, n_rounds = 0, n_rays = 0;
-#ifdef ENVIDR_SECTION_TIMERS
-    // per-wave cycle accounting (s_memtime), build with -DENVIDR_SECTION_TIMERS; stats[4..11]
-    unsigned long long tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tmark = __builtin_amdgcn_s_memtime();
-#define ENVIDR_TICK(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tsec[i] += now_ - tmark; tmark = now_; } while (0)
-#else
-#define ENVIDR_TICK(i) do {} while (0)
-#endif
 
     auto finish_ray = [&]() {
         const size_t id = (size_t)ray;
@@ -616,12 +586,12 @@ __global__ void __launch_bounds__(kBlockThreads, (SH_DEG > 0 ? kPlainWaves : 1))
             if (!__any(again)) break;
         }
         // the four waves share the weight pipe: the block keeps going while any of them has a sample
-        if (kSharedWeights ? !__syncthreads_or((int)have) : !__any(have)) break;
-        ENVIDR_TICK(0);   // refill + march
+        if (!__any(have)) break;
+   // refill + march
         n_samples += have ? 1 : 0;
         n_rounds += 1;
         if (!have) { px = py = pz = 0; }
-        float* park = s_park + (kSharedWeights ? wave * (kParked * 64) : 0u) + lane;
+        float* park = s_park + lane;
         {
             const float v[kParked] = {rg.ox, rg.oy, rg.oz, rg.rdx, rg.rdy, rg.rdz, far, t_ray, t_resume, acc.ws, acc.depth, acc.r, acc.g,
                                       acc.b, acc.t, an[0], an[1], an[2], ad[0], ad[1], ad[2], as[0], as[1], as[2], arough,
@@ -638,7 +608,7 @@ __global__ void __launch_bounds__(kBlockThreads, (SH_DEG > 0 ? kPlainWaves : 1))
         // The 96 Jacobian entries per sample are parked in LDS ([entry][lane]: conflict-free) until the SDF
         // backward pass needs them; keeping them in VGPRs across the SDF network spills.
         float feat[2 * kLevels];
-        float* jac_col = s_jac + (kSharedWeights ? wave * (kLevels * 6 * 64) : 0u) + lane;
+        float* jac_col = s_jac + lane;
         {
             // (xyz + bound) / (2 bound)  -- hashencoder/hashgrid.py:161
             const float x01[3] = {(px + a.mk.bound) / a.bound2, (py + a.mk.bound) / a.bound2, (pz + a.mk.bound) / a.bound2};
@@ -670,7 +640,7 @@ __global__ void __launch_bounds__(kBlockThreads, (SH_DEG > 0 ? kPlainWaves : 1))
             }(std::make_integer_sequence<int, kLevels>{});
         }
 
-        ENVIDR_TICK(1);   // hash grid
+   // hash grid
         // ================= SDF network forward + input gradient (matrix cores) ===================
         float h3[32];      // raw outputs of the last SDF layer for this lane's sample (rows 0..14 used)
         float gfeat[32];   // d sdf / d feat
@@ -736,7 +706,7 @@ __global__ void __launch_bounds__(kBlockThreads, (SH_DEG > 0 ? kPlainWaves : 1))
             }
         }
 
-        ENVIDR_TICK(2);   // sdf mlp fwd+bwd
+   // sdf mlp fwd+bwd
         // ================= per-sample geometry terms =============================================
         const float sdf = h3[0];
         float geo[12];
@@ -779,7 +749,7 @@ __global__ void __launch_bounds__(kBlockThreads, (SH_DEG > 0 ? kPlainWaves : 1))
             }
         }
 
-        ENVIDR_TICK(3);   // geometry terms
+   // geometry terms
         // ================= shading: environment MLP x2 + diffuse / specular heads ===================
         float cd[3] = {0, 0, 0}, cs[3] = {0, 0, 0};
         if constexpr (!GEOM) if (!a.geometry_only) {
@@ -789,13 +759,12 @@ __global__ void __launch_bounds__(kBlockThreads, (SH_DEG > 0 ? kPlainWaves : 1))
                                     a.kappa_diffuse, a.light_scale};
             const float vd[3] = {rg.dx, rg.dy, rg.dz};
             float env_r[12];
-            shade_sample<IDE_DEG, ENV_T, SH_DEG>(wp, lane, sc, nrm, nenv, wr, vd, ndot, geo, rough, cd, cs, env_r,
-                                                 [&](int i) { (void)i; ENVIDR_TICK(i); });
+            shade_sample<IDE_DEG, ENV_T, SH_DEG>(wp, lane, sc, nrm, nenv, wr, vd, ndot, geo, rough, cd, cs, env_r, [](int) {});
             if constexpr (kEnvNet) if (renv)
                 shade_renv(wp, lane, a.renv_blob, a.spec2_blob, a.sdf_blob, kSdfChunks, rimg, rough, a.rough_scale, a.indir_rough_thresh,
                            h3[14], geo, nrm, ndot, cs);
         }
-        ENVIDR_TICK(6);   // heads (+ env unpack)
+   // heads (+ env unpack)
         {
             asm volatile("" ::: "memory");
             float v[kParked];
@@ -885,7 +854,7 @@ __global__ void __launch_bounds__(kBlockThreads, (SH_DEG > 0 ? kPlainWaves : 1))
                 for (int i = 0; i < 12; ++i) a.ex_geo[12 * (size_t)slot + i] = geo[i];
             }
         }
-        ENVIDR_TICK(7);   // composite
+   // composite
     }
 
     if (a.stats) {
@@ -899,9 +868,6 @@ __global__ void __launch_bounds__(kBlockThreads, (SH_DEG > 0 ? kPlainWaves : 1))
             atomicAdd(&a.stats[0], n_samples);
             atomicAdd(&a.stats[1], n_rounds);
             atomicAdd(&a.stats[2], n_rays);
-#ifdef ENVIDR_SECTION_TIMERS
-            for (int i = 0; i < 8; ++i) atomicAdd(&a.stats[4 + i], tsec[i]);
-#endif
         }
     }
 }
@@ -924,18 +890,16 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_shade_samples(const ShadeA
     constexpr uint32_t kRenvChunks = pass_chunks(kRenvFrags);
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    __shared__ __attribute__((aligned(16))) float s_weights[kSharedWeights ? 2 * kChunkFloats : 4];
-    std::conditional_t<kSharedWeights, WeightPipe, WeightRing<kRingDepth>> wp;
+    WeightRing<kRingDepth> wp;
     // the first blob a round streams: the environment MLP, or the heads when there is none
     const float* first_blob = (kEnvNet && !PRE_ENV) ? a.env_blob : a.head_blob;
     constexpr uint32_t kFirstChunks = (kEnvNet && !PRE_ENV) ? kEnvChunks : kHeadChunks;
-    wp.start(s_weights, lane, wave, first_blob, kFirstChunks);
+    wp.start(lane, first_blob, kFirstChunks);
     const ShadeConsts sc = {a.env_blob, a.head_blob, RENV ? a.renv_blob : first_blob, RENV ? kRenvChunks : kFirstChunks, a.kappa_diffuse, a.light_scale};
     const uint32_t waves = gridDim.x * (kBlockThreads / 64);
     // a frame whose records did not fit (count beyond the capacity) is not shaded at all: the host redoes it
     uint32_t M = a.M;
     if (a.m_dev) { const uint32_t md = __builtin_amdgcn_readfirstlane(*a.m_dev); M = md > a.M ? 0u : md; }
-    // every wave of a block runs the same number of rounds (the shared weight stream has block-wide barriers)
     for (uint32_t base = (blockIdx.x * (kBlockThreads / 64)) * 64; base < M; base += waves * 64) {
         const uint32_t id = base + wave * 64 + lane;
         const bool on = id < M;
@@ -1194,11 +1158,10 @@ int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const f
     // persistent grid: one 4-wave workgroup per CU (one wave per SIMD; the kernel uses the full
     // 512-register budget so exactly one wave fits a SIMD), fewer when the batch is small
     const uint32_t waves_per_block = kBlockThreads / 64;
-    const uint32_t waves_per_simd = d->dir_sh_degree ? (uint32_t)kPlainWaves : 1u;
-    const uint32_t blocks = std::min((uint32_t)device_cu_count() * (4 / waves_per_block) * waves_per_simd, ceil_div(N, kBlockThreads));
+    const uint32_t blocks = std::min((uint32_t)device_cu_count() * (4 / waves_per_block), ceil_div(N, kBlockThreads));
     const dim3 grid(blocks), block(kBlockThreads);
 #define ENVIDR_LAUNCH(DEG, HT, SH) hipLaunchKernelGGL((k_render_persistent<DEG, HT, SH>), grid, block, 0, s, a)
-    if (d->geometry_only && !kSharedWeights) hipLaunchKernelGGL((k_render_persistent<4, 4, 0, true>), grid, block, 0, s, a);
+    if (d->geometry_only) hipLaunchKernelGGL((k_render_persistent<4, 4, 0, true>), grid, block, 0, s, a);
     else if (d->dir_sh_degree == 4) ENVIDR_LAUNCH(4, 0, 4);
     else if (d->dir_sh_degree != 0) {
         set_error("render_rays: unsupported dir_sh_degree=%u (no-environment family is built for SH degree 4)", d->dir_sh_degree);

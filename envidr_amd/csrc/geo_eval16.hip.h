@@ -105,10 +105,7 @@ __device__ __forceinline__ void e16_layer_from_tiles(Src& wp, uint32_t quarter, 
     }(std::make_integer_sequence<int, KT>{});
 }
 
-#ifndef ENVIDR_GEO_E16_WAVES
-#define ENVIDR_GEO_E16_WAVES 12
-#endif
-constexpr int kE16Waves = ENVIDR_GEO_E16_WAVES;           // per workgroup = per CU: three per SIMD (four if the registers allow)
+constexpr int kE16Waves = 12;           // per workgroup = per CU: three per SIMD (four if the registers allow)
 constexpr int kE16Threads = kE16Waves * 64;
 constexpr int kE16LevelSteps = kLevels / 4;
 
@@ -128,13 +125,9 @@ __global__ void __launch_bounds__(kE16Threads, 1) k_geo_eval16(const GeoEvalArgs
         if (blockIdx.x == 0 && threadIdx.x == 0) a.begin_io[1] = end;
     }
     const uint32_t batches = (count + 15u) / 16u;
-#if ENVIDR_GEO_XCD
-    const uint32_t xcd = blockIdx.x & 7u, in_xcd = blockIdx.x >> 3, per_xcd_blocks = (gridDim.x + 7u - xcd) >> 3;
+    const uint32_t xcd = blockIdx.x & 7u, in_xcd = blockIdx.x >> 3, per_xcd_blocks = (gridDim.x + 7u - xcd) >> 3;      // XCD-aware batch order, as k_geo_eval32
     const uint32_t share = (batches + 7u) / 8u;
     const uint32_t b_lo = min(xcd * share, batches), b_hi = min(b_lo + share, batches);
-#else
-    const uint32_t in_xcd = blockIdx.x, per_xcd_blocks = gridDim.x, b_lo = 0, b_hi = batches;
-#endif
     if (b_lo + in_xcd * kE16Waves >= b_hi) return;
     {
         const float4* src = reinterpret_cast<const float4*>(a.sdf_e16_blob);
@@ -147,7 +140,7 @@ __global__ void __launch_bounds__(kE16Threads, 1) k_geo_eval16(const GeoEvalArgs
     wp.start(s_w + lane);
     const float* w3row = s_w + kE16BlobFloats + 4 * quarter;        // + 16 T: this quarter's four entries of tile T
     float* jac_col = s_jac + wave * (kE16LevelSteps * 6 * 64) + lane;
-    constexpr int kAhead = ENVIDR_GEO_AHEAD < kE16LevelSteps ? ENVIDR_GEO_AHEAD : kE16LevelSteps - 1;
+    constexpr int kAhead = kGeoAhead < kE16LevelSteps ? kGeoAhead : kE16LevelSteps - 1;
     const __amdgpu_buffer_rsrc_t table = table_rsrc(a.table, a.table_bytes);
     const uint32_t stride = per_xcd_blocks * kE16Waves;
     typedef float f32x3 __attribute__((ext_vector_type(3)));

@@ -8,15 +8,17 @@
 //                or left the scene, and marches the next chunk of samples of the others (march_core.hip.h, the
 //                standalone operator's bit-exact code) into a compact sample list, laid out sample-major per block so
 //                that every access of the wave is contiguous (see "Memory layout of the rounds").  The first chunk is
-//                sized from the caller's per-ray hint when there is one, else 16; later chunks extend what a ray has by
-//                half (8, 12, 18, 27 ...).  No host round trip: counts and the list of live blocks stay on the device,
-//                the host enqueues a fixed number of rounds.
+//                sized from the caller's per-ray hint when there is one, else 16; later chunks are sized per ray from
+//                what the compositor has just seen (transmittance left and the last opacity: see "chunk prediction").
+//                No host round trip: counts and the list of live blocks stay on the device, the host enqueues a fixed
+//                number of rounds.
 //   k_geo_eval32 one lane per (sample, half of the hash levels) of the round's list, nothing per ray: 16-level hash
 //                gathers with analytic Jacobian, SDF network forward and backward on the matrix cores, per-sample
 //                geometry terms.  32 samples per wave, two waves per SIMD (one in its gather / interpolation phase
 //                while the other owns the matrix pipe); the SDF weights are read from HBM once per workgroup and stay
 //                in LDS, and so does the Jacobian of a batch until the backward pass has produced the feature gradients.
-//                (k_geo_eval is the earlier 64-samples-per-wave form, one wave per SIMD; kept for A/B measurements.)
+//                (k_geo_eval16, geo_eval16.hip.h, is the same evaluation on 16-column MFMAs: a tested, selectable
+//                alternative.  Earlier forms and their A/B switches live in tools/geo/variants.py as source patches.)
 //
 // Sample positions are those of the reference loop with one sample per ray per iteration (the marcher is resumed
 // from the composited ray time after every sample, which does not depend on the densities), i.e. exactly the samples
@@ -69,57 +71,11 @@ template <int PF> struct is_weight_ring<WeightLdsRing<PF>> { static constexpr bo
 }
 namespace {
 
-#ifndef ENVIDR_GEO_RING
-#define ENVIDR_GEO_RING 8
-#endif
-constexpr int kGeoRing = ENVIDR_GEO_RING;
-#ifndef ENVIDR_GEO_WAVES
-#define ENVIDR_GEO_WAVES 4
-#endif
-#ifndef ENVIDR_GEO_AHEAD
-#define ENVIDR_GEO_AHEAD 2
-#endif
-#ifndef ENVIDR_GEO_XCD
-#define ENVIDR_GEO_XCD 1
-#endif
-#ifndef ENVIDR_GEO_NOMLP
-#define ENVIDR_GEO_NOMLP 0
-#endif
-#ifndef ENVIDR_GEO_NOSWEEP2
-#define ENVIDR_GEO_NOSWEEP2 0
-#endif
-#ifndef ENVIDR_GEO_NOSTORE
-#define ENVIDR_GEO_NOSTORE 0
-#endif
-#ifndef ENVIDR_GEO_JMODE
-#define ENVIDR_GEO_JMODE 2      // 0: second gather sweep (no stored Jacobian), 1: Jacobian parked in per-wave global scratch, 2: in LDS
-#endif
-#ifndef ENVIDR_GEO_IOMODE
-#define ENVIDR_GEO_IOMODE 1      // 1: MLP inputs / outputs move between lane order and tile order by half-wave swaps (registers); 0: through LDS
-#endif
-#ifndef ENVIDR_GEO_NT_FROM
-#define ENVIDR_GEO_NT_FROM 99     // hash levels >= this are gathered with the non-temporal hint
-#endif
-#ifndef ENVIDR_GEO_PREFETCH
-#define ENVIDR_GEO_PREFETCH 0     // 1: the first AHEAD levels of the next batch are gathered before the matrix-core section of this one
-#endif
-#ifndef ENVIDR_GEO_RAYS_DEBUG
-#define ENVIDR_GEO_RAYS_DEBUG 0
-#endif
-#ifndef ENVIDR_GEO_KERNEL16
-#define ENVIDR_GEO_KERNEL16 1      // 1: k_geo_eval16 (16 samples per wave, 16-column MFMAs) when the descriptor carries its weight packing
-#endif
-#ifndef ENVIDR_GEO_KERNEL32
-#define ENVIDR_GEO_KERNEL32 1      // 1: k_geo_eval32 (32 samples per wave, two waves per SIMD), 0: k_geo_eval (64, one per SIMD)
-#endif
-#ifndef ENVIDR_GEO_UNROLL_GROUPS
-#define ENVIDR_GEO_UNROLL_GROUPS 0
-#endif
-constexpr int kEvalWaves = ENVIDR_GEO_WAVES;        // waves per workgroup: two per SIMD
-constexpr int kEvalThreads = kEvalWaves * 64;
+
+constexpr int kGeoRing = 8;                         // LDS weight fragments read ahead of the MFMAs that consume them
+constexpr int kGeoAhead = 2;                        // hash levels whose corner gathers are in flight ahead of the one being interpolated
 constexpr int kSdfBlobFloats = kSdfFrags * 64;
 constexpr int kW3RowFloats = 64;                    // packed row vector of W3[0, :] (two tiles x 32)
-constexpr int kXchgFloats = (32 + 16) * 64;         // per-wave exchange area: [32 features][64 samples] + [16 outputs][64 samples]
 
 struct GeoEvalArgs {
     const float* xyz;           // [cap,3] sample positions
@@ -146,7 +102,11 @@ struct GeoEvalArgs {
     float* geo;                 // [cap,12] unit
     float* rough;               // [cap]
     float* blend;               // [cap]    raw output 14 of the SDF network (learn_indir_blend logit)
-    float* jscratch;            // [waves in the grid][96][64] parking space of the Jacobians (L2-resident)
+    // test-only exports of the PROBE instantiation (envidr_geometry_probe): what the hash section computed
+    float* probe_feat;          // [M,32]   hash features as they enter the SDF network (level-major, 2 channels)
+    uint32_t* probe_rows;       // [M,16,8] table row (within its level) of corner bx | by << 1 | bz << 2
+    float* probe_raw;           // [M,16]   raw outputs of the last SDF layer (row 0 = sdf)
+    float* probe_grad;          // [M,3]    d sdf / d xyz before normalisation
 };
 
 // compiler-level ordering of this wave's LDS traffic between two phases (a wave's DS operations execute in order;
@@ -157,359 +117,6 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// first SDF layer with its B operands read from the per-wave exchange area ([feature][sample], conflict-free):
-// step s of group grp: lane l supplies feature 2 s + (l >> 5) of sample 32 grp + (l & 31)
-template <int STEPS, int MT, int F0, int FRAGS, typename Src>
-__device__ __forceinline__ void pipe_layer_from_lds(Src& wp, uint32_t lane, const float* col, f32x16 (&acc)[MT]) {
-    zero_acc<MT>(acc);
-    bias_step<MT, F0, FRAGS>(wp, lane, acc);
-    float in[STEPS];
-#pragma unroll
-    for (int q = 0; q < STEPS; ++q) in[q] = col[(2 * q) * 64];
-    __builtin_amdgcn_sched_barrier(0);
-    pipe_steps<STEPS, MT, F0 + MT, FRAGS>(wp, acc, [&](int q) { return in[q]; });
-}
-
-__global__ void __launch_bounds__(kEvalThreads, (kEvalWaves + 3) / 4) k_geo_eval(const GeoEvalArgs a) {
-    __shared__ __attribute__((aligned(16))) float s_w[kSdfBlobFloats + kW3RowFloats];
-    __shared__ float s_x[ENVIDR_GEO_IOMODE == 0 ? kEvalWaves * kXchgFloats : 64];
-    __shared__ float s_jac[ENVIDR_GEO_JMODE == 2 ? kEvalWaves * kLevels * 6 * 64 : 64];
-    const uint32_t lane = lane_id();
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint32_t begin = 0, count = a.M;
-    if (a.range) { begin = __builtin_amdgcn_readfirstlane(a.range[0]); count = min(__builtin_amdgcn_readfirstlane(a.range[1]), a.M - min(begin, a.M)); }
-    else if (a.head) {
-        begin = __builtin_amdgcn_readfirstlane(a.begin_io[0]);
-        const uint32_t end = min(__builtin_amdgcn_readfirstlane(*a.head), a.M);
-        count = end - min(begin, end);
-        if (blockIdx.x == 0 && threadIdx.x == 0) a.begin_io[1] = end;
-    }
-    const uint32_t batches = (count + 63u) / 64u;
-#if ENVIDR_GEO_XCD
-    // XCD-aware batch order: workgroup b runs on XCD b % 8 (observed; speed only), and each XCD takes one contiguous
-    // eighth of the sample list, so image-space neighbours -- whose gathers share table rows -- meet in the same L2
-    const uint32_t xcd = blockIdx.x & 7u, in_xcd = blockIdx.x >> 3, per_xcd_blocks = (gridDim.x + 7u - xcd) >> 3;
-    const uint32_t share = (batches + 7u) / 8u;
-    const uint32_t b_lo = min(xcd * share, batches), b_hi = min(b_lo + share, batches);
-#else
-    const uint32_t in_xcd = blockIdx.x, per_xcd_blocks = gridDim.x, b_lo = 0, b_hi = batches;
-#endif
-    if (b_lo + in_xcd * kEvalWaves >= b_hi) return;          // nothing for this workgroup (most rounds of a frame are empty)
-    {
-        // the workgroup's copy of the weights: 16-byte loads, once
-        const float4* src = reinterpret_cast<const float4*>(a.sdf_blob);
-        float4* dst = reinterpret_cast<float4*>(s_w);
-        for (uint32_t i = threadIdx.x; i < kSdfBlobFloats / 4; i += kEvalThreads) dst[i] = src[i];
-        if (threadIdx.x < kW3RowFloats) s_w[kSdfBlobFloats + threadIdx.x] = a.sdf_w3r0[threadIdx.x];
-    }
-    __syncthreads();
-    WeightLdsRing<kGeoRing> wp;
-    wp.start(s_w + lane);
-    const float* w3row = s_w + kSdfBlobFloats + (lane >> 5) * 16;      // this lane half's 16 floats of a packed row-vector tile
-    float* xf = s_x + (ENVIDR_GEO_IOMODE == 0 ? wave * kXchgFloats : 0u);                              // [32][64]: features in, d sdf / d feature out
-    [[maybe_unused]] float* xo = xf + 32 * 64;                                          // [16][64]: raw outputs of the last SDF layer
-    constexpr int kSdfN = (kSdfFrags + kGeoRing - 1) / kGeoRing * kGeoRing;     // fragments per pass as the ring sees them
-
-    // Jacobian parking: 96 values per sample, [entry][lane] rows of 256 bytes in this wave's private slab (written once,
-    // read once ~30 k cycles later: it lives in the XCD's L2)
-    // (buffer addressing: one descriptor for the slab, voffset = lane * 4, the entry as an immediate / scalar offset;
-    // flat addressing makes the compiler hoist and spill a 64-bit address per 4 KiB window)
-    // per level one 16-byte and one 8-byte access per lane, both fully coalesced: [level][lane][4] then [level][lane][2]
-    const __amdgpu_buffer_rsrc_t jslab = __builtin_amdgcn_make_buffer_rsrc(
-        a.jscratch + (size_t)(blockIdx.x * kEvalWaves + wave) * (kLevels * 6 * 64), 0, kLevels * 6 * 64 * 4, 0x00020000);
-    const uint32_t lane16 = lane * 16u, lane8 = lane * 8u;
-    constexpr uint32_t kJB = kLevels * 64 * 16;      // byte offset of the 8-byte part
-    auto jstore = [&](int l, const float (&g)[3][2]) {
-        const u32x4 v4 = {__float_as_uint(g[0][0]), __float_as_uint(g[0][1]), __float_as_uint(g[1][0]), __float_as_uint(g[1][1])};
-        const u32x2 v2 = {__float_as_uint(g[2][0]), __float_as_uint(g[2][1])};
-        __builtin_amdgcn_raw_buffer_store_b128(v4, jslab, lane16, (uint32_t)(l * 1024), 0);
-        __builtin_amdgcn_raw_buffer_store_b64(v2, jslab, lane8, kJB + (uint32_t)(l * 512), 0);
-    };
-    auto jload = [&](int l, float (&g)[3][2]) {
-        const u32x4 v4 = __builtin_amdgcn_raw_buffer_load_b128(jslab, lane16, (uint32_t)(l * 1024), 0);
-        const u32x2 v2 = __builtin_amdgcn_raw_buffer_load_b64(jslab, lane8, kJB + (uint32_t)(l * 512), 0);
-        g[0][0] = __uint_as_float(v4[0]); g[0][1] = __uint_as_float(v4[1]); g[1][0] = __uint_as_float(v4[2]); g[1][1] = __uint_as_float(v4[3]);
-        g[2][0] = __uint_as_float(v2[0]); g[2][1] = __uint_as_float(v2[1]);
-    };
-    (void)jstore; (void)jload;
-    float* jac_col = s_jac + (ENVIDR_GEO_JMODE == 2 ? wave * (kLevels * 6 * 64) : 0u) + lane;     // [entry][lane]: conflict-free
-    (void)jac_col;
-    constexpr int kAhead = ENVIDR_GEO_AHEAD;           // levels whose corner gathers are in flight ahead of the one being interpolated
-    const __amdgpu_buffer_rsrc_t table = table_rsrc(a.table, a.table_bytes);
-    const uint32_t stride = per_xcd_blocks * kEvalWaves;
-
-    struct Sample { float xc[3]; size_t slot; bool inside, on; };
-    auto load_sample = [&](uint32_t bb) {
-        Sample sm;
-        const uint32_t sidx = bb * 64u + lane;
-        sm.on = sidx < count;
-        sm.slot = (size_t)begin + (sm.on ? sidx : 0u);
-        typedef float f32x3 __attribute__((ext_vector_type(3)));
-        f32x3 pv = {0.0f, 0.0f, 0.0f};
-        if (sm.on) pv = *reinterpret_cast<const f32x3*>(a.xyz + 3 * sm.slot);       // one 12-byte load
-        // (xyz + bound) / (2 bound)  -- hashencoder/hashgrid.py:161; outside the unit cube every level contributes zeros
-        // (hashencoder.cu:124-149): evaluate at a clamped position and mask, which keeps the gathers in bounds
-        const float x01[3] = {(pv[0] + a.bound) / a.bound2, (pv[1] + a.bound) / a.bound2, (pv[2] + a.bound) / a.bound2};
-        sm.inside = x01[0] >= 0 && x01[0] <= 1 && x01[1] >= 0 && x01[1] <= 1 && x01[2] >= 0 && x01[2] <= 1;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) sm.xc[d] = sm.inside ? x01[d] : 0.5f;
-        return sm;
-    };
-    LeanStage st[kAhead + 1];
-    auto prime = [&](const Sample& sm) {
-        [&]<int... I>(std::integer_sequence<int, I...>) {
-            (lean_prepare<(I >= ENVIDR_GEO_NT_FROM ? 2 : 0)>(a.lv[I], table, sm.xc, st[I]), ...);
-        }(std::make_integer_sequence<int, kAhead>{});
-    };
-    uint32_t b = b_lo + in_xcd * kEvalWaves + wave;
-    Sample nxt = {};
-#if ENVIDR_GEO_PREFETCH
-    if (b < b_hi) { nxt = load_sample(b); prime(nxt); }
-#endif
-    for (; b < b_hi; b += stride) {
-#if ENVIDR_GEO_PREFETCH
-        const Sample cur = nxt;
-#else
-        const Sample cur = load_sample(b);
-        prime(cur);
-#endif
-        const bool on = cur.on, inside = cur.inside;
-        const size_t slot = cur.slot;
-        const float xc[3] = {cur.xc[0], cur.xc[1], cur.xc[2]};
-
-        // ================= phase 1: hash grid values (+ Jacobian -> parking slab) ============================
-        float feat[ENVIDR_GEO_IOMODE == 0 ? 1 : 2 * kLevels];
-        (void)feat;
-        {
-            __builtin_amdgcn_sched_barrier(0);
-            auto level = [&](auto lc, LeanStage& now, LeanStage& ahead) {
-                constexpr int l = decltype(lc)::value;
-                if constexpr (l + kAhead < kLevels) lean_prepare<(l + kAhead >= ENVIDR_GEO_NT_FROM ? 2 : 0)>(a.lv[l + kAhead], table, xc, ahead);
-                __builtin_amdgcn_sched_barrier(0);
-                float o[2];
-#if ENVIDR_GEO_JMODE == 1
-                float g[3][2];
-                lean_finish(now, inside ? a.lv[l].on : 0.0f, o, g);    // network.py:390-393 level mask; zeros outside the cube
-                jstore(l, g);
-#elif ENVIDR_GEO_JMODE == 2
-                float g[3][2];
-                lean_finish(now, inside ? a.lv[l].on : 0.0f, o, g);
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    jac_col[((l * 3 + d) * 2 + 0) * 64] = g[d][0];
-                    jac_col[((l * 3 + d) * 2 + 1) * 64] = g[d][1];
-                }
-#else
-                lean_value(now, inside ? a.lv[l].on : 0.0f, o);
-#endif
-#if ENVIDR_GEO_IOMODE == 0
-                xf[(2 * l) * 64 + lane] = o[0];
-                xf[(2 * l + 1) * 64 + lane] = o[1];
-#else
-                feat[2 * l] = o[0]; feat[2 * l + 1] = o[1];
-#endif
-            };
-            [&]<int... L>(std::integer_sequence<int, L...>) {
-                (level(std::integral_constant<int, L>{}, st[L % (kAhead + 1)], st[(L + kAhead) % (kAhead + 1)]), ...);
-            }(std::make_integer_sequence<int, kLevels>{});
-        }
-        wave_lds_sync();
-#if ENVIDR_GEO_PREFETCH
-        // every stage is free again: the next batch's first levels go out now and land under the matrix-core section
-        if (b + stride < b_hi) { nxt = load_sample(b + stride); prime(nxt); }
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-
-        // ================= phase 2: SDF network forward + input gradient (matrix cores) ===================
-        // 32 samples ("group") at a time; activations stay in accumulator tiles between layers (mlp_mfma.hip.h); results
-        // return through the exchange area: raw outputs 0..15 -> xo, d sdf / d feature -> xf (the group's own columns)
-#if ENVIDR_GEO_IOMODE == 1
-        float inA[kLevels], inB[kLevels];
-#pragma unroll
-        for (int q = 0; q < kLevels; ++q) {
-            float e = feat[2 * q], o = feat[2 * q + 1];
-            pack_pair(e, o);
-            inA[q] = e; inB[q] = o;
-        }
-        f32x16 outA, outB, gfA, gfB;
-#endif
-#if ENVIDR_GEO_UNROLL_GROUPS
-#pragma unroll
-#else
-#pragma unroll 1
-#endif
-        for (int grp = 0; grp < (ENVIDR_GEO_NOMLP ? 0 : 2); ++grp) {
-            __builtin_amdgcn_sched_barrier(0);
-            f32x16 h1[2], h2[2], o3[1];
-            uint32_t pos1 = 0, pos2 = 0;
-#if ENVIDR_GEO_IOMODE == 0
-            const uint32_t colbase = (lane >> 5) * 64 + 32 * grp + (lane & 31);      // + feature pair row * 128
-            pipe_layer_from_lds<kLevels, 2, kSdfW1, kSdfN>(wp, lane, xf + colbase, h1);
-#else
-            float in[kLevels];
-#pragma unroll
-            for (int q = 0; q < kLevels; ++q) in[q] = grp ? inB[q] : inA[q];
-            pipe_layer_from_lanes<kLevels, 2, kSdfW1, kSdfN>(wp, lane, in, h1);
-#endif
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) pos1 |= (h1[t][r] > 0 ? 1u : 0u) << (16 * t + r);
-            pipe_layer_from_tiles<2, 2, kSdfW2, kSdfN, true>(wp, lane, h1, h2);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) pos2 |= (h2[t][r] > 0 ? 1u : 0u) << (16 * t + r);
-            pipe_layer_from_tiles<2, 1, kSdfW3, kSdfN, true>(wp, lane, h2, o3);
-#if ENVIDR_GEO_IOMODE == 0
-            // rows 0..15 of the output tile: registers 0..7 of both lane halves
-            const uint32_t ocol = 32 * grp + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) xo[(tile_row(r, 0) + 4 * (lane >> 5)) * 64 + ocol] = o3[0][r];
-#endif
-            // backward of sdf = o3[row 0]:  g2 = W3[0,:] * [h2 > 0];  g1 = (W2^T g2) * [h1 > 0];  gfeat = W1^T g1
-            f32x16 g2[2], g1[2], gf[1];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) g2[t][r] = (pos2 >> (16 * t + r)) & 1u ? w3row[t * 32 + r] : 0.0f;
-            pipe_layer_from_tiles<2, 2, kSdfW2t, kSdfN, false, false>(wp, lane, g2, g1);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) g1[t][r] = (pos1 >> (16 * t + r)) & 1u ? g1[t][r] : 0.0f;
-            pipe_layer_from_tiles<2, 1, kSdfW1t, kSdfN, false, false>(wp, lane, g1, gf);
-            wp.template end_pass<kSdfFrags>();
-#if ENVIDR_GEO_IOMODE == 0
-            // this group's features are consumed: its columns of xf now take d sdf / d feature
-#pragma unroll
-            for (int r = 0; r < 16; ++r) xf[(tile_row(r, 0) + 4 * (lane >> 5)) * 64 + ocol] = gf[0][r];
-#else
-            if (grp == 0) { outA = o3[0]; gfA = gf[0]; } else { outB = o3[0]; gfB = gf[0]; }
-#endif
-        }
-        wave_lds_sync();
-#if ENVIDR_GEO_IOMODE == 1
-        float h3r[16], gfeat[32];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float p = gfA[r], q = gfB[r];
-            unpack_pair(p, q);
-            gfeat[tile_row(r, 0)] = p; gfeat[tile_row(r, 1)] = q;
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {          // rows 0..15 of the output tile live in registers 0..7
-            float u = outA[r], v = outB[r];
-            unpack_pair(u, v);
-            h3r[tile_row(r, 0)] = u; h3r[tile_row(r, 1)] = v;
-        }
-#endif
-
-        // ================= phase 3: normal = J^T (d sdf / d feat) by a second gather sweep =========================
-        // The Jacobian (96 values per sample) is never stored: the corners are gathered again (L2 / Infinity-Cache hot)
-        // and contracted with the two feature gradients of their level on the fly.
-        float nrm[3] = {0, 0, 0};
-#if ENVIDR_GEO_JMODE == 2
-        {
-#pragma unroll
-            for (int l = 0; l < kLevels; ++l) {
-#if ENVIDR_GEO_IOMODE == 0
-                const float g0 = xf[(2 * l) * 64 + lane], g1 = xf[(2 * l + 1) * 64 + lane];
-#else
-                const float g0 = gfeat[2 * l], g1 = gfeat[2 * l + 1];
-#endif
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    nrm[d] += g0 * jac_col[((l * 3 + d) * 2 + 0) * 64];
-                    nrm[d] += g1 * jac_col[((l * 3 + d) * 2 + 1) * 64];
-                }
-            }
-        }
-#elif ENVIDR_GEO_JMODE == 1
-        {
-            // kernel_input_backward order: levels outer, channels inner (hashencoder.cu:346-372)
-#pragma unroll
-            for (int l = 0; l < kLevels; ++l) {
-#if ENVIDR_GEO_IOMODE == 0
-                const float g0 = xf[(2 * l) * 64 + lane], g1 = xf[(2 * l + 1) * 64 + lane];
-#else
-                const float g0 = gfeat[2 * l], g1 = gfeat[2 * l + 1];
-#endif
-                float jg[3][2];
-                jload(l, jg);
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    nrm[d] += g0 * jg[d][0];
-                    nrm[d] += g1 * jg[d][1];
-                }
-            }
-        }
-#else
-        if (!ENVIDR_GEO_NOSWEEP2) {
-            // made opaque: otherwise the compiler recognises phase 1's cells, weights and gathered rows and keeps all of
-            // them alive across the matrix-core section instead of recomputing them
-            float x2[3] = {xc[0], xc[1], xc[2]};
-            asm volatile("" : "+v"(x2[0]), "+v"(x2[1]), "+v"(x2[2]));
-            LeanStage st[kAhead + 1];
-            [&]<int... I>(std::integer_sequence<int, I...>) {
-                (lean_prepare(a.lv[I], table, x2, st[I]), ...);
-            }(std::make_integer_sequence<int, kAhead>{});
-            __builtin_amdgcn_sched_barrier(0);
-            auto level2 = [&](auto lc, LeanStage& now, LeanStage& ahead) {
-                constexpr int l = decltype(lc)::value;
-                if constexpr (l + kAhead < kLevels) lean_prepare(a.lv[l + kAhead], table, x2, ahead);
-                __builtin_amdgcn_sched_barrier(0);
-                lean_contract(now, inside ? a.lv[l].on : 0.0f, xf[(2 * l) * 64 + lane], xf[(2 * l + 1) * 64 + lane], nrm);
-                // anchor: without it the optimiser sinks every level's arithmetic to the end of the sweep (its only use) and
-                // all 16 levels of gathered rows stay live until then
-                asm volatile("" : "+v"(nrm[0]), "+v"(nrm[1]), "+v"(nrm[2]));
-            };
-            [&]<int... L>(std::integer_sequence<int, L...>) {
-                (level2(std::integral_constant<int, L>{}, st[L % (kAhead + 1)], st[(L + kAhead) % (kAhead + 1)]), ...);
-            }(std::make_integer_sequence<int, kLevels>{});
-        }
-#endif
-#pragma unroll
-        for (int d = 0; d < 3; ++d) nrm[d] = nrm[d] / a.bound2;                         // d x01 / d xyz
-        normalize_n<3>(nrm, 1e-10f);                                                    // renderer.py:192
-
-        // ================= per-sample geometry terms (same statements as k_render_persistent) ===========
-        float h3[16];
-#pragma unroll
-#if ENVIDR_GEO_IOMODE == 0
-        for (int i = 0; i < 15; ++i) h3[i] = xo[i * 64 + lane];
-#else
-        for (int i = 0; i < 15; ++i) h3[i] = h3r[i];
-#endif
-        const float sdf = h3[0];
-        float geo[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) geo[i] = h3[1 + i];
-        normalize_n<12>(geo, 1e-12f);                                                   // network.py:434-435
-        const float rough = a.rough_act_scale * softplusf(h3[13] + a.rough_bias) * a.rough_scale;   // network.py:443-448
-        // Laplace density (network.py:32-37): (1/beta) (0.5 + 0.5 sign(s) expm1(-|s| / beta))
-        const float sgn = sdf > 0 ? 1.0f : (sdf < 0 ? -1.0f : 0.0f);
-        const float sigma = a.inv_beta * (0.5f + 0.5f * sgn * expm1f(-fabsf(sdf) / a.beta)) * a.density_scale;
-        if (on && (!ENVIDR_GEO_NOSTORE || sigma == 12345.0f)) {
-            if (a.alpha) a.alpha[slot] = 1.0f - expf(-sigma * a.dt[slot]);
-            if (a.sigma) a.sigma[slot] = sigma;
-            if (a.rough) a.rough[slot] = rough;
-            if (a.blend) a.blend[slot] = h3[14];
-            // wide stores: a store instruction costs texture-address cycles per instruction, not per byte
-            if (a.normal) {
-                typedef float f32x3 __attribute__((ext_vector_type(3)));
-                const f32x3 nv = {nrm[0], nrm[1], nrm[2]};
-                *reinterpret_cast<f32x3*>(a.normal + 3 * slot) = nv;
-            }
-            if (a.geo) {
-                float4* gp = reinterpret_cast<float4*>(a.geo + 12 * slot);          // 48-byte rows: 16-byte aligned
-#pragma unroll
-                for (int i = 0; i < 3; ++i) gp[i] = make_float4(geo[4 * i], geo[4 * i + 1], geo[4 * i + 2], geo[4 * i + 3]);
-            }
-        }
-        wave_lds_sync();      // the exchange area is rewritten by the next batch
-    }
-}
 
 // =====================================================================================================================
 // k_geo_eval32: the same evaluation with 32 samples per wave and the 16 hash levels split between the two lane halves
@@ -524,6 +131,9 @@ constexpr int kE32Waves = 8;
 constexpr int kE32Threads = kE32Waves * 64;
 constexpr int kE32Steps = kLevels / 2;            // level pairs: step i covers level 2 i (lower lanes) and 2 i + 1 (upper lanes)
 
+// PROBE: the test-only instantiation behind envidr_geometry_probe -- the same statements, plus stores of what the hash section
+// computed (features, corner rows) and of the raw network outputs / the unnormalised gradient
+template <bool PROBE>
 __global__ void __launch_bounds__(kE32Threads, 2) k_geo_eval32(const GeoEvalArgs a) {
     __shared__ __attribute__((aligned(16))) float s_w[kSdfBlobFloats + kW3RowFloats];
     __shared__ __attribute__((aligned(16))) LeanLevel s_lv[kLevels];
@@ -540,14 +150,12 @@ __global__ void __launch_bounds__(kE32Threads, 2) k_geo_eval32(const GeoEvalArgs
         if (blockIdx.x == 0 && threadIdx.x == 0) a.begin_io[1] = end;
     }
     const uint32_t batches = (count + 31u) / 32u;
-#if ENVIDR_GEO_XCD
+    // XCD-aware batch order: workgroup b runs on XCD b % 8 (observed; speed only), and each XCD takes one contiguous
+    // eighth of the sample list, so image-space neighbours -- whose gathers share table rows -- meet in the same L2
     const uint32_t xcd = blockIdx.x & 7u, in_xcd = blockIdx.x >> 3, per_xcd_blocks = (gridDim.x + 7u - xcd) >> 3;
     const uint32_t share = (batches + 7u) / 8u;
     const uint32_t b_lo = min(xcd * share, batches), b_hi = min(b_lo + share, batches);
-#else
-    const uint32_t in_xcd = blockIdx.x, per_xcd_blocks = gridDim.x, b_lo = 0, b_hi = batches;
-#endif
-    if (b_lo + in_xcd * kE32Waves >= b_hi) return;
+    if (b_lo + in_xcd * kE32Waves >= b_hi) return;          // nothing for this workgroup (most rounds of a frame are empty)
     {
         const float4* src = reinterpret_cast<const float4*>(a.sdf_blob);
         float4* dst = reinterpret_cast<float4*>(s_w);
@@ -561,7 +169,7 @@ __global__ void __launch_bounds__(kE32Threads, 2) k_geo_eval32(const GeoEvalArgs
     const float* w3row = s_w + kSdfBlobFloats + half * 16;
     float* jac_col = s_jac + wave * (kE32Steps * 6 * 64) + lane;
     constexpr int kSdfN = (kSdfFrags + kGeoRing - 1) / kGeoRing * kGeoRing;
-    constexpr int kAhead = ENVIDR_GEO_AHEAD;
+    constexpr int kAhead = kGeoAhead;
     const __amdgpu_buffer_rsrc_t table = table_rsrc(a.table, a.table_bytes);
     const uint32_t stride = per_xcd_blocks * kE32Waves;
 
@@ -588,7 +196,14 @@ __global__ void __launch_bounds__(kE32Threads, 2) k_geo_eval32(const GeoEvalArgs
             LeanLevel lvs[kAhead + 1];
             auto prep = [&](int i, LeanStage& stg, LeanLevel& lv) {
                 lv = s_lv[2 * i + half];                                       // per-lane level constants (two distinct rows: broadcast)
-                lean_prepare<0, true>(lv, table, xc, stg);
+                uint32_t rows[8];
+                lean_prepare<0, true>(lv, table, xc, stg, PROBE ? rows : nullptr);
+                if constexpr (PROBE) {
+                    if (on && a.probe_rows) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) a.probe_rows[(slot * kLevels + (2 * i + half)) * 8 + c] = rows[c];
+                    }
+                }
             };
             [&]<int... I>(std::integer_sequence<int, I...>) { (prep(I, st[I], lvs[I]), ...); }(std::make_integer_sequence<int, kAhead>{});
             __builtin_amdgcn_sched_barrier(0);
@@ -599,6 +214,12 @@ __global__ void __launch_bounds__(kE32Threads, 2) k_geo_eval32(const GeoEvalArgs
                 float o[2], g[3][2];
                 lean_finish(now, inside ? lvnow.on : 0.0f, o, g);
                 f0[i] = o[0]; f1[i] = o[1];
+                if constexpr (PROBE) {
+                    if (on && a.probe_feat) {
+                        a.probe_feat[slot * (2 * kLevels) + 2 * (2 * i + half)] = o[0];
+                        a.probe_feat[slot * (2 * kLevels) + 2 * (2 * i + half) + 1] = o[1];
+                    }
+                }
 #pragma unroll
                 for (int d = 0; d < 3; ++d) {
                     jac_col[((i * 3 + d) * 2 + 0) * 64] = g[d][0];
@@ -677,6 +298,12 @@ __global__ void __launch_bounds__(kE32Threads, 2) k_geo_eval32(const GeoEvalArgs
             swap_halves(lo, hi);             // lo = the lower half's sum in every lane, hi = the upper half's
             nrm[d] = (lo + hi) / a.bound2;                                              // even levels + odd levels; d x01 / d xyz
         }
+        if constexpr (PROBE) {
+            if (on && half == 0 && a.probe_grad) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) a.probe_grad[slot * 3 + d] = nrm[d];
+            }
+        }
         normalize_n<3>(nrm, 1e-10f);                                                    // renderer.py:192
         // raw outputs 0..15 of the last layer: rows 0-3, 8-11 in the lower lanes' registers 0..7, rows 4-7, 12-15 in the upper lanes'
         float h3[16];
@@ -686,12 +313,19 @@ __global__ void __launch_bounds__(kE32Threads, 2) k_geo_eval32(const GeoEvalArgs
             swap_halves(lo, hi);
             h3[tile_row(r, 0)] = lo; h3[tile_row(r, 1)] = hi;
         }
+        if constexpr (PROBE) {
+            if (on && half == 0 && a.probe_raw) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) a.probe_raw[slot * 16 + i] = h3[i];
+            }
+        }
         const float sdf = h3[0];
         float geo[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) geo[i] = h3[1 + i];
         normalize_n<12>(geo, 1e-12f);                                                   // network.py:434-435
         const float rough = a.rough_act_scale * softplusf(h3[13] + a.rough_bias) * a.rough_scale;   // network.py:443-448
+        // Laplace density (network.py:32-37): (1/beta) (0.5 + 0.5 sign(s) expm1(-|s| / beta))
         const float sgn = sdf > 0 ? 1.0f : (sdf < 0 ? -1.0f : 0.0f);
         const float sigma = a.inv_beta * (0.5f + 0.5f * sgn * expm1f(-fabsf(sdf) / a.beta)) * a.density_scale;
         if (on && half == 0) {
@@ -749,7 +383,7 @@ struct RayState {
 constexpr uint32_t kCntSampleHead = 0, kCntRecordHead = 1, kCntOverflow = 2, kCntAlive = 8, kCntBegin = 40, kCntOcc = 72, kGeoCounterWords = 80;
 // kCntOcc + 0..2: max over occupied cells of (H - 1 - coordinate) (i.e. the minimum, as a maximum: the words start at zero),
 // kCntOcc + 3..5: max coordinate; written by k_linearize_bitfield
-constexpr uint32_t kMaxRounds = 30;
+constexpr uint32_t kMaxRounds = 30;     // counter words reserved per round-indexed array
 
 struct GeoRayArgs {
     const float* rays_o; const float* rays_d;
@@ -758,7 +392,9 @@ struct GeoRayArgs {
     Aabb box;
     float min_near, T_thresh;
     uint32_t max_samples;
-    uint32_t chunk;            // samples to march this round; 0: only composite (last round)
+    uint32_t chunk;            // samples to march this round (round 0: per ray without a hint; later rounds: the most a ray may
+                               // get, see predicted_chunk); 0: only composite (last round)
+    uint32_t predict;          // rounds >= 1: size each ray's chunk from its compositing state instead of taking `chunk`
     uint32_t round;
     uint32_t* counters;
     const uint32_t* alive_in;  // rounds >= 1: ids of the blocks that still have a live ray
@@ -890,7 +526,27 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // then every ray still alive marches its next `chunk` samples (march_core.hip.h; the ray time is resumed from the
 // composited time after EVERY sample, as the reference loop does with one sample per iteration -- that time does not
 // depend on the densities, so marching ahead of the compositor changes nothing) into freshly allocated slots.
-constexpr uint32_t kTimeCache = 32;      // chunks up to this many samples (the first five rounds) are marched once
+constexpr uint32_t kTimeCache = 32;      // the first this many samples of an un-hinted chunk are marched once
+
+// Chunk prediction.  A ray that is still alive after compositing n samples has transmittance T >= T_thresh left and saw the
+// opacity `alpha` at its last sample.  If the opacity stayed there, the compositor (which stops AFTER the first sample whose
+// incoming transmittance is below the threshold) would take j + 1 more samples, j = ceil(ln(T_thresh / T) / ln(1 - alpha)).
+// Near a surface of an SDF-derived density the opacity only rises along the ray, so this over-estimates a little and the ray
+// is usually finished by the chunk it sizes; in thin media (tiny alpha) the prediction is huge and the cap -- what the ray
+// has composited so far, i.e. its sample count at most doubles per round -- decides, which is the schedule a ray without
+// any information gets.  Results never depend on the chunking (the marcher is resumed from the composited time after every
+// sample whatever the chunks are); what depends on it is how many samples are evaluated past a ray's end: 1.17x the
+// composited ones with chunks that grow by half regardless of the ray, 1.06x with this (tests/tools/chunk_sim.py on the
+// benchmark scenes), in fewer rounds.
+constexpr uint32_t kMinChunk = 2;
+__device__ __forceinline__ uint32_t predicted_chunk(float T, float alpha, float T_thresh, uint32_t n_taken, uint32_t most) {
+    if (!(T > T_thresh)) return 1u;               // already below the threshold: the compositor takes exactly one more sample
+    const uint32_t cap = min(max(8u, n_taken), most);
+    if (!(alpha > 1e-6f)) return cap;
+    if (alpha >= 1.0f) return kMinChunk;
+    const float j = ceilf(__logf(T_thresh / T) / __logf(1.0f - alpha));          // both logarithms negative
+    return (uint32_t)fminf(fmaxf(j + 2.0f, (float)kMinChunk), (float)cap);     // j + 1 samples, + 1 of margin
+}
 
 template <bool FIRST, int MODE>
 __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
@@ -909,6 +565,7 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
         RayGeom rg = {};
         float near = 0, far = 0, t_first = 0;
         RayState st = {};
+        uint32_t chunk_next = a.chunk;   // samples this ray marches next
         bool alive = false;          // still needs samples after this round's compositing
         bool finish = false;         // write the ray's outputs now
         if constexpr (FIRST) {
@@ -916,17 +573,9 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
                 rg = load_ray(a.rays_o, a.rays_d, ray);
                 ray_range(a, rg, near, far);
                 float t = near, x, y, z, dt;
-#if ENVIDR_GEO_RAYS_DEBUG == 1
-                const bool hit = false;
-#else
                 const bool hit = (!a.ray_mask || a.ray_mask[ray]) && geo_march<MODE>(a, rg, far, t, x, y, z, dt, &t_first);
-#endif
                 st.acc_t = near;
-#if ENVIDR_GEO_RAYS_DEBUG == 2
-                alive = false; if (hit) st.depth = t_first;
-#else
                 alive = hit;
-#endif
                 finish = !hit;
             }
         } else {
@@ -955,6 +604,7 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
             const uint32_t base = __builtin_amdgcn_readfirstlane(a.block_base[blk]);
             uint32_t k = 0;              // samples of the chunk that get composited
             bool terminated = false;
+            float last_alpha = 0.0f;
             {
                 float ws = st.ws;        // pass 1: how many records does each ray append
                 bool going = active;
@@ -989,6 +639,7 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
                     roff += (uint32_t)__popcll(mk);
                     if (c < k) {
                         const float alpha = a.alpha[slot];
+                        last_alpha = alpha;
                         const float T = 1 - st.ws;
                         const float w = alpha * T;
                         st.ws += w;
@@ -1006,13 +657,14 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
                 finish = terminated || last || st.n_taken >= a.max_samples;
                 alive = !finish;
             }
+            if (alive && a.predict) chunk_next = predicted_chunk(1 - st.ws, last_alpha, a.T_thresh, st.n_taken, a.chunk);
         }
 
         // ---- march the next chunk ------------------------------------------------------------------------------
         // Round 0 sizes a ray's first chunk from the caller's hint when there is one (samples the ray took in an earlier
         // render of about the same camera: exact for the frames of a fixed-camera video): the ray is then done in one
         // round with nothing evaluated past its end.  A wrong hint costs a round or some wasted samples, never accuracy.
-        uint32_t chunk = a.chunk;
+        uint32_t chunk = chunk_next;
         if constexpr (FIRST) {
             if (alive && a.ray_cost) { const uint32_t h = a.ray_cost[ray]; if (h) chunk = min(h, 4096u); }
         }
@@ -1028,7 +680,7 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
                 for (; want < chunk && st.n_taken + want < a.max_samples; ++want) {
                     float t = first ? t_first : tr, x, y, z, dt, t_at;
                     if (!geo_march<MODE>(a, rg, far, t, x, y, z, dt, &t_at)) break;
-                    if (want < kTimeCache) t_cache[want * 64] = t_at;      // the write pass below restarts from these
+                    if (want < kTimeCache) t_cache[want * 64] = t_at;      // the write pass below takes these instead of marching again
                     tr = tr + (t - tr);
                     first = false;
                 }
@@ -1044,7 +696,7 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
         }
         uint32_t marched = 0;
         {
-            const bool cached = !hinted && a.chunk <= kTimeCache;
+            const bool counted = !hinted;     // the counting pass left the ray times of the first kTimeCache samples in LDS
             float tr = st.acc_t;
             bool first = FIRST, ended = false;
             uint32_t off = 0;
@@ -1055,7 +707,7 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
                 off += (uint32_t)__popcll(m);
                 if (c < want) {
                     float x = 0, y = 0, z = 0, dt = 0, dd = 0;
-                    if (cached) {
+                    if (counted && c < kTimeCache) {
                         // the counting pass found this sample at ray time t_at: position, step and ray-time bookkeeping are
                         // the marcher's own statements for an occupied cell
                         const float t_at = t_cache[c * 64];
@@ -1066,6 +718,7 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
                         const float t = t_at + dt;
                         dd = t - tr;
                         tr = tr + dd;
+                        first = false;
                         ++marched;
                     } else if (!ended) {
                         float t = first ? t_first : tr;
@@ -1138,39 +791,22 @@ int fill_eval_args(const envidr_render_desc* d, GeoEvalArgs& a, const char* who)
     ENVIDR_REQUIRE(!err, "%s: %s", who, err);
     a.bound = d->bound; a.bound2 = 2 * d->bound;
     a.sdf_blob = d->sdf_blob; a.sdf_w3r0 = d->sdf_w3_row0;
-    a.sdf_e16_blob = ENVIDR_GEO_KERNEL16 ? d->sdf_geo_blob : nullptr;
+    a.sdf_e16_blob = d->sdf_geo_blob;
     a.beta = d->beta; a.inv_beta = 1 / d->beta; a.density_scale = d->density_scale;
     a.rough_bias = d->roughness_bias; a.rough_act_scale = d->roughness_act_scale; a.rough_scale = d->roughness_scale;
     return ENVIDR_OK;
 }
 
 void launch_eval(const GeoEvalArgs& a, uint32_t max_samples, hipStream_t s) {
-    // one 8-wave workgroup per CU (the LDS-resident weights and the parked Jacobians fill the CU's LDS)
-    const uint32_t blocks = std::max(1u, std::min((uint32_t)device_cu_count(), ceil_div(max_samples, kEvalThreads)));
-    GeoEvalArgs b = a;
-#if !ENVIDR_GEO_KERNEL32 && ENVIDR_GEO_JMODE == 1
-    {
-        // experiment (k_geo_eval with the Jacobians parked in global memory): one slab per wave of the persistent grid
-        static float* g_scratch[16] = {};
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        dev &= 15;
-        if (!g_scratch[dev]) (void)hipMalloc(&g_scratch[dev], (size_t)device_cu_count() * kEvalWaves * kLevels * 6 * 64 * sizeof(float));
-        b.jscratch = g_scratch[dev];
-    }
-#endif
-    if (b.sdf_e16_blob) {
+    // one workgroup per CU (the LDS-resident weights and the parked Jacobians fill the CU's LDS), persistent over the batches
+    if (a.sdf_e16_blob) {
         const uint32_t blocks16 = std::max(1u, std::min((uint32_t)device_cu_count(), ceil_div(max_samples, kE16Waves * 16u)));
-        hipLaunchKernelGGL(k_geo_eval16, dim3(blocks16), dim3(kE16Threads), 0, s, b);
+        hipLaunchKernelGGL(k_geo_eval16, dim3(blocks16), dim3(kE16Threads), 0, s, a);
         return;
     }
-#if ENVIDR_GEO_KERNEL32
     const uint32_t blocks32 = std::max(1u, std::min((uint32_t)device_cu_count(), ceil_div(max_samples, kE32Waves * 32u)));
-    hipLaunchKernelGGL(k_geo_eval32, dim3(blocks32), dim3(kE32Threads), 0, s, b);
-    (void)blocks;
-#else
-    hipLaunchKernelGGL(k_geo_eval, dim3(blocks), dim3(kEvalThreads), 0, s, b);
-#endif
+    if (a.probe_feat || a.probe_rows || a.probe_raw || a.probe_grad) hipLaunchKernelGGL(k_geo_eval32<true>, dim3(blocks32), dim3(kE32Threads), 0, s, a);
+    else hipLaunchKernelGGL(k_geo_eval32<false>, dim3(blocks32), dim3(kE32Threads), 0, s, a);
 }
 
 
@@ -1258,18 +894,17 @@ int envidr_geometry_pass(const envidr_render_desc* d, const float* rays_o, const
     a.ray_mask = d->ray_mask;
     uint32_t* alive[2] = {reinterpret_cast<uint32_t*>(ws + L.alive0), reinterpret_cast<uint32_t*>(ws + L.alive1)};
 
-    // chunk schedule: 16 samples, then each round extends what a ray has so far by half (16, 8, 12, 18, 27, 40 ...): a ray
-    // that terminates after n samples has had at most ~1.5 n evaluated.  A ray still alive after six rounds (121 samples)
-    // is crossing something thin or translucent and is given all that is left in one go (the counting pass allocates only
-    // what it can actually march): 7 rounds instead of 12 cover max_steps = 1024, and a frame whose rays are all done after
-    // the first round or two -- the hinted frames of a video -- pays for fewer empty launches.
-    uint32_t chunks[kMaxRounds], rounds = 0, covered = 0;
-    while (covered < d->max_steps && rounds < kMaxRounds - 1) {
-        const uint32_t grow = rounds == 0 ? 16u : std::max(8u, covered / 2);
-        chunks[rounds] = std::min(rounds >= 6 ? d->max_steps : grow, d->max_steps - covered);
-        covered += chunks[rounds++];
-    }
-    ENVIDR_REQUIRE(covered >= d->max_steps, "geometry_pass: max_steps %u exceeds what %u rounds cover", d->max_steps, kMaxRounds);
+    // Chunk schedule.  Round 0: the caller's per-ray hint, else 16 samples.  Rounds 1..5: each live ray sizes its own chunk
+    // (predicted_chunk: at least kMinChunk, at most what it has composited so far).  A ray still alive after six rounds is
+    // crossing something thin or translucent and is given ALL that is left in one go (the counting pass allocates only what
+    // it can actually march, bounded by max_steps - composited): whatever the hints and predictions were, seven rounds
+    // cover max_steps, and a frame whose rays are all done after the first round or two -- the hinted frames of a video --
+    // pays for few empty launches.
+    constexpr uint32_t kRounds = 7;
+    static_assert(kRounds + 2 <= kMaxRounds, "round-indexed counters");
+    uint32_t chunks[kRounds];
+    for (uint32_t r = 0; r < kRounds; ++r) chunks[r] = r == 0 ? std::min(16u, d->max_steps) : d->max_steps;
+    const uint32_t rounds = kRounds;
 
     if (hipMemsetAsync(counters, 0, kGeoCounterWords * 4, s) != hipSuccess) return check_launch("geometry_pass memset");
     // one cascade on a power-of-two grid (every scene of the reference): the marcher reads a linear-order copy of the bitfield
@@ -1291,6 +926,7 @@ int envidr_geometry_pass(const envidr_render_desc* d, const float* rays_o, const
     for (uint32_t r = 0; r <= rounds; ++r) {
         a.round = r;
         a.chunk = r < rounds ? chunks[r] : 0u;
+        a.predict = (r >= 1 && r + 1 < rounds) ? 1u : 0u;
         a.alive_in = alive[(r + 1) & 1];
         a.alive_out = alive[r & 1];
         const dim3 grid(r == 0 ? ray_blocks : std::min(ray_blocks, 1024u));
@@ -1342,6 +978,23 @@ int envidr_geometry_eval(const envidr_render_desc* d, const float* xyz, const fl
     a.alpha = out->alpha; a.sigma = out->sigma; a.normal = out->normal; a.geo = out->geo_feat; a.rough = out->roughness; a.blend = out->blend;
     launch_eval(a, M, as_stream(stream));
     return check_launch("k_geo_eval");
+}
+
+
+int envidr_geometry_probe(const envidr_render_desc* d, const float* xyz, uint32_t M, float* features, uint32_t* corner_rows,
+                          float* raw_outputs, float* sdf_gradient, envidr_stream_t stream) {
+    ENVIDR_REQUIRE(d, "geometry_probe: null descriptor");
+    if (M == 0) return ENVIDR_OK;
+    ENVIDR_REQUIRE(xyz && (features || corner_rows || raw_outputs || sdf_gradient), "geometry_probe: null sample pointer / nothing to export");
+    GeoEvalArgs a;
+    memset(&a, 0, sizeof(a));
+    const int rc = fill_eval_args(d, a, "geometry_probe");
+    if (rc) return rc;
+    a.sdf_e16_blob = nullptr;                   // the probe instantiation exists for k_geo_eval32, the kernel the frames run
+    a.xyz = xyz; a.M = M;
+    a.probe_feat = features; a.probe_rows = corner_rows; a.probe_raw = raw_outputs; a.probe_grad = sdf_gradient;
+    launch_eval(a, M, as_stream(stream));
+    return check_launch("k_geo_eval32<probe>");
 }
 
 }  // extern "C"

@@ -69,7 +69,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const float* table,
 // LANE_LEVEL: the level differs between lanes (its constants live in vector registers): the level's first row then goes
 // into the per-lane offset instead of the scalar offset of the buffer instruction
 template <int AUX = 0, bool LANE_LEVEL = false>
-__device__ __forceinline__ void lean_prepare(const LeanLevel& lv, __amdgpu_buffer_rsrc_t table, const float (&x)[3], LeanStage& st) {
+// rows_out (tests only, null in every production call): the eight corner rows within the level, index bx | by << 1 | bz << 2
+__device__ __forceinline__ void lean_prepare(const LeanLevel& lv, __amdgpu_buffer_rsrc_t table, const float (&x)[3], LeanStage& st,
+                                             uint32_t* rows_out = nullptr) {
     uint32_t cell[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -102,6 +104,10 @@ __device__ __forceinline__ void lean_prepare(const LeanLevel& lv, __amdgpu_buffe
             r1[j] = min(i1, i1 - lv.size);
             base[j] = min(r0[j], lv.size - 2u);           // the pair must not run past the level's last row
         }
+    }
+    if (rows_out) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { rows_out[2 * j] = r0[j]; rows_out[2 * j + 1] = r1[j]; }
     }
     uint32_t sel = 0;
     bool need = false;
@@ -164,45 +170,6 @@ __device__ __forceinline__ void lean_finish(const LeanStage& st, float m, float 
         g[1][ch] = fmaf(wz, F[1] - F[0], F[0]) * sy;
         g[2][ch] = G * sz;
     }
-}
-
-// value only (first sweep of a level whose Jacobian is not kept)
-__device__ __forceinline__ void lean_value(const LeanStage& st, float m, float (&out)[2]) {
-    float2 cc[8];
-    lean_corners(st, cc);
-    const float wx = st.w[0], wy = st.w[1], wz = st.w[2];
-#pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
-        float a[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const float c0 = ch ? cc[2 * j].y : cc[2 * j].x, c1 = ch ? cc[2 * j + 1].y : cc[2 * j + 1].x; a[j] = fmaf(wx, c1 - c0, c0); }
-        const float b0 = fmaf(wy, a[1] - a[0], a[0]), b1 = fmaf(wy, a[3] - a[2], a[2]);
-        out[ch] = fmaf(wz, b1 - b0, b0) * m;
-    }
-}
-
-// second sweep: d (g0 * value_0 + g1 * value_1) / d x01 accumulated into n[3] -- the level's share of J^T g without
-// ever materialising J: the corner rows are contracted with (g0, g1) first, then one scalar trilinear gradient
-__device__ __forceinline__ void lean_contract(const LeanStage& st, float m, float g0, float g1, float (&n)[3]) {
-    float2 cc[8];
-    lean_corners(st, cc);
-    const float wx = st.w[0], wy = st.w[1], wz = st.w[2];
-    float s[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s[i] = fmaf(cc[i].y, g1, cc[i].x * g0);
-    float D[4], a[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { D[j] = s[2 * j + 1] - s[2 * j]; a[j] = fmaf(wx, D[j], s[2 * j]); }
-    float F[2], b[2], E[2];
-#pragma unroll
-    for (int z = 0; z < 2; ++z) {
-        F[z] = a[2 * z + 1] - a[2 * z];
-        b[z] = fmaf(wy, F[z], a[2 * z]);
-        E[z] = fmaf(wy, D[2 * z + 1] - D[2 * z], D[2 * z]);
-    }
-    n[0] = fmaf(fmaf(wz, E[1] - E[0], E[0]), st.sdw[0] * m, n[0]);
-    n[1] = fmaf(fmaf(wz, F[1] - F[0], F[0]), st.sdw[1] * m, n[1]);
-    n[2] = fmaf(b[1] - b[0], st.sdw[2] * m, n[2]);
 }
 
 }  // namespace envidr

@@ -140,92 +140,15 @@ __device__ __forceinline__ f32x16 load_rowvec(const ParamBuf& p, int tile) {
 }
 
 // =============================================================================================
-// Workgroup-shared weight pipe (LDS)
+// Weight stream
 // =============================================================================================
-// The four waves of a workgroup (one per SIMD of a CU) run the same layer sequence, so they consume
-// the same A fragments in the same order.  Instead of every wave streaming every fragment from L2
-// (4x the traffic, and a per-wave register ring to hide the latency), the workgroup streams the
-// weights ONCE through a double-buffered LDS ring in 16 KiB chunks of 64 fragments:
-//
-//   boundary of chunk g:   __syncthreads()                      all waves are done with chunk g-1; chunk g is visible
-//                          staged registers (chunk g+1) -> LDS slot (g+1)&1   (loaded one chunk-time ago: landed)
-//                          issue global loads of chunk g+2 -> staged registers (in flight during chunk g)
-//   inside chunk g:        fragment f = one conflict-free ds_read_b32 (lane-consecutive) per MFMA
-//
-// Each wave moves a quarter of every chunk (4 x 16 B per lane).  Weights are laid out in memory in
-// consumption order ("pass blobs", padded to whole chunks, see pack_pass on the host side), so the
-// stream is a linear copy; at the end of a pass the prefetcher rolls over into the next pass's blob.
+// Weights are laid out in memory in consumption order ("pass blobs": the layers of a pass concatenated, zero-padded to
+// whole 16 KiB chunks of 64 fragments -- fused.py `blob`), so a pass is one linear stream of 256-byte fragments.
 constexpr int kChunkFrags = 64;
 constexpr int kChunkFloats = kChunkFrags * 64;      // 4096 floats = 16 KiB
 constexpr uint32_t kChunkBytes = kChunkFloats * 4;
 
-struct WeightPipe {
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    float* lds;                 // workgroup base of float[2][kChunkFloats]
-    uint32_t lane, wave;
-    uint32_t slot;              // LDS slot holding the chunk being consumed
-    const float* frag;          // lds + slot * kChunkFloats + lane  (this lane's column of the current chunk)
-    u32x4 stage[4];             // this wave's quarter of the NEXT-NEXT chunk, in flight / landed
-    __amdgpu_buffer_rsrc_t cur_rsrc, next_rsrc;
-    uint32_t cur_chunks;        // chunks in the current pass
-    uint32_t local;             // index of the chunk being consumed within the current pass
-
-    __device__ __forceinline__ static __amdgpu_buffer_rsrc_t rsrc_of(const float* blob, uint32_t chunks) {
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(blob), 0, (int)(chunks * kChunkBytes), 0x00020000);
-    }
-    __device__ __forceinline__ uint32_t voff() const { return (wave * 256u + lane) * 16u; }
-    __device__ __forceinline__ void load_stage(__amdgpu_buffer_rsrc_t r, uint32_t chunk) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) stage[i] = __builtin_amdgcn_raw_buffer_load_b128(r, voff(), chunk * kChunkBytes + (uint32_t)i * 1024u, 0);
-    }
-    __device__ __forceinline__ void store_stage(uint32_t to_slot) {
-        u32x4* dst = reinterpret_cast<u32x4*>(lds + to_slot * kChunkFloats) + wave * 256u + lane;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dst[i * 64] = stage[i];
-    }
-    // kernel prologue: chunk 0 of the first pass -> slot 0, chunk 1 -> staged
-    __device__ __forceinline__ void start(float* lds_base, uint32_t lane_, uint32_t wave_, const float* first_blob, uint32_t first_chunks) {
-        lds = lds_base; lane = lane_; wave = wave_;
-        cur_rsrc = next_rsrc = rsrc_of(first_blob, first_chunks);
-        cur_chunks = first_chunks;
-        load_stage(cur_rsrc, 0);
-        store_stage(1);                       // boundary 0 flips to slot... see begin_pass: first boundary makes slot 1 -> current
-        load_stage(cur_rsrc, 1);
-        slot = 0;                             // boundary() of the first chunk toggles to 1
-        local = 0xffffffffu;                  // so that the first boundary sees local + 1 == 0
-        frag = lds + lane;
-    }
-    // declare the pass that starts at the next boundary and the blob that follows it
-    __device__ __forceinline__ void begin_pass(const float* blob, uint32_t chunks, const float* next_blob, uint32_t next_chunks) {
-        cur_rsrc = rsrc_of(blob, chunks);
-        next_rsrc = rsrc_of(next_blob, next_chunks);
-        cur_chunks = chunks;
-        local = 0xffffffffu;
-    }
-    // called exactly once per chunk by every wave, before the chunk's first fragment is read
-    __device__ __forceinline__ void boundary() {
-        __syncthreads();
-        ++local;                                           // chunk `local` of the current pass is now consumed
-        slot ^= 1u;                                        // ... from this slot (written at the previous boundary)
-        store_stage(slot ^ 1u);                            // staged chunk local+1 (or the next pass's chunk 0) -> other slot
-        const uint32_t ahead = local + 2;                  // issue loads for the chunk after that
-        if (ahead < cur_chunks) load_stage(cur_rsrc, ahead);
-        else load_stage(next_rsrc, ahead - cur_chunks);
-        frag = lds + slot * kChunkFloats + lane;
-        // pin the prefetch HERE: left alone, the scheduler sinks these loads down to their use (the next
-        // boundary's LDS write) to shorten their live range, which exposes the whole L2 round trip there
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // fragment I of the current pass (I compile-time): chunk boundary every kChunkFrags fragments
-    template <int I, int FRAGS>
-    __device__ __forceinline__ float take() {
-        if constexpr (I % kChunkFrags == 0) boundary();
-        return frag[(I % kChunkFrags) * 64];
-    }
-    template <int FRAGS> __device__ __forceinline__ void end_pass() {}
-};
-
-// Per-wave alternative: every wave streams the pass blobs itself from L2 through a ring of PF registers
+// Every wave streams the pass blobs itself from L2 through a ring of PF registers
 // (fragment I lives in ring[I % PF]; taking it re-issues the load of fragment I + PF).  The ring runs
 // CONTINUOUSLY across layers, passes and rounds -- at the end of a pass it rolls over into the next
 // pass's blob -- so the L2 latency is exposed once per kernel, not once per layer.  Requires every
@@ -238,7 +161,7 @@ struct WeightRing {
     __device__ __forceinline__ static __amdgpu_buffer_rsrc_t rsrc_of(const float* blob, uint32_t chunks) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(blob), 0, (int)(chunks * kChunkBytes), 0x00020000);
     }
-    __device__ __forceinline__ void start(float*, uint32_t lane, uint32_t, const float* first_blob, uint32_t first_chunks) {
+    __device__ __forceinline__ void start(uint32_t lane, const float* first_blob, uint32_t first_chunks) {
         cur_rsrc = next_rsrc = rsrc_of(first_blob, first_chunks);
         lane_off = lane * 4u;
 #pragma unroll

@@ -35,10 +35,7 @@ namespace envidr {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr float kSplitMaxAct = 60000.0f;          // activations are clamped here before the fp16 split (fp16 max 65504)
-#ifndef ENVIDR_SPLIT_GROUP
-#define ENVIDR_SPLIT_GROUP 2
-#endif
-constexpr int kSplitGroup = ENVIDR_SPLIT_GROUP;
+constexpr int kSplitGroup = 2;                    // output tiles accumulated together (their fp16 conversion drains in the next group's MFMA gaps)
 
 enum SplitOrder : int { kSplitLaneOrder = 0, kSplitTileOrder = 1 };
 __host__ __device__ constexpr int split_k(SplitOrder o, int s, int h, int i) {
@@ -102,16 +99,7 @@ inline void pack_split_weight(const float* W, uint32_t m_out, uint32_t k_in, Spl
 }
 
 // ---- device side ------------------------------------------------------------------------------------------------------
-#ifndef ENVIDR_SPLIT_DEBUG
-#define ENVIDR_SPLIT_DEBUG 0
-#endif
-#ifndef ENVIDR_SPLIT_PIN
-#define ENVIDR_SPLIT_PIN 1        // 2: a scheduling barrier after every MFMA + filler piece, 1: one per reduction step, 0: none
-#endif
-#ifndef ENVIDR_SPLIT_CHUNK_FRAGS
-#define ENVIDR_SPLIT_CHUNK_FRAGS 32
-#endif
-constexpr int kSplitChunkFrags = ENVIDR_SPLIT_CHUNK_FRAGS;            // a chunk must outlast the L2 round trip of its successor's
+constexpr int kSplitChunkFrags = 32;            // a chunk must outlast the L2 round trip of its successor's
 constexpr uint32_t kSplitChunkBytes = kSplitChunkFrags * 1024u;       // prefetch: 32 KiB = 48 MFMAs = 1536 cycles; two of them in LDS
 constexpr int kSplitStage = kSplitChunkFrags / 4;                     // 16-byte registers per lane holding a quarter chunk in flight
 constexpr int split_pass_chunks(int frags) { return (frags + kSplitChunkFrags - 1) / kSplitChunkFrags; }
@@ -156,9 +144,6 @@ struct SplitWeightPipe {
         frag = lds + lane;
     }
     __device__ __forceinline__ void boundary() {
-#if ENVIDR_SPLIT_DEBUG == 2
-        slot ^= 1u; frag = lds + slot * (kSplitChunkFrags * 64u) + lane; return;          // timing experiment: no barrier, no streaming
-#endif
         __syncthreads();                                       // everybody is done reading the other slot, and done writing this one
         ++local;
         if (local == chunks) local = 0;                        // the next pass streams the same blob again
@@ -174,17 +159,11 @@ struct SplitWeightPipe {
     __device__ __forceinline__ half8 take() {
         constexpr int c = I % kSplitChunkFrags;
         if constexpr (c == 0) boundary();
-#if ENVIDR_SPLIT_DEBUG != 1 && ENVIDR_SPLIT_DEBUG != 2         // (timing experiments without the streaming)
         // piece c / 4 of the staged chunk (local + 1) goes to the other slot, and its register is refilled from chunk local + 2
         if constexpr (c % 4 == 1 && c / 4 < kSplitStage) {
-#if ENVIDR_SPLIT_DEBUG != 4                                     // (4: loads only, 5: LDS writes only -- timing experiments)
             store_piece<c / 4>(slot ^ 1u);
-#endif
-#if ENVIDR_SPLIT_DEBUG != 5
             load_piece<c / 4>(ahead_off);
-#endif
         }
-#endif
         return __builtin_bit_cast(half8, frag[c * 64]);
     }
 };
@@ -193,9 +172,7 @@ struct SplitWeightPipe {
 // in ring[I % PF]; taking it re-issues the read of fragment I + PF, rolling over into the next pass at the end): left to
 // the compiler, the four ds_read_b128 of a step are issued right in front of its MFMAs and every step waits out the LDS
 // latency (measured: 80 k instead of 30 k cycles per pass).  FRAGS must be a multiple of PF (end_pass pads).
-#ifndef ENVIDR_SPLIT_AHEAD
-#define ENVIDR_SPLIT_AHEAD 8
-#endif
+constexpr int kSplitAhead = 8;                    // fragments read from LDS ahead of the MFMAs that consume them
 template <int PF>
 struct SplitFragRing {
     SplitWeightPipe pipe;
@@ -223,49 +200,6 @@ struct SplitFragRing {
 __device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
     hi = (_Float16)v;
     lo = (_Float16)(v - (float)hi);
-}
-
-// reduction steps S .. NSTEPS-1 of one group of GT output tiles whose first fragment (of step 0) is FG; FRAGS: padded pass length
-template <int S, int NSTEPS, int GT, int FG, int FRAGS, class Ring>
-__device__ __forceinline__ void split_steps(Ring& wp, const half8 (&xh)[NSTEPS], const half8 (&xl)[NSTEPS], f32x16 (&acc)[GT]) {
-    if constexpr (S < NSTEPS) {
-        half8 ah[GT], al[GT];
-        [&]<int... T>(std::integer_sequence<int, T...>) {
-            ((ah[T] = wp.template take<FG + (S * GT + T) * 2, FRAGS>(), al[T] = wp.template take<FG + (S * GT + T) * 2 + 1, FRAGS>()), ...);
-            __builtin_amdgcn_sched_barrier(0);            // the reads issued above are for a LATER step: keep them ahead of these MFMAs
-            ((acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[T], xh[S], acc[T], 0, 0, 0)), ...);
-            ((acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[T], xl[S], acc[T], 0, 0, 0)), ...);
-            ((acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[T], xh[S], acc[T], 0, 0, 0)), ...);
-        }(std::make_integer_sequence<int, GT>{});
-        split_steps<S + 1, NSTEPS, GT, FG, FRAGS>(wp, xh, xl, acc);
-    }
-}
-
-// One layer.  xh / xl: the B operands (NSTEPS reduction steps of 16), F0: index of the layer's first fragment in the pass,
-// bias(t): the f32x16 the accumulator of output tile t starts from, emit(t, acc): called once per finished output tile.
-template <int NSTEPS, int MT, int F0, int FRAGS, int T0 = 0, class Ring, class Bias, class Emit>
-__device__ __forceinline__ void split_layer(Ring& wp, const half8 (&xh)[NSTEPS], const half8 (&xl)[NSTEPS], Bias&& bias, Emit&& emit) {
-    if constexpr (T0 < MT) {
-        constexpr int G = kSplitGroup, GT = (MT - T0) < G ? (MT - T0) : G, FG = F0 + 2 * NSTEPS * T0;
-        f32x16 acc[GT];
-#pragma unroll
-        for (int t = 0; t < GT; ++t) acc[t] = bias(T0 + t);
-        split_steps<0, NSTEPS, GT, FG, FRAGS>(wp, xh, xl, acc);
-        [&]<int... T>(std::integer_sequence<int, T...>) { (emit(std::integral_constant<int, T0 + T>{}, acc[T]), ...); }(std::make_integer_sequence<int, GT>{});
-        split_layer<NSTEPS, MT, F0, FRAGS, T0 + G>(wp, xh, xl, bias, emit);
-    }
-}
-
-// accumulator tile (bias included) -> ReLU -> the two reduction steps of the next layer it forms (tile order)
-__device__ __forceinline__ void split_tile_to_steps(const f32x16& v, half8& h0, half8& l0, half8& h1, half8& l1) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float a = __builtin_amdgcn_fmed3f(v[i], 0.0f, kSplitMaxAct);            // ReLU (+ fp16 range clamp)
-        const float b = __builtin_amdgcn_fmed3f(v[8 + i], 0.0f, kSplitMaxAct);
-        _Float16 hi, lo;
-        split_f16(a, hi, lo); h0[i] = hi; l0[i] = lo;
-        split_f16(b, hi, lo); h1[i] = hi; l1[i] = lo;
-    }
 }
 
 // accumulator registers 2 J, 2 J + 1 of a tile (bias included) -> ReLU -> their two slots of the reduction step (h, l) they belong to
@@ -322,14 +256,9 @@ __device__ __forceinline__ void split_steps_filled(Ring& wp, const half8 (&xh)[N
                 constexpr int kind = Q / GT, t = Q % GT;          // 0: a_hi b_hi, 1: a_hi b_lo, 2: a_lo b_hi
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kind == 2 ? al[t] : ah[t], kind == 1 ? xl[S] : xh[S], acc[t], 0, 0, 0);
                 if constexpr (S < ACT) fill.template piece<S * GAPS + Q, ACT * GAPS>();
-#if ENVIDR_SPLIT_PIN == 2
-                __builtin_amdgcn_sched_barrier(0);
-#endif
             }(), ...);
         }(std::make_integer_sequence<int, GAPS>{});
-#if ENVIDR_SPLIT_PIN == 1
-        __builtin_amdgcn_sched_barrier(0);
-#endif
+        __builtin_amdgcn_sched_barrier(0);          // one scheduling fence per reduction step
         split_steps_filled<S + 1, NSTEPS, GT, FG, FRAGS>(wp, xh, xl, acc, fill);
     }
 }

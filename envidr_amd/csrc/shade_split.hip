@@ -15,9 +15,6 @@ using namespace envidr;
 
 namespace {
 
-#ifndef ENVIDR_SPLIT_PIPED
-#define ENVIDR_SPLIT_PIPED 1
-#endif
 constexpr uint32_t kSplitThreads = 256;
 
 template <int IDE_DEG, int ENV_T>
@@ -27,7 +24,7 @@ struct EnvSplitLayout {
                          F4 = F3 + split_layer_frags(SH, ENV_T), Frags = F4 + split_layer_frags(SH, 1);
     // pass length in fragments: whole LDS chunks (the staging of the next chunk is driven by the takes of the current one) and a
     // multiple of the ring depth
-    static_assert(kSplitChunkFrags % ENVIDR_SPLIT_AHEAD == 0, "ring depth must divide the chunk");
+    static_assert(kSplitChunkFrags % kSplitAhead == 0, "ring depth must divide the chunk");
     static constexpr int Padded = (Frags + kSplitChunkFrags - 1) / kSplitChunkFrags * kSplitChunkFrags;
     static constexpr int Chunks = split_pass_chunks(Padded);
     static constexpr int BiasTiles = 3 * ENV_T + 1;
@@ -44,7 +41,7 @@ __global__ void __launch_bounds__(kSplitThreads, 1) k_env_split(const ShadeArgs 
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (uint32_t i = threadIdx.x; i < (uint32_t)L::BiasTiles * 32; i += kSplitThreads) s_bias[i] = bias[i];
     __syncthreads();
-    SplitFragRing<ENVIDR_SPLIT_AHEAD> wp;
+    SplitFragRing<kSplitAhead> wp;
     wp.start(s_w, lane, wave, blob, L::Chunks);
     const float* bias_lane = s_bias + (lane >> 5) * 16;
     auto bias_tile = [&](int tile) {
@@ -112,7 +109,6 @@ __global__ void __launch_bounds__(kSplitThreads, 1) k_env_split(const ShadeArgs 
 #pragma unroll
             for (int j = 0; j < S1; ++j) { xh[j] = grp ? inh[1][j] : inh[0][j]; xl[j] = grp ? inl[1][j] : inl[0][j]; }
             half8 ph[SH], pl[SH], qh[SH], ql[SH];
-#if ENVIDR_SPLIT_PIPED
             // every tile group's fp16 conversion runs in the MFMA gaps of the group after it (mlp_split.hip.h, "pending")
             f32x16 accA[kSplitGroup], accB[kSplitGroup], o;
             auto sink_p = [&](auto tc, auto jc, const f32x16& v) {
@@ -138,22 +134,6 @@ __global__ void __launch_bounds__(kSplitThreads, 1) k_env_split(const ShadeArgs 
                       });
                   });
               });
-#else
-            split_layer<S1, ENV_T, L::F1, L::Padded>(wp, xh, xl, [&](int t) { return bias_tile(t); }, [&](auto tc, const f32x16& v) {
-                constexpr int t = decltype(tc)::value;
-                split_tile_to_steps(v, ph[2 * t], pl[2 * t], ph[2 * t + 1], pl[2 * t + 1]);
-            });
-            split_layer<SH, ENV_T, L::F2, L::Padded>(wp, ph, pl, [&](int t) { return bias_tile(ENV_T + t); }, [&](auto tc, const f32x16& v) {
-                constexpr int t = decltype(tc)::value;
-                split_tile_to_steps(v, qh[2 * t], ql[2 * t], qh[2 * t + 1], ql[2 * t + 1]);
-            });
-            split_layer<SH, ENV_T, L::F3, L::Padded>(wp, qh, ql, [&](int t) { return bias_tile(2 * ENV_T + t); }, [&](auto tc, const f32x16& v) {
-                constexpr int t = decltype(tc)::value;
-                split_tile_to_steps(v, ph[2 * t], pl[2 * t], ph[2 * t + 1], pl[2 * t + 1]);
-            });
-            f32x16 o;
-            split_layer<SH, 1, L::F4, L::Padded>(wp, ph, pl, [&](int) { return bias_tile(3 * ENV_T); }, [&](auto, const f32x16& v) { o = v; });
-#endif
             wp.template end_pass<L::Frags, L::Padded>();
             if (grp == 0) outA = o; else outB = o;
         }

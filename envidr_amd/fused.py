@@ -133,6 +133,8 @@ def _bind_render(lib):
     lib.envidr_composite_records.restype = ctypes.c_int
     lib.envidr_geometry_eval.argtypes = [ctypes.POINTER(RenderDesc), _FP, _FP, ctypes.c_uint32, _FP, ctypes.POINTER(SamplesOut), _FP]
     lib.envidr_geometry_eval.restype = ctypes.c_int
+    lib.envidr_geometry_probe.argtypes = [ctypes.POINTER(RenderDesc), _FP, ctypes.c_uint32, _FP, _FP, _FP, _FP, _FP]
+    lib.envidr_geometry_probe.restype = ctypes.c_int
     lib.envidr_geometry_workspace_bytes.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
     lib.envidr_geometry_workspace_bytes.restype = ctypes.c_uint64
     lib.envidr_geometry_pass.argtypes = [ctypes.POINTER(RenderDesc), _FP, _FP, ctypes.c_uint32, ctypes.POINTER(RenderOut),
@@ -461,8 +463,18 @@ class FusedRenderer:
         """the box rays are intersected with (NeRFRenderer.aabb_infer); None = [-bound, bound]^3"""
         if aabb is None:
             self.desc.has_aabb = 0
+            self._aabb_key = None
             return
-        vals = [float(v) for v in (aabb.detach().cpu().reshape(-1).tolist() if isinstance(aabb, torch.Tensor) else np.asarray(aabb).reshape(-1))]
+        if isinstance(aabb, torch.Tensor):
+            # the host copy of a device buffer costs a synchronisation: keep it until the tensor is replaced or written to
+            key = (aabb.data_ptr(), aabb._version, aabb.device)
+            if self.__dict__.get("_aabb_key") == key and self.desc.has_aabb:
+                return
+            vals = [float(v) for v in aabb.detach().cpu().reshape(-1).tolist()]
+            self._aabb_key = key
+        else:
+            vals = [float(v) for v in np.asarray(aabb).reshape(-1)]
+            self._aabb_key = None
         if len(vals) != 6:
             raise _lib.EnvidrError("aabb must have six values: xmin, ymin, zmin, xmax, ymax, zmax")
         for i, v in enumerate(vals):
@@ -605,6 +617,21 @@ class FusedRenderer:
                                            M, None, ctypes.byref(so), torch.cuda.current_stream(dev).cuda_stream)
         if rc:
             raise _lib.EnvidrError(f"envidr_geometry_eval failed ({rc}): {self.lib.envidr_last_error().decode()}")
+        return out
+
+    def geometry_probe(self, xyz: torch.Tensor, want=("features", "corner_rows", "raw_outputs", "sdf_gradient")) -> dict:
+        """envidr_geometry_probe (test hook): what the hash section and the SDF network of the frames' geometry kernel compute for
+        positions [M,3]: features [M,32], corner_rows [M,16,8] int32 (bit pattern of uint32), raw_outputs [M,16], sdf_gradient [M,3]"""
+        xyz = xyz.contiguous().view(-1, 3).float()
+        M, dev = xyz.shape[0], xyz.device
+        spec = {"features": ((M, 32), torch.float32), "corner_rows": ((M, 16, 8), torch.int32), "raw_outputs": ((M, 16), torch.float32),
+                "sdf_gradient": ((M, 3), torch.float32)}
+        out = {k: torch.zeros(*spec[k][0], dtype=spec[k][1], device=dev) for k in want}
+        ptr = lambda k: out[k].data_ptr() if k in out else None
+        rc = self.lib.envidr_geometry_probe(ctypes.byref(self.desc), xyz.data_ptr(), M, ptr("features"), ptr("corner_rows"), ptr("raw_outputs"),
+                                            ptr("sdf_gradient"), torch.cuda.current_stream(dev).cuda_stream)
+        if rc:
+            raise _lib.EnvidrError(f"envidr_geometry_probe failed ({rc}): {self.lib.envidr_last_error().decode()}")
         return out
 
     def _frame_buffers(self, N: int, dev, samples_per_ray: float) -> dict:

@@ -27,6 +27,17 @@ def _state(N, nears, device):
             "alive": ids, "buf": ids, "spare": torch.empty(N, dtype=torch.int32, device=device), "t": nears.clone()}
 
 
+def fused_eligible(model, r_images=None, geometry_only=False, fused=True, ray_depth=None, perturb=False, bg_color=None, N=None,
+                   max_steps=1024, **_) -> bool:
+    """the preconditions under which run_cuda takes the fused path (one place: _render_indirect asks the same question
+    before it commits to the ray-mask form of the three passes, which only the fused path implements)"""
+    if not fused or ray_depth is not None or perturb or not 1 <= int(max_steps) <= 65535:
+        return False
+    if torch.is_tensor(bg_color) and not (bg_color.dim() == 2 and N is not None and bg_color.shape[0] == N):
+        return False
+    return bool(model.supports_fused(r_images=r_images, geometry_only=geometry_only))
+
+
 def run_cuda(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024,
              T_thresh=1e-4, get_normal_image=False, use_specular_color=True, early_stop_steps=-1, ray_depth=None,
              main_pass=True, r_images=None, geometry_only=False, grad_ray=False, bg_sphere=True, env_rot_radian=None,
@@ -54,12 +65,14 @@ def run_cuda(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, fo
     # ---------------- fused persistent kernel ----------------
     # a per-ray background (the sphere model) is blended after the fused render: it runs with background 0
     tensor_bg = bg_color if (torch.is_tensor(bg_color) and bg_color.dim() == 2 and bg_color.shape[0] == N) else None
-    scalar_bg = tensor_bg is not None or not torch.is_tensor(bg_color)
-    if (fused and ray_depth is None and not perturb and scalar_bg and max_steps == opt.max_steps and T_thresh == opt.T_thresh
-            and dt_gamma == opt.dt_gamma and self.supports_fused(r_images=r_images, geometry_only=geometry_only)):
+    if fused_eligible(self, r_images=r_images, geometry_only=geometry_only, fused=fused, ray_depth=ray_depth, perturb=perturb,
+                      bg_color=bg_color, N=N, max_steps=max_steps):
         fr = self.fused_renderer()
         fr.desc.bg_color = 0.0 if tensor_bg is not None else float(bg_color)
         fr.desc.min_near = float(self.min_near)
+        # per-call march parameters (the reflected pass of indirect rendering has its own max_steps; callers may pass their own
+        # T_thresh / dt_gamma): plain descriptor fields, read by the kernels at launch
+        fr.desc.max_steps, fr.desc.T_thresh, fr.desc.dt_gamma = int(max_steps), float(T_thresh), float(dt_gamma)
         fr.set_aabb(self.aabb_infer)               # the operator loop's near_far_from_aabb box, not just +-bound
         # The geometry pipeline (march rounds + sample-parallel hash / SDF kernel -> record shading -> composite;
         # FusedRenderer.render_frame) renders every fused configuration: both network families, the geometry-only first pass

@@ -301,6 +301,8 @@ class NeRFRenderer(nn.Module):
         ref_d = reflect_dir(-rays_d, normals)
         saved_bg, saved_near = kwargs.get("bg_color"), self.min_near
         bg = 0 if saved_bg is None else saved_bg
+        if geo.get("sphere_bg") is not None:
+            bg = geo["sphere_bg"].reshape(1, -1, 3)        # the background model's colours, computed by the first pass (reference renderer.py:466-467)
         self.min_near = dt * 2
         kw2 = dict(kwargs, bg_color=0, max_steps=self.opt.indir_max_steps, early_stop_steps=self.opt.indir_early_stop_steps,
                    force_all_rays=True)
@@ -332,9 +334,14 @@ class NeRFRenderer(nn.Module):
         """three passes (reference renderer.py:437-513): geometry only -> reflected rays -> main pass
         with the reflected radiance fed to the renv branch."""
         batch = self.opt.max_ray_batch_cuda
-        if (fused and kwargs.get("two_phase") is not False and (batch is None or batch <= 0 or rays_o.shape[1] <= batch)
-                and not torch.is_tensor(kwargs.get("bg_color")) and not kwargs.get("perturb")
-                and self.supports_fused(geometry_only=True) and self.supports_fused(r_images=rays_o.new_zeros(1, 1, 4))):
+        # the ray-mask form needs every one of its three passes to take run_cuda's fused branch (the operator loop has no
+        # ray_mask): ask run_cuda's own eligibility test, with each pass's arguments
+        gate = dict(fused=fused, ray_depth=kwargs.get("ray_depth"), perturb=kwargs.get("perturb", False))
+        if (kwargs.get("two_phase") is not False and (batch is None or batch <= 0 or rays_o.shape[1] <= batch)
+                and not torch.is_tensor(kwargs.get("bg_color"))
+                and render_func.fused_eligible(self, geometry_only=True, max_steps=kwargs.get("max_steps", 1024), **gate)
+                and render_func.fused_eligible(self, max_steps=self.opt.indir_max_steps, **gate)
+                and render_func.fused_eligible(self, r_images=rays_o.new_zeros(1, 1, 4), max_steps=kwargs.get("max_steps", 1024), **gate)):
             return self._render_indirect_masked(rays_o, rays_d, get_normal_image, use_specular_color, env_net_index, env_rot_radian, **kwargs)
         dt = 2 * SQRT3 / self.opt.indir_max_steps
         geo = self._run(rays_o, rays_d, get_normal_image=get_normal_image, main_pass=False, geometry_only=True,
@@ -348,6 +355,8 @@ class NeRFRenderer(nn.Module):
         ref_d = reflect_dir(-rays_d, normals)
         saved_bg, saved_near = kwargs.get("bg_color"), self.min_near
         bg = 0 if saved_bg is None else saved_bg
+        if geo.get("sphere_bg") is not None:
+            bg = geo["sphere_bg"].reshape(1, -1, 3)        # the background model's colours, computed by the first pass (reference renderer.py:466-467)
         self.min_near = dt * 2
         kw2 = dict(kwargs, bg_color=0, max_steps=self.opt.indir_max_steps, early_stop_steps=self.opt.indir_early_stop_steps,
                    force_all_rays=True)

@@ -22,15 +22,25 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
+def init_from_env(backend: str | None = None, force: bool = False) -> tuple[int, int, int]:
     """(rank, world, local_rank) from the torchrun environment; initialises the process group when
-    WORLD_SIZE > 1.  Rendezvous on 127.0.0.1 unless MASTER_ADDR says otherwise."""
+    WORLD_SIZE > 1 -- or, with `force`, also for a world of one (the collectives then run for real on a
+    single rank: how the multi-GPU code path is exercised on a one-GPU box).  Rendezvous on 127.0.0.1
+    unless MASTER_ADDR says otherwise."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            if world == 1:
+                import socket
+                s = socket.socket()
+                s.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+                s.close()
+            else:
+                os.environ["MASTER_PORT"] = "29500"
         # the host driver only supports dmabuf IPC; without this RCCL fails with hipIpcGetMemHandle: invalid argument
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:

@@ -177,12 +177,14 @@ def make_mlp(rng, dims):
 
 
 def toaster_scene(table_scale: float = 0.1, shape=None, sdf_bias: float = 0.005, beta: float = 0.01,
-                  hidden_env: int = 256, ide_deg: int = 5, seed: int = 0) -> SceneParams:
+                  hidden_env: int = 256, ide_deg: int = 5, seed: int = 0, arrays: bool = True) -> SceneParams:
     """The BASELINE config-#3 network (configs/scenes/toaster.ini shapes) with seeded
-    weights on an analytic occupancy shape; defaults reproduce the survey's probe scene."""
+    weights on an analytic occupancy shape; defaults reproduce the survey's probe scene.
+    arrays=False leaves out the two big arrays (table, bitfield: None) -- for ranks that receive them by broadcast."""
     rng = np.random.default_rng(seed)
     offsets, pls = hash_level_offsets()
-    table = np.random.default_rng(seed + 1).uniform(-table_scale, table_scale, size=(int(offsets[-1]), 2)).astype(np.float32)
+    table = (np.random.default_rng(seed + 1).uniform(-table_scale, table_scale, size=(int(offsets[-1]), 2)).astype(np.float32)
+             if arrays else None)
     ide_dim = (2 ** ide_deg - 1 + ide_deg) * 2
     mlps = {
         "sdf": make_mlp(rng, [32, 64, 64, 15]),
@@ -193,7 +195,7 @@ def toaster_scene(table_scale: float = 0.1, shape=None, sdf_bias: float = 0.005,
     }
     mlps["sdf"][-1][1][0] = sdf_bias            # mean sdf slightly positive -> sigma ~ 1/(2 beta) scale
     mlps["specular"][-1][1][:] -= math.log(3)   # network.py:332: lower specular at init
-    bitfield = occupancy_bitfield(shape or shell())
+    bitfield = occupancy_bitfield(shape or shell()) if arrays else None
     return SceneParams(bitfield=bitfield, offsets=offsets, per_level_scale=pls, table=table, mlps=mlps, beta=beta)
 
 

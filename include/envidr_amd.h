@@ -34,7 +34,7 @@ extern "C" {
 typedef void* envidr_stream_t;     /* hipStream_t */
 
 const char* envidr_last_error(void);
-/* ABI version of this library: bumped on any signature or struct-layout change (currently 2). */
+/* ABI version of this library: bumped on any signature or struct-layout change and when entry points are added (see csrc/capi.hip for the history). */
 int envidr_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------

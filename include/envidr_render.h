@@ -280,6 +280,19 @@ typedef struct envidr_geometry_samples_out {
 int envidr_geometry_eval(const envidr_render_desc* desc, const float* xyz, const float* dt, uint32_t M,
                          const uint32_t* range_dev, const envidr_geometry_samples_out* out, envidr_stream_t stream);
 
+/* ABI 6, TEST HOOK: what the hash section and the SDF network of the geometry kernel (k_geo_eval32, the kernel every frame of
+ * the pipeline runs) compute for positions xyz [M,3], before any per-sample term is derived from it -- so that the benchmarked
+ * gather path can be compared with the reference's index arithmetic (hashencoder/src/hashencoder.cu:36-69,103-254) as integers
+ * and per value, not only through rendered images.  Any output may be NULL:
+ *   features     [M,32]    hash features as they enter the network (level-major, 2 channels; zeros outside the unit cube)
+ *   corner_rows  [M,16,8]  row within its level of corner bx | by << 1 | bz << 2 (the reference's `(index % hashmap_size)`);
+ *                          for positions outside the cube the rows of the clamped stand-in position (their features are masked)
+ *   raw_outputs  [M,16]    the last SDF layer's outputs 0..15 (0 = sdf, 1..12 = geo_feat before normalisation, 13 = roughness
+ *                          logit, 14 = blend logit, 15 = padding)
+ *   sdf_gradient [M,3]     d sdf / d xyz before normalisation */
+int envidr_geometry_probe(const envidr_render_desc* desc, const float* xyz, uint32_t M, float* features, uint32_t* corner_rows,
+                          float* raw_outputs, float* sdf_gradient, envidr_stream_t stream);
+
 /* The geometry half of a frame as a device-driven pipeline (two-phase frames; envidr_amd/csrc/geometry_pass.hip):
  *     nerf/render_func/cuda_ray.py:277-346  the march -> evaluate -> composite -> compact loop, geometry part
  * Rays march in chunks (16, 32, ... samples); each round one per-ray kernel composites the previous chunk (appending

@@ -462,6 +462,36 @@ API int oracle_hash_encode_forward(const float* inputs, const float* embeddings,
     if (D != 2 && D != 3) return -1;
     return grid_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, calc_grad_inputs ? dy_dx : NULL, 1, 0, 0);
 }
+/* The table rows kernel_grid<float,3,C> reads for one point: for every level the eight corners
+ * pos_grid_local = cell + (bit d of idx) (hashencoder.cu:175-190), each through get_grid_index (:55-70) =
+ * grid_row() above; rows_out [B, L, 8], corner index = idx (bit d <-> dimension d).  Points outside [0,1]^3 read nothing
+ * (:124-149): their rows are written as 0xffffffff.  Test hook for the index arithmetic of GPU gather paths. */
+API int oracle_hash_corner_rows(const float* inputs, const int32_t* offsets, uint32_t* rows_out, uint32_t B, uint32_t L, float S,
+                                uint32_t H) {
+    const uint32_t D = 3;
+    for (uint32_t l = 0; l < L; ++l) {
+        const float scale = exp2f(l * S) * H - 1.0f;
+        const uint32_t resolution = (uint32_t)ceilf(scale) + 1;
+        const uint32_t size = (uint32_t)(offsets[l + 1] - offsets[l]);
+#pragma omp parallel for schedule(static)
+        for (int64_t b = 0; b < (int64_t)B; ++b) {
+            const float* x = inputs + (size_t)b * D;
+            uint32_t* out = rows_out + ((size_t)b * L + l) * 8;
+            int oob = 0;
+            for (uint32_t d = 0; d < D; ++d) if (x[d] < 0 || x[d] > 1) oob = 1;
+            if (oob) { for (uint32_t i = 0; i < 8; ++i) out[i] = 0xffffffffu; continue; }
+            uint32_t cell[3];
+            for (uint32_t d = 0; d < D; ++d) cell[d] = (uint32_t)floorf(x[d] * scale);
+            for (uint32_t idx = 0; idx < 8; ++idx) {
+                uint32_t q[3];
+                for (uint32_t d = 0; d < D; ++d) q[d] = cell[d] + ((idx >> d) & 1u);
+                out[idx] = grid_row(q, D, size, resolution, 1);
+            }
+        }
+    }
+    return 0;
+}
+
 /* gridencoder.cu:423-450 */
 API int oracle_grid_encode_forward(const float* inputs, const float* embeddings, const int32_t* offsets, float* outputs,
                                    uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, float* dy_dx,

@@ -34,3 +34,19 @@ def test_single_rank_and_torchrun_style_environment():
     # a rank launched by torch.distributed.run (environment already set) does not spawn again
     j = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--stub"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert j["n_gpus"] == 1
+
+
+def test_strong_scaling_mode_shards_one_frame_by_tiles():
+    """--scaling strong: every rank renders its interleaved 8x8-pixel tiles of ONE frame, rank 0 gathers (padded: the shards are
+    ragged for 3 ranks on a 16x16 frame) and assembles; the stub's pixels carry their ray ids, checked inside bench.py"""
+    for gpus in (2, 3):
+        j = _run(["--gpus", str(gpus), "--steps", "3", "--warmup", "2", "--stub", "--scaling", "strong"])
+        assert j["n_gpus"] == gpus and j["scaling"] == "strong" and j["dist"]["gathered_equals_rendered"] is True
+        assert j["config"]["rays_per_step_per_gpu"] in (128, 64) and j["value"] > 0
+
+
+def test_force_dist_runs_one_rank_through_the_collective_path():
+    j = _run(["--gpus", "1", "--steps", "3", "--warmup", "2", "--stub", "--force-dist"])
+    assert j["n_gpus"] == 1 and j["dist"]["world"] == 1 and j["dist"]["force_dist"] is True and j["dist"]["gathered_equals_rendered"] is True
+    j = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--stub", "--force-dist", "--scaling", "strong"])
+    assert j["scaling"] == "strong" and j["dist"]["gathered_equals_rendered"] is True

@@ -148,8 +148,9 @@ def test_full_size_counts_equal_the_persistent_kernel(renderer):
 
 
 def test_frames_do_not_depend_on_the_hint(renderer):
-    """the per-ray count hint only sizes allocations: exact, absent, over-estimating (zero-filled slots inside the blocks'
-    sample-major layout), under-estimating (extra rounds) and garbage hints all give the same frame, bit for bit"""
+    """the per-ray count hint only sizes allocations: exact, absent (16 samples, then chunks predicted per ray from its
+    transmittance and last opacity), over-estimating (zero-filled slots inside the blocks' sample-major layout),
+    under-estimating (extra rounds, predicted chunks again), all-ones and garbage hints all give the same frame, bit for bit"""
     import torch
     ro_, rd_ = (torch.from_numpy(a).cuda() for a in scenes.camera_rays(160, 160, theta=65.0, phi=35.0))
     N = ro_.shape[0]
@@ -164,6 +165,7 @@ def test_frames_do_not_depend_on_the_hint(renderer):
         "under": (exact.to(torch.int32) // 2).to(exact.dtype),
         "garbage": torch.randint(0, 200, (N,), device="cuda", generator=gen, dtype=torch.int32).to(exact.dtype),
         "over on rays that miss": torch.full_like(exact, 25),
+        "ones": torch.ones_like(exact),
     }
     for name, h in hints.items():
         st["cost"].copy_(h)
@@ -173,6 +175,37 @@ def test_frames_do_not_depend_on_the_hint(renderer):
         torch.cuda.synchronize()
         assert torch.equal(got["ray_cost"], exact), name
         for k in keys:
+            assert torch.equal(got[k], want[k]), (name, k)
+
+
+def test_rays_that_run_to_max_steps_are_complete_under_any_hint():
+    """a ray whose sample count is max_steps (the cube's diagonal through a transparent, fully occupied grid) gets every one of
+    its samples whatever its hint was: the last scheduled round hands out all that is left, not max_steps minus what an
+    un-hinted ray would have had by then (a hint of 1 used to truncate such a ray by up to 15 samples)"""
+    import dataclasses
+    import torch
+    from envidr_amd.fused import FusedOptions, FusedRenderer
+    base = scenes.toaster_scene(sdf_bias=0.2)                     # sigma ~ 1e-7: nothing terminates on transmittance
+    full = dataclasses.replace(base, bitfield=np.full_like(base.bitfield, 255))
+    r = FusedRenderer.from_scene(full, FusedOptions(bound=full.bound, grid_size=full.grid_size, min_near=0.05))
+    d0 = -np.ones(3) / np.sqrt(3)
+    rng = np.random.default_rng(4)
+    d = d0 + rng.normal(scale=2e-3, size=(96, 3)); d[:8] = d0
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    ro_ = torch.tensor(np.tile([[1.5, 1.5, 1.5]], (96, 1)), dtype=torch.float32, device="cuda")
+    rd_ = torch.tensor(d, dtype=torch.float32, device="cuda")
+    want = {k: v.clone() for k, v in r.render_frame(ro_, rd_, None, use_cost_hint=False, samples_per_ray_hint=1100).items() if hasattr(v, "clone")}
+    counts = want["ray_cost"].to(torch.int32)
+    assert int(counts.max()) >= 1024 - 2 and int(counts.min()) > 900, (int(counts.max()), int(counts.min()))
+    st = r._frames[96]
+    for name, h in {"ones": torch.ones_like(want["ray_cost"]), "short": (counts // 3).to(torch.int16), "exact": want["ray_cost"].clone()}.items():
+        st["cost"].copy_(h)
+        for tag in list(st["costs"]):
+            st["costs"][tag].copy_(h)
+        got = r.render_frame(ro_, rd_, None, use_cost_hint=True, samples_per_ray_hint=1100)
+        torch.cuda.synchronize()
+        assert torch.equal(got["ray_cost"], want["ray_cost"]), (name, int((got["ray_cost"].int() - counts).abs().max()))
+        for k in ("image", "depth", "weights_sum", "normal_image"):
             assert torch.equal(got[k], want[k]), (name, k)
 
 

@@ -109,11 +109,9 @@ def test_config0_demo_sphere_matches_notebook():
     pose = scenes.nerf_matrix_to_ngp(scenes.pose_spherical(float(g["theta"]), -float(g["phi"]), float(g["radius"])), scale=1.0)
     ro_, rd_ = scenes.get_rays(pose, scenes.intrinsics_for(res, res), res, res)
     o, d = torch.from_numpy(ro_), torch.from_numpy(rd_)
-    b = (d * o).sum(-1, keepdim=True)
-    nabla = b ** 2 - (o.norm(2, 1, keepdim=True) ** 2 - 1.0)
-    mask = (nabla >= -1e-4)[..., 0]
-    assert np.array_equal(mask.numpy(), g["mask"])
-    near = -b - torch.sqrt(nabla.clamp_min(0.0))
+    from envidr_amd.nerf.render_func.sph_ray import get_sphere_intersections        # the product's host-side geometry of configs[0]
+    near, far, mask = get_sphere_intersections(o, d)
+    assert np.array_equal(mask.numpy(), g["mask"]) and bool((far[mask] >= near[mask]).all())
     dirs, normals = d[mask], o[mask] + d[mask] * near[mask]
     h = torch.cat([torch.from_numpy(g["xyz_encoding"]), torch.tensor([float(g["roughness"]), float(g["metallic"])]),
                    torch.from_numpy(g["base_color"])])[None]

@@ -86,3 +86,40 @@ def test_tile_shard_is_a_partition():
         assert sum(sizes) == H * W
     # 800x800 over 8 ranks is perfectly balanced and every shard is whole 64-ray tiles
     assert set(parallel.shard_sizes(800, 800, 8)) == {80000}
+
+
+def _scene_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    parallel.init_from_env(backend="gloo")
+    import bench
+    sc = bench.load_scene(rank, world, True, torch.device("cpu"))
+    import hashlib
+    q.put((rank, hashlib.sha256(sc.table.numpy().tobytes()).hexdigest(), hashlib.sha256(sc.bitfield.numpy().tobytes()).hexdigest(),
+           float(sc.mlps["env"][1][0][3, 5]), tuple(sc.table.shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_scene_is_generated_once_and_broadcast():
+    """bench.load_scene: rank 0 generates the 48.8 MB table and the bitfield, the other ranks receive them by broadcast (and
+    generate only the small MLPs from the seed): every rank ends up with the same scene as a locally generated one"""
+    import hashlib
+    import sys
+    from pathlib import Path
+    from envidr_amd import scenes
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_scene_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = scenes.toaster_scene()
+    th, bh = hashlib.sha256(want.table.tobytes()).hexdigest(), hashlib.sha256(want.bitfield.tobytes()).hexdigest()
+    for rank, t, b, w, shape in results:
+        assert (t, b) == (th, bh) and w == float(want.mlps["env"][1][0][3, 5]) and shape == want.table.shape, rank
+    assert scenes.toaster_scene(arrays=False).table is None

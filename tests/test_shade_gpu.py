@@ -21,44 +21,33 @@ def sequential(g, name):
 
 
 def test_demo_sphere_surface_rendering():
+    """BASELINE configs[0] through the PRODUCT entry point (envidr_amd.nerf.render_func.sph_ray.render_surface: sphere hit ->
+    FusedShader -> composition), against the notebook's own images"""
     import torch
-    import torch.nn.functional as F
     from envidr_amd.fused import FusedShader
+    from envidr_amd.nerf.render_func import sph_ray
     g = np.load(GOLD / "demo_sphere.npz")
     res = int(g["res"])
-    # rays and the sphere hit exactly as the notebook computes them (cells 5, 7, 17): host-side plumbing in torch
     pose = scenes.nerf_matrix_to_ngp(scenes.pose_spherical(float(g["theta"]), -float(g["phi"]), float(g["radius"])), scale=1.0)
     ro, rd = scenes.get_rays(pose, scenes.intrinsics_for(res, res), res, res)
     ro, rd = torch.from_numpy(ro).cuda(), torch.from_numpy(rd).cuda()
-    b = (rd * ro).sum(-1, keepdim=True)
-    nabla = b ** 2 - (ro.norm(2, 1, keepdim=True) ** 2 - 1.0)
-    near = -b - torch.sqrt(nabla.clamp_min(0.0))
-    mask = (nabla >= -1e-4)[..., 0]
-    assert np.array_equal(mask.cpu().numpy(), g["mask"])
-    dirs = rd[mask]
-    normals = ro[mask] + dirs * near[mask]                  # unit sphere: the hit point is the normal
-    # the material network on the single constant hash feature (1 x 37 -> 14): host-side, one vector
-    sdf = sequential(g, "sdf_net")
-    h = torch.cat([torch.from_numpy(g["xyz_encoding"]), torch.tensor([float(g["roughness"]), float(g["metallic"])]),
-                   torch.from_numpy(g["base_color"])])[None]
-    for i, (W, bias) in enumerate(sdf):
-        h = F.linear(h, torch.from_numpy(W), torch.from_numpy(bias))
-        if i < len(sdf) - 1:
-            h = F.relu(h)
-    geo_feat = F.normalize(h[..., 1:13], dim=-1)[0]
-    kappa_inv = 1.0 * F.softplus(h[..., -1] - 1)[0]
+    geo_feat, kappa_inv = sph_ray.material_features(sequential(g, "sdf_net"), torch.from_numpy(g["xyz_encoding"]).cuda(), float(g["roughness"]),
+                                                    float(g["metallic"]), [float(v) for v in g["base_color"]])
     assert abs(float(kappa_inv) - float(g["kappa_inv"])) < 1e-6
     shader = FusedShader({"env": sequential(g, "env_net"), "diffuse": sequential(g, "diffuse_net"),
                           "specular": sequential(g, "specular_net")}, ide_degree=4, diffuse_kappa_inv=0.64)
-    out = shader.shade(normals, dirs, geo_feat.cuda(), kappa_inv.cuda())
+    out = sph_ray.render_surface(shader, ro, rd, geo_feat, kappa_inv)
     torch.cuda.synchronize()
-    bg = torch.ones(res * res, 3, device="cuda")
-    for key, val in [("diffuse", out["c_diffuse"]), ("specular", out["c_specular"]), ("image", out["c_diffuse"] + out["c_specular"])]:
-        img = bg.masked_scatter(mask[:, None], val).cpu().numpy()
-        err = rel_l2(img, g[key])
+    assert np.array_equal(out["mask"].cpu().numpy(), g["mask"])
+    for key, name in [("diffuse", "diffuse_image"), ("specular", "specular_image"), ("image", "image")]:
+        err = rel_l2(out[name].cpu().numpy(), g[key])
         assert err <= 1e-4, f"{key}: rel-L2 {err:.3e}"
     # SURVEY.md section 6 anchor (400 x 400): recomputed by the generator from the same notebook run
     assert np.allclose(g["mean_rgb_400"], [0.62849, 0.70200, 0.82242], atol=2e-5)
+    # rays that all miss: background only
+    miss = sph_ray.render_surface(shader, ro[:5] * 0 + torch.tensor([0.0, 0.0, 4.0], device="cuda"), ro[:5] * 0 + torch.tensor([0.0, 1.0, 0.0], device="cuda"),
+                                  geo_feat, kappa_inv)
+    assert not miss["mask"].any() and torch.all(miss["image"] == 1)
 
 
 @pytest.mark.parametrize("tag", ["toaster", "toaster_rot"])

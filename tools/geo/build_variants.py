@@ -1,60 +1,77 @@
-"""Build experiment variants of the geometry kernel: libenvidr_amd.so re-linked with geometry_pass.hip compiled under
-different -D switches (tools/geo/variants/<name>.so; selected at run time through ENVIDR_AMD_LIB)."""
-import subprocess, sys
+"""Build experiment variants of the fused kernels WITHOUT build switches in the product sources: every variant is a set of
+textual patches applied to a scratch copy of envidr_amd/csrc (tools/geo/variants/<name>/src), whose patched translation unit
+is compiled and linked with the product's other objects into tools/geo/variants/<name>.so (selected at run time through
+ENVIDR_AMD_LIB).  A patch whose `old` text is not found exactly once is an error, so variants cannot silently rot.
+
+    python tools/geo/build_variants.py [name ...]
+
+Earlier forms of the kernels that these switches used to select (the 64-samples-per-wave k_geo_eval, Jacobian parked in global
+scratch, LDS-shared weight stream of the persistent kernel, un-piped split layers, section timers) were removed from the
+sources in round 3; they are in the history up to commit 42365ab.
+"""
+import shutil
+import subprocess
+import sys
 from pathlib import Path
+
 ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
-from envidr_amd import build as B
+from envidr_amd import build as B  # noqa: E402
 
+# name -> (translation unit, [(file, old, new), ...])
 VARIANTS = {
-    "k32": [],
-    "k32_a1": ["-DENVIDR_GEO_AHEAD=1"],
-    "k32_a3": ["-DENVIDR_GEO_AHEAD=3"],
-    "k64": ["-DENVIDR_GEO_KERNEL32=0", "-DENVIDR_GEO_KERNEL16=0"],
-    "k32only": ["-DENVIDR_GEO_KERNEL16=0"],
-    "k16": [],
-    "k16_a1": ["-DENVIDR_GEO_AHEAD=1"],
-    "k16_a3": ["-DENVIDR_GEO_AHEAD=3"],
-    "k16_w16_a1": ["-DENVIDR_GEO_E16_WAVES=16", "-DENVIDR_GEO_AHEAD=1"],
-    "k16_w8": ["-DENVIDR_GEO_E16_WAVES=8"],
-    "rays_dbg1": ["-DENVIDR_GEO_RAYS_DEBUG=1"],
-    "rays_dbg2": ["-DENVIDR_GEO_RAYS_DEBUG=2"],
+    "base": ("geometry_pass", []),
+    "geo_ahead1": ("geometry_pass", [("geometry_pass.hip", "constexpr int kGeoAhead = 2;", "constexpr int kGeoAhead = 1;")]),
+    "geo_ahead3": ("geometry_pass", [("geometry_pass.hip", "constexpr int kGeoAhead = 2;", "constexpr int kGeoAhead = 3;")]),
+    "geo_ring4": ("geometry_pass", [("geometry_pass.hip", "constexpr int kGeoRing = 8;", "constexpr int kGeoRing = 4;")]),
+    "e16_waves16": ("geometry_pass", [("geo_eval16.hip.h", "constexpr int kE16Waves = 12;", "constexpr int kE16Waves = 16;")]),
+    "e16_waves8": ("geometry_pass", [("geo_eval16.hip.h", "constexpr int kE16Waves = 12;", "constexpr int kE16Waves = 8;")]),
+    # chunk prediction off: every live ray takes the round's cap (its count at most doubles per round)
+    "no_chunk_prediction": ("geometry_pass", [("geometry_pass.hip", "a.predict = (r >= 1 && r + 1 < rounds) ? 1u : 0u;", "a.predict = 0u;"),
+                                              ("geometry_pass.hip", "chunks[r] = r == 0 ? std::min(16u, d->max_steps) : d->max_steps;",
+                                               "chunks[r] = r == 0 ? std::min(16u, d->max_steps) : (r < 6 ? std::min(d->max_steps, 8u << r) : d->max_steps);")]),
+    "first_chunk12": ("geometry_pass", [("geometry_pass.hip", "std::min(16u, d->max_steps)", "std::min(12u, d->max_steps)")]),
+    "first_chunk24": ("geometry_pass", [("geometry_pass.hip", "std::min(16u, d->max_steps)", "std::min(24u, d->max_steps)")]),
+    "split_group4": ("shade_split", [("mlp_split.hip.h", "constexpr int kSplitGroup = 2;", "constexpr int kSplitGroup = 4;")]),
+    "split_ahead4": ("shade_split", [("mlp_split.hip.h", "constexpr int kSplitAhead = 8;", "constexpr int kSplitAhead = 4;")]),
+    "ring16": ("fused_render", [("fused_render.hip", "constexpr int kRingDepth = 32;", "constexpr int kRingDepth = 16;")]),
 }
 
-SPLIT_VARIANTS = {
-    "split": [],
-    "split_nostream": ["-DENVIDR_SPLIT_DEBUG=1"],
-    "split_nobarrier": ["-DENVIDR_SPLIT_DEBUG=2"],
-    "split_noconv": ["-DENVIDR_SPLIT_DEBUG=3"],
-    "split_loadsonly": ["-DENVIDR_SPLIT_DEBUG=4"],
-    "split_writesonly": ["-DENVIDR_SPLIT_DEBUG=5"],
-    "split_g4": ["-DENVIDR_SPLIT_GROUP=4"],
-    "split_pin0": ["-DENVIDR_SPLIT_PIN=0"],
-    "split_pin1": ["-DENVIDR_SPLIT_PIN=1"],
-    "split_pin2": ["-DENVIDR_SPLIT_PIN=2"],
-    "split_unpiped": ["-DENVIDR_SPLIT_PIPED=0"],
-    "split_pf4": ["-DENVIDR_SPLIT_AHEAD=4"],
-}
 
 def main(names):
     B.build(verbose=False)
     out = ROOT / "tools" / "geo" / "variants"
     out.mkdir(exist_ok=True)
     for name in names or VARIANTS:
-        src = "shade_split" if name in SPLIT_VARIANTS else "geometry_pass"
-        objs = [str(o) for o in sorted((B.CSRC / "build").glob("*.o")) if o.stem != src]
-        flags = SPLIT_VARIANTS[name] if name in SPLIT_VARIANTS else VARIANTS[name]
+        unit, patches = VARIANTS[name]
+        # same depth below the repository root as envidr_amd/csrc: the sources include "../../include/*.h"
+        src = out / name / "csrc"
+        if src.parent.exists():
+            shutil.rmtree(src.parent)
+        shutil.copytree(B.CSRC, src, ignore=shutil.ignore_patterns("build", "*.o"))
+        inc = out / "include"
+        if inc.is_symlink() or inc.exists():
+            inc.unlink()
+        inc.symlink_to(ROOT / "include")
+        for fname, old, new in patches:
+            text = (src / fname).read_text()
+            if text.count(old) != 1:
+                raise SystemExit(f"variant {name}: patch text not found exactly once in {fname}: {old!r}")
+            (src / fname).write_text(text.replace(old, new))
         obj = out / f"{name}.o"
-        cmd = [B.hipcc(), *B.HIPCC_FLAGS, *flags, "-Rpass-analysis=kernel-resource-usage", "-c", str(B.CSRC / f"{src}.hip"), "-o", str(obj)]
+        cmd = [B.hipcc(), *B.HIPCC_FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", str(src / f"{unit}.hip"), "-o", str(obj)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
-            print(name, "FAILED\n", r.stderr[-3000:]); continue
-        info = [l.split("remark:")[1].strip().replace("[-Rpass-analysis=kernel-resource-usage]", "") for l in r.stderr.splitlines()
-                if any(k in l for k in ("VGPRs:", "VGPRs Spill", "ScratchSize", "LDS Size"))]
+            print(name, "FAILED\n", r.stderr[-3000:])
+            continue
+        info = [line.split("remark:")[1].strip().replace("[-Rpass-analysis=kernel-resource-usage]", "") for line in r.stderr.splitlines()
+                if any(k in line for k in ("VGPRs:", "VGPRs Spill", "ScratchSize", "LDS Size"))]
+        objs = [str(o) for o in sorted((B.CSRC / "build").glob("*.o")) if o.stem != unit]
         lib = out / f"{name}.so"
         r = subprocess.run([B.hipcc(), f"--offload-arch={B.ARCH}", "-shared", "-fPIC", "-fno-gpu-rdc", *objs, str(obj), "-o", str(lib)],
                            capture_output=True, text=True)
-        print(name, "|", " ".join(info), "|", "link ok" if r.returncode == 0 else r.stderr[-500:])
+        print(name, "|", " ".join(info)[:600], "|", "link ok" if r.returncode == 0 else r.stderr[-500:])
+
 
 if __name__ == "__main__":
     main(sys.argv[1:])
