@@ -380,7 +380,8 @@ struct RayState {
 //  slots -- kept for every lane of a live block: the sample-major slot layout of the block is defined by these counts)
 
 // counters (device uint32[kGeoCounterWords]), zeroed by the host before every frame
-constexpr uint32_t kCntSampleHead = 0, kCntRecordHead = 1, kCntOverflow = 2, kCntAlive = 8, kCntBegin = 40, kCntOcc = 72, kGeoCounterWords = 80;
+constexpr uint32_t kCntSampleHead = 0, kCntRecordHead = 1, kCntOverflow = 2, kCntAlive = 8, kCntBegin = 40, kCntOcc = 72, kCntSpare = 80, kGeoCounterWords = 256;
+// (words kCntSpare .. : unused by the product, zeroed with the rest; the timer variant of tools/geo/build_variants.py accumulates there)
 // kCntOcc + 0..2: max over occupied cells of (H - 1 - coordinate) (i.e. the minimum, as a maximum: the words start at zero),
 // kCntOcc + 3..5: max coordinate; written by k_linearize_bitfield
 constexpr uint32_t kMaxRounds = 30;     // counter words reserved per round-indexed array
@@ -423,18 +424,26 @@ struct GeoRayArgs {
 // gets an empty range).  Beyond that point the marcher can only skip empty cells until it runs out at `far`, so the
 // samples are the same; what goes away is that walk -- ~200 cells for every ray that misses the object, the longest
 // lanes of the first round.  Only with the linear bitfield copy (its kernel reduces the box) and a model box inside the cube.
-__device__ __forceinline__ void ray_range(const GeoRayArgs& a, const RayGeom& rg, float& near, float& far) {
-    near_far(rg, a.box, a.min_near, near, far);
+__device__ __forceinline__ Aabb occupied_box(const GeoRayArgs& a) {       // wave-uniform: once per wave, ahead of the block loop
+    Aabb ob = a.box;
     if (a.occ_clip) {
         const uint32_t H1 = (1u << a.log2H) - 1u;
         const float cs = 2.0f * a.mk.bound / (float)(H1 + 1u);
-        Aabb ob;
+        uint32_t w[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) w[q] = a.counters[kCntOcc + q];            // six independent loads: one latency
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const int lo = (int)H1 - (int)a.counters[kCntOcc + d], hi = (int)a.counters[kCntOcc + 3 + d];
+            const int lo = (int)H1 - (int)w[d], hi = (int)w[3 + d];
             ob.lo[d] = -a.mk.bound + (float)(lo - 1) * cs;
             ob.hi[d] = -a.mk.bound + (float)(hi + 2) * cs;
         }
+    }
+    return ob;
+}
+__device__ __forceinline__ void ray_range(const GeoRayArgs& a, const Aabb& ob, const RayGeom& rg, float& near, float& far) {
+    near_far(rg, a.box, a.min_near, near, far);
+    if (a.occ_clip) {
         float n2, f2;
         near_far(rg, ob, 0.0f, n2, f2);
         far = n2 == FLT_MAX ? 0.0f : fminf(far, f2);
@@ -447,6 +456,14 @@ __device__ __forceinline__ bool geo_march(const GeoRayArgs& a, const RayGeom& r,
                                           float* t_at = nullptr) {
     if constexpr (MODE == 0) return march_next(a.mk, r, far, t, x, y, z, dt, t_at);
     else return march_next_c1<MODE == 2>(a.mk, a.linear_grid, a.log2H, r, far, t, x, y, z, dt, t_at);
+}
+
+// one visit of the marcher's loop (march_core.hip.h: march_visit*): the flat loops below advance every lane by one visit per
+// iteration instead of letting the lanes of a wave wait for each other inside per-sample marching loops
+template <int MODE>
+__device__ __forceinline__ bool geo_visit(const GeoRayArgs& a, const RayGeom& r, float& t, float& x, float& y, float& z, float& dt) {
+    if constexpr (MODE == 0) return a.mk.H_pow2 ? march_visit<true>(a.mk, r, t, x, y, z, dt) : march_visit<false>(a.mk, r, t, x, y, z, dt);
+    else return march_visit_c1<MODE == 2>(a.mk, a.linear_grid, a.log2H, r, t, x, y, z, dt);
 }
 
 __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
@@ -527,6 +544,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // composited time after EVERY sample, as the reference loop does with one sample per iteration -- that time does not
 // depend on the densities, so marching ahead of the compositor changes nothing) into freshly allocated slots.
 constexpr uint32_t kTimeCache = 32;      // the first this many samples of an un-hinted chunk are marched once
+constexpr uint32_t kSlotTable = 128;     // samples per ray whose slots the flat write loop can address (per-wave table in LDS)
 
 // Chunk prediction.  A ray that is still alive after compositing n samples has transmittance T >= T_thresh left and saw the
 // opacity `alpha` at its last sample.  If the opacity stayed there, the compositor (which stops AFTER the first sample whose
@@ -552,11 +570,19 @@ template <bool FIRST, int MODE>
 __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
     // ray times of the samples the counting pass found (un-hinted chunks), so that the write pass does not march again
     __shared__ float s_time[kBlock / 64][kTimeCache][64];
+    // slot layout of the chunk being written, for the flat write loop: entry i describes sample index c0 + i of the block:
+    // the lanes that have such a sample, and how many slots the samples before it take
+    __shared__ unsigned long long s_mask[kBlock / 64][kSlotTable];
+    __shared__ uint32_t s_before[kBlock / 64][kSlotTable];
     const uint32_t lane = threadIdx.x & 63;
     float* const t_cache = &s_time[threadIdx.x >> 6][0][lane];
+    unsigned long long* const tab_mask = s_mask[threadIdx.x >> 6];
+    uint32_t* const tab_before = s_before[threadIdx.x >> 6];
     const unsigned long long below = (1ull << lane) - 1ull;
     const uint32_t n_in = FIRST ? (a.N + 63u) / 64u : __builtin_amdgcn_readfirstlane(a.counters[kCntAlive + a.round]);
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    if (((blockIdx.x * blockDim.x + threadIdx.x) >> 6) >= n_in) return;
+    const Aabb occ = occupied_box(a);
     for (uint32_t bi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; bi < n_in; bi += n_waves) {
         const uint32_t blk = FIRST ? bi : __builtin_amdgcn_readfirstlane(a.alive_in[bi]);
         const uint32_t ray = blk * 64u + lane;
@@ -571,7 +597,7 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
         if constexpr (FIRST) {
             if (in_range) {
                 rg = load_ray(a.rays_o, a.rays_d, ray);
-                ray_range(a, rg, near, far);
+                ray_range(a, occ, rg, near, far);
                 float t = near, x, y, z, dt;
                 const bool hit = (!a.ray_mask || a.ray_mask[ray]) && geo_march<MODE>(a, rg, far, t, x, y, z, dt, &t_first);
                 st.acc_t = near;
@@ -580,45 +606,60 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
             }
         } else {
             // ---- composite the previous chunk ------------------------------------------------------------------
+            // everything a lane needs is loaded in one batch (counts, the state fields, the ray): the fields of a finished ray
+            // are stale and unused, but waiting for the counts before asking for the rest doubled the latency of this prologue
             uint32_t cnt = 0, alloc = 0;
             bool last = false;
             if (in_range) {
                 const uint32_t cc = sp[kFChunk * (size_t)a.n_pad];
+                alloc = sp[kFAlloc * (size_t)a.n_pad];
+                uint32_t f[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) f[q] = sp[(size_t)q * a.n_pad];          // kFAccT .. kFTaken
+                static_assert(kFAccT == 0 && kFTaken == 7 && kFChunk == 8, "state field order");
+                rg = load_ray(a.rays_o, a.rays_d, ray);
                 cnt = cc & 0x7fffffffu;
                 last = (cc >> 31) != 0;
-                alloc = sp[kFAlloc * (size_t)a.n_pad];
+                st.acc_t = __uint_as_float(f[kFAccT]); st.ws = __uint_as_float(f[kFWs]); st.depth = __uint_as_float(f[kFDepth]);
+                st.an[0] = __uint_as_float(f[kFAn0]); st.an[1] = __uint_as_float(f[kFAn1]); st.an[2] = __uint_as_float(f[kFAn2]);
+                st.arough = __uint_as_float(f[kFRough]); st.n_taken = f[kFTaken];
             }
             const bool active = cnt != 0;
-            if (active) {
-                rg = load_ray(a.rays_o, a.rays_d, ray);
-                ray_range(a, rg, near, far);
-                st.acc_t = __uint_as_float(sp[kFAccT * (size_t)a.n_pad]);
-                st.ws = __uint_as_float(sp[kFWs * (size_t)a.n_pad]);
-                st.depth = __uint_as_float(sp[kFDepth * (size_t)a.n_pad]);
-                st.an[0] = __uint_as_float(sp[kFAn0 * (size_t)a.n_pad]);
-                st.an[1] = __uint_as_float(sp[kFAn1 * (size_t)a.n_pad]);
-                st.an[2] = __uint_as_float(sp[kFAn2 * (size_t)a.n_pad]);
-                st.arough = __uint_as_float(sp[kFRough * (size_t)a.n_pad]);
-                st.n_taken = sp[kFTaken * (size_t)a.n_pad];
-            }
+            if (active) ray_range(a, occ, rg, near, far);
+            else st = RayState{};
             const uint32_t base = __builtin_amdgcn_readfirstlane(a.block_base[blk]);
             uint32_t k = 0;              // samples of the chunk that get composited
             bool terminated = false;
             float last_alpha = 0.0f;
+            // Both passes below walk the chunk in groups of kGroup samples: the slot addresses of a group depend only on the
+            // per-ray counts, so its loads are issued together and ONE memory latency is paid per group instead of one per
+            // sample (the arrays were written by k_geo_eval32 on other XCDs: every load comes from the fabric, ~2 us under
+            // load, and a wave's chain of them WAS this kernel's run time).  Lanes without a sample read the block's first
+            // slot (a valid address) and ignore the value; the arithmetic and its order are unchanged.
+            constexpr uint32_t kGroup = 8;
             {
                 float ws = st.ws;        // pass 1: how many records does each ray append
                 bool going = active;
                 uint32_t off = 0;
-                for (uint32_t c = 0;; ++c) {
-                    const unsigned long long m = __ballot(c < alloc);
-                    if (!__ballot(going && c < cnt)) break;
-                    const uint32_t slot = base + off + (uint32_t)__popcll(m & below);
-                    off += (uint32_t)__popcll(m);
-                    if (going && c < cnt) {
-                        const float T = 1 - ws;
-                        ws += a.alpha[slot] * T;
-                        ++k;
-                        if (T < a.T_thresh) { terminated = true; going = false; }
+                for (uint32_t c0 = 0;; c0 += kGroup) {
+                    if (!__ballot(going && c0 < cnt)) break;
+                    float al[kGroup];
+#pragma unroll
+                    for (uint32_t j = 0; j < kGroup; ++j) {
+                        const uint32_t c = c0 + j;
+                        const unsigned long long m = __ballot(c < alloc);
+                        const uint32_t slot = base + off + (uint32_t)__popcll(m & below);
+                        off += (uint32_t)__popcll(m);
+                        al[j] = a.alpha[c < cnt ? slot : base];
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < kGroup; ++j) {
+                        if (going && c0 + j < cnt) {
+                            const float T = 1 - ws;
+                            ws += al[j] * T;
+                            ++k;
+                            if (T < a.T_thresh) { terminated = true; going = false; }
+                        }
                     }
                 }
             }
@@ -629,27 +670,45 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
             const bool fits = rec_base + wave_records <= a.rec_cap;
             if (!fits && lane == 0) a.counters[kCntOverflow] = 1u;
             {
+                typedef float f32x3 __attribute__((ext_vector_type(3)));
+                constexpr uint32_t kGroup2 = 4;
                 uint32_t off = 0, roff = 0;
-                for (uint32_t c = 0;; ++c) {                    // pass 2: the recurrence itself + the records
-                    const unsigned long long m = __ballot(c < alloc), mk = __ballot(c < k);
-                    if (!mk) break;
-                    const uint32_t slot = base + off + (uint32_t)__popcll(m & below);
-                    const uint32_t r = rec_base + roff + (uint32_t)__popcll(mk & below);
-                    off += (uint32_t)__popcll(m);
-                    roff += (uint32_t)__popcll(mk);
-                    if (c < k) {
-                        const float alpha = a.alpha[slot];
-                        last_alpha = alpha;
-                        const float T = 1 - st.ws;
-                        const float w = alpha * T;
-                        st.ws += w;
-                        st.acc_t = st.acc_t + a.dd[slot];
-                        st.depth += w * st.acc_t;
+                for (uint32_t c0 = 0;; c0 += kGroup2) {            // pass 2: the recurrence itself + the records
+                    if (!__ballot(c0 < k)) break;
+                    uint32_t slot[kGroup2], rec[kGroup2];
+                    float al[kGroup2], dd[kGroup2], ro[kGroup2];
+                    f32x3 nv[kGroup2];
 #pragma unroll
-                        for (int d = 0; d < 3; ++d) st.an[d] += w * a.normal[3 * (size_t)slot + d];
-                        st.arough += w * a.rough[slot];
-                        if (fits) { a.rec_ray[r] = ray; a.rec_idx[r] = st.n_taken; a.rec_w[r] = w; a.rec_slot[r] = slot; }
-                        ++st.n_taken;
+                    for (uint32_t j = 0; j < kGroup2; ++j) {
+                        const uint32_t c = c0 + j;
+                        const unsigned long long m = __ballot(c < alloc), mk = __ballot(c < k);
+                        slot[j] = base + off + (uint32_t)__popcll(m & below);
+                        rec[j] = rec_base + roff + (uint32_t)__popcll(mk & below);
+                        off += (uint32_t)__popcll(m);
+                        roff += (uint32_t)__popcll(mk);
+                        const uint32_t at = c < k ? slot[j] : base;
+                        al[j] = a.alpha[at];
+                        dd[j] = a.dd[at];
+                        ro[j] = a.rough[at];
+                        nv[j] = *reinterpret_cast<const f32x3*>(a.normal + 3 * (size_t)at);
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < kGroup2; ++j) {
+                        if (c0 + j < k) {
+                            const float alpha = al[j];
+                            last_alpha = alpha;
+                            const float T = 1 - st.ws;
+                            const float w = alpha * T;
+                            st.ws += w;
+                            st.acc_t = st.acc_t + dd[j];
+                            st.depth += w * st.acc_t;
+#pragma unroll
+                            for (int d = 0; d < 3; ++d) st.an[d] += w * nv[j][d];
+                            st.arough += w * ro[j];
+                            const uint32_t r = rec[j];
+                            if (fits) { a.rec_ray[r] = ray; a.rec_idx[r] = st.n_taken; a.rec_w[r] = w; a.rec_slot[r] = slot[j]; }
+                            ++st.n_taken;
+                        }
                     }
                 }
             }
@@ -665,24 +724,44 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
         // render of about the same camera: exact for the frames of a fixed-camera video): the ray is then done in one
         // round with nothing evaluated past its end.  A wrong hint costs a round or some wasted samples, never accuracy.
         uint32_t chunk = chunk_next;
+        bool lane_hinted = false;
         if constexpr (FIRST) {
-            if (alive && a.ray_cost) { const uint32_t h = a.ray_cost[ray]; if (h) chunk = min(h, 4096u); }
+            if (alive && a.ray_cost) { const uint32_t h = a.ray_cost[ray]; if (h) { chunk = min(h, 4096u); lane_hinted = true; } }
         }
         // With a hint the ray's slots are sized by it and the ray is marched once (slots the ray turns out not to need
-        // are zero-filled: evaluated, never composited); without one the marcher first counts.
-        const bool hinted = FIRST && chunk != a.chunk;
+        // are zero-filled: evaluated, never composited); without one the marcher first counts.  The choice is made per WAVE
+        // (the sample-major slot layout is walked by the whole wave together): a block in which some live ray has no hint --
+        // a silhouette of a moving camera -- counts, with the hints of the others as their chunk sizes.
+        const bool hinted = FIRST && !__any(alive && !lane_hinted);
+        // Marching is written as FLAT loops: every iteration each lane that still has something to do makes ONE visit of the
+        // marcher's loop (an occupied cell = a sample; an empty cell = a hop to its exit).  With a marching loop per sample
+        // inside a loop over samples, a wave pays, for every sample index, the longest walk any of its lanes makes there --
+        // one ray leaving the shell and crossing the hollow interior stalls the other 63 for ~60 visits, and in a block on the
+        // silhouette a different lane does so at almost every index: ~1000 visits per block instead of ~190, and the kernel
+        // ran as long as its worst block (tools/sim/march_sim.py).
         uint32_t want = 0;           // slots to allocate
         if (alive && a.chunk) {
             if (hinted) want = min(chunk, a.max_samples - min(st.n_taken, a.max_samples));
-            else {
-                float tr = st.acc_t;
-                bool first = FIRST;
-                for (; want < chunk && st.n_taken + want < a.max_samples; ++want) {
-                    float t = first ? t_first : tr, x, y, z, dt, t_at;
-                    if (!geo_march<MODE>(a, rg, far, t, x, y, z, dt, &t_at)) break;
-                    if (want < kTimeCache) t_cache[want * 64] = t_at;      // the write pass below takes these instead of marching again
-                    tr = tr + (t - tr);
-                    first = false;
+        }
+        if (!hinted) {
+            // counting pass: how many samples can the ray take (at most `chunk`); the ray times of the first kTimeCache of
+            // them stay in LDS, the write pass below does not march again for those
+            const uint32_t most = (alive && a.chunk) ? min(chunk, a.max_samples - min(st.n_taken, a.max_samples)) : 0u;
+            float tr = st.acc_t, t = FIRST ? t_first : st.acc_t;
+            bool going = most != 0;
+            while (__any(going)) {
+                if (going) {
+                    if (!(t < far)) going = false;
+                    else {
+                        float x, y, z, dt;
+                        if (geo_visit<MODE>(a, rg, t, x, y, z, dt)) {
+                            if (want < kTimeCache) t_cache[want * 64] = t;
+                            const float ta = t + dt;
+                            tr = tr + (ta - tr);
+                            t = tr;                              // the reference resumes from the composited ray time
+                            going = ++want < most;
+                        }
+                    }
                 }
             }
         }
@@ -696,46 +775,82 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
         }
         uint32_t marched = 0;
         {
-            const bool counted = !hinted;     // the counting pass left the ray times of the first kTimeCache samples in LDS
-            float tr = st.acc_t;
-            bool first = FIRST, ended = false;
-            uint32_t off = 0;
-            for (uint32_t c = 0;; ++c) {                         // the march, written out sample-major
+            float tr = st.acc_t, t_head = FIRST ? t_first : st.acc_t;
+            bool ended = false;
+            uint32_t off = 0, c = 0;
+            auto store = [&](size_t slot, float x, float y, float z, float dt, float dd) {
+                a.xyz[3 * slot] = x; a.xyz[3 * slot + 1] = y; a.xyz[3 * slot + 2] = z;
+                a.dt[slot] = dt;
+                a.dd[slot] = dd;
+            };
+            // (A) samples whose ray times the counting pass left in LDS: no marching, the wave walks the sample indices together
+            const uint32_t n_cached = hinted ? 0u : kTimeCache;
+            for (; c < n_cached; ++c) {
                 const unsigned long long m = __ballot(c < want);
                 if (!m) break;
                 const size_t slot = (size_t)base + off + (uint32_t)__popcll(m & below);
                 off += (uint32_t)__popcll(m);
                 if (c < want) {
-                    float x = 0, y = 0, z = 0, dt = 0, dd = 0;
-                    if (counted && c < kTimeCache) {
-                        // the counting pass found this sample at ray time t_at: position, step and ray-time bookkeeping are
-                        // the marcher's own statements for an occupied cell
-                        const float t_at = t_cache[c * 64];
-                        x = clampf(rg.ox + t_at * rg.dx, -a.mk.bound, a.mk.bound);
-                        y = clampf(rg.oy + t_at * rg.dy, -a.mk.bound, a.mk.bound);
-                        z = clampf(rg.oz + t_at * rg.dz, -a.mk.bound, a.mk.bound);
-                        dt = step_size(a.mk, t_at);
-                        const float t = t_at + dt;
-                        dd = t - tr;
-                        tr = tr + dd;
-                        first = false;
-                        ++marched;
-                    } else if (!ended) {
-                        float t = first ? t_first : tr;
-                        if (geo_march<MODE>(a, rg, far, t, x, y, z, dt)) {
-                            dd = t - tr;
-                            tr = tr + dd;
-                            first = false;
-                            ++marched;
-                        } else {
-                            ended = true;                        // only after an over-estimating hint: the rest is zero-filled
-                            x = y = z = dt = 0;
+                    // position, step and ray-time bookkeeping are the marcher's own statements for an occupied cell
+                    const float t_at = t_cache[c * 64];
+                    const float x = clampf(rg.ox + t_at * rg.dx, -a.mk.bound, a.mk.bound);
+                    const float y = clampf(rg.oy + t_at * rg.dy, -a.mk.bound, a.mk.bound);
+                    const float z = clampf(rg.oz + t_at * rg.dz, -a.mk.bound, a.mk.bound);
+                    const float dt = step_size(a.mk, t_at);
+                    const float t = t_at + dt;
+                    const float dd = t - tr;
+                    tr = tr + dd;
+                    t_head = tr;
+                    ++marched;
+                    store(slot, x, y, z, dt, dd);
+                }
+            }
+            // (B) the rest is marched here.  The slot of (lane, sample index) depends on the other lanes' counts: a per-wave
+            // table of the next kSlotTable sample indices -- which lanes have that sample, how many slots come before it --
+            // lets every lane advance at its own pace, one visit per iteration; rays that end before their hint said
+            // (an over-estimating hint) zero-fill what is left of their slots.
+            while (true) {
+                const uint32_t c0 = c;                                        // wave-uniform: first sample index of this table
+                const unsigned long long some = __ballot(c0 < want);
+                if (!some) break;
+                uint32_t filled = 0;
+                for (uint32_t i = 0; i < kSlotTable; ++i) {
+                    const unsigned long long m = __ballot(c0 + i < want);
+                    if (!m) break;
+                    if (lane == 0) { tab_mask[i] = m; tab_before[i] = off; }
+                    off += (uint32_t)__popcll(m);
+                    filled = i + 1;
+                }
+                wave_lds_sync();
+                const uint32_t c_end = c0 + filled;
+                uint32_t ci = c0;                                              // this lane's next sample index
+                bool busy = ci < want;
+                while (__any(busy)) {
+                    if (busy) {
+                        float x = 0, y = 0, z = 0, dt = 0, dd = 0;
+                        bool emit = ended;
+                        if (!ended) {
+                            if (!(t_head < far)) { ended = true; emit = true; }
+                            else if (geo_visit<MODE>(a, rg, t_head, x, y, z, dt)) {
+                                const float ta = t_head + dt;
+                                dd = ta - tr;
+                                tr = tr + dd;
+                                t_head = tr;
+                                ++marched;
+                                emit = true;
+                            }
+                        }
+                        if (emit) {
+                            if (ended) x = y = z = dt = dd = 0;
+                            const uint32_t i = ci - c0;
+                            store((size_t)base + tab_before[i] + (uint32_t)__popcll(tab_mask[i] & below), x, y, z, dt, dd);
+                            ++ci;
+                            busy = ci < want && ci < c_end;
                         }
                     }
-                    a.xyz[3 * slot] = x; a.xyz[3 * slot + 1] = y; a.xyz[3 * slot + 2] = z;
-                    a.dt[slot] = dt;
-                    a.dd[slot] = dd;
                 }
+                wave_lds_sync();
+                c = c_end;
             }
         }
         if (alive) {

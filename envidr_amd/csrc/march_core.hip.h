@@ -93,6 +93,48 @@ __device__ __forceinline__ float exit_time(const MarchConsts& k, int n, float d,
     return (((n + 0.5f + 0.5f * copysignf(1.0f, d)) * k.rH * 2 - 1) * mip_bound - p) * rd;
 }
 
+// One VISIT of the marcher's loop -- the body of the reference's `while (t < far)` (raymarching.cu:885-940) -- for the cell
+// the ray is in at time t (the caller has checked t < far).  Occupied: returns true with the clamped sample position and
+// the step `dt`, t unchanged (the caller emits the sample and advances by dt).  Empty: returns false with t moved to where
+// the loop lands next (past the voxel's exit face, in whole steps).  march_next_* below are loops over this; kernels whose
+// lanes would otherwise wait for each other inside nested per-sample loops call it directly, one visit per lane per
+// iteration (geometry_pass.hip).
+template <bool POW2>
+__device__ __forceinline__ bool march_visit(const MarchConsts& k, const RayGeom& r, float& t, float& x, float& y, float& z, float& dt) {
+    x = clampf(r.ox + t * r.dx, -k.bound, k.bound);
+    y = clampf(r.oy + t * r.dy, -k.bound, k.bound);
+    z = clampf(r.oz + t * r.dz, -k.bound, k.bound);
+    dt = step_size(k, t);
+
+    const int lvl_pos = clamp_level(k, fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))));
+    // the reference's (dt * H) * 0.5 promotes to double: halving is exact, so the fp32 product has the same bits
+    const int lvl_dt = clamp_level(k, (dt * k.Hf) * 0.5f);
+    const int level = max(lvl_pos, lvl_dt);
+
+    // mip_bound = min(2^level, bound); its reciprocal is exactly 2^-level, or the precomputed 1 / bound: the reference's
+    // `1 / mip_bound` without a division per step
+    const float pow2 = scalbnf(1.0f, level);
+    const float mip_bound = fminf(pow2, k.bound);
+    const float mip_rbound = pow2 <= k.bound ? scalbnf(1.0f, -level) : k.rbound;
+
+    const int nx = voxel_coord<POW2>(k, x, mip_rbound);
+    const int ny = voxel_coord<POW2>(k, y, mip_rbound);
+    const int nz = voxel_coord<POW2>(k, z, mip_rbound);
+
+    // level * H3 + morton is a float expression in the reference (H3 is float)
+    const uint32_t bit = (uint32_t)((float)level * k.H3 + (float)morton_encode(nx, ny, nz));
+    if (k.grid[bit >> 3] & (1u << (bit & 7))) return true;
+
+    const float tx = exit_time(k, nx, r.dx, r.rdx, x, mip_bound);
+    const float ty = exit_time(k, ny, r.dy, r.rdy, y, mip_bound);
+    const float tz = exit_time(k, nz, r.dz, r.rdz, z, mip_bound);
+    const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    do {
+        t += step_size(k, t);
+    } while (t < tt);
+    return false;
+}
+
 // Advance `t` to the next occupied sample strictly before `far`.
 // On success: (x,y,z) is the clamped sample position, dt the step used for alpha, and `t` has
 // already been advanced past the sample (t_after = t_sample + dt).  Returns false when the ray
@@ -104,42 +146,11 @@ template <bool POW2>
 __device__ __forceinline__ bool march_next_impl(const MarchConsts& k, const RayGeom& r, float far, float& t,
                                                 float& x, float& y, float& z, float& dt, float* t_at) {
     while (t < far) {
-        x = clampf(r.ox + t * r.dx, -k.bound, k.bound);
-        y = clampf(r.oy + t * r.dy, -k.bound, k.bound);
-        z = clampf(r.oz + t * r.dz, -k.bound, k.bound);
-        dt = step_size(k, t);
-
-        const int lvl_pos = clamp_level(k, fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))));
-        // the reference's (dt * H) * 0.5 promotes to double: halving is exact, so the fp32 product has the same bits
-        const int lvl_dt = clamp_level(k, (dt * k.Hf) * 0.5f);
-        const int level = max(lvl_pos, lvl_dt);
-
-        // mip_bound = min(2^level, bound); its reciprocal is exactly 2^-level, or the precomputed 1 / bound: the reference's
-        // `1 / mip_bound` without a division per step
-        const float pow2 = scalbnf(1.0f, level);
-        const float mip_bound = fminf(pow2, k.bound);
-        const float mip_rbound = pow2 <= k.bound ? scalbnf(1.0f, -level) : k.rbound;
-
-        const int nx = voxel_coord<POW2>(k, x, mip_rbound);
-        const int ny = voxel_coord<POW2>(k, y, mip_rbound);
-        const int nz = voxel_coord<POW2>(k, z, mip_rbound);
-
-        // level * H3 + morton is a float expression in the reference (H3 is float)
-        const uint32_t bit = (uint32_t)((float)level * k.H3 + (float)morton_encode(nx, ny, nz));
-        const bool occupied = k.grid[bit >> 3] & (1u << (bit & 7));
-
-        if (occupied) {
+        if (march_visit<POW2>(k, r, t, x, y, z, dt)) {
             if (t_at) *t_at = t;
             t += dt;
             return true;
         }
-        const float tx = exit_time(k, nx, r.dx, r.rdx, x, mip_bound);
-        const float ty = exit_time(k, ny, r.dy, r.rdy, y, mip_bound);
-        const float tz = exit_time(k, nz, r.dz, r.rdz, z, mip_bound);
-        const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
-        do {
-            t += step_size(k, t);
-        } while (t < tt);
     }
     return false;
 }
@@ -153,7 +164,7 @@ __device__ __forceinline__ bool march_next(const MarchConsts& k, const RayGeom& 
 // The same marcher for the geometry every scene of the reference has -- ONE cascade (bound <= 1: every level clamp gives 0,
 // mip_bound = bound, 1 / mip_bound = 1 / bound) on a power-of-two grid of at most 256^3 cells -- reading a copy of the
 // bitfield in x-fastest LINEAR cell order (k_linearize_bitfield) instead of Morton order.  Every float operation that
-// produces t, the position, dt or the voxel coordinates is the statement of march_next_impl<true>, so the samples are the
+// produces t, the position, dt or the voxel coordinates is the statement of march_visit<true>, so the samples are the
 // same bits; what is gone is the arithmetic whose result is a constant here (two frexp level clamps, the scalbn pair, the
 // float bit index) and the 3 x 10-operation bit interleave.  These kernels are VALU-issue bound (a ray that misses the
 // object walks ~200 empty cells), so the instruction count per cell is their run time.
@@ -161,32 +172,38 @@ __device__ __forceinline__ bool march_next(const MarchConsts& k, const RayGeom& 
 __device__ __forceinline__ bool march_fast_ok(const MarchConsts& k) { return k.cascades == 1.0f && k.H_pow2 && k.H <= 256u; }
 
 template <bool GAMMA0>
+__device__ __forceinline__ bool march_visit_c1(const MarchConsts& k, const uint8_t* __restrict__ linear_grid, uint32_t log2H, const RayGeom& r,
+                                               float& t, float& x, float& y, float& z, float& dt) {
+    const float dtc = step_size(k, 0.0f);
+    x = clampf(r.ox + t * r.dx, -k.bound, k.bound);
+    y = clampf(r.oy + t * r.dy, -k.bound, k.bound);
+    z = clampf(r.oz + t * r.dz, -k.bound, k.bound);
+    dt = GAMMA0 ? dtc : step_size(k, t);
+    const int nx = voxel_coord<true>(k, x, k.rbound);
+    const int ny = voxel_coord<true>(k, y, k.rbound);
+    const int nz = voxel_coord<true>(k, z, k.rbound);
+    const uint32_t bit = (uint32_t)nx | ((uint32_t)ny << log2H) | ((uint32_t)nz << (2 * log2H));
+    if (linear_grid[bit >> 3] & (1u << (bit & 7))) return true;
+    const float tx = exit_time(k, nx, r.dx, r.rdx, x, k.bound);
+    const float ty = exit_time(k, ny, r.dy, r.rdy, y, k.bound);
+    const float tz = exit_time(k, nz, r.dz, r.rdz, z, k.bound);
+    const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    if constexpr (GAMMA0) {
+        do { t += dtc; } while (t < tt);
+    } else {
+        do { t += step_size(k, t); } while (t < tt);
+    }
+    return false;
+}
+
+template <bool GAMMA0>
 __device__ __forceinline__ bool march_next_c1(const MarchConsts& k, const uint8_t* __restrict__ linear_grid, uint32_t log2H, const RayGeom& r,
                                               float far, float& t, float& x, float& y, float& z, float& dt, float* t_at) {
-    const float dtc = step_size(k, 0.0f);
     while (t < far) {
-        x = clampf(r.ox + t * r.dx, -k.bound, k.bound);
-        y = clampf(r.oy + t * r.dy, -k.bound, k.bound);
-        z = clampf(r.oz + t * r.dz, -k.bound, k.bound);
-        dt = GAMMA0 ? dtc : step_size(k, t);
-        const int nx = voxel_coord<true>(k, x, k.rbound);
-        const int ny = voxel_coord<true>(k, y, k.rbound);
-        const int nz = voxel_coord<true>(k, z, k.rbound);
-        const uint32_t bit = (uint32_t)nx | ((uint32_t)ny << log2H) | ((uint32_t)nz << (2 * log2H));
-        const bool occupied = linear_grid[bit >> 3] & (1u << (bit & 7));
-        if (occupied) {
+        if (march_visit_c1<GAMMA0>(k, linear_grid, log2H, r, t, x, y, z, dt)) {
             if (t_at) *t_at = t;
             t += dt;
             return true;
-        }
-        const float tx = exit_time(k, nx, r.dx, r.rdx, x, k.bound);
-        const float ty = exit_time(k, ny, r.dy, r.rdy, y, k.bound);
-        const float tz = exit_time(k, nz, r.dz, r.rdz, z, k.bound);
-        const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
-        if constexpr (GAMMA0) {
-            do { t += dtc; } while (t < tt);
-        } else {
-            do { t += step_size(k, t); } while (t < tt);
         }
     }
     return false;

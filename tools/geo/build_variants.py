@@ -30,6 +30,37 @@ VARIANTS = {
     "no_chunk_prediction": ("geometry_pass", [("geometry_pass.hip", "a.predict = (r >= 1 && r + 1 < rounds) ? 1u : 0u;", "a.predict = 0u;"),
                                               ("geometry_pass.hip", "chunks[r] = r == 0 ? std::min(16u, d->max_steps) : d->max_steps;",
                                                "chunks[r] = r == 0 ? std::min(16u, d->max_steps) : (r < 6 ? std::min(d->max_steps, 8u << r) : d->max_steps);")]),
+    # per-section clocks of the per-ray rounds -> counters[80 + 16 round + 2 section] (sum over blocks, in 64-tick units) and
+    # [... + 1] (max over blocks): sections 0 prologue + count records, 1 composite, 2 first hit / counting march, 3 allocate + write
+    # march, 4 state write-back, 5 finished rays' outputs; words 12 / 13 of a round: whole block sum / max, word 14: blocks
+    # (read back with tools/geo/rays_timers_probe.py)
+    "rays_timers": ("geometry_pass", [
+        ("geometry_pass.hip", "        bool alive = false;          // still needs samples after this round's compositing\n",
+         "        bool alive = false;\n        unsigned long long tm_[7]; tm_[0] = tm_[1] = tm_[2] = __builtin_amdgcn_s_memtime();\n"),
+        ("geometry_pass.hip", "            const uint32_t wave_records = wave_sum(k);\n",
+         "            tm_[1] = __builtin_amdgcn_s_memtime();\n            const uint32_t wave_records = wave_sum(k);\n"),
+        ("geometry_pass.hip", "            if (active) {\n                finish = terminated || last || st.n_taken >= a.max_samples;\n",
+         "            __builtin_amdgcn_s_waitcnt(0); tm_[2] = __builtin_amdgcn_s_memtime();\n"
+         "            if (active) {\n                finish = terminated || last || st.n_taken >= a.max_samples;\n"),
+        ("geometry_pass.hip", "        const uint32_t wave_slots = wave_sum(want);\n",
+         "        tm_[3] = __builtin_amdgcn_s_memtime();\n        const uint32_t wave_slots = wave_sum(want);\n"),
+        ("geometry_pass.hip", "        if (alive) {\n            st.chunk_count = marched | ((marched < chunk) ? 0x80000000u : 0u);\n",
+         "        tm_[4] = __builtin_amdgcn_s_memtime();\n        if (alive) {\n            st.chunk_count = marched | ((marched < chunk) ? 0x80000000u : 0u);\n"),
+        ("geometry_pass.hip", "        if (finish) {\n            // run_cuda epilogue for this ray",
+         "        tm_[5] = __builtin_amdgcn_s_memtime();\n        if (finish) {\n            // run_cuda epilogue for this ray"),
+        ("geometry_pass.hip", "            if (a.ray_cost) a.ray_cost[id] = (uint16_t)min(st.n_taken, 65535u);\n        }\n",
+         "            if (a.ray_cost) a.ray_cost[id] = (uint16_t)min(st.n_taken, 65535u);\n        }\n"
+         "        tm_[6] = __builtin_amdgcn_s_memtime();\n"
+         "        if (lane == 0) {\n"
+         "            uint32_t* w_ = a.counters + kCntSpare + 16u * min(a.round, 7u);\n"
+         "            for (int s_ = 0; s_ < 6; ++s_) { const uint32_t d_ = (uint32_t)((tm_[s_ + 1] - tm_[s_]) >> 6); atomicAdd(w_ + 2 * s_, d_); atomicMax(w_ + 2 * s_ + 1, d_); }\n"
+         "            const uint32_t all_ = (uint32_t)((tm_[6] - tm_[0]) >> 6); atomicAdd(w_ + 12, all_); atomicMax(w_ + 13, all_); atomicAdd(w_ + 14, 1u);\n"
+         "        }\n"),
+    ]),
+    "grid_full": ("geometry_pass", [("geometry_pass.hip", "const dim3 grid(r == 0 ? ray_blocks : std::min(ray_blocks, 1024u));", "const dim3 grid(ray_blocks);")]),
+    "tcache16": ("geometry_pass", [("geometry_pass.hip", "constexpr uint32_t kTimeCache = 32;", "constexpr uint32_t kTimeCache = 16;")]),
+    "grid_full_tcache16": ("geometry_pass", [("geometry_pass.hip", "const dim3 grid(r == 0 ? ray_blocks : std::min(ray_blocks, 1024u));", "const dim3 grid(ray_blocks);"),
+                                             ("geometry_pass.hip", "constexpr uint32_t kTimeCache = 32;", "constexpr uint32_t kTimeCache = 16;")]),
     "first_chunk12": ("geometry_pass", [("geometry_pass.hip", "std::min(16u, d->max_steps)", "std::min(12u, d->max_steps)")]),
     "first_chunk24": ("geometry_pass", [("geometry_pass.hip", "std::min(16u, d->max_steps)", "std::min(24u, d->max_steps)")]),
     "split_group4": ("shade_split", [("mlp_split.hip.h", "constexpr int kSplitGroup = 2;", "constexpr int kSplitGroup = 4;")]),
