@@ -48,6 +48,7 @@ SIGNATURES: dict[str, str] = {
     "sh_encode_backward": "ppuuupp",
     # ide_encoder (ide_encoder.py:98-130)
     "ide_encode_forward": "ppfuup",
+    "ide_encode_backward": "pppfuupp",
 }
 
 _CTYPE = {"p": ctypes.c_void_p, "u": ctypes.c_uint32, "f": ctypes.c_float, "i": ctypes.c_int}

@@ -35,3 +35,37 @@ extern "C" int envidr_ide_encode_forward(const float* dirs, const float* roughne
     }
     return check_launch("k_ide_forward");
 }
+
+// backward: one lane per direction (reference: torch autograd through ide_encoder.py:98-130)
+template <int DEG_VIEW>
+__global__ void __launch_bounds__(kBlock) k_ide_backward(const float* __restrict__ grad, const float* __restrict__ dirs,
+                                                         const float* __restrict__ roughness, float roughness_scalar, uint32_t B,
+                                                         float* __restrict__ grad_dirs, float* __restrict__ grad_roughness) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    constexpr int N = ide_terms(DEG_VIEW);
+    const float kinv = roughness ? roughness[b] : roughness_scalar;
+    const float* g = grad + (size_t)b * 2 * N;
+    float gd[3], gk;
+    ide_grad<DEG_VIEW>(dirs[3 * (size_t)b], dirs[3 * (size_t)b + 1], dirs[3 * (size_t)b + 2], kinv,
+                       [&](int j, float& gre, float& gim) { gre = g[j]; gim = g[N + j]; }, gd, gk);
+    if (grad_dirs) { grad_dirs[3 * (size_t)b] = gd[0]; grad_dirs[3 * (size_t)b + 1] = gd[1]; grad_dirs[3 * (size_t)b + 2] = gd[2]; }
+    if (grad_roughness) grad_roughness[b] = gk;
+}
+
+extern "C" int envidr_ide_encode_backward(const float* grad, const float* dirs, const float* roughness_ptr, float roughness_scalar,
+                                          uint32_t B, uint32_t deg_view, float* grad_dirs, float* grad_roughness, envidr_stream_t stream) {
+    ENVIDR_REQUIRE(deg_view >= 1 && deg_view <= 5, "ide_encode_backward: deg_view must be in [1, 5]");
+    if (B == 0) return ENVIDR_OK;
+    ENVIDR_REQUIRE(grad && dirs && (grad_dirs || grad_roughness), "ide_encode_backward: null pointer");
+    const dim3 grid(ceil_div(B, kBlock)), block(kBlock);
+    hipStream_t s = as_stream(stream);
+    switch (deg_view) {
+        case 1: hipLaunchKernelGGL(k_ide_backward<1>, grid, block, 0, s, grad, dirs, roughness_ptr, roughness_scalar, B, grad_dirs, grad_roughness); break;
+        case 2: hipLaunchKernelGGL(k_ide_backward<2>, grid, block, 0, s, grad, dirs, roughness_ptr, roughness_scalar, B, grad_dirs, grad_roughness); break;
+        case 3: hipLaunchKernelGGL(k_ide_backward<3>, grid, block, 0, s, grad, dirs, roughness_ptr, roughness_scalar, B, grad_dirs, grad_roughness); break;
+        case 4: hipLaunchKernelGGL(k_ide_backward<4>, grid, block, 0, s, grad, dirs, roughness_ptr, roughness_scalar, B, grad_dirs, grad_roughness); break;
+        case 5: hipLaunchKernelGGL(k_ide_backward<5>, grid, block, 0, s, grad, dirs, roughness_ptr, roughness_scalar, B, grad_dirs, grad_roughness); break;
+    }
+    return check_launch("k_ide_backward");
+}

@@ -85,4 +85,53 @@ __device__ __forceinline__ void ide_eval(float xf, float yf, float zf, float kap
 
 __host__ __device__ constexpr int ide_terms(int deg_view) { return (1 << deg_view) - 1 + deg_view; }
 
+// Gradient of the encoding (the reference gets it from torch autograd through ide_encoder.py:98-130, which its training
+// branch differentiates: colours -> IDE(reflected direction, roughness) -> normals / roughness head).  Term j is
+// v = c^m P(z) att, c = x + i y, P the table polynomial, att = exp(-sigma_l kappa_inv); with upstream gradients (gre, gim)
+// of its real and imaginary outputs:
+//   d/dx = m P att (gre Re c^(m-1) + gim Im c^(m-1)),   d/dy = m P att (gim Re c^(m-1) - gre Im c^(m-1)),
+//   d/dz = P'(z) att (gre Re c^m + gim Im c^m),          d/dkappa_inv = -sigma_l (gre Re v + gim Im v).
+// grad(j, gre, gim) supplies the upstream pair of term j.  Same fp64 Horner on the fp32-rounded table as ide_eval.
+template <int DEG_VIEW, typename Grad>
+__device__ __forceinline__ void ide_grad(float xf, float yf, float zf, float kappa_inv, Grad&& grad, float (&gdir)[3], float& gkappa) {
+    constexpr int LMAX = 1 << (DEG_VIEW - 1);
+    double x = xf, y = yf;
+    const double z = zf;
+    if (xf == 0.0f && yf == 0.0f) y += 1.0;
+    double re[LMAX + 1], im[LMAX + 1];
+    complex_powers<LMAX + 1, double>(x, y, re, im);
+    const double z2 = z * z;
+    double gx = 0, gy = 0, gz = 0, gk = 0;
+    int j = 0;
+#pragma unroll
+    for (int i = 0; i < DEG_VIEW; ++i) {
+        const int l = 1 << i;
+        const float sigma = 0.5f * (float)(l * (l + 1));
+        const double att = (double)expf(-sigma * kappa_inv);
+#pragma unroll
+        for (int m = 0; m <= l; ++m, ++j) {
+            const int start = kIdeStart[j], cnt = kIdeCount[j];
+            double q = kIdeCoef[start], dq = 0;              // q(z^2) and q'(z^2), Horner
+#pragma unroll
+            for (int k = 1; k < cnt; ++k) { dq = dq * z2 + q; q = q * z2 + kIdeCoef[start + k]; }
+            const bool odd = (l - m) & 1;
+            const double P = odd ? q * z : q;
+            const double dP = odd ? q + 2 * z2 * dq : 2 * z * dq;
+            float gre, gim;
+            grad(j, gre, gim);
+            const double a = gre, b = gim;
+            if (m > 0) {
+                const double s = (double)m * P * att;
+                gx += s * (a * re[m - 1] + b * im[m - 1]);
+                gy += s * (b * re[m - 1] - a * im[m - 1]);
+            }
+            const double w = a * re[m] + b * im[m];
+            gz += dP * att * w;
+            gk -= (double)sigma * P * att * w;
+        }
+    }
+    gdir[0] = (float)gx; gdir[1] = (float)gy; gdir[2] = (float)gz;
+    gkappa = (float)gk;
+}
+
 }  // namespace envidr

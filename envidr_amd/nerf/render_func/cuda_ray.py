@@ -10,8 +10,10 @@
     per iteration instead of a nonzero + gather + sync).  Used for model configurations the fused kernel
     does not implement (and on request, `fused=False`).
 
-The training branch of run_cuda (march_rays_train + composite_rays_train + losses) belongs to the
-Trainer and is out of scope; its operators exist in envidr_amd.raymarching.
+The training branch (`model.training`, reference cuda_ray.py:64-237) is `_run_cuda_train` below: march_rays_train ->
+forward_sigma (normals through autograd with create_graph, i.e. the hash encoder's second-order backward) -> forward_color ->
+composite_rays_train (custom backward), everything differentiable on the HIP operators.  The Trainer around it (losses,
+optimisers, schedules) stays out of scope; what this branch returns is what the reference's Trainer consumes.
 """
 from __future__ import annotations
 
@@ -38,18 +40,124 @@ def fused_eligible(model, r_images=None, geometry_only=False, fused=True, ray_de
     return bool(model.supports_fused(r_images=r_images, geometry_only=geometry_only))
 
 
+SQRT3 = 3 ** 0.5
+
+
+def _run_cuda_train(self, rays_o, rays_d, prefix, dt_gamma, bg_color, perturb, force_all_rays, max_steps, T_thresh, use_specular_color,
+                    early_stop_steps, ray_depth, main_pass, r_images, geometry_only, grad_ray, bg_sphere):
+    """run_cuda, `if self.training` branch (reference nerf/render_func/cuda_ray.py:64-237, minus its debug plotting): returns
+    image / depth / weights_sum plus the per-sample tensors the reference's losses read (sigmas, sdfs, sdf_gradients and, when
+    a relative-sdf style loss is on, the relsdf block).  Loss switches are the attributes the reference's Trainer toggles on
+    `opt` (eikonal_loss, backsdf_loss, relsdf_loss, orientation_loss, dist_bound); absent attributes count as off."""
+    opt = self.opt
+    flag = lambda name: bool(getattr(opt, name, False))
+    N, device = rays_o.shape[0], rays_o.device
+    use_relsdf_loss = flag("relsdf_loss") or flag("dist_bound")
+    use_orientation_loss, use_backsdf_loss, use_eikonal_loss = flag("orientation_loss"), flag("backsdf_loss"), flag("eikonal_loss")
+    use_neus = flag("use_neus_sdf")
+    use_sdf_sigma_grad = (use_relsdf_loss or use_backsdf_loss or use_eikonal_loss or use_orientation_loss or self.use_normal_with_mlp
+                          or self.use_n_dot_viewdir or self.use_reflected_dir or use_neus)
+    if ray_depth is not None:
+        dt = 2 * SQRT3 / max_steps
+        valid_ray = ray_depth > 0
+        nears = ((ray_depth - 4 * dt) * valid_ray).float().contiguous().view(-1)
+        fars = ((ray_depth + 4 * dt) * valid_ray).float().contiguous().view(-1)
+    else:
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train, self.min_near)
+    results = {}
+    if self.bg_radius > 0 and bg_sphere:
+        sph = raymarching.sph_from_ray(rays_o, rays_d, self.bg_radius)
+        bg_color = self.background(sph, rays_d)
+        results["sphere_bg"] = bg_color
+    elif bg_color is None:
+        bg_color = 1
+    if not force_all_rays:
+        counter = self.step_counter[self.local_step % 16]
+        counter.zero_()
+        self.local_step += 1
+    else:
+        counter = None
+    with torch.no_grad():                                   # the marcher has no backward (reference :76)
+        stratified = flag("stratified_sampling")
+        xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size,
+                                                                nears, fars, counter, self.mean_count, (not stratified) and perturb, 128,
+                                                                force_all_rays, dt_gamma, max_steps, early_stop_steps)
+        if stratified:
+            dt = 2 * SQRT3 / max_steps
+            noise = (torch.rand_like(deltas[..., :1]) * 2 - 1) * 0.5 * dt
+            shift = noise.roll(1, dims=-2) - noise
+            deltas = deltas + shift
+            xyzs = xyzs + shift * dirs
+    if use_sdf_sigma_grad:
+        xyzs.requires_grad = True
+    scatter_idx = None
+    if r_images is not None:
+        scatter_idx = raymarching.get_scatter_idx(rays, rays.new_zeros(xyzs.shape[0])).long()
+        r_images = r_images[0, scatter_idx]
+    if grad_ray:
+        if scatter_idx is None:
+            scatter_idx = raymarching.get_scatter_idx(rays, rays.new_zeros(xyzs.shape[0])).long()
+        dirs = rays_d[scatter_idx]
+        o_s = rays_o[scatter_idx]
+        scale = getattr(opt, "grad_rays_scale", 1.0)
+        xyzs = xyzs - scale * o_s.detach() + scale * o_s
+    sdfs, sigmas, geo_feats, normals, eikonal = self.forward_sigma(xyzs, use_sdf_sigma_grad=use_sdf_sigma_grad, dirs=dirs, dists=deltas[..., 0])
+    sigmas = self.density_scale * sigmas
+    roughness = getattr(self, "roughness", opt.default_roughness)
+    weights = None
+    if geometry_only:
+        with torch.set_grad_enabled(not opt.detach_normal):
+            weights_sum, depth, normal_image, weights = raymarching.composite_rays_train(sigmas, normals, deltas, rays, T_thresh, False, use_neus)
+        depth = ((depth + nears) * (depth != 0)).view(*prefix)
+        results["normal_image"] = F.normalize(normal_image, dim=-1).view(*prefix, 3)
+        image = None
+    else:
+        n_enc, w_r_enc, n_dot, n_env_enc = self.get_color_mlp_extra_params(normals, dirs, roughness)
+        rgbs = self.forward_color(geo_feats, dirs, n_enc, w_r_enc, n_dot, use_specular_color, n_env_enc=n_env_enc, r_images=r_images,
+                                  roughness=roughness)
+        ret_weights = use_backsdf_loss or use_relsdf_loss or use_orientation_loss or flag("weighted_eikonal")
+        weights_sum, depth, image, weights = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh, ret_weights, use_neus)
+        image = (image + (1 - weights_sum).unsqueeze(-1) * bg_color).view(*prefix, 3)
+        depth = ((depth + nears) * (depth != 0)).view(*prefix)
+    results.update(image=image, depth=depth, weights_sum=weights_sum.view(*prefix), sigmas=sigmas, sdfs=sdfs)
+    if flag("cauchy_roughness_weighted"):
+        results["roughness"] = roughness
+    if use_eikonal_loss:
+        results["sdf_gradients"] = eikonal * weights.detach()[..., None] if flag("weighted_eikonal") else eikonal
+    if main_pass and not geometry_only and (use_relsdf_loss or use_backsdf_loss or use_orientation_loss):
+        # consecutive-sample sdf differences against their first-order estimate along the ray (reference :168-212)
+        M = sigmas.shape[0]
+        point_mask = torch.ones_like(sigmas, dtype=torch.bool)
+        ray_valid = (rays[:, 2] > 0) & (rays[:, 1] + rays[:, 2] < M)
+        start = rays[ray_valid, 1]
+        point_mask[(start + rays[ray_valid, 2] - 1).long()] = False            # a ray's last sample has no successor
+        shifted = torch.roll(deltas, -1, 0)
+        point_mask = point_mask & (shifted[:, 0] > 0) & (shifted[:, 1] > 0) & (shifted[:, 1] < 1.2 * shifted[:, 0])
+        if self.obj_aabb is not None:
+            point_mask = point_mask & (xyzs >= self.obj_aabb[:3]).all(-1) & (xyzs <= self.obj_aabb[3:]).all(-1)
+        s_ = sdfs if self.use_sdf else -sigmas
+        relsdf = torch.roll(s_, -1, dims=0) - s_
+        cos = (dirs * normals).sum(-1)
+        results.update(relsdf=relsdf[point_mask], est_relsdf=(shifted[:, 1] * cos.detach())[point_mask], cos=cos[point_mask],
+                       sdf_weights=weights[point_mask], sdf_dist=shifted[point_mask, 1], sdfs=s_[point_mask])
+    return results
+
+
 def run_cuda(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024,
              T_thresh=1e-4, get_normal_image=False, use_specular_color=True, early_stop_steps=-1, ray_depth=None,
              main_pass=True, r_images=None, geometry_only=False, grad_ray=False, bg_sphere=True, env_rot_radian=None,
              fused=True, two_phase=None, ray_mask=None, frame_tag="", wait=True, **kwargs):
     self = model
-    if self.training:
-        raise NotImplementedError("run_cuda training branch is out of scope (operators are in envidr_amd.raymarching)")
     prefix = rays_o.shape[:-1]
     rays_o = rays_o.contiguous().view(-1, 3)
     rays_d = rays_d.contiguous().view(-1, 3)
     N, device = rays_o.shape[0], rays_o.device
     opt = self.opt
+    if self.training:
+        return _run_cuda_train(self, rays_o, rays_d, prefix, dt_gamma=dt_gamma, bg_color=bg_color, perturb=perturb, force_all_rays=force_all_rays,
+                               max_steps=max_steps, T_thresh=T_thresh, use_specular_color=use_specular_color, early_stop_steps=early_stop_steps,
+                               ray_depth=ray_depth, main_pass=main_pass, r_images=r_images, geometry_only=geometry_only, grad_ray=grad_ray,
+                               bg_sphere=bg_sphere)
     sphere_bg = None
     if self.bg_radius > 0 and bg_sphere:
         # background model (reference cuda_ray.py:56-60): where the ray leaves the sphere of radius bg_radius -> 2-D grid

@@ -190,6 +190,13 @@ int envidr_sh_encode_backward(const float* grad, const float* inputs, uint32_t B
 int envidr_ide_encode_forward(const float* dirs, const float* roughness_ptr,
                               float roughness_scalar, uint32_t B, uint32_t deg_view,
                               float* outputs, envidr_stream_t stream);
+/* ABI 6: its gradient -- what torch autograd computes through the reference's forward, which the training branch of
+ * run_cuda differentiates (nerf/render_func/cuda_ray.py:118-119 -> renderer.py:147-180).  grad [B, 2 n]: upstream gradient of
+ * the outputs; grad_dirs [B,3] and / or grad_roughness [B] (per-direction d / d kappa_inv; sum it for a shared scalar): either
+ * may be NULL. */
+int envidr_ide_encode_backward(const float* grad, const float* dirs, const float* roughness_ptr,
+                               float roughness_scalar, uint32_t B, uint32_t deg_view,
+                               float* grad_dirs, float* grad_roughness, envidr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -794,3 +794,51 @@ API int oracle_ide_encode_forward(const float* dirs, const float* roughness_ptr,
     free(mat);
     return 0;
 }
+
+/* gradient of the encoding w.r.t. the direction and kappa_inv (torch autograd through ide_encoder.py:98-130): term
+ * v = (x + i y)^m P(z) att; partials in closed form, in double, on the same fp32-rounded table as the forward */
+API int oracle_ide_encode_backward(const float* grad, const float* dirs, const float* roughness_ptr, float roughness_scalar, uint32_t B,
+                                   uint32_t deg_view, float* grad_dirs, float* grad_roughness) {
+    if (deg_view < 1 || deg_view > 5) return -1;
+    int ml_m[64], ml_l[64], n = 0;
+    for (uint32_t i = 0; i < deg_view; ++i) { const int l = 1 << i; for (int m = 0; m <= l; ++m) { ml_m[n] = m; ml_l[n] = l; ++n; } }
+    const int lmax = 1 << (deg_view - 1);
+    double* mat = (double*)calloc((size_t)(lmax + 1) * n, sizeof(double));
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k <= ml_l[i] - ml_m[i]; ++k)
+            mat[(size_t)k * n + i] = (double)(float)ide_coeff(ml_l[i], ml_m[i], k);
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < (int64_t)B; ++b) {
+        const double x = dirs[3 * b], z = dirs[3 * b + 2];
+        double y = dirs[3 * b + 1];
+        if (x == 0 && y == 0) y += 1;
+        const float kinv = roughness_ptr ? roughness_ptr[b] : roughness_scalar;
+        double zp[17], re[17], im[17];
+        zp[0] = 1; re[0] = 1; im[0] = 0;
+        for (int k = 1; k <= lmax; ++k) {
+            zp[k] = zp[k - 1] * z;
+            re[k] = re[k - 1] * x - im[k - 1] * y; im[k] = re[k - 1] * y + im[k - 1] * x;
+        }
+        double gx = 0, gy = 0, gz = 0, gk = 0;
+        for (int i = 0; i < n; ++i) {
+            const int m = ml_m[i];
+            double P = 0, dP = 0;
+            for (int k = 0; k <= lmax; ++k) { P += zp[k] * mat[(size_t)k * n + i]; if (k) dP += k * zp[k - 1] * mat[(size_t)k * n + i]; }
+            const float sigma = 0.5f * (float)(ml_l[i] * (ml_l[i] + 1));
+            const double att = (double)expf(-sigma * kinv);
+            const double a = grad[(size_t)b * 2 * n + i], c = grad[(size_t)b * 2 * n + n + i];
+            if (m > 0) {
+                gx += m * P * att * (a * re[m - 1] + c * im[m - 1]);
+                gy += m * P * att * (c * re[m - 1] - a * im[m - 1]);
+            }
+            const double w = a * re[m] + c * im[m];
+            gz += dP * att * w;
+            gk -= (double)sigma * P * att * w;
+        }
+        if (grad_dirs) { grad_dirs[3 * b] = (float)gx; grad_dirs[3 * b + 1] = (float)gy; grad_dirs[3 * b + 2] = (float)gz; }
+        if (grad_roughness) grad_roughness[b] = (float)gk;
+    }
+    free(mat);
+    return 0;
+}
+

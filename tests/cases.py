@@ -301,6 +301,13 @@ def ide_cases():
         rough = rng.uniform(0, 0.3, B).astype(F)
         rough[:8] = 0
         out.append((f"ide_deg{deg}_rough", "ide_encode_forward", (d, rough, 0.0, B, deg, np.zeros((B, n), F)), 2e-6))
+        # gradients w.r.t. the direction and kappa_inv (roughness away from 0 like the roughness head's outputs: at 0 the
+        # l = 16 derivative terms reach ~1e4 and fp32 rounding of the result dominates any comparison)
+        gout = rng.normal(size=(B, n)).astype(F)
+        rough_b = rng.uniform(0.02, 0.3, B).astype(F)
+        out.append((f"ide_deg{deg}_bwd_rough", "ide_encode_backward", (gout, d, rough_b, 0.0, B, deg, np.zeros((B, 3), F), np.zeros(B, F)), 2e-6))
+        out.append((f"ide_deg{deg}_bwd_scalar", "ide_encode_backward", (gout, d, None, 0.64, B, deg, np.zeros((B, 3), F), None), 2e-6))
+        out.append((f"ide_deg{deg}_bwd_rough_only", "ide_encode_backward", (gout, d, rough_b, 0.0, B, deg, None, np.zeros(B, F)), 2e-6))
     return out
 
 

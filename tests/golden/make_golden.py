@@ -417,6 +417,26 @@ def golden_ide():
         out[f"mat{deg}"] = enc.mat.numpy()
     np.savez_compressed(OUT / "ide.npz", **out)
     print("[golden] ide: deg 4 and 5, per-sample and scalar roughness")
+    # the gradient torch autograd takes through the reference's forward (what its training branch back-propagates): upstream
+    # gradient = a fixed random matrix; roughness in the range the roughness head produces (the l = 16 terms of the reference's
+    # fp32 polynomial are pure rounding noise near |z| = 1: with these roughness values they are attenuated by > e^-4)
+    out = {}
+    for deg in (4, 5):
+        enc = IntegratedDirEncoder(3, deg)
+        d = rng.normal(size=(1500, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        d = d.astype(F)
+        d[0] = (0.6, 0.8, 0.0)
+        rough = rng.uniform(0.03, 0.3, size=(1500, 1)).astype(F)
+        gout = rng.normal(size=(1500, enc.output_dim)).astype(F)
+        dt, rt = torch.from_numpy(d).requires_grad_(True), torch.from_numpy(rough).requires_grad_(True)
+        (enc(dt, rt) * torch.from_numpy(gout)).sum().backward()
+        out.update({f"dirs{deg}": d, f"rough{deg}": rough, f"gout{deg}": gout, f"gdirs{deg}": dt.grad.numpy(), f"grough{deg}": rt.grad.numpy()})
+        dt2 = torch.from_numpy(d).requires_grad_(True)
+        (enc(dt2, 0.64) * torch.from_numpy(gout)).sum().backward()
+        out[f"gdirs{deg}_k064"] = dt2.grad.numpy()
+    np.savez_compressed(OUT / "ide_grad.npz", **out)
+    print("[golden] ide_grad: deg 4 and 5, autograd of the reference's forward")
 
 
 def golden_ops():
@@ -442,12 +462,76 @@ def golden_ops():
     print(f"[golden] ops_ref: {len(out)} arrays from {len(keep)} cases")
 
 
+def train_targets(n):
+    """deterministic stand-in for ground-truth pixels of a training batch"""
+    i = np.arange(n, dtype=np.float64)
+    return np.stack([0.5 + 0.3 * np.sin(0.37 * i), 0.5 + 0.3 * np.cos(0.11 * i + 1.0), 0.4 + 0.2 * np.sin(0.05 * i + 2.0)], -1).astype(F)
+
+
+def train_loss(res, target):
+    """a scalar that reads every differentiable output of run_cuda's training branch the reference's Trainer reads
+    (nerf/utils.py:700-800: colour, eikonal, back-sdf style terms, mask), with fixed weights; the GPU test uses this very function"""
+    loss = ((res["image"].reshape(-1, 3) - target) ** 2).mean()
+    loss = loss + 0.05 * ((res["sdf_gradients"].norm(p=2, dim=-1) - 1) ** 2).mean()
+    loss = loss + 0.02 * ((res["relsdf"] - res["est_relsdf"]).abs() * res["sdf_weights"]).sum() / max(res["relsdf"].shape[0], 1)
+    loss = loss + 0.1 * (res["weights_sum"].reshape(-1) - 0.7).abs().mean() + 0.03 * res["depth"].reshape(-1).mean()
+    return loss
+
+
+def golden_train(tag, scene, config=None, H=32, W=32, theta=55.0, phi=-30.0):
+    """One training-mode forward + backward of the REFERENCE: model.train(), render() -> run_cuda's training branch
+    (cuda_ray.py:64-237: march_rays_train -> forward_sigma with autograd normals -> forward_color -> composite_rays_train),
+    eikonal + back-sdf switches on, loss = train_loss, .backward() through the reference's own autograd Functions
+    (_hash_encode second-order backward, _composite_rays_train backward) on the reference kernel bodies.  Stored: the
+    forward outputs, the per-ray sample counts, and the gradients of every MLP parameter, beta and the hash table
+    (table: per-level norms, touched-row counts and a sample of rows)."""
+    model, opt = build_reference_model(scene, config=config)
+    model.train()
+    opt.eikonal_loss, opt.backsdf_loss = True, True
+    ro, rd = scenes.camera_rays(H, W, theta=theta, phi=phi)
+    N = H * W
+    target = torch.from_numpy(train_targets(N))
+    kw = dict(vars(opt))
+    res = model.render(torch.from_numpy(ro)[None], torch.from_numpy(rd)[None], staged=False, bg_color=1, perturb=False, force_all_rays=False, **kw)
+    loss = train_loss(res, target)
+    model.zero_grad()
+    loss.backward()
+    out = {"H": H, "W": W, "theta": theta, "phi": phi, "loss": np.float64(loss.item()), "image": res["image"].detach().numpy().reshape(N, 3),
+           "depth": res["depth"].detach().numpy().reshape(N), "weights_sum": res["weights_sum"].detach().numpy().reshape(N),
+           "n_samples": np.int64(res["sigmas"].shape[0]), "n_relsdf": np.int64(res["relsdf"].shape[0]),
+           "counter": model.step_counter[0].numpy().copy()}
+    nets = ["sdf_net", "diffuse_net", "color_net"] + (["env_net"] if getattr(model, "env_net", None) is not None else [])
+    for name in nets:
+        for k, prm in getattr(model, name).named_parameters():
+            g = prm.grad.numpy().astype(F)
+            out[f"norm/{name}.{k}"] = np.float64(np.linalg.norm(g.astype(np.float64)))
+            out[f"grad/{name}.{k}"] = g if (name != "env_net" or g.ndim == 1) else g.reshape(-1)[::7].copy()
+    out["grad/beta"] = model.sdf_density.beta.grad.numpy().astype(F)
+    ge = model.encoder.embeddings.grad.numpy()
+    offs = model.encoder.offsets.numpy()
+    out["emb/level_norm"] = np.array([np.linalg.norm(ge[offs[l]:offs[l + 1]].astype(np.float64)) for l in range(16)])
+    touched = np.nonzero(np.any(ge != 0, axis=1))[0]
+    out["emb/level_touched"] = np.array([int(((touched >= offs[l]) & (touched < offs[l + 1])).sum()) for l in range(16)], np.int64)
+    pick = touched[:: max(1, touched.size // 4096)][:4096]
+    out["emb/rows"], out["emb/values"] = pick.astype(np.int64), ge[pick].astype(F)
+    np.savez_compressed(OUT / f"train_{tag}.npz", **out)
+    print(f"[golden] train_{tag}: {H}x{W}, {int(out['n_samples'])} samples, loss {loss.item():.6f}, |grad sdf_net.0.weight| "
+          f"{out['norm/sdf_net.0.weight']:.4e}, table rows touched {touched.size}, beta grad {float(out['grad/beta']):.4e}")
+
+
 def main():
     if not REFERENCE.exists():
         raise SystemExit("/root/reference is not present: golden vectors can only be regenerated in the build container")
     torch.manual_seed(0)
     torch.set_num_threads(8)
     install_reference()
+    if sys.argv[1:] == ["ide"]:
+        golden_ide()
+        return
+    if sys.argv[1:] == ["train"]:              # only the training-branch fixtures
+        golden_train("toaster", scenes.toaster_scene())
+        golden_train("lego", scenes.lego_scene(seed=8), config=OUT / "lego_like.ini", theta=110.0, phi=-40.0)
+        return
     golden_ops()
     golden_rays()
     golden_ide()
@@ -472,6 +556,8 @@ def main():
     model2, opt2 = build_reference_model(scenes.lego_scene(seed=8), config=OUT / "lego_like.ini")
     golden_frame(model2, opt2, "lego_48", 48, 48, theta=110.0, phi=-40.0)
     golden_shading(model2, opt2, "lego", n=1024)
+    golden_train("toaster", scenes.toaster_scene())
+    golden_train("lego", scenes.lego_scene(seed=8), config=OUT / "lego_like.ini", theta=110.0, phi=-40.0)
 
 
 if __name__ == "__main__":

@@ -189,3 +189,19 @@ def test_get_rays_matches_reference():
     for b in range(2):
         o, d = scenes.get_rays(g["poses"][b], g["intrinsics"], H, W)
         assert np.allclose(d, g["rays_d"][b], atol=1e-6, rtol=0) and np.allclose(o, g["rays_o"][b], atol=0)
+
+
+def test_ide_gradient_oracle_vs_reference_autograd():
+    """oracle_ide_encode_backward (closed-form partials, fp64 on the fp32-rounded table) against the gradient torch autograd takes
+    through the reference's own IntegratedDirEncoder.forward (tests/golden/make_golden.py golden_ide -> ide_grad.npz).
+    Degree 4 agrees to fp32 rounding; at degree 5 the difference IS the reference's fp32 cancellation noise in its l = 16 terms
+    (DESIGN.md 4.4), ~1e-5 of the gradient at these roughness values."""
+    from tests.util import run_op
+    g = np.load(GOLD / "ide_grad.npz")
+    for deg, tol_d, tol_r in ((4, 5e-6, 5e-6), (5, 1e-4, 5e-4)):
+        d, r, go = g[f"dirs{deg}"], g[f"rough{deg}"].reshape(-1).copy(), g[f"gout{deg}"]
+        B = d.shape[0]
+        res = run_op("oracle", "ide_encode_backward", go, d, r, 0.0, B, deg, np.zeros((B, 3), np.float32), np.zeros(B, np.float32))
+        assert rel_l2(res[-2], g[f"gdirs{deg}"]) <= tol_d and rel_l2(res[-1], g[f"grough{deg}"].reshape(-1)) <= tol_r, deg
+        res = run_op("oracle", "ide_encode_backward", go, d, None, 0.64, B, deg, np.zeros((B, 3), np.float32), None)
+        assert rel_l2(res[-2], g[f"gdirs{deg}_k064"]) <= 5e-6, deg

@@ -57,7 +57,7 @@ def test_hip_matches_oracle(cid, op, args, tol):
     _compare(cid, op, got, want, tol)
 
 
-SHIM_CASES = [c for c in CASES if c[1] not in ("compact_alive", "ide_encode_forward")]
+SHIM_CASES = [c for c in CASES if c[1] not in ("compact_alive", "ide_encode_forward", "ide_encode_backward")]
 
 
 @pytest.mark.parametrize("cid,op,args,tol", SHIM_CASES, ids=[c[0] for c in SHIM_CASES])
