@@ -81,7 +81,7 @@ def host_cpu_info() -> dict:
 
 def cpu_baseline(scene, env_rot: float, frames: int, res: int) -> dict:
     """the CPU restatement (oracle: C/OpenMP ops + torch CPU fp32 GEMMs, reference n_step schedule) timed on the host cores
-    on the benchmark's own frame.  Thread count: every candidate in {16, 32, 64, all hardware threads} renders a 400x400 frame
+    on the benchmark's own frame.  Thread count: every candidate in {16, 32, 64} (capped at the hardware threads) renders a 400x400 frame
     of the SAME scene and camera once (160 000 rays: the first loop iterations are 160 k-row GEMMs, the regime of the full
     frame -- a 96x96 probe is not), after a small warm-up; the fastest is used.  Then the median of `frames` full frames."""
     from envidr_amd import scenes
@@ -91,7 +91,9 @@ def cpu_baseline(scene, env_rot: float, frames: int, res: int) -> dict:
     probe_o, probe_d = scenes.camera_rays(probe_res, probe_res)
     best, threads, tried = None, 1, {}
     ncpu = os.cpu_count() or 1
-    for th in sorted({min(c, ncpu) for c in (16, 32, 64, ncpu)}):
+    # (all hardware threads is not a candidate: on the 2 x 64-core, 256-thread host of the GPU box that setting took 413 s for
+    # the probe frame the others render in 9-15 s -- profiles/r03g/bench.json -- and would alone take the run past ten minutes)
+    for th in sorted({min(c, ncpu) for c in (16, 32, 64)}):
         torch.set_num_threads(th)
         ro.render_rays(scene, probe_o[:256], probe_d[:256], opt, env_rot)    # warm-up (library loads, thread pools)
         t0 = time.perf_counter()
@@ -195,6 +197,10 @@ def run(argv: list[str]) -> None:
     rank, world, local = parallel.init_from_env(backend="gloo" if stub else None, force=args.force_dist)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if rank != 0:
+        # only rank 0 reports; whatever libraries print on the other ranks' stdout must not land behind its JSON line
+        sys.stdout.flush()
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     dist_on = world > 1 or args.force_dist         # the collective code path (a world of one with --force-dist)
     strong = args.scaling == "strong"
     if stub:
@@ -295,6 +301,9 @@ def run(argv: list[str]) -> None:
     res = None
     for i in range(args.warmup):
         res = step(i)
+    if dist_on:
+        fence()
+        _flush_c_stdio()          # the communicator exists now: its start-up banner goes out here, not at exit
 
     # HIP events on the stream the kernels are launched on (torch's current stream), recorded at the pass boundaries
     ev = None if stub else [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
@@ -380,9 +389,7 @@ def run(argv: list[str]) -> None:
                               "scene": "none (stub)" if stub else ("generated on rank 0, table + bitfield broadcast" if world > 1 else "generated locally")}
         if stub:
             result["config"]["workload"] = "STUB (CPU plumbing test)"
-            print(json.dumps(result))
-            if dist_on:
-                dist.destroy_process_group()
+            _finish(result, dist_on)
             return
         result["roofline"] = {
             "bound": "mfma", "achieved": flops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": flops / PEAK_FP32_MFMA_TFLOPS,
@@ -446,9 +453,31 @@ def run(argv: list[str]) -> None:
                                      "agree to ~1e-7 (tests/test_geometry_gpu.py::test_integer_trace_is_the_oracles)")
             result["cpu_baseline"] = cpu
             result["speedup_vs_cpu_baseline"] = rays_per_s / cpu["value"]
-        print(json.dumps(result))
-    if dist_on:
+        _finish(result, dist_on)
+        return
+    _finish(None, dist_on)
+
+
+def _flush_c_stdio() -> None:
+    """RCCL writes a version banner with C stdio (buffered until the process exits, i.e. AFTER anything Python has printed):
+    push it out now so that the JSON line is the last thing on stdout"""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:       # noqa: BLE001
+        pass
+
+
+def _finish(result, dist_on: bool) -> None:
+    """tear the process group down first (whatever the communication library still has to say comes out here), then rank 0
+    prints the ONE JSON line, last"""
+    import torch.distributed as dist
+    if dist_on and dist.is_initialized():
         dist.destroy_process_group()
+    _flush_c_stdio()
+    if result is not None:
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
 
 
 def context_legs(result, renderer, dev, steps: int, N: int) -> None:

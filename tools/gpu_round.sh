@@ -13,6 +13,13 @@ fi
 timeout 1500 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" >> $OUT/bench.err
 # kernel trace + stats of the same command (CPU leg skipped: it launches no kernels)
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --headline-only > $OUT/trace.log 2>&1 )
+# the same for COLD frames (no per-ray hint): kernel trace + stats
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cold -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --headline-only --cold > $OUT/trace_cold.log 2>&1 )
+# the multi-GPU code path on this one GPU (RCCL world of one) and the strong-scaling mode
+timeout 600 python bench.py --headline-only --force-dist > $OUT/bench_force_dist.json 2> $OUT/bench_force_dist.err
+timeout 600 python bench.py --headline-only --force-dist --scaling strong > $OUT/bench_strong.json 2> $OUT/bench_strong.err
+# random-line gather ceiling of the chip (the bound the geometry evaluation is measured against)
+[ -x tools/probe/gather_probe ] && timeout 300 tools/probe/gather_probe > $OUT/gather_probe.txt 2>&1
 # PMC passes, each on its own (no trace domains mixed in)
 for SET in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
   N=$(echo $SET | tr ' ' '_' | cut -c1-30)
@@ -56,3 +63,12 @@ json.dump(summary, open(out + "/summary.json", "w"), indent=1)
 print(json.dumps(summary, indent=1)[:3000])
 PY
 tail -3 $OUT/pytest_gpu.log $OUT/smoke.log 2>/dev/null; cat $OUT/bench.json | cut -c1-1500; tail -2 $OUT/bench.err
+# what gets committed under profiles/<tag>/
+P=$OUT/profile; mkdir -p $P
+cp $OUT/bench.json $OUT/summary.json $P/ 2>/dev/null
+cp $OUT/bench_force_dist.json $OUT/bench_strong.json $OUT/gather_probe.txt $P/ 2>/dev/null
+find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $P/kernel_stats.csv \;
+find $OUT/trace_cold -name "*kernel_stats.csv" -exec cp {} $P/kernel_stats_cold.csv \;
+for d in $OUT/pmc_*/; do n=$(basename $d); find $d -name "*counter_collection.csv" -exec cp {} $P/$n.csv \; ; done
+tail -5 $OUT/pytest_gpu.log > $P/pytest_gpu_tail.txt; tail -2 $OUT/smoke.log >> $P/pytest_gpu_tail.txt
+
