@@ -40,6 +40,11 @@ SIGNATURES: dict[str, str] = {
     # gridencoder (gridencoder.h:12-13)
     "grid_encode_forward": "ppppuuuufupui",
     "grid_encode_backward": "pppppuuuufuppui",
+    # half-precision tables (the at::Half dispatch of the two grid encoders; include/envidr_amd.h "ABI 6")
+    "hash_encode_forward_f16": "ppppuuuufuip",
+    "hash_encode_backward_f16": "pppppuuuufuipp",
+    "grid_encode_forward_f16": "ppppuuuufupui",
+    "grid_encode_backward_f16": "pppppuuuufuppui",
     # freqencoder (freqencoder.h:6-9)
     "freq_encode_forward": "puuuup",
     "freq_encode_backward": "ppuuuup",

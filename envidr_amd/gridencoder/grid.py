@@ -1,5 +1,7 @@
 """`gridencoder` (encoding = hashgrid / tiledgrid): torch-ngp's linear-interpolation grid on the HIP
-library.  Mirrors gridencoder/grid.py (grid_encode :89, GridEncoder :92-175).  fp32 tables only."""
+library.  Mirrors gridencoder/grid.py (grid_encode :89, GridEncoder :92-175).  The table may be fp32 or fp16: like the
+reference (grid.py:37-40) the inputs stay fp32 and a half table -- given as such, or narrowed under torch autocast when the
+channel count is even -- selects the at::Half instantiation (`grid_encode_*_f16`); outputs / dy_dx take the table's dtype."""
 from __future__ import annotations
 
 import numpy as np
@@ -16,27 +18,36 @@ class _GridEncode(Function):
     @staticmethod
     def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0,
                 align_corners=False):
-        inputs, embeddings, offsets = inputs.float().contiguous(), embeddings.float().contiguous(), offsets.contiguous()
+        inputs, offsets = inputs.float().contiguous(), offsets.contiguous()
         B, D = inputs.shape
         L, C = offsets.shape[0] - 1, embeddings.shape[1]
         S, H = float(np.log2(per_level_scale)), int(base_resolution)
-        outputs = torch.empty(L, B, C, device=inputs.device, dtype=torch.float32)
-        dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=torch.float32) if calc_grad_inputs else None
-        _lib.call("grid_encode_forward", inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, int(align_corners))
+        # manual autocast like the reference: only the embeddings go to half, and only for even C (grid.py:37-40)
+        if torch.is_autocast_enabled() and C % 2 == 0:
+            embeddings = embeddings.to(torch.half)
+        half = embeddings.dtype == torch.half
+        embeddings = embeddings.contiguous() if half else embeddings.float().contiguous()
+        dtype = embeddings.dtype
+        outputs = torch.empty(L, B, C, device=inputs.device, dtype=dtype)
+        dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=dtype) if calc_grad_inputs else None
+        _lib.call("grid_encode_forward_f16" if half else "grid_encode_forward", inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx,
+                  gridtype, int(align_corners))
         ctx.save_for_backward(inputs, embeddings, offsets, dy_dx if dy_dx is not None else torch.empty(1, device=inputs.device))
         ctx.dims = (B, D, C, L, S, H, gridtype)
-        ctx.calc_grad_inputs, ctx.align_corners = calc_grad_inputs, align_corners
+        ctx.calc_grad_inputs, ctx.align_corners, ctx.half = calc_grad_inputs, align_corners, half
         return outputs.permute(1, 0, 2).reshape(B, L * C)
 
     @staticmethod
     def backward(ctx, grad):
         inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
         B, D, C, L, S, H, gridtype = ctx.dims
-        grad = grad.view(B, L, C).permute(1, 0, 2).contiguous()
+        grad = grad.to(embeddings.dtype).view(B, L, C).permute(1, 0, 2).contiguous()
         grad_embeddings = torch.zeros_like(embeddings)
-        grad_inputs = torch.zeros_like(inputs) if ctx.calc_grad_inputs else None
-        _lib.call("grid_encode_backward", grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H,
-                  dy_dx if ctx.calc_grad_inputs else None, grad_inputs, gridtype, int(ctx.align_corners))
+        grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if ctx.calc_grad_inputs else None
+        _lib.call("grid_encode_backward_f16" if ctx.half else "grid_encode_backward", grad, inputs, embeddings, offsets, grad_embeddings, B, D, C,
+                  L, S, H, dy_dx if ctx.calc_grad_inputs else None, grad_inputs, gridtype, int(ctx.align_corners))
+        if grad_inputs is not None:
+            grad_inputs = grad_inputs.to(inputs.dtype)
         return grad_inputs, grad_embeddings, None, None, None, None, None, None
 
 

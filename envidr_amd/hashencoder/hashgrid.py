@@ -1,6 +1,8 @@
 """`hashencoder` (encoding_pos = hashgrid_diff): smoothstep multiresolution hash grid with analytic
 input derivative and first/second-order backward, on the HIP library.  Mirrors the reference's
-hashencoder/hashgrid.py (hash_encode :107, HashEncoder :110-169)."""
+hashencoder/hashgrid.py (hash_encode :107, HashEncoder :110-169).  fp32, or -- like the reference's
+`custom_fwd(cast_inputs=torch.half)` (hashgrid.py:19) -- fp16 for inputs, table, outputs and dy_dx when the table is given in
+half or torch autocast is on (`hash_encode_*_f16`, the at::Half instantiation; first-order backward only)."""
 from __future__ import annotations
 
 import numpy as np
@@ -14,23 +16,33 @@ from .. import _lib
 class _HashEncode(Function):
     @staticmethod
     def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False):
-        inputs, embeddings, offsets = inputs.float().contiguous(), embeddings.float().contiguous(), offsets.contiguous()
+        half = embeddings.dtype == torch.half or torch.is_autocast_enabled()
+        dtype = torch.half if half else torch.float32
+        inputs, embeddings, offsets = inputs.to(dtype).contiguous(), embeddings.to(dtype).contiguous(), offsets.contiguous()
         B, D = inputs.shape
         L, C = offsets.shape[0] - 1, embeddings.shape[1]
         S, H = float(np.log2(per_level_scale)), int(base_resolution)
-        outputs = torch.empty(L, B, C, device=inputs.device, dtype=torch.float32)     # level-major, like the reference
-        dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=torch.float32) if calc_grad_inputs else None
-        _lib.call("hash_encode_forward", inputs, embeddings, offsets, outputs, B, D, C, L, S, H, int(calc_grad_inputs), dy_dx)
+        outputs = torch.empty(L, B, C, device=inputs.device, dtype=dtype)     # level-major, like the reference
+        dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=dtype) if calc_grad_inputs else None
+        _lib.call("hash_encode_forward_f16" if half else "hash_encode_forward", inputs, embeddings, offsets, outputs, B, D, C, L, S, H,
+                  int(calc_grad_inputs), dy_dx)
         ctx.save_for_backward(inputs, embeddings, offsets, dy_dx if dy_dx is not None else torch.empty(1, device=inputs.device))
         ctx.dims = (B, D, C, L, S, H)
-        ctx.calc_grad_inputs = calc_grad_inputs
+        ctx.calc_grad_inputs, ctx.half = calc_grad_inputs, half
         return outputs.permute(1, 0, 2).reshape(B, L * C)
 
     @staticmethod
     def backward(ctx, grad):
         inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
         B, D, C, L, S, H = ctx.dims
-        grad = grad.view(B, L, C).permute(1, 0, 2).contiguous()
+        grad = grad.to(embeddings.dtype).view(B, L, C).permute(1, 0, 2).contiguous()
+        if ctx.half:
+            # the at::Half instantiation: first-order only (the half second backward of the reference is not provided)
+            grad_inputs = torch.zeros_like(inputs) if ctx.calc_grad_inputs else None
+            grad_embeddings = torch.zeros_like(embeddings) if ctx.needs_input_grad[1] else None
+            _lib.call("hash_encode_backward_f16", grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H,
+                      int(ctx.calc_grad_inputs), dy_dx if ctx.calc_grad_inputs else None, grad_inputs)
+            return grad_inputs, grad_embeddings, None, None, None, None
         # whether the table gradient is wanted is known HERE (needs_input_grad); inside _HashEncodeBackward.forward grad
         # mode is always off, so asking torch.is_grad_enabled() there would never produce it
         grad_inputs, grad_embeddings = _HashEncodeBackward.apply(grad, inputs, embeddings, offsets, B, D, C, L, S, H,

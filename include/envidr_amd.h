@@ -183,6 +183,34 @@ int envidr_sh_encode_backward(const float* grad, const float* inputs, uint32_t B
                               envidr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * ABI 6: half-precision tables -- the `scalar_t = at::Half` side of the reference's
+ * AT_DISPATCH_FLOATING_TYPES_AND_HALF for the two grid encoders (hashencoder.cu:747,778; gridencoder.cu:443,474), i.e. what
+ * `hashencoder/hashgrid.py:19` (custom_fwd(cast_inputs=torch.half)) and `gridencoder/grid.py:37-40` (half table under autocast)
+ * dispatch to.  uint16_t* = IEEE binary16 storage (torch.half `data_ptr()`).  hashencoder narrows inputs, table, outputs,
+ * dy_dx and gradients; gridencoder keeps fp32 inputs (its kernels take `const float* inputs`).  Arithmetic narrows where
+ * c10::Half narrows (csrc/grid_half.hip); same argument order as the fp32 entry points.  Not provided in half: the second
+ * backward, freq / SH / raymarching (the reference's Python wrappers force fp32 there: shencoder/sphere_harmonics.py:16
+ * `cast_inputs=torch.float32`, raymarching.py `.float()`, freqencoder.cu `data_ptr<float>()`).
+ * ------------------------------------------------------------------------------------------ */
+int envidr_hash_encode_forward_f16(const uint16_t* inputs, const uint16_t* embeddings, const int32_t* offsets,
+                                   uint16_t* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                   float S, uint32_t H, int calc_grad_inputs, uint16_t* dy_dx,
+                                   envidr_stream_t stream);
+int envidr_hash_encode_backward_f16(const uint16_t* grad, const uint16_t* inputs, const uint16_t* embeddings,
+                                    const int32_t* offsets, uint16_t* grad_embeddings, uint32_t B, uint32_t D,
+                                    uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs,
+                                    const uint16_t* dy_dx, uint16_t* grad_inputs, envidr_stream_t stream);
+int envidr_grid_encode_forward_f16(const float* inputs, const uint16_t* embeddings, const int32_t* offsets,
+                                   uint16_t* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                   float S, uint32_t H, uint16_t* dy_dx, uint32_t gridtype, int align_corners,
+                                   envidr_stream_t stream);
+int envidr_grid_encode_backward_f16(const uint16_t* grad, const float* inputs, const uint16_t* embeddings,
+                                    const int32_t* offsets, uint16_t* grad_embeddings, uint32_t B, uint32_t D,
+                                    uint32_t C, uint32_t L, float S, uint32_t H, const uint16_t* dy_dx,
+                                    uint16_t* grad_inputs, uint32_t gridtype, int align_corners,
+                                    envidr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * ide_encoder  (reference: ide_encoder/ide_encoder.py:98-130 -- pure PyTorch there; a HIP op
  * here).  dirs [B,3]; roughness: per-sample [B] when roughness_ptr != NULL, else the scalar
  * roughness_scalar; deg_view in 1..5; outputs [B, 2*(2^deg_view - 1 + deg_view)] = [Re | Im].

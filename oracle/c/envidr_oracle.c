@@ -749,6 +749,224 @@ API int oracle_sh_encode_backward(const float* grad, const float* inputs, uint32
     return 0;
 }
 
+/* ============================ feature grids, half precision ============================ */
+/* The reference dispatches its grid kernels on at::Half too (AT_DISPATCH_FLOATING_TYPES_AND_HALF: hashencoder.cu:747,778;
+ * gridencoder.cu:443,474): `scalar_t` = at::Half for the table, the outputs, dy_dx and the gradients (hashencoder: also the
+ * inputs; gridencoder keeps `const float* inputs`).  c10::Half does ALL arithmetic in float and narrows (round to nearest
+ * even) only where a value becomes a Half again (c10/util/Half-inl.h):
+ *     Half (+,-,*) Half -> Half(float(a) op float(b))            e.g. `grid[r] - grid[l]`, `grad * dy_dx`
+ *     float op Half     -> float                                  e.g. `w * grid[i]`, `w * grad_cur[c]`
+ *     Half += float     -> a = Half(float(a) + float(Half(b)))   (operator+=(Half&, const Half&): the float narrows FIRST)
+ * The functions below restate the kernels with those narrowing points written out (H() = narrow, F() = widen). */
+static uint16_t f2h(float f) {
+    uint32_t x; memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0u));
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);
+    if (x < 0x38800000u) {
+        if (x < 0x33000000u) return (uint16_t)sign;
+        const int e = (int)(x >> 23);
+        const uint32_t m = (x & 0x7fffffu) | 0x800000u;
+        const int shift = 126 - e;
+        uint32_t r = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (r & 1u))) ++r;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = (x - 0x38000000u) >> 13;
+    const uint32_t rem = x & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r;
+    return (uint16_t)(sign | r);
+}
+static float h2f(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    uint32_t x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else { const float f = (float)m * 5.9604644775390625e-08f; memcpy(&x, &f, 4); x |= sign; }
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112u) << 23) | (m << 13);
+    float f; memcpy(&f, &x, 4); return f;
+}
+API uint16_t oracle_float_to_half(float f) { return f2h(f); }
+API float oracle_half_to_float(uint16_t h) { return h2f(h); }
+#define H(x) f2h(x)
+#define F(x) h2f(x)
+static inline uint16_t h_add_f(uint16_t a, float b) { return H(F(a) + F(H(b))); }      /* Half += float */
+
+/* one (point, level) of kernel_grid<at::Half, D, C>: x in float (hashencoder: widened from its Half inputs, `(float)inputs[d]`) */
+static void grid_point_level_h(const float* x, const uint16_t* table, uint32_t D, uint32_t C, uint32_t size, float scale, int smooth,
+                               float offset, uint32_t stride_step, int allow_hash, uint16_t* out, uint16_t* dydx /* [D][C] or NULL */) {
+    float pos[MAXD], dpos[MAXD];
+    uint32_t cell[MAXD];
+    for (uint32_t d = 0; d < D; ++d) {
+        pos[d] = x[d] * scale + offset;
+        cell[d] = (uint32_t)floorf(pos[d]);
+        pos[d] -= (float)cell[d];
+        if (smooth) { dpos[d] = 6 * pos[d] * (1.0f - pos[d]); pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]); }
+        else dpos[d] = 1.0f;
+    }
+    uint16_t res[MAXC];
+    for (uint32_t c = 0; c < C; ++c) res[c] = H(0.0f);
+    for (uint32_t idx = 0; idx < (1u << D); ++idx) {
+        float w = 1;
+        uint32_t q[MAXD];
+        for (uint32_t d = 0; d < D; ++d) {
+            if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; q[d] = cell[d]; }
+            else { w *= pos[d]; q[d] = cell[d] + 1; }
+        }
+        const uint32_t row = grid_row(q, D, size, stride_step, allow_hash);
+        for (uint32_t c = 0; c < C; ++c) res[c] = h_add_f(res[c], w * F(table[(size_t)row * C + c]));    /* results[ch] += w * grid[..] */
+    }
+    for (uint32_t c = 0; c < C; ++c) out[c] = res[c];
+    if (!dydx) return;
+    for (uint32_t gd = 0; gd < D; ++gd) {
+        uint16_t acc[MAXC];
+        for (uint32_t c = 0; c < C; ++c) acc[c] = H(0.0f);
+        for (uint32_t idx = 0; idx < (1u << (D - 1)); ++idx) {
+            float w = scale;
+            uint32_t q[MAXD];
+            for (uint32_t nd = 0; nd < D - 1; ++nd) {
+                const uint32_t d = nd >= gd ? nd + 1 : nd;
+                if ((idx & (1u << nd)) == 0) { w *= 1 - pos[d]; q[d] = cell[d]; }
+                else { w *= pos[d]; q[d] = cell[d] + 1; }
+            }
+            q[gd] = cell[gd];
+            const uint32_t left = grid_row(q, D, size, stride_step, allow_hash);
+            q[gd] = cell[gd] + 1;
+            const uint32_t right = grid_row(q, D, size, stride_step, allow_hash);
+            for (uint32_t c = 0; c < C; ++c) {
+                const uint16_t diff = H(F(table[(size_t)right * C + c]) - F(table[(size_t)left * C + c]));     /* Half - Half -> Half */
+                const float t = smooth ? w * F(diff) * dpos[gd] : w * F(diff);
+                acc[c] = h_add_f(acc[c], t);
+            }
+        }
+        for (uint32_t c = 0; c < C; ++c) dydx[gd * C + c] = acc[c];
+    }
+}
+
+static int grid_forward_h(const void* inputs, int inputs_half, const uint16_t* emb, const int32_t* offsets, uint16_t* outputs, uint32_t B,
+                          uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H_, uint16_t* dy_dx, int smooth, uint32_t gridtype,
+                          int align_corners) {
+    if (D < 1 || D > MAXD || C < 1 || C > MAXC) return -1;
+    for (uint32_t l = 0; l < L; ++l) {
+        const float scale = exp2f(l * S) * H_ - 1.0f;
+        const uint32_t resolution = (uint32_t)ceilf(scale) + 1;
+        const uint32_t size = (uint32_t)(offsets[l + 1] - offsets[l]);
+        const uint16_t* table = emb + (size_t)offsets[l] * C;
+        const float offset = smooth ? 0.0f : (align_corners ? 0.0f : 0.5f);
+        const uint32_t step = smooth ? resolution : (align_corners ? resolution : resolution + 1);
+        const int allow_hash = smooth ? 1 : (gridtype == 0);
+#pragma omp parallel for schedule(static)
+        for (int64_t b = 0; b < (int64_t)B; ++b) {
+            float x[MAXD];
+            for (uint32_t d = 0; d < D; ++d)
+                x[d] = inputs_half ? F(((const uint16_t*)inputs)[(size_t)b * D + d]) : ((const float*)inputs)[(size_t)b * D + d];
+            uint16_t* out = outputs + ((size_t)l * B + b) * C;
+            uint16_t* g = dy_dx ? dy_dx + ((size_t)b * L + l) * D * C : NULL;
+            int oob = 0;
+            for (uint32_t d = 0; d < D; ++d) if (x[d] < 0 || x[d] > 1) oob = 1;
+            if (oob) {
+                for (uint32_t c = 0; c < C; ++c) out[c] = H(0.0f);
+                if (g) for (uint32_t i = 0; i < D * C; ++i) g[i] = H(0.0f);
+                continue;
+            }
+            grid_point_level_h(x, table, D, C, size, scale, smooth, offset, step, allow_hash, out, g);
+        }
+    }
+    return 0;
+}
+
+/* kernel_grid_backward<at::Half,..> (paired __half2 atomics: each w * grad narrowed, then an fp16 add per component) +
+ * kernel_input_backward<at::Half,..> (Half product, Half running sum); serial over points like grid_backward() */
+static int grid_backward_h(const uint16_t* grad, const void* inputs, int inputs_half, const int32_t* offsets, uint16_t* grad_emb, uint32_t B,
+                           uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H_, const uint16_t* dy_dx, uint16_t* grad_inputs, int smooth,
+                           uint32_t gridtype, int align_corners) {
+    if (D < 1 || D > MAXD || C < 1 || C > MAXC) return -1;
+    if (grad_emb) {
+        for (uint32_t l = 0; l < L; ++l) {
+            const float scale = exp2f(l * S) * H_ - 1.0f;
+            const uint32_t resolution = (uint32_t)ceilf(scale) + 1;
+            const uint32_t size = (uint32_t)(offsets[l + 1] - offsets[l]);
+            uint16_t* table = grad_emb + (size_t)offsets[l] * C;
+            const float offset = smooth ? 0.0f : (align_corners ? 0.0f : 0.5f);
+            const uint32_t step = smooth ? resolution : (align_corners ? resolution : resolution + 1);
+            const int allow_hash = smooth ? 1 : (gridtype == 0);
+            for (uint32_t b = 0; b < B; ++b) {
+                float x[MAXD];
+                int oob = 0;
+                for (uint32_t d = 0; d < D; ++d) {
+                    x[d] = inputs_half ? F(((const uint16_t*)inputs)[(size_t)b * D + d]) : ((const float*)inputs)[(size_t)b * D + d];
+                    if (x[d] < 0 || x[d] > 1) oob = 1;
+                }
+                if (oob) continue;
+                float pos[MAXD]; uint32_t cell[MAXD];
+                for (uint32_t d = 0; d < D; ++d) {
+                    pos[d] = x[d] * scale + offset;
+                    cell[d] = (uint32_t)floorf(pos[d]);
+                    pos[d] -= (float)cell[d];
+                    if (smooth) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
+                }
+                const uint32_t NC = C < 2 ? C : 2;
+                for (uint32_t ch = 0; ch < C; ch += NC) {
+                    for (uint32_t idx = 0; idx < (1u << D); ++idx) {
+                        float w = 1; uint32_t q[MAXD];
+                        for (uint32_t d = 0; d < D; ++d) {
+                            if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; q[d] = cell[d]; }
+                            else { w *= pos[d]; q[d] = cell[d] + 1; }
+                        }
+                        const uint32_t row = grid_row(q, D, size, step, allow_hash);
+                        for (uint32_t c = 0; c < NC; ++c) {
+                            uint16_t* t = &table[(size_t)row * C + ch + c];
+                            const uint16_t v = H(w * F(grad[((size_t)l * B + b) * C + ch + c]));      /* (__half)(w * grad_cur[c]) */
+                            *t = H(F(*t) + F(v));                                                     /* fp16 atomic add      */
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (dy_dx && grad_inputs) {
+#pragma omp parallel for schedule(static)
+        for (int64_t t = 0; t < (int64_t)B * D; ++t) {
+            const uint32_t b = (uint32_t)(t / D), d = (uint32_t)(t - (int64_t)b * D);
+            uint16_t acc = H(0.0f);
+            for (uint32_t l = 0; l < L; ++l)
+                for (uint32_t c = 0; c < C; ++c) {
+                    const uint16_t prod = H(F(grad[((size_t)l * B + b) * C + c]) * F(dy_dx[(size_t)b * L * D * C + (size_t)l * D * C + d * C + c]));
+                    acc = H(F(acc) + F(prod));
+                }
+            grad_inputs[t] = acc;
+        }
+    }
+    return 0;
+}
+API int oracle_hash_encode_forward_f16(const uint16_t* inputs, const uint16_t* embeddings, const int32_t* offsets, uint16_t* outputs, uint32_t B,
+                                       uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H_, int calc_grad_inputs, uint16_t* dy_dx) {
+    if (D != 2 && D != 3) return -1;
+    return grid_forward_h(inputs, 1, embeddings, offsets, outputs, B, D, C, L, S, H_, calc_grad_inputs ? dy_dx : NULL, 1, 0, 0);
+}
+API int oracle_hash_encode_backward_f16(const uint16_t* grad, const uint16_t* inputs, const uint16_t* embeddings, const int32_t* offsets,
+                                        uint16_t* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H_,
+                                        int calc_grad_inputs, const uint16_t* dy_dx, uint16_t* grad_inputs) {
+    (void)embeddings;
+    if (D != 2 && D != 3) return -1;
+    return grid_backward_h(grad, inputs, 1, offsets, grad_embeddings, B, D, C, L, S, H_, calc_grad_inputs ? dy_dx : NULL, grad_inputs, 1, 0, 0);
+}
+API int oracle_grid_encode_forward_f16(const float* inputs, const uint16_t* embeddings, const int32_t* offsets, uint16_t* outputs, uint32_t B,
+                                       uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H_, uint16_t* dy_dx, uint32_t gridtype, int align_corners) {
+    return grid_forward_h(inputs, 0, embeddings, offsets, outputs, B, D, C, L, S, H_, dy_dx, 0, gridtype, align_corners);
+}
+API int oracle_grid_encode_backward_f16(const uint16_t* grad, const float* inputs, const uint16_t* embeddings, const int32_t* offsets,
+                                        uint16_t* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H_,
+                                        const uint16_t* dy_dx, uint16_t* grad_inputs, uint32_t gridtype, int align_corners) {
+    (void)embeddings;
+    return grid_backward_h(grad, inputs, 0, offsets, grad_embeddings, B, D, C, L, S, H_, dy_dx, grad_inputs, 0, gridtype, align_corners);
+}
+#undef H
+#undef F
+
 /* ============================ integrated directional encoding ============================ */
 /* ide_encoder/ide_encoder.py:5-55 (coefficient tables) and :98-130 (forward).  Evaluated in double
  * from the closed forms on the reference's fp32-rounded coefficient table, rounded once: this is the

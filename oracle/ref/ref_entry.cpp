@@ -220,6 +220,67 @@ EXPORT int ref_grid_encode_backward(const float* grad, const float* inputs, cons
     return 0;
 }
 
+/* ---- the at::Half instantiations of the same kernel templates (AT_DISPATCH_FLOATING_TYPES_AND_HALF: hashencoder.cu:747,778,
+ *      gridencoder.cu:443,474).  Pointers to 16-bit storage; hashencoder narrows inputs, table, outputs and dy_dx, gridencoder
+ *      keeps the inputs in float (its kernels take `const float* inputs`). ---- */
+typedef at::Half H16;
+template <uint32_t D, uint32_t C>
+static void hash_fwd_h(const H16* in, const H16* emb, const int* off, H16* out, uint32_t B, uint32_t L, float S, uint32_t H, bool g, H16* dy_dx) {
+    emu_launch(emu_blocks(B, 512), L, 512, [&] { ref_hash::kernel_grid<H16, D, C>(in, emb, off, out, B, L, S, H, g, dy_dx); });
+}
+template <uint32_t D, uint32_t C, uint32_t NC>
+static void hash_bwd_h(const H16* grad, const H16* in, const H16* emb, const int* off, H16* gemb, uint32_t B, uint32_t L, float S, uint32_t H,
+                       bool g, const H16* dy_dx, H16* gin) {
+    if (gemb)
+        emu_launch(emu_blocks(B * C / NC, 256), L, 256, [&] { ref_hash::kernel_grid_backward<H16, D, C, NC>(grad, in, emb, off, gemb, B, L, S, H); });
+    if (g) emu_launch(emu_blocks(B * D, 256), 1, 256, [&] { ref_hash::kernel_input_backward<H16, D, C>(grad, dy_dx, gin, B, L); });
+}
+EXPORT int ref_hash_encode_forward_f16(const uint16_t* inputs, const uint16_t* embeddings, const int32_t* offsets, uint16_t* outputs,
+                                       uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs, uint16_t* dy_dx) {
+#define F2(c, nc) hash_fwd_h<2, c>((const H16*)inputs, (const H16*)embeddings, offsets, (H16*)outputs, B, L, S, H, calc_grad_inputs != 0, (H16*)dy_dx)
+#define F3(c, nc) hash_fwd_h<3, c>((const H16*)inputs, (const H16*)embeddings, offsets, (H16*)outputs, B, L, S, H, calc_grad_inputs != 0, (H16*)dy_dx)
+    DC_SWITCH(F2, F3)
+#undef F2
+#undef F3
+    return 0;
+}
+EXPORT int ref_hash_encode_backward_f16(const uint16_t* grad, const uint16_t* inputs, const uint16_t* embeddings, const int32_t* offsets,
+                                        uint16_t* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                        int calc_grad_inputs, const uint16_t* dy_dx, uint16_t* grad_inputs) {
+#define F2(c, nc) hash_bwd_h<2, c, nc>((const H16*)grad, (const H16*)inputs, (const H16*)embeddings, offsets, (H16*)grad_embeddings, B, L, S, H, calc_grad_inputs != 0, (const H16*)dy_dx, (H16*)grad_inputs)
+#define F3(c, nc) hash_bwd_h<3, c, nc>((const H16*)grad, (const H16*)inputs, (const H16*)embeddings, offsets, (H16*)grad_embeddings, B, L, S, H, calc_grad_inputs != 0, (const H16*)dy_dx, (H16*)grad_inputs)
+    DC_SWITCH(F2, F3)
+#undef F2
+#undef F3
+    return 0;
+}
+template <uint32_t D, uint32_t C>
+static void grid_fwd_h(const float* in, const H16* emb, const int* off, H16* out, uint32_t B, uint32_t L, float S, uint32_t H, H16* dy_dx,
+                       uint32_t gt, bool ac) {
+    emu_launch(emu_blocks(B, 512), L, 512, [&] { ref_grid::kernel_grid<H16, D, C>(in, emb, off, out, B, L, S, H, dy_dx, gt, ac); });
+}
+template <uint32_t D, uint32_t C, uint32_t NC>
+static void grid_bwd_h(const H16* grad, const float* in, const H16* emb, const int* off, H16* gemb, uint32_t B, uint32_t L, float S, uint32_t H,
+                       const H16* dy_dx, H16* gin, uint32_t gt, bool ac) {
+    emu_launch(emu_blocks(B * C / NC, 256), L, 256, [&] { ref_grid::kernel_grid_backward<H16, D, C, NC>(grad, in, emb, off, gemb, B, L, S, H, gt, ac); });
+    if (dy_dx) emu_launch(emu_blocks(B * D, 256), 1, 256, [&] { ref_grid::kernel_input_backward<H16, D, C>(grad, dy_dx, gin, B, L); });
+}
+EXPORT int ref_grid_encode_forward_f16(const float* inputs, const uint16_t* embeddings, const int32_t* offsets, uint16_t* outputs, uint32_t B,
+                                       uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint16_t* dy_dx, uint32_t gridtype, int align_corners) {
+#define FN(d, c, nc) case d * 10 + c: grid_fwd_h<d, c>(inputs, (const H16*)embeddings, offsets, (H16*)outputs, B, L, S, H, (H16*)dy_dx, gridtype, align_corners != 0); break;
+    GRID_DISPATCH(FN)
+#undef FN
+    return 0;
+}
+EXPORT int ref_grid_encode_backward_f16(const uint16_t* grad, const float* inputs, const uint16_t* embeddings, const int32_t* offsets,
+                                        uint16_t* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                        const uint16_t* dy_dx, uint16_t* grad_inputs, uint32_t gridtype, int align_corners) {
+#define FN(d, c, nc) case d * 10 + c: grid_bwd_h<d, c, nc>((const H16*)grad, inputs, (const H16*)embeddings, offsets, (H16*)grad_embeddings, B, L, S, H, (const H16*)dy_dx, (H16*)grad_inputs, gridtype, align_corners != 0); break;
+    GRID_DISPATCH(FN)
+#undef FN
+    return 0;
+}
+
 /* ---- freqencoder (freqencoder.cu:97,113) ---- */
 EXPORT int ref_freq_encode_forward(const float* inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float* outputs) {
     emu_launch(emu_blocks(B * C, 128), 1, 128, [&] { ref_freq::kernel_freq(inputs, B, D, deg, C, outputs); });

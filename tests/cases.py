@@ -311,10 +311,52 @@ def ide_cases():
     return out
 
 
+def half_cases():
+    """the at::Half dispatch of the two grid encoders: fp16 tables / outputs / dy_dx (hashencoder: fp16 inputs too).  Arrays are
+    int16 views of IEEE binary16 data.  Forward passes and input gradients are compared bit for bit (tol None); table gradients
+    are sums of fp16 atomic adds whose rounding depends on the order of the adds (GPU) -- tolerance in units of fp16 rounding."""
+    from oracle import clib
+    rng = np.random.default_rng(23)
+    h = lambda a: np.ascontiguousarray(a, dtype=np.float16).view(np.int16)
+    out = []
+    for D, C, L, log2T, base, desired in [(3, 2, 16, 19, 16, 2048), (2, 2, 4, 19, 16, 2048), (3, 1, 5, 12, 4, 40), (3, 4, 6, 14, 8, 200), (2, 8, 4, 10, 4, 60)]:
+        offsets, pls = scenes.hash_level_offsets(D, L, base, log2T, desired)
+        S = float(np.log2(pls))
+        B = 300
+        x = _points(rng, B, D).astype(np.float16)                       # faces, outside points ... narrowed to half
+        table = rng.uniform(-1, 1, size=(int(offsets[-1]), C)).astype(np.float16)
+        cid = f"hash16_D{D}C{C}L{L}"
+        dy = np.zeros((B, L * D * C), np.int16)
+        out.append((cid + "_fwd_grad", "hash_encode_forward_f16", (h(x), h(table), offsets, np.zeros((L, B, C), np.int16), B, D, C, L, S, base, 1, dy), None))
+        out.append((cid + "_fwd", "hash_encode_forward_f16", (h(x), h(table), offsets, np.zeros((L, B, C), np.int16), B, D, C, L, S, base, 0, None), None))
+        dy = dy.copy()
+        clib.oracle().lib.oracle_hash_encode_forward_f16  # noqa: B018 (symbol must exist)
+        clib.oracle().call("hash_encode_forward_f16", h(x), h(table), offsets, np.zeros((L, B, C), np.int16), B, D, C, L, S, base, 1, dy)
+        grad = h(rng.normal(size=(L, B, C)) * 0.1)
+        # input gradient: bit-exact; table gradient: order-dependent fp16 sums -> two separate cases
+        out.append((cid + "_bwd_inputs", "hash_encode_backward_f16", (grad, h(x), h(table), offsets, None, B, D, C, L, S, base, 1, dy, np.zeros((B, D), np.int16)), None))
+        out.append((cid + "_bwd_table", "hash_encode_backward_f16", (grad, h(x), h(table), offsets, np.zeros((int(offsets[-1]), C), np.int16), B, D, C, L, S, base, 0, None, None), "f16"))
+    for D, C, L, log2T, base, desired, gridtype, align in [(3, 2, 8, 16, 16, 512, 0, 0), (2, 4, 4, 10, 4, 40, 1, 1), (1, 2, 4, 8, 4, 64, 0, 1), (4, 2, 3, 10, 2, 8, 0, 0)]:
+        offsets, pls = scenes.grid_level_offsets(D, L, base, log2T, desired, bool(align))
+        S = float(np.log2(pls))
+        B = 250
+        x = _points(rng, B, D)
+        table = rng.uniform(-1, 1, size=(int(offsets[-1]), C)).astype(np.float16)
+        cid = f"grid16_D{D}C{C}L{L}g{gridtype}a{align}"
+        dy = np.zeros((B, L * D * C), np.int16)
+        out.append((cid + "_fwd_grad", "grid_encode_forward_f16", (x, h(table), offsets, np.zeros((L, B, C), np.int16), B, D, C, L, S, base, dy, gridtype, align), None))
+        out.append((cid + "_fwd", "grid_encode_forward_f16", (x, h(table), offsets, np.zeros((L, B, C), np.int16), B, D, C, L, S, base, None, gridtype, align), None))
+        dy = dy.copy()
+        clib.oracle().call("grid_encode_forward_f16", x, h(table), offsets, np.zeros((L, B, C), np.int16), B, D, C, L, S, base, dy, gridtype, align)
+        grad = h(rng.normal(size=(L, B, C)) * 0.1)
+        out.append((cid + "_bwd", "grid_encode_backward_f16", (grad, x, h(table), offsets, np.zeros((int(offsets[-1]), C), np.int16), B, D, C, L, S, base, dy, np.zeros((B, D), np.int16), gridtype, align), "f16"))
+    return out
+
+
 ALL_GROUPS = {
     "near_far": near_far_cases, "misc": misc_cases, "march": march_cases, "composite": composite_cases,
     "train": train_cases, "hash": hash_cases, "hash_bwd": hash_backward_cases, "grid": grid_cases,
-    "grid_bwd": grid_backward_cases, "freq_sh": freq_sh_cases, "ide": ide_cases,
+    "grid_bwd": grid_backward_cases, "freq_sh": freq_sh_cases, "ide": ide_cases, "half": half_cases,
 }
 
 

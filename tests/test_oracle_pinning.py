@@ -27,6 +27,8 @@ def test_oracle_matches_reference_bodies(cid, op, args, tol, ref_lib):
     for k, (g, w) in enumerate(zip(got, want)):
         if g is None:
             continue
+        if tol == "f16":
+            tol = None          # serial on both sides: the fp16 sums are built in the same order, bit for bit
         if op in DERIVED:
             assert rel_l2(g, w) <= DERIVED[op], f"{cid}: pointer arg {k} rel-L2 {rel_l2(g, w):.3e}"
             if g.size:

@@ -30,8 +30,12 @@ def run_op(backend: str, name: str, *args):
     if backend == "shim":
         # through the reference-named backend modules (envidr_amd.compat): `<pkg>._ext._<pkg>.<name>(tensors...)`
         from envidr_amd.compat.backends import EXTENSIONS, make_backend
-        pkg = next(p for p, names in EXTENSIONS.items() if name in names)
-        getattr(make_backend(pkg), name)(*[bool(a) if k == "i" else a for k, a in zip(sig, work)])
+        base = name[:-4] if name.endswith("_f16") else name          # half cases go through the SAME pybind name, with half tensors
+        pkg = next(p for p, names in EXTENSIONS.items() if base in names)
+        targs = [bool(a) if k == "i" else a for k, a in zip(sig, work)]
+        if base != name:
+            targs = [a.view(torch.float16) if isinstance(a, torch.Tensor) and a.dtype == torch.int16 else a for a in targs]
+        getattr(make_backend(pkg), base)(*targs)
     else:
         _lib.call(name, *work)
     torch.cuda.synchronize()
