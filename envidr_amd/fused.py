@@ -640,6 +640,21 @@ class FusedRenderer:
         frames = self.__dict__.setdefault("_frames", {})
         st = frames.get(N)
         cap = max(int(N * samples_per_ray), 4096)
+        # trim: buffers more than twice the PEAK any frame of this ray count has needed so far (evaluated samples or records,
+        # + 25 %) are given back after 64 frames and re-made at that size -- the first guess of 20 samples per ray is ~0.9 GB at
+        # 800^2, harmless on 288 GB, but a long-lived renderer should converge on what it uses.  The peak never decreases, so a
+        # trimmed buffer still fits every frame seen (the passes of an indirect frame share N with different needs); the per-ray
+        # count hints are carried over.
+        carry = None
+        if st is not None and samples_per_ray <= st["hint"]:
+            cap = min(cap, st["cap"])              # the guess that sized (or a trim that re-sized) these buffers does not grow them again
+        if st is not None and st.get("peak") and not st["pending"] and st["cap"] >= cap:
+            need = int(1.25 * st["peak"]) + 4096
+            st["slack"] = st.get("slack", 0) + 1 if st["cap"] > 2 * need else 0
+            if st["slack"] >= 64:
+                carry = (st["costs"], st["peak"])
+                frames.pop(N)
+                st, cap = None, need
         if st is None or st["cap"] < cap:
             if st is None and len(frames) >= 4:
                 frames.pop(next(iter(frames)))
@@ -651,7 +666,9 @@ class FusedRenderer:
                       cost=torch.zeros(N, dtype=torch.int16, device=dev), costs={}, offsets=torch.zeros(N + 1, dtype=torch.int32, device=dev),
                       stats=torch.zeros(3, dtype=torch.int64, device=dev), worst=torch.zeros(3, dtype=torch.int64, device=dev),
                       host=torch.zeros(6, dtype=torch.int64).pin_memory(),
-                      event=torch.cuda.Event(), pending=False, hint=samples_per_ray)
+                      event=torch.cuda.Event(), pending=False, hint=samples_per_ray, peak=0)
+            if carry is not None:
+                st["costs"], st["peak"] = carry
             frames[N] = st
         self.__dict__["_frame"] = st
         return st
@@ -674,6 +691,8 @@ class FusedRenderer:
             st["last"] = (samples, records)
             st["worst"].zero_()
             samples, records = max(samples, w_samples), max(records, w_records)
+            if not overflow:
+                st["peak"] = max(st.get("peak", 0), samples, records)
             if overflow:
                 self.__dict__.setdefault("_frame_hints", {})[N] = max(2.0 * st["cap"] / N, 1.5 * max(samples, records) / N)
                 del self.__dict__["_frames"][N]

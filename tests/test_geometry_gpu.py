@@ -295,3 +295,22 @@ def test_no_environment_family_on_the_pipeline():
     for key in KEYS:
         err = rel_l2(out[key], want[key].reshape(out[key].shape))
         assert err <= 2e-5, f"{key} vs oracle: rel-L2 {err:.3e}"
+
+
+def test_frame_buffers_converge_on_what_the_frames_use(renderer):
+    """a first guess of the sample / record capacity that is far too large (here 100 per ray; 20 by default) is trimmed to 1.25x the peak the frames have needed once it
+    has been more than twice that for 64 frames; the frames do not change, the per-ray hint survives the re-allocation"""
+    import torch
+    renderer.__dict__.pop("_frames", None); renderer.__dict__.pop("_frame_hints", None)
+    ro_, rd_ = (torch.from_numpy(a).cuda() for a in scenes.camera_rays(128, 128, theta=20.0, phi=10.0))
+    want = {k: v.clone() for k, v in renderer.render_frame(ro_, rd_, 0.2, samples_per_ray_hint=100.0).items() if hasattr(v, "clone")}
+    cap0 = renderer._frame["cap"]
+    for _ in range(70):
+        got = renderer.render_frame(ro_, rd_, 0.2)
+    torch.cuda.synchronize()
+    st = renderer._frame
+    assert st["cap"] < cap0 and st["cap"] >= st["peak"] and st["cap"] <= 2 * st["peak"] + 8192, (cap0, st["cap"], st["peak"])
+    for k in ("image", "depth", "weights_sum", "normal_image", "ray_cost"):
+        assert torch.equal(got[k], want[k]), k
+    assert got["n_samples"] == got["n_records"]            # the hint was carried over: still one exact round
+    renderer.__dict__.pop("_frames", None)
