@@ -245,8 +245,10 @@ def run(argv: list[str]) -> None:
 
     def frame(view: int, slot: int, events=None):
         if pipeline:
+            # (weak mode: the rays ARE a row-major 800-wide image -- the layout hint lets the pipeline form its 64-ray blocks from
+            #  8x8-pixel tiles; strong mode already lists a rank's rays tile by tile)
             return renderer.render_frame(rays_o, rays_d, env_rot(view) if not stub else float(view), out=outs[slot], events=events, wait=False,
-                                         use_cost_hint=not args.cold)
+                                         use_cost_hint=not args.cold, image_width=0 if strong else n_side)
         if events:
             events[0].record()
         res = renderer.render(rays_o, rays_d, env_rot(view), extras=True, stats=True, out=outs[slot], ray_cost=ray_cost)
@@ -494,12 +496,12 @@ def context_legs(result, renderer, dev, steps: int, N: int) -> None:
         renderer.frame_log = {}
         for i in range(warm):
             o, d = make_rays(i)
-            renderer.render_frame(o, d, 0.1, out=out, wait=False, use_cost_hint=use_hint)
+            renderer.render_frame(o, d, 0.1, out=out, wait=False, use_cost_hint=use_hint, image_width=W)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for i in range(steps):
             o, d = make_rays(warm + i)
-            renderer.render_frame(o, d, 0.1, out=out, events=ev[i], wait=False, use_cost_hint=use_hint)
+            renderer.render_frame(o, d, 0.1, out=out, events=ev[i], wait=False, use_cost_hint=use_hint, image_width=W)
             log.append(renderer.frame_log[""])
         torch.cuda.synchronize(dev)
         dt = (time.perf_counter() - t0) / steps

@@ -985,8 +985,11 @@ __global__ void __launch_bounds__(kBlock) k_composite_records(const uint32_t* __
                                                               const float* __restrict__ cs, const float* __restrict__ ws, uint32_t N,
                                                               float intensity, float bg, float* __restrict__ image,
                                                               float* __restrict__ diffuse, float* __restrict__ specular,
-                                                              const uint32_t* __restrict__ m_dev, uint32_t capacity) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+                                                              const uint32_t* __restrict__ m_dev, uint32_t capacity, uint32_t tile_w) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    // the geometry pass appended the records block by block; with 8x8-pixel tiles as blocks (tile_w: the image width) a wave takes
+    // the rays of one tile here too, so that what its lanes read through perm[] is one contiguous run of records again
+    if (tile_w) { const uint32_t blk = r >> 6, lane = r & 63u, tiles_x = tile_w >> 3; r = ((blk / tiles_x) * 8u + (lane >> 3)) * tile_w + (blk % tiles_x) * 8u + (lane & 7u); }
     if (r >= N || *m_dev > capacity) return;
     float ar = 0, ag = 0, ab = 0, d0 = 0, d1 = 0, d2 = 0, s0 = 0, s1 = 0, s2 = 0;
     for (uint32_t j = offsets[r]; j < offsets[r + 1]; ++j) {
@@ -1280,7 +1283,8 @@ int envidr_composite_records(const envidr_geometry_export* rec, const uint32_t* 
         if (rc) return rc;
     }
     hipLaunchKernelGGL(k_composite_records, dim3(ceil_div(N, kBlock)), dim3(kBlock), 0, s, offsets, perm, rec->w, c_diffuse, c_specular,
-                       weights_sum, N, intensity_scale, bg_color, image, diffuse_image, specular_image, rec->counter, rec->capacity);
+                       weights_sum, N, intensity_scale, bg_color, image, diffuse_image, specular_image, rec->counter, rec->capacity,
+                       (rec->image_width && rec->image_width % 8u == 0 && N % rec->image_width == 0 && (N / rec->image_width) % 8u == 0) ? rec->image_width : 0u);
     return check_launch("k_composite_records");
 }
 

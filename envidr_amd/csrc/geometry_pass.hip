@@ -417,6 +417,8 @@ struct GeoRayArgs {
     const uint8_t* linear_grid; // one-cascade fast marcher (march_core.hip.h): the bitfield in linear cell order, or null
     uint32_t log2H;
     uint32_t occ_clip;          // ray_range(): clip rays to the box of the occupied cells
+    uint32_t tile_w, tiles_x;   // tile_w != 0: the rays are a row-major image tile_w pixels wide and block b is the 8x8-pixel tile
+                                // (b / tiles_x, b % tiles_x), lane l its pixel (l / 8, l % 8); else block b = rays 64 b .. 64 b + 63
 };
 
 // [near, far) of a ray: the slab test against the model's box (near_far: the reference's arithmetic), with `far` pulled in to
@@ -585,9 +587,12 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
     const Aabb occ = occupied_box(a);
     for (uint32_t bi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; bi < n_in; bi += n_waves) {
         const uint32_t blk = FIRST ? bi : __builtin_amdgcn_readfirstlane(a.alive_in[bi]);
-        const uint32_t ray = blk * 64u + lane;
+        // a ray's id is its position in the caller's list (every input and output is indexed by it); the per-ray state of the
+        // pass lives at the block's own 64 slots
+        uint32_t ray = blk * 64u + lane;
+        if (a.tile_w) ray = ((blk / a.tiles_x) * 8u + (lane >> 3)) * a.tile_w + (blk % a.tiles_x) * 8u + (lane & 7u);
         const bool in_range = ray < a.N;
-        uint32_t* const sp = a.state + ray;
+        uint32_t* const sp = a.state + (blk * 64u + lane);
         RayGeom rg = {};
         float near = 0, far = 0, t_first = 0;
         RayState st = {};
@@ -1007,6 +1012,10 @@ int envidr_geometry_pass(const envidr_render_desc* d, const float* rays_o, const
     a.depth = out->depth; a.ws = out->weights_sum; a.nimg = out->normal_image; a.rimg = out->roughness_image;
     a.ray_cost = d->ray_cost;
     a.ray_mask = d->ray_mask;
+    if (d->image_width && d->image_width % 8u == 0 && N % d->image_width == 0 && (N / d->image_width) % 8u == 0) {
+        a.tile_w = d->image_width;
+        a.tiles_x = d->image_width / 8u;
+    }
     uint32_t* alive[2] = {reinterpret_cast<uint32_t*>(ws + L.alive0), reinterpret_cast<uint32_t*>(ws + L.alive1)};
 
     // Chunk schedule.  Round 0: the caller's per-ray hint, else 16 samples.  Rounds 1..5: each live ray sizes its own chunk
@@ -1068,6 +1077,7 @@ int envidr_geometry_pass(const envidr_render_desc* d, const float* rays_o, const
     hipLaunchKernelGGL(k_geo_finalize, dim3(1), dim3(1), 0, s, counters, rec->counter, reinterpret_cast<unsigned long long*>(out->stats));
     // where the records' per-sample data lives (indexed through rec->slot)
     rec->normal = e.normal; rec->geo_feat = e.geo; rec->roughness = e.rough; rec->blend = e.blend;
+    rec->image_width = a.tile_w;
     return check_launch("k_geo_finalize");
 }
 

@@ -24,7 +24,7 @@ _FP = ctypes.c_void_p
 class GeometryExport(ctypes.Structure):
     """mirror of `envidr_geometry_export`"""
     _fields_ = [("counter", _FP), ("capacity", ctypes.c_uint32), ("ray", _FP), ("idx", _FP), ("w", _FP), ("normal", _FP),
-                ("geo_feat", _FP), ("roughness", _FP), ("slot", _FP), ("blend", _FP)]
+                ("geo_feat", _FP), ("roughness", _FP), ("slot", _FP), ("blend", _FP), ("image_width", ctypes.c_uint32)]
 
 
 class SamplesOut(ctypes.Structure):
@@ -51,7 +51,7 @@ class RenderDesc(ctypes.Structure):
         ("ray_cost", _FP), ("scratch", _FP), ("scratch_bytes", ctypes.c_uint64),
         ("has_aabb", ctypes.c_int32), ("aabb", ctypes.c_float * 6), ("ray_mask", _FP),
         ("env_split_blob", _FP), ("env_split_bias", _FP), ("env_features", _FP),
-        ("sdf_geo_blob", _FP),
+        ("sdf_geo_blob", _FP), ("image_width", ctypes.c_uint32),
     ]
 
 
@@ -703,7 +703,7 @@ class FusedRenderer:
     def render_frame(self, rays_o: torch.Tensor, rays_d: torch.Tensor, env_rot_radian: float | None = None, out: dict | None = None,
                      samples_per_ray_hint: float = 20.0, events: list | None = None, geometry_only: bool = False, wait: bool = True,
                      use_cost_hint: bool = True, r_images: torch.Tensor | None = None, ray_mask: torch.Tensor | None = None,
-                     tag: str = "", env_precision: str | None = None) -> dict:
+                     tag: str = "", env_precision: str | None = None, image_width: int = 0) -> dict:
         """One frame as: geometry pipeline (envidr_geometry_pass: march rounds + per-sample hash grid / SDF network, one record
         per composited sample) -> shading of the records (k_shade_samples) -> per-ray composite.  Both network families
         (environment MLP; SH heads without one); `r_images` [N,4] (reflected radiance + visibility per ray) selects the
@@ -714,7 +714,9 @@ class FusedRenderer:
         chunk (use_cost_hint; results do not depend on it).  Nothing waits for the device while the frame is enqueued; with wait=False the call does not wait at the end either
         (video loops: check_frames() -- called by the next frame -- raises FrameOverflow if a frame did not fit).
         `events`: four torch.cuda.Event(enable_timing=True) recorded at the pass boundaries (geometry | shading | composite).
-        `env_precision`: "fp32" / "f16x2" for this frame (default: FusedOptions.env_precision)."""
+        `env_precision`: "fp32" / "f16x2" for this frame (default: FusedOptions.env_precision).
+        `image_width`: the rays are the pixels of a row-major image this wide (layout hint: blocks of 64 rays are then 8x8-pixel
+        tiles; same outputs, bit for bit; ignored unless width and height are multiples of 8)."""
         self.check_frames(block=False)
         rays_o = rays_o.contiguous().view(-1, 3).float()
         rays_d = rays_d.contiguous().view(-1, 3).float()
@@ -744,6 +746,7 @@ class FusedRenderer:
                 if ray_mask.shape[0] != N or not ray_mask.is_cuda:
                     raise _lib.EnvidrError("render_frame: ray_mask must be [N] on the GPU")
             self.desc.ray_mask = None if ray_mask is None else ray_mask.data_ptr()
+            self.desc.image_width = int(image_width)
             self.desc.geometry_only, self.desc.r_images, self.desc.geometry_export = 0, None, None
             ev = events
             if ev: ev[0].record()
@@ -751,6 +754,7 @@ class FusedRenderer:
                                                st["ws"].data_ptr(), st["ws"].numel(), cap, stream)
             self.desc.ray_cost = None
             self.desc.ray_mask = None
+            self.desc.image_width = 0
             if rc:
                 raise _lib.EnvidrError(f"envidr_geometry_pass failed ({rc}): {self.lib.envidr_last_error().decode()}")
             if ev: ev[1].record()

@@ -79,6 +79,9 @@ typedef struct envidr_geometry_export {
      * (the geometry pipeline leaves the per-sample data where the evaluation kernel wrote it and hands out indices)        */
     const uint32_t* slot;  /* [capacity] or NULL                                                                            */
     float* blend;          /* raw SDF-network output 14 (learn_indir_blend logit), or NULL                                  */
+    /* ABI 6: set by envidr_geometry_pass when it laid its blocks out as 8x8-pixel tiles (desc.image_width), else 0; lets
+     * envidr_composite_records walk the rays in the same order, so that a wave's records are again one contiguous run */
+    uint32_t image_width;
 } envidr_geometry_export;
 
 /* ---- scene / model description ---------------------------------------------------------------- */
@@ -203,6 +206,14 @@ typedef struct envidr_render_desc {
      * envidr_sdf_geometry_floats() floats).  With it the geometry entry points run k_geo_eval16 (16 samples per wave, three
      * waves per SIMD); without it k_geo_eval32 on sdf_blob.  Same results up to fp32 summation order. */
     const float* sdf_geo_blob;
+
+    /* ABI 6, optional, geometry pipeline only: the rays of this call are the pixels of a row-major image `image_width` pixels
+     * wide (N a multiple of it, width and height multiples of 8).  A layout hint: the pipeline then forms its blocks of 64 rays
+     * from 8x8-pixel tiles instead of 64 consecutive pixels of a row, so that the samples a wave evaluates together are
+     * neighbours in both image directions (their hash gathers share more lines: -8 % geometry time at 800x800).  Every output
+     * is still indexed by the ray's position in the call's list and has the same bits; 0 (or a size that does not qualify) =
+     * list order. */
+    uint32_t image_width;
 } envidr_render_desc;
 
 /* ---- per-call outputs (device pointers; any optional pointer may be NULL) --------------------- */

@@ -314,3 +314,27 @@ def test_frame_buffers_converge_on_what_the_frames_use(renderer):
         assert torch.equal(got[k], want[k]), k
     assert got["n_samples"] == got["n_records"]            # the hint was carried over: still one exact round
     renderer.__dict__.pop("_frames", None)
+
+
+def test_image_width_hint_changes_the_block_layout_not_the_frame(renderer):
+    """image_width: blocks of 64 rays become 8x8-pixel tiles (the samples a wave evaluates are then neighbours in both image
+    directions); every output stays indexed by the ray's position in the list and keeps its bits -- hinted and cold, with a ray
+    mask, and for sizes that do not qualify (ignored)"""
+    import torch
+    H, W = 96, 128
+    ro_, rd_ = (torch.from_numpy(a).cuda() for a in scenes.camera_rays(H, W, theta=40.0, phi=15.0))
+    keys = ("image", "depth", "weights_sum", "normal_image", "diffuse_image", "specular_image", "roughness_image", "ray_cost")
+    for hint in (False, True):
+        want = {k: v.clone() for k, v in renderer.render_frame(ro_, rd_, 0.3, use_cost_hint=hint).items() if k in keys}
+        got = renderer.render_frame(ro_, rd_, 0.3, use_cost_hint=hint, image_width=W)
+        torch.cuda.synchronize()
+        for k in keys:
+            assert torch.equal(got[k], want[k]), (hint, k)
+    mask = (torch.arange(H * W, device="cuda") % 3 != 0)
+    want = {k: v.clone() for k, v in renderer.render_frame(ro_, rd_, 0.3, ray_mask=mask).items() if k in keys}
+    got = renderer.render_frame(ro_, rd_, 0.3, ray_mask=mask, image_width=W)
+    for k in keys:
+        assert torch.equal(got[k], want[k]), k
+    odd = renderer.render_frame(ro_[: 90 * W], rd_[: 90 * W], 0.3, image_width=W)         # 90 rows: not a multiple of 8 -> list order
+    ref = renderer.render_frame(ro_[: 90 * W], rd_[: 90 * W], 0.3)
+    assert torch.equal(odd["image"], ref["image"])
