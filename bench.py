@@ -555,7 +555,7 @@ def other_configs(result, dev, rays_o, rays_d, N) -> None:
     # BASELINE configs[1] (no environment MLP; gather / latency-bound regime)
     plain = FusedRenderer.from_scene(scenes.lego_scene(), FusedOptions(dir_sh_degree=4), device=dev)
     pout: dict = {}
-    pdt = _time(lambda: plain.render_frame(rays_o, rays_d, None, out=pout, wait=False), 5, dev)
+    pdt = _time(lambda: plain.render_frame(rays_o, rays_d, None, out=pout, wait=False, image_width=W), 5, dev)
     plain.check_frames()
     psamples = int(plain._frame["last"][1])
     oc["configs[1] hash-grid SDF + diffuse/specular MLPs (SH view dir, no env MLP), 800x800, 1 GPU"] = {
@@ -575,7 +575,7 @@ def other_configs(result, dev, rays_o, rays_d, N) -> None:
     # the relight variant of SURVEY 8d: IDE degree 4, env hidden 160 (shape of the shipped env_net_3.pth), kernel <4,5>
     relight = FusedRenderer.from_scene(scenes.toaster_scene(hidden_env=160, ide_deg=4), FusedOptions(ide_degree=4), device=dev)
     rout: dict = {}
-    rdt = _time(lambda: relight.render_frame(rays_o, rays_d, 0.3, out=rout, wait=False), 5, dev)
+    rdt = _time(lambda: relight.render_frame(rays_o, rays_d, 0.3, out=rout, wait=False, image_width=W), 5, dev)
     relight.check_frames()
     rs = int(relight._frame["last"][1])
     oc["configs[2] relight variant: IDE deg 4 + env MLP 38-160-160-160-12 x2 (shape of the shipped env nets), 800x800, 1 GPU"] = {
@@ -595,7 +595,7 @@ def other_configs(result, dev, rays_o, rays_d, N) -> None:
     # only, NEVER the headline (whose dtype is f32 throughout); error measured against the fp32 frame of the same view
     ref = {k_: v.clone() for k_, v in headline.render_frame(rays_o, rays_d, 0.1, out={}).items() if k_ in ("image", "specular_image")}
     sout: dict = {}
-    sdt = _time(lambda: headline.render_frame(rays_o, rays_d, 0.1, out=sout, wait=False, env_precision="f16x2"), 5, dev)
+    sdt = _time(lambda: headline.render_frame(rays_o, rays_d, 0.1, out=sout, wait=False, env_precision="f16x2", image_width=W), 5, dev)
     headline.check_frames()
     split = headline.render_frame(rays_o, rays_d, 0.1, out=sout, env_precision="f16x2")
     srel = {k_: float(torch.linalg.norm(split[k_] - ref[k_]) / torch.linalg.norm(ref[k_])) for k_ in ref}
