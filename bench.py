@@ -608,7 +608,7 @@ def other_configs(result, dev, rays_o, rays_d, N) -> None:
     iopt = toaster_options(indir_ref=True)
     imodel = NeRFNetwork.from_scene(scenes.toaster_scene(shape=scenes.torus(), seed=3), iopt, device=dev)
     ikw = dict(staged=True, bg_color=1, perturb=False, get_normal_image=True, max_steps=iopt.max_steps, T_thresh=iopt.T_thresh,
-               dt_gamma=iopt.dt_gamma)
+               dt_gamma=iopt.dt_gamma, image_width=W)
     idt = _time(lambda: imodel.render(rays_o[None], rays_d[None], **ikw), 3, dev)
     ifr = imodel.fused_renderer()
     ifr.frame_log = {}

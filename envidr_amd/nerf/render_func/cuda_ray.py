@@ -189,8 +189,11 @@ def run_cuda(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, fo
         # `two_phase=False` asks for the single persistent kernel instead (envidr_render_rays).
         pipeline = two_phase is not False
         if pipeline:
+            # `image_width` (not a reference argument; optional): the rays are a row-major image this wide -- a layout hint that
+            # lets the pipeline form its blocks from 8x8-pixel tiles (same outputs)
             res = fr.render_frame(rays_o, rays_d, env_rot_radian, geometry_only=geometry_only,
-                                  r_images=None if r_images is None else r_images[0], ray_mask=ray_mask, tag=frame_tag, wait=wait)
+                                  r_images=None if r_images is None else r_images[0], ray_mask=ray_mask, tag=frame_tag, wait=wait,
+                                  image_width=int(kwargs.get("image_width", 0) or 0))
         else:
             if ray_mask is not None:
                 raise NotImplementedError("ray_mask is a feature of the geometry pipeline (two_phase)")

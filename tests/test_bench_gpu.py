@@ -43,3 +43,21 @@ def test_strong_scaling_mode_on_one_rank():
     j = _run(["--gpus", "1", "--steps", "4", "--warmup", "2", "--headline-only", "--force-dist", "--scaling", "strong"])
     assert j["scaling"] == "strong" and j["dist"]["gathered_equals_rendered"] is True
     assert j["config"]["rays_per_step_per_gpu"] == 640000 and j["value"] > 5e6
+
+
+def test_renderer_built_from_a_broadcast_scene_is_the_same_renderer():
+    """ranks other than 0 receive the table and the bitfield as device tensors (bench.load_scene) and regenerate only the MLPs:
+    the renderer built from that is bit-identical to one built from a locally generated scene"""
+    import torch
+    from envidr_amd import scenes
+    from envidr_amd.fused import FusedRenderer
+    full = scenes.toaster_scene()
+    recv = scenes.toaster_scene(arrays=False)
+    assert recv.table is None and recv.bitfield is None
+    recv.table, recv.bitfield = torch.from_numpy(full.table).cuda(), torch.from_numpy(full.bitfield).cuda()
+    a, b = FusedRenderer.from_scene(full), FusedRenderer.from_scene(recv)
+    ro, rd = (torch.from_numpy(x).cuda() for x in scenes.camera_rays(64, 64))
+    ra, rb = a.render_frame(ro, rd, 0.4, image_width=64), b.render_frame(ro, rd, 0.4, image_width=64)
+    torch.cuda.synchronize()
+    for k in ("image", "depth", "weights_sum", "normal_image", "diffuse_image", "specular_image"):
+        assert torch.equal(ra[k], rb[k]), k
