@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(kE16Threads, 1) k_geo_eval16(const GeoEvalArgs
                 constexpr int i = decltype(ic)::value;
                 if constexpr (i + kAhead < kE16LevelSteps) prep(i + kAhead, ahead, lvahead);
                 __builtin_amdgcn_sched_barrier(0);
-                float o[2], g[3][2];
+                f32x2 o, g[3];
                 lean_finish(now, inside ? lvnow.on : 0.0f, o, g);
                 f[i][0] = o[0]; f[i][1] = o[1];
 #pragma unroll

@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(kE32Threads, 2) k_geo_eval32(const GeoEvalArgs
     WeightLdsRing<kGeoRing> wp;
     wp.start(s_w + lane);
     const float* w3row = s_w + kSdfBlobFloats + half * 16;
-    float* jac_col = s_jac + wave * (kE32Steps * 6 * 64) + lane;
+    f32x2* jac_col = reinterpret_cast<f32x2*>(s_jac + wave * (kE32Steps * 6 * 64)) + lane;      // [step * 3 + axis][lane] of channel pairs
     constexpr int kSdfN = (kSdfFrags + kGeoRing - 1) / kGeoRing * kGeoRing;
     constexpr int kAhead = kGeoAhead;
     const __amdgpu_buffer_rsrc_t table = table_rsrc(a.table, a.table_bytes);
@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(kE32Threads, 2) k_geo_eval32(const GeoEvalArgs
                 constexpr int i = decltype(ic)::value;
                 if constexpr (i + kAhead < kE32Steps) prep(i + kAhead, ahead, lvahead);
                 __builtin_amdgcn_sched_barrier(0);
-                float o[2], g[3][2];
+                f32x2 o, g[3];
                 lean_finish(now, inside ? lvnow.on : 0.0f, o, g);
                 f0[i] = o[0]; f1[i] = o[1];
                 if constexpr (PROBE) {
@@ -221,10 +221,7 @@ __global__ void __launch_bounds__(kE32Threads, 2) k_geo_eval32(const GeoEvalArgs
                     }
                 }
 #pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    jac_col[((i * 3 + d) * 2 + 0) * 64] = g[d][0];
-                    jac_col[((i * 3 + d) * 2 + 1) * 64] = g[d][1];
-                }
+                for (int d = 0; d < 3; ++d) jac_col[(i * 3 + d) * 64] = g[d];          // one 8-byte LDS write per axis
             };
             [&]<int... I>(std::integer_sequence<int, I...>) {
                 (step(std::integral_constant<int, I>{}, st[I % (kAhead + 1)], lvs[I % (kAhead + 1)], st[(I + kAhead) % (kAhead + 1)],
@@ -241,31 +238,25 @@ __global__ void __launch_bounds__(kE32Threads, 2) k_geo_eval32(const GeoEvalArgs
         }
 
         // ================= phase 2: SDF network forward + input gradient: one 32-sample group ===================
+        // (the hidden pre-activations h1, h2 stay in their accumulator tiles until the backward pass has used their signs: a ReLU
+        //  mask is then one compare + one select per value where it is needed; packing the signs into bit words and unpacking
+        //  them again cost ~450 of the ~2900 vector instructions of a batch, and this kernel is issue-bound)
         f32x16 o3[1], gf[1];
         {
             f32x16 h1[2], h2[2];
-            uint32_t pos1 = 0, pos2 = 0;
             pipe_layer_from_lanes<kLevels, 2, kSdfW1, kSdfN>(wp, lane, in, h1);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) pos1 |= (h1[t][r] > 0 ? 1u : 0u) << (16 * t + r);
             pipe_layer_from_tiles<2, 2, kSdfW2, kSdfN, true>(wp, lane, h1, h2);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) pos2 |= (h2[t][r] > 0 ? 1u : 0u) << (16 * t + r);
             pipe_layer_from_tiles<2, 1, kSdfW3, kSdfN, true>(wp, lane, h2, o3);
             f32x16 g2[2], g1[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) g2[t][r] = (pos2 >> (16 * t + r)) & 1u ? w3row[t * 32 + r] : 0.0f;
+                for (int r = 0; r < 16; ++r) g2[t][r] = h2[t][r] > 0 ? w3row[t * 32 + r] : 0.0f;
             pipe_layer_from_tiles<2, 2, kSdfW2t, kSdfN, false, false>(wp, lane, g2, g1);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) g1[t][r] = (pos1 >> (16 * t + r)) & 1u ? g1[t][r] : 0.0f;
+                for (int r = 0; r < 16; ++r) g1[t][r] = h1[t][r] > 0 ? g1[t][r] : 0.0f;
             pipe_layer_from_tiles<2, 1, kSdfW1t, kSdfN, false, false>(wp, lane, g1, gf);
             wp.template end_pass<kSdfFrags>();
         }
@@ -288,8 +279,9 @@ __global__ void __launch_bounds__(kE32Threads, 2) k_geo_eval32(const GeoEvalArgs
         for (int i = 0; i < kE32Steps; ++i)
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                part[d] += g0[i] * jac_col[((i * 3 + d) * 2 + 0) * 64];
-                part[d] += g1c[i] * jac_col[((i * 3 + d) * 2 + 1) * 64];
+                const f32x2 j = jac_col[(i * 3 + d) * 64];
+                part[d] += g0[i] * j[0];
+                part[d] += g1c[i] * j[1];
             }
         float nrm[3];
 #pragma unroll

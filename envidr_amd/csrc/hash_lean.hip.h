@@ -143,33 +143,36 @@ __device__ __forceinline__ void lean_corners(const LeanStage& st, float2 (&c)[8]
     }
 }
 
-// value (2 channels) and d value / d x01 (3 x 2), multiplied by `m` (level mask x inside-the-cube mask)
-__device__ __forceinline__ void lean_finish(const LeanStage& st, float m, float (&out)[2], float (&g)[3][2]) {
+// value (2 channels) and d value / d x01 (3 x 2), multiplied by `m` (level mask x inside-the-cube mask).  The two channels of a
+// row go through identical arithmetic: it is written on 2-vectors so that it compiles to packed fp32 instructions
+// (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: two IEEE operations per issue slot -- the geometry kernel is issue-bound);
+// per channel the operations and their order are those of the scalar form, so the bits are too.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+__device__ __forceinline__ void lean_finish(const LeanStage& st, float m, f32x2& out, f32x2 (&g)[3]) {
     float2 cc[8];
     lean_corners(st, cc);
-    const float wx = st.w[0], wy = st.w[1], wz = st.w[2];
+    f32x2 c[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c[i] = f32x2{cc[i].x, cc[i].y};
+    const f32x2 wx = {st.w[0], st.w[0]}, wy = {st.w[1], st.w[1]}, wz = {st.w[2], st.w[2]};
     const float sx = st.sdw[0] * m, sy = st.sdw[1] * m, sz = st.sdw[2] * m;
+    f32x2 D[4], a[4];                 // x differences and x-interpolated values for the four (y, z) corners
 #pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
-        float c[8];
+    for (int j = 0; j < 4; ++j) { D[j] = c[2 * j + 1] - c[2 * j]; a[j] = pk_fma(wx, D[j], c[2 * j]); }
+    f32x2 F[2], b[2], E[2];           // y differences / y-interpolated values / y-interpolated x differences for z = 0, 1
 #pragma unroll
-        for (int i = 0; i < 8; ++i) c[i] = ch ? cc[i].y : cc[i].x;
-        float D[4], a[4];                 // x differences and x-interpolated values for the four (y, z) corners
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { D[j] = c[2 * j + 1] - c[2 * j]; a[j] = fmaf(wx, D[j], c[2 * j]); }
-        float F[2], b[2], E[2];           // y differences / y-interpolated values / y-interpolated x differences for z = 0, 1
-#pragma unroll
-        for (int z = 0; z < 2; ++z) {
-            F[z] = a[2 * z + 1] - a[2 * z];
-            b[z] = fmaf(wy, F[z], a[2 * z]);
-            E[z] = fmaf(wy, D[2 * z + 1] - D[2 * z], D[2 * z]);
-        }
-        const float G = b[1] - b[0];
-        out[ch] = fmaf(wz, G, b[0]) * m;
-        g[0][ch] = fmaf(wz, E[1] - E[0], E[0]) * sx;
-        g[1][ch] = fmaf(wz, F[1] - F[0], F[0]) * sy;
-        g[2][ch] = G * sz;
+    for (int z = 0; z < 2; ++z) {
+        F[z] = a[2 * z + 1] - a[2 * z];
+        b[z] = pk_fma(wy, F[z], a[2 * z]);
+        E[z] = pk_fma(wy, D[2 * z + 1] - D[2 * z], D[2 * z]);
     }
+    const f32x2 G = b[1] - b[0];
+    out = pk_fma(wz, G, b[0]) * f32x2{m, m};
+    g[0] = pk_fma(wz, E[1] - E[0], E[0]) * f32x2{sx, sx};
+    g[1] = pk_fma(wz, F[1] - F[0], F[0]) * f32x2{sy, sy};
+    g[2] = G * f32x2{sz, sz};
 }
 
 }  // namespace envidr

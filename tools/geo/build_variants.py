@@ -61,6 +61,15 @@ VARIANTS = {
     "tcache16": ("geometry_pass", [("geometry_pass.hip", "constexpr uint32_t kTimeCache = 32;", "constexpr uint32_t kTimeCache = 16;")]),
     "grid_full_tcache16": ("geometry_pass", [("geometry_pass.hip", "const dim3 grid(r == 0 ? ray_blocks : std::min(ray_blocks, 1024u));", "const dim3 grid(ray_blocks);"),
                                              ("geometry_pass.hip", "constexpr uint32_t kTimeCache = 32;", "constexpr uint32_t kTimeCache = 16;")]),
+    # ablations of k_geo_eval32 (what bounds it?): no matrix phase / no table gathers / neither
+    "eval_nomlp": ("geometry_pass", [("geometry_pass.hip", "            pipe_layer_from_lanes<kLevels, 2, kSdfW1, kSdfN>(wp, lane, in, h1);\n            pipe_layer_from_tiles<2, 2, kSdfW2, kSdfN, true>(wp, lane, h1, h2);\n            pipe_layer_from_tiles<2, 1, kSdfW3, kSdfN, true>(wp, lane, h2, o3);\n",
+                                      "            for (int r_ = 0; r_ < 16; ++r_) { h1[0][r_] = in[r_]; h1[1][r_] = in[r_]; h2[0][r_] = in[r_]; h2[1][r_] = in[r_]; o3[0][r_] = in[r_]; }\n"),
+                                     ("geometry_pass.hip", "            pipe_layer_from_tiles<2, 2, kSdfW2t, kSdfN, false, false>(wp, lane, g2, g1);\n", "            g1[0] = g2[1]; g1[1] = g2[0];\n"),
+                                     ("geometry_pass.hip", "            pipe_layer_from_tiles<2, 1, kSdfW1t, kSdfN, false, false>(wp, lane, g1, gf);\n            wp.template end_pass<kSdfFrags>();\n", "            gf[0] = g1[0] + g1[1];\n")]),
+    "eval_nogather": ("geometry_pass", [("hash_lean.hip.h", "        st.pair[j] = __builtin_amdgcn_raw_buffer_load_b128(table, base[j] * 8u + (LANE_LEVEL ? lv.row0_bytes : 0u), LANE_LEVEL ? 0u : lv.row0_bytes, AUX);",
+                                         "        st.pair[j] = u32x4{r0[j], r1[j], base[j], lv.row0_bytes};"),
+                                        ("hash_lean.hip.h", "            st.solo[j] = __builtin_amdgcn_raw_buffer_load_b64(table, r1[j] * 8u + (LANE_LEVEL ? lv.row0_bytes : 0u), LANE_LEVEL ? 0u : lv.row0_bytes, AUX);",
+                                         "            st.solo[j] = u32x2{r1[j], base[j]};")]),
     "first_chunk12": ("geometry_pass", [("geometry_pass.hip", "std::min(16u, d->max_steps)", "std::min(12u, d->max_steps)")]),
     "first_chunk24": ("geometry_pass", [("geometry_pass.hip", "std::min(16u, d->max_steps)", "std::min(24u, d->max_steps)")]),
     "split_group4": ("shade_split", [("mlp_split.hip.h", "constexpr int kSplitGroup = 2;", "constexpr int kSplitGroup = 4;")]),
