@@ -99,72 +99,112 @@ inline void pack_split_weight(const float* W, uint32_t m_out, uint32_t k_in, Spl
 }
 
 // ---- device side ------------------------------------------------------------------------------------------------------
-constexpr int kSplitChunkFrags = 32;            // a chunk must outlast the L2 round trip of its successor's
-constexpr uint32_t kSplitChunkBytes = kSplitChunkFrags * 1024u;       // prefetch: 32 KiB = 48 MFMAs = 1536 cycles; two of them in LDS
-constexpr int kSplitStage = kSplitChunkFrags / 4;                     // 16-byte registers per lane holding a quarter chunk in flight
-constexpr int split_pass_chunks(int frags) { return (frags + kSplitChunkFrags - 1) / kSplitChunkFrags; }
+constexpr uint32_t kSplitBlobGrain = 32u * 1024u; // the host pads a blob to a multiple of this (zero fragments)
+constexpr int kSplitChunkFrags = 8;             // a chunk of the streamed part: 8 KiB = 12 MFMAs = ~0.45 k cycles
+constexpr int kSplitSlots = 8;                  // chunk slots in LDS (64 KiB)
+constexpr int kSplitPieces = kSplitChunkFrags / 4;                    // 1-KiB pieces of a chunk each of the four waves moves
+constexpr int kSplitAhead = 8;                  // fragments read from LDS ahead of the MFMAs that consume them
+constexpr int kSplitMeetAt = 4;                 // read index inside a chunk at which the block meets (see SplitWeightPipe)
+constexpr int kSplitResident = 88;              // fragments at the head of a pass that stay in LDS for the whole kernel
+constexpr uint32_t kSplitLdsBytes = (uint32_t)(kSplitSlots * kSplitChunkFrags + kSplitResident) * 1024u;
 
-// WeightPipe (mlp_mfma.hip.h) for 1-KiB fragments, with one difference: the staged copy global -> registers -> LDS of the
-// NEXT chunk is not done in one burst at the chunk boundary but one 1-KiB piece per wave every four fragments.  LDS takes
-// writes at 64 B/clk: the 32 KiB of a chunk written at once kept it busy for ~500 cycles, and the fragment reads of the
-// chunk just started queued behind them (the boundaries cost ~740 cycles each, a quarter of the kernel).
+// The weight stream of a workgroup.  Four waves in lock step read the same 1-KiB fragments from LDS; what bounds the kernel is
+// the bandwidth at which the 256 CUs can pull that stream out of L2 (every CU streams the same 624 KiB per 32 x 4 items: 6.2 TB/s
+// measured, the chip's L2 -> LDS fill ceiling), so
+//   * the first kSplitResident fragments of a pass are loaded ONCE per workgroup and stay resident (LDS is 160 KiB);
+//   * the rest is streamed through a ring of eight 8-KiB chunk slots that the waves fill, a quarter each, with LDS-DMA --
+//     `buffer_load_dwordx4 ... lds`: global -> LDS without a register or a ds_write in between, wave-uniform destination
+//     M0 + 16 B per lane, which IS the fragment layout.
+//
+// One s_barrier per chunk, at read index kSplitMeetAt of chunk b ("B_b"), with no LDS wait in front of it:
+//   * the register ring is kSplitAhead = 8 fragments deep and a reduction step takes four, so at B_b every read of chunk b-2
+//     has been consumed by an MFMA that precedes B_b in program order: after B_b the slot of chunk b-2 is overwritten with
+//     chunk b+6 (two pieces per wave, issued in the fragments that follow);
+//   * before B_{b+1} a wave waits for all but its eight youngest vector-memory operations (`vmcnt(8)`: the pieces of chunks
+//     b+3 .. b+6) -- so its pieces of chunk b+2, issued after B_{b-4}, have landed; after the barrier that holds for all four
+//     waves, and chunk b+2 is read from four fragments later on.  A piece has five chunk periods (~2 k cycles) to land.  (Other
+//     vector-memory operations of the wave -- the round's own loads and stores -- are younger than those pieces and only make
+//     the wait stricter; the counter retires in issue order.)
+// The compiler does not know about the DMA (inline asm): it neither counts it nor orders LDS reads behind it; the two rules
+// above are what orders them.
 struct SplitWeightPipe {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    u32x4* lds;                 // workgroup base of u32x4[2][kSplitChunkFrags * 64]
-    uint32_t lane, wave, slot;
-    const u32x4* frag;          // this lane's column of the chunk being consumed
-    u32x4 stage[kSplitStage];   // this wave's quarter of the next chunk (landed) / of the one after (in flight)
-    __amdgpu_buffer_rsrc_t rsrc;
-    uint32_t chunks;            // chunks in the (only) pass: the stream wraps around to chunk 0
-    uint32_t local;
-    uint32_t ahead_off;         // byte offset of the chunk whose loads are issued during the current chunk
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const u32x4* res;           // this lane's column of the resident fragments
+    const u32x4* ring;          // this lane's column of slot 0
+    const u32x4* frag;          // this lane's column of the chunk being read
+    u32x4 rsrc;                 // raw buffer descriptor of the blob
+    uint32_t voff;              // this lane's byte offset inside a chunk: wave * 2 KiB + lane * 16
+    uint32_t lds_wave;          // LDS byte address of this wave's first piece in slot 0
+    uint32_t chunks;            // chunks in the streamed part of the (only) pass: the stream wraps around to chunk 0
+    uint32_t slot;              // slot of the chunk being read
+    uint32_t fill_off, fill_lds;    // blob byte offset / LDS byte address (this wave's pieces) of the chunk being filled
+    uint32_t next_fill;         // chunk the next barrier starts to fill
 
-    // wave w moves fragments [w * kSplitStage, (w + 1) * kSplitStage) of every chunk
-    __device__ __forceinline__ uint32_t voff() const { return (wave * (kSplitStage * 64u) + lane) * 16u; }
-    template <int I>
-    __device__ __forceinline__ void load_piece(uint32_t chunk_off) {
-        stage[I] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff(), chunk_off + (uint32_t)I * 1024u, 0);
+    __device__ __forceinline__ void dma(uint32_t lds_dst, uint32_t v, uint32_t blob_off) const {
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"(lds_dst), "v"(v), "s"(rsrc), "s"(blob_off)
+                     : "memory");
     }
-    template <int I>
-    __device__ __forceinline__ void store_piece(uint32_t to_slot) {
-        u32x4* dst = lds + to_slot * (kSplitChunkFrags * 64u) + wave * (kSplitStage * 64u) + lane;
-        dst[I * 64] = stage[I];
+    template <int P>
+    __device__ __forceinline__ void dma_piece() const { dma(fill_lds + (uint32_t)P * 1024u, voff, fill_off + (uint32_t)P * 1024u); }
+    __device__ __forceinline__ void aim(uint32_t chunk, uint32_t to_slot) {
+        fill_off = (uint32_t)kSplitResident * 1024u + chunk * (uint32_t)(kSplitChunkFrags * 1024);
+        fill_lds = lds_wave + to_slot * (uint32_t)(kSplitChunkFrags * 1024);
     }
-    __device__ __forceinline__ void start(void* lds_base, uint32_t lane_, uint32_t wave_, const void* blob, uint32_t chunks_) {
-        lds = reinterpret_cast<u32x4*>(lds_base); lane = lane_; wave = wave_; chunks = chunks_;
-        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(blob), 0, (int)(chunks_ * kSplitChunkBytes), 0x00020000);
-        [&]<int... I>(std::integer_sequence<int, I...>) {
-            (load_piece<I>(0), ...);
-            (store_piece<I>(1), ...);                          // chunk 0 -> slot 1 (the first boundary flips to it)
-            (load_piece<I>(chunks_ > 1 ? kSplitChunkBytes : 0u), ...);        // chunk 1 staged
-        }(std::make_integer_sequence<int, kSplitStage>{});
-        slot = 0;
-        local = 0xffffffffu;
-        ahead_off = 0;
-        frag = lds + lane;
+    // `frags`: fragments of a pass (a multiple of kSplitAhead, and of kSplitChunkFrags past the resident part)
+    __device__ __forceinline__ void start(void* lds_base, uint32_t lane, uint32_t wave, const void* blob, uint32_t frags) {
+        static_assert(kSplitSlots == 8 && kSplitChunkFrags == 8 && kSplitAhead == 8 && kSplitMeetAt == 4 && kSplitResident % 4 == 0, "the schedule in the comment above");
+        const u32x4* lds = reinterpret_cast<const u32x4*>(lds_base);
+        ring = lds + lane;
+        res = lds + kSplitSlots * kSplitChunkFrags * 64 + lane;
+        chunks = (frags - (uint32_t)kSplitResident) / (uint32_t)kSplitChunkFrags;
+        const uint64_t addr = (uint64_t)blob;
+        rsrc = u32x4{(uint32_t)addr, (uint32_t)(addr >> 32) & 0xffffu, (frags * 1024u + kSplitBlobGrain - 1u) / kSplitBlobGrain * kSplitBlobGrain, 0x00020000u};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rsrc[q] = __builtin_amdgcn_readfirstlane(rsrc[q]);
+        const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr_t)lds_base);
+        voff = (wave * (uint32_t)kSplitPieces * 64u + lane) * 16u;
+        lds_wave = lds0 + wave * (uint32_t)kSplitPieces * 1024u;
+        // resident fragments: wave w moves fragments [w, w + 1) * kSplitResident / 4
+        constexpr uint32_t per_wave = kSplitResident / 4;
+        for (uint32_t q = 0; q < per_wave; ++q)
+            dma(lds0 + (uint32_t)(kSplitSlots * kSplitChunkFrags) * 1024u + (wave * per_wave + q) * 1024u, lane * 16u, (wave * per_wave + q) * 1024u);
+        // chunks 0 .. 5 -> slots 0 .. 5 (the first barrier starts chunk 6)
+        uint32_t c = 0;
+        for (uint32_t sl = 0; sl < (uint32_t)kSplitSlots - 2u; ++sl) {
+            aim(c, sl);
+            [&]<int... P>(std::integer_sequence<int, P...>) { (dma_piece<P>(), ...); }(std::make_integer_sequence<int, kSplitPieces>{});
+            if (++c == chunks) c = 0;
+        }
+        next_fill = c;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        slot = kSplitSlots - 1;            // the first streamed take() steps to slot 0
+        frag = ring;
     }
-    __device__ __forceinline__ void boundary() {
-        __syncthreads();                                       // everybody is done reading the other slot, and done writing this one
-        ++local;
-        if (local == chunks) local = 0;                        // the next pass streams the same blob again
-        slot ^= 1u;
-        uint32_t ahead = local + 2;
-        if (ahead >= chunks) ahead -= chunks;
-        if (ahead >= chunks) ahead -= chunks;
-        ahead_off = ahead * kSplitChunkBytes;
-        frag = lds + slot * (kSplitChunkFrags * 64u) + lane;
+    __device__ __forceinline__ void next_chunk() {
+        slot = (slot + 1u) & (uint32_t)(kSplitSlots - 1);
+        frag = ring + slot * (uint32_t)(kSplitChunkFrags * 64);
+    }
+    __device__ __forceinline__ void meet() {
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kSplitPieces * (kSplitSlots - 4)) : "memory");
+        aim(next_fill, (slot + (uint32_t)kSplitSlots - 2u) & (uint32_t)(kSplitSlots - 1));          // the slot of chunk b - 2
+        if (++next_fill == chunks) next_fill = 0;
         __builtin_amdgcn_sched_barrier(0);
     }
     template <int I>
     __device__ __forceinline__ half8 take() {
-        constexpr int c = I % kSplitChunkFrags;
-        if constexpr (c == 0) boundary();
-        // piece c / 4 of the staged chunk (local + 1) goes to the other slot, and its register is refilled from chunk local + 2
-        if constexpr (c % 4 == 1 && c / 4 < kSplitStage) {
-            store_piece<c / 4>(slot ^ 1u);
-            load_piece<c / 4>(ahead_off);
+        if constexpr (I < kSplitResident) return __builtin_bit_cast(half8, res[I * 64]);
+        else {
+            constexpr int c = (I - kSplitResident) % kSplitChunkFrags;
+            if constexpr (c == 0) next_chunk();
+            if constexpr (c == kSplitMeetAt) meet();
+            if constexpr (c == kSplitMeetAt + 1) dma_piece<0>();
+            if constexpr (c == kSplitMeetAt + 3) dma_piece<1>();
+            return __builtin_bit_cast(half8, frag[c * 64]);
         }
-        return __builtin_bit_cast(half8, frag[c * 64]);
     }
 };
 
@@ -172,13 +212,12 @@ struct SplitWeightPipe {
 // in ring[I % PF]; taking it re-issues the read of fragment I + PF, rolling over into the next pass at the end): left to
 // the compiler, the four ds_read_b128 of a step are issued right in front of its MFMAs and every step waits out the LDS
 // latency (measured: 80 k instead of 30 k cycles per pass).  FRAGS must be a multiple of PF (end_pass pads).
-constexpr int kSplitAhead = 8;                    // fragments read from LDS ahead of the MFMAs that consume them
 template <int PF>
 struct SplitFragRing {
     SplitWeightPipe pipe;
     half8 ring[PF];
-    __device__ __forceinline__ void start(void* lds_base, uint32_t lane, uint32_t wave, const void* blob, uint32_t chunks) {
-        pipe.start(lds_base, lane, wave, blob, chunks);
+    __device__ __forceinline__ void start(void* lds_base, uint32_t lane, uint32_t wave, const void* blob, uint32_t frags) {
+        pipe.start(lds_base, lane, wave, blob, frags);
         [&]<int... I>(std::integer_sequence<int, I...>) { ((ring[I] = pipe.template take<I>()), ...); }(std::make_integer_sequence<int, PF>{});
     }
     template <int I, int FRAGS>

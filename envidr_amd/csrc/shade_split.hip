@@ -22,11 +22,10 @@ struct EnvSplitLayout {
     static constexpr int TERMS = ide_terms(IDE_DEG), K1 = 2 * TERMS, S1 = (K1 + 15) / 16, SH = 2 * ENV_T;
     static constexpr int F1 = 0, F2 = F1 + split_layer_frags(S1, ENV_T), F3 = F2 + split_layer_frags(SH, ENV_T),
                          F4 = F3 + split_layer_frags(SH, ENV_T), Frags = F4 + split_layer_frags(SH, 1);
-    // pass length in fragments: whole LDS chunks (the staging of the next chunk is driven by the takes of the current one) and a
-    // multiple of the ring depth
-    static_assert(kSplitChunkFrags % kSplitAhead == 0, "ring depth must divide the chunk");
-    static constexpr int Padded = (Frags + kSplitChunkFrags - 1) / kSplitChunkFrags * kSplitChunkFrags;
-    static constexpr int Chunks = split_pass_chunks(Padded);
+    // pass length in fragments: a multiple of the ring depth, and whole chunks past the resident part (mlp_split.hip.h)
+    static_assert(kSplitAhead % kSplitChunkFrags == 0 && kSplitResident % kSplitChunkFrags == 0, "one padding serves both");
+    static constexpr int Padded = (Frags + kSplitAhead - 1) / kSplitAhead * kSplitAhead;
+    static_assert(Padded >= kSplitResident + kSplitSlots * kSplitChunkFrags, "a pass shorter than the resident part plus the ring");
     static constexpr int BiasTiles = 3 * ENV_T + 1;
 };
 
@@ -35,14 +34,14 @@ __global__ void __launch_bounds__(kSplitThreads, 1) k_env_split(const ShadeArgs 
     using L = EnvSplitLayout<IDE_DEG, ENV_T>;
     constexpr int TERMS = L::TERMS, S1 = L::S1, SH = L::SH;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    __shared__ u32x4 s_w[2 * kSplitChunkFrags * 64];
+    __shared__ u32x4 s_w[kSplitLdsBytes / 16];
     __shared__ __attribute__((aligned(16))) float s_bias[L::BiasTiles * 32];
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (uint32_t i = threadIdx.x; i < (uint32_t)L::BiasTiles * 32; i += kSplitThreads) s_bias[i] = bias[i];
     __syncthreads();
     SplitFragRing<kSplitAhead> wp;
-    wp.start(s_w, lane, wave, blob, L::Chunks);
+    wp.start(s_w, lane, wave, blob, L::Padded);
     const float* bias_lane = s_bias + (lane >> 5) * 16;
     auto bias_tile = [&](int tile) {
         f32x16 b;
@@ -183,7 +182,7 @@ uint32_t envidr_split_layer_halves(int k_order, uint32_t k_in, uint32_t m_out) {
     return (uint32_t)split_layer_frags((int)split_steps_for(o, k_in), (int)(round_up(m_out, 32) / 32)) * kSplitFragHalves;
 }
 uint32_t envidr_split_group(void) { return (uint32_t)kSplitGroup; }
-uint32_t envidr_split_chunk_bytes(void) { return kSplitChunkBytes; }
+uint32_t envidr_split_chunk_bytes(void) { return kSplitBlobGrain; }
 
 int envidr_pack_layer_split(const float* W_host, uint32_t m_out, uint32_t k_in, int k_order, uint16_t* dst_host) {
     ENVIDR_REQUIRE(W_host && dst_host && m_out && k_in, "pack_layer_split: null / empty argument");

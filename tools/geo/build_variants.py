@@ -70,6 +70,24 @@ VARIANTS = {
                                          "        st.pair[j] = u32x4{r0[j], r1[j], base[j], lv.row0_bytes};"),
                                         ("hash_lean.hip.h", "            st.solo[j] = __builtin_amdgcn_raw_buffer_load_b64(table, r1[j] * 8u + (LANE_LEVEL ? lv.row0_bytes : 0u), LANE_LEVEL ? 0u : lv.row0_bytes, AUX);",
                                          "            st.solo[j] = u32x2{r1[j], base[j]};")]),
+    # ablations / parameters of k_env_split (timing only where marked: results are wrong)
+    "split_base": ("shade_split", []),
+    "split_nodma": ("shade_split", [("mlp_split.hip.h", "            if constexpr (c == kSplitMeetAt + 1) dma_piece<0>();\n            if constexpr (c == kSplitMeetAt + 3) dma_piece<1>();\n", "")]),       # timing only
+    "split_halfdma": ("shade_split", [("mlp_split.hip.h", "            if constexpr (c == kSplitMeetAt + 3) dma_piece<1>();\n", "")]),       # timing only
+    "split_nobarrier": ("shade_split", [("mlp_split.hip.h", 'asm volatile("s_waitcnt vmcnt(%0)\\n\\ts_barrier" ::"n"(kSplitPieces * (kSplitSlots - 4)) : "memory");', "")]),       # timing only (racy)
+    "split_nt": ("shade_split", [("mlp_split.hip.h", "offen lds\\n", "offen nt lds\\n")]),
+    "split_sc": ("shade_split", [("mlp_split.hip.h", "offen lds\\n", "offen sc1 lds\\n")]),
+    # L2 channel hot-spot experiment: workgroup i streams copy i % 4 of the blob, copies 512 B + a blob apart (run with
+    # tools/geo/split_probe.py --copies 4, which tiles the blob accordingly)
+    "split_copies4": ("shade_split", [("shade_split.hip", "    wp.start(s_w, lane, wave, blob, L::Padded);",
+                                       "    wp.start(s_w, lane, wave, (const char*)blob + (blockIdx.x & 3u) * (((uint32_t)L::Padded * 1024u + kSplitBlobGrain - 1u) / kSplitBlobGrain * kSplitBlobGrain + 512u), L::Padded);")]),
+    "split_nowait": ("shade_split", [("mlp_split.hip.h", 'asm volatile("s_waitcnt vmcnt(%0)\\n\\ts_barrier" ::"n"(kSplitPieces * (kSplitSlots - 4)) : "memory");', 'asm volatile("s_barrier" ::: "memory");')]),       # timing only (racy)
+    "split_res8": ("shade_split", [("mlp_split.hip.h", "constexpr int kSplitResident = 88; ", "constexpr int kSplitResident = 8;  ")]),
+    "split_res48": ("shade_split", [("mlp_split.hip.h", "constexpr int kSplitResident = 88; ", "constexpr int kSplitResident = 48; ")]),
+    "split_sc01nt": ("shade_split", [("mlp_split.hip.h", "offen lds\\n", "offen sc0 sc1 nt lds\\n")]),
+    "split_sc0": ("shade_split", [("mlp_split.hip.h", "offen lds\\n", "offen sc0 lds\\n")]),
+    "split_noconvert": ("shade_split", [("mlp_split.hip.h", "    split_f16(a, hi, lo); h[r % 8] = hi; l[r % 8] = lo;\n    split_f16(b, hi, lo); h[(r + 1) % 8] = hi; l[(r + 1) % 8] = lo;\n",
+                                          "    hi = (_Float16)a; lo = (_Float16)b; h[r % 8] = hi; l[r % 8] = lo; h[(r + 1) % 8] = lo; l[(r + 1) % 8] = hi;\n")]),       # timing only
     "first_chunk12": ("geometry_pass", [("geometry_pass.hip", "std::min(16u, d->max_steps)", "std::min(12u, d->max_steps)")]),
     "first_chunk24": ("geometry_pass", [("geometry_pass.hip", "std::min(16u, d->max_steps)", "std::min(24u, d->max_steps)")]),
     "split_group4": ("shade_split", [("mlp_split.hip.h", "constexpr int kSplitGroup = 2;", "constexpr int kSplitGroup = 4;")]),

@@ -5,6 +5,15 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 import torch
 from envidr_amd import scenes
 from envidr_amd.fused import FusedRenderer
+import numpy as np
+from envidr_amd import fused
+if "--copies" in sys.argv:          # split_copies4 variant: workgroups stream different copies of the blob
+    n = int(sys.argv[sys.argv.index("--copies") + 1])
+    orig = fused.pack_env_split
+    def tiled(env):
+        blob, bias = orig(env)
+        return np.concatenate([np.concatenate([blob, np.zeros(256, np.uint16)]) for _ in range(n)]), bias
+    fused.pack_env_split = tiled
 dev = torch.device("cuda:0")
 r = FusedRenderer.from_scene(scenes.toaster_scene(), device=dev)
 ro, rd = (torch.from_numpy(a).to(dev) for a in scenes.camera_rays(800, 800))
