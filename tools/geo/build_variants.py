@@ -88,6 +88,17 @@ VARIANTS = {
     "split_sc0": ("shade_split", [("mlp_split.hip.h", "offen lds\\n", "offen sc0 lds\\n")]),
     "split_noconvert": ("shade_split", [("mlp_split.hip.h", "    split_f16(a, hi, lo); h[r % 8] = hi; l[r % 8] = lo;\n    split_f16(b, hi, lo); h[(r + 1) % 8] = hi; l[(r + 1) % 8] = lo;\n",
                                           "    hi = (_Float16)a; lo = (_Float16)b; h[r % 8] = hi; l[r % 8] = lo; h[(r + 1) % 8] = lo; l[(r + 1) % 8] = hi;\n")]),       # timing only
+    # matrix-phase token per SIMD: of the waves that share a SIMD only one is in the MFMA phase at a time
+    "eval_token": ("geometry_pass", [
+        ("geometry_pass.hip", "    __shared__ float s_jac[kE32Waves * kE32Steps * 6 * 64];\n    const uint32_t lane = lane_id();\n",
+         "    __shared__ float s_jac[kE32Waves * kE32Steps * 6 * 64];\n    __shared__ uint32_t s_token[4];\n    const uint32_t lane = lane_id();\n    const uint32_t simd = __builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));\n"),
+        ("geometry_pass.hip", "        if (threadIdx.x < kLevels) s_lv[threadIdx.x] = a.lv[threadIdx.x];\n    }\n    __syncthreads();\n    WeightLdsRing<kGeoRing> wp;",
+         "        if (threadIdx.x < kLevels) s_lv[threadIdx.x] = a.lv[threadIdx.x];\n        if (threadIdx.x < 4) s_token[threadIdx.x] = 0;\n    }\n    __syncthreads();\n    WeightLdsRing<kGeoRing> wp;"),
+        ("geometry_pass.hip", "            f32x16 h1[2], h2[2];\n            pipe_layer_from_lanes<kLevels, 2, kSdfW1, kSdfN>(wp, lane, in, h1);\n",
+         "            f32x16 h1[2], h2[2];\n            if (lane == 0) while (__hip_atomic_exchange(&s_token[simd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) __builtin_amdgcn_s_sleep(2);\n            __builtin_amdgcn_sched_barrier(0);\n            pipe_layer_from_lanes<kLevels, 2, kSdfW1, kSdfN>(wp, lane, in, h1);\n"),
+        ("geometry_pass.hip", "            pipe_layer_from_tiles<2, 1, kSdfW1t, kSdfN, false, false>(wp, lane, g1, gf);\n            wp.template end_pass<kSdfFrags>();\n",
+         "            pipe_layer_from_tiles<2, 1, kSdfW1t, kSdfN, false, false>(wp, lane, g1, gf);\n            wp.template end_pass<kSdfFrags>();\n            __builtin_amdgcn_sched_barrier(0);\n            if (lane == 0) __hip_atomic_store(&s_token[simd], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"),
+    ]),
     "first_chunk12": ("geometry_pass", [("geometry_pass.hip", "std::min(16u, d->max_steps)", "std::min(12u, d->max_steps)")]),
     "first_chunk24": ("geometry_pass", [("geometry_pass.hip", "std::min(16u, d->max_steps)", "std::min(24u, d->max_steps)")]),
     "split_group4": ("shade_split", [("mlp_split.hip.h", "constexpr int kSplitGroup = 2;", "constexpr int kSplitGroup = 4;")]),
