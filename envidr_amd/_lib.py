@@ -43,6 +43,7 @@ SIGNATURES: dict[str, str] = {
     # half-precision tables (the at::Half dispatch of the two grid encoders; include/envidr_amd.h "ABI 6")
     "hash_encode_forward_f16": "ppppuuuufuip",
     "hash_encode_backward_f16": "pppppuuuufuipp",
+    "hash_encode_second_backward_f16": "ppppuuuufuipppp",
     "grid_encode_forward_f16": "ppppuuuufupui",
     "grid_encode_backward_f16": "pppppuuuufuppui",
     # freqencoder (freqencoder.h:6-9)

@@ -433,8 +433,7 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
     constexpr int kDiffIn = kEnvNet ? 24 : 12, kSpecIn = kEnvNet ? 28 : 2 * kShDim + 13;
     constexpr int kDSteps = (kDiffIn + 1) / 2, kSSteps = (kSpecIn + 1) / 2;
     using Head = HeadLayout<kDSteps, kSSteps>;
-    constexpr int kHeadD1 = Head::D1, kHeadD2 = Head::D2, kHeadS1 = Head::S1, kHeadS2 = Head::S2, kHeadS3 = Head::S3,
-                  kHeadFrags = Head::Frags;
+    constexpr int kHeadFrags = Head::Frags;
     constexpr int TERMS = ide_terms(IDE_DEG);      // IDE_DIM = 2 * TERMS input features, TERMS lane-order steps
     constexpr int kEnv0 = 0, kEnv1 = kEnv0 + lane_layer_frags(TERMS, ENV_T, true), kEnv2 = kEnv1 + tile_layer_frags(ENV_T, ENV_T, true),
                   kEnv3 = kEnv2 + tile_layer_frags(ENV_T, ENV_T, true), kEnvFrags = kEnv3 + tile_layer_frags(ENV_T, 1, true);
@@ -449,7 +448,7 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
     WeightRing<kRingDepth> wp;
     wp.start(lane, a.sdf_blob, kSdfChunks);
     // fragments per pass as the weight source sees them (the ring pads every pass to a multiple of its depth)
-    constexpr int kSdfN = ring_padded(kSdfFrags), kEnvN = ring_padded(kEnvFrags), kHeadN = ring_padded(kHeadFrags);
+    constexpr int kSdfN = ring_padded(kSdfFrags);
 
     // ---- per-lane ray slot ---------------------------------------------------------------------
     int ray = -1;
@@ -754,7 +753,7 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
         float cd[3] = {0, 0, 0}, cs[3] = {0, 0, 0};
         if constexpr (!GEOM) if (!a.geometry_only) {
             const bool renv = kEnvNet && a.r_images != nullptr;
-            constexpr uint32_t kRenvChunks = pass_chunks(kRenvFrags), kSpec2Chunks = pass_chunks(kSpec2Frags);
+            constexpr uint32_t kRenvChunks = pass_chunks(kRenvFrags);
             const ShadeConsts sc = {a.env_blob, a.head_blob, renv ? a.renv_blob : a.sdf_blob, renv ? kRenvChunks : kSdfChunks,
                                     a.kappa_diffuse, a.light_scale};
             const float vd[3] = {rg.dx, rg.dy, rg.dz};

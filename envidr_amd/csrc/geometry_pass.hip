@@ -372,8 +372,8 @@ struct RayState {
 //  slots -- kept for every lane of a live block: the sample-major slot layout of the block is defined by these counts)
 
 // counters (device uint32[kGeoCounterWords]), zeroed by the host before every frame
-constexpr uint32_t kCntSampleHead = 0, kCntRecordHead = 1, kCntOverflow = 2, kCntAlive = 8, kCntBegin = 40, kCntOcc = 72, kCntSpare = 80, kGeoCounterWords = 256;
-// (words kCntSpare .. : unused by the product, zeroed with the rest; the timer variant of tools/geo/build_variants.py accumulates there)
+constexpr uint32_t kCntSampleHead = 0, kCntRecordHead = 1, kCntOverflow = 2, kCntAlive = 8, kCntBegin = 40, kCntOcc = 72, kGeoCounterWords = 256;
+// (words 80 .. : unused by the product, zeroed with the rest; the timer variant of tools/geo/build_variants.py accumulates there)
 // kCntOcc + 0..2: max over occupied cells of (H - 1 - coordinate) (i.e. the minimum, as a maximum: the words start at zero),
 // kCntOcc + 3..5: max coordinate; written by k_linearize_bitfield
 constexpr uint32_t kMaxRounds = 30;     // counter words reserved per round-indexed array

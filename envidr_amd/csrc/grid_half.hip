@@ -214,6 +214,99 @@ __global__ void __launch_bounds__(kBlock) k_grid_input_backward_h(const h16* __r
     grad_inputs[t] = acc;
 }
 
+// kernel_grid_second_backward_grad<at::Half, D, C, N_C> (hashencoder.cu:375-428): a Half product and a Half sum per term
+template <int D, int C>
+__global__ void __launch_bounds__(kBlock) k_second_backward_grad_h(const h16* __restrict__ ggx, const h16* __restrict__ dy_dx,
+                                                                   h16* __restrict__ grad_grad, uint32_t B, uint32_t L) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t level = blockIdx.y;
+    if (b >= B) return;
+    const h16* j = dy_dx + ((size_t)b * L + level) * (D * C);
+    h16 r[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) r[c] = H(0.0f);
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int c = 0; c < C; ++c) r[c] = H(F(r[c]) + F(H(F(ggx[(size_t)b * D + d]) * F(j[d * C + c]))));
+#pragma unroll
+    for (int c = 0; c < C; ++c) grad_grad[((size_t)level * B + b) * C + c] = r[c];
+}
+
+// kernel_grid_second_backward_embedding<at::Half, D, C, N_C> (hashencoder.cu:431-595): the corner cache is Half -- every
+// `cache +-= w * grad * ggx[gd] * smoothstep'` narrows the float product, then adds / subtracts in Half -- and is scattered
+// with packed fp16 atomics
+template <int D, int C>
+__global__ void __launch_bounds__(kBlock) k_second_backward_table_h(const h16* __restrict__ grad, const h16* __restrict__ inputs,
+                                                                    const int32_t* __restrict__ offsets, const h16* __restrict__ ggx,
+                                                                    h16* __restrict__ grad2_table, uint32_t B, uint32_t L, LevelScale ls) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t level = blockIdx.y;
+    if (b >= B) return;
+    float x[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        x[d] = F(inputs[(size_t)b * D + d]);
+        if (x[d] < 0 || x[d] > 1) return;
+    }
+    const uint32_t row0 = (uint32_t)offsets[level];
+    const uint32_t size = (uint32_t)offsets[level + 1] - row0;
+    const LevelGeom<D> g = make_level_geom<D>(size, ls.resolution[level], true);
+    const float scale = ls.scale[level];
+    float w1[D], dw[D];
+    uint32_t cell[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        float p = x[d] * scale;
+        cell[d] = (uint32_t)floorf(p);
+        p -= (float)cell[d];
+        dw[d] = 6 * p * (1.0f - p);
+        w1[d] = p * p * (3.0f - 2.0f * p);
+    }
+    h16 gcur[C], gg[D];
+#pragma unroll
+    for (int c = 0; c < C; ++c) gcur[c] = grad[((size_t)level * B + b) * C + c];
+#pragma unroll
+    for (int d = 0; d < D; ++d) gg[d] = ggx[(size_t)b * D + d];
+    h16 corner[1 << D][C];
+#pragma unroll
+    for (int i = 0; i < (1 << D); ++i)
+#pragma unroll
+        for (int c = 0; c < C; ++c) corner[i][c] = H(0.0f);
+#pragma unroll
+    for (int gd = 0; gd < D; ++gd) {
+#pragma unroll
+        for (int j = 0; j < (1 << (D - 1)); ++j) {
+            float w = scale;
+            int lo = 0;
+#pragma unroll
+            for (int nd = 0; nd < D - 1; ++nd) {
+                const int d = nd >= gd ? nd + 1 : nd;
+                const int bit = (j >> nd) & 1;
+                w *= bit ? w1[d] : 1 - w1[d];
+                lo |= bit << d;
+            }
+            const int hi = lo | (1 << gd);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const h16 v = H(w * F(gcur[c]) * F(gg[gd]) * dw[gd]);
+                corner[hi][c] = H(F(corner[hi][c]) + F(v));
+                corner[lo][c] = H(F(corner[lo][c]) - F(v));
+            }
+        }
+    }
+    h16* t = grad2_table + (size_t)row0 * C;
+#pragma unroll
+    for (int i = 0; i < (1 << D); ++i) {
+        uint32_t q[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) q[d] = cell[d] + ((i >> d) & 1);
+        const uint32_t row = cell_row<D>(g, q);
+#pragma unroll
+        for (int c = 0; c < C; c += 2) atomic_add_h2(t + (size_t)row * C + c, corner[i][c], corner[i][c + 1]);
+    }
+}
+
 template <typename Fn>
 int dispatch_dc_h(uint32_t D, uint32_t C, uint32_t d_lo, uint32_t d_hi, const char* who, Fn&& fn) {
 #define ENVIDR_CASE(DD, CC) if (D == DD && C == CC) return fn(std::integral_constant<int, DD>{}, std::integral_constant<int, CC>{});
@@ -291,6 +384,34 @@ int envidr_hash_encode_backward_f16(const uint16_t* grad, const uint16_t* inputs
     ENVIDR_REQUIRE(!calc_grad_inputs || (dy_dx && grad_inputs) || B == 0, "hash_encode_backward_f16: dy_dx/grad_inputs null");
     return backward_h<true>(grad, reinterpret_cast<const h16*>(inputs), offsets, grad_embeddings, B, D, C, L, S, H, calc_grad_inputs ? dy_dx : nullptr,
                             grad_inputs, 0, 0, stream, "hash_encode_backward_f16");
+}
+
+int envidr_hash_encode_second_backward_f16(const uint16_t* grad, const uint16_t* inputs, const uint16_t* embeddings, const int32_t* offsets,
+                                           uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H_, int calc_grad_inputs,
+                                           const uint16_t* dy_dx, const uint16_t* grad_grad_inputs, uint16_t* grad_grad, uint16_t* grad2_embeddings,
+                                           envidr_stream_t stream) {
+    (void)embeddings; (void)calc_grad_inputs;
+    const char* who = "hash_encode_second_backward_f16";
+    ENVIDR_REQUIRE(L >= 1 && L <= (uint32_t)kMaxLevels, "%s: L=%u out of range", who, L);
+    if (B == 0) return ENVIDR_OK;
+    ENVIDR_REQUIRE(grad && inputs && offsets && dy_dx && grad_grad_inputs && grad_grad && grad2_embeddings, "%s: null pointer", who);
+    ENVIDR_REQUIRE(C != 1, "%s: C=1 is not supported (reference: hashencoder.cu:673-679)", who);
+    const LevelScale ls = make_level_scale(L, S, H_);
+    return dispatch_dc_h(D, C, 2, 3, who, [&](auto d, auto c) {
+        constexpr int DD = decltype(d)::value, CC = decltype(c)::value;
+        if constexpr (CC == 1) return (int)ENVIDR_EINVAL;
+        else {
+            const dim3 grid(ceil_div(B, kBlock), L);
+            hipLaunchKernelGGL((k_second_backward_grad_h<DD, CC>), grid, dim3(kBlock), 0, as_stream(stream), reinterpret_cast<const h16*>(grad_grad_inputs),
+                               reinterpret_cast<const h16*>(dy_dx), reinterpret_cast<h16*>(grad_grad), B, L);
+            int rc = check_launch("k_second_backward_grad_h");
+            if (rc) return rc;
+            hipLaunchKernelGGL((k_second_backward_table_h<DD, CC>), grid, dim3(kBlock), 0, as_stream(stream), reinterpret_cast<const h16*>(grad),
+                               reinterpret_cast<const h16*>(inputs), offsets, reinterpret_cast<const h16*>(grad_grad_inputs),
+                               reinterpret_cast<h16*>(grad2_embeddings), B, L, ls);
+            return check_launch("k_second_backward_table_h");
+        }
+    });
 }
 
 int envidr_grid_encode_forward_f16(const float* inputs, const uint16_t* embeddings, const int32_t* offsets, uint16_t* outputs, uint32_t B,

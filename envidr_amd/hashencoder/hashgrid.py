@@ -2,7 +2,7 @@
 input derivative and first/second-order backward, on the HIP library.  Mirrors the reference's
 hashencoder/hashgrid.py (hash_encode :107, HashEncoder :110-169).  fp32, or -- like the reference's
 `custom_fwd(cast_inputs=torch.half)` (hashgrid.py:19) -- fp16 for inputs, table, outputs and dy_dx when the table is given in
-half or torch autocast is on (`hash_encode_*_f16`, the at::Half instantiation; first-order backward only)."""
+half or torch autocast is on (`hash_encode_*_f16`, the at::Half instantiations, second backward included)."""
 from __future__ import annotations
 
 import numpy as np
@@ -36,13 +36,6 @@ class _HashEncode(Function):
         inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
         B, D, C, L, S, H = ctx.dims
         grad = grad.to(embeddings.dtype).view(B, L, C).permute(1, 0, 2).contiguous()
-        if ctx.half:
-            # the at::Half instantiation: first-order only (the half second backward of the reference is not provided)
-            grad_inputs = torch.zeros_like(inputs) if ctx.calc_grad_inputs else None
-            grad_embeddings = torch.zeros_like(embeddings) if ctx.needs_input_grad[1] else None
-            _lib.call("hash_encode_backward_f16", grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H,
-                      int(ctx.calc_grad_inputs), dy_dx if ctx.calc_grad_inputs else None, grad_inputs)
-            return grad_inputs, grad_embeddings, None, None, None, None
         # whether the table gradient is wanted is known HERE (needs_input_grad); inside _HashEncodeBackward.forward grad
         # mode is always off, so asking torch.is_grad_enabled() there would never produce it
         grad_inputs, grad_embeddings = _HashEncodeBackward.apply(grad, inputs, embeddings, offsets, B, D, C, L, S, H,
@@ -59,7 +52,8 @@ class _HashEncodeBackward(Function):
         # the table gradient is only materialised when somebody consumes it (need_table = needs_input_grad of the
         # embeddings): at inference (normals only) the reference still zero-fills and scatters into 48.8 MB every iteration
         grad_embeddings = torch.zeros_like(embeddings) if need_table else None
-        _lib.call("hash_encode_backward", grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H,
+        half = embeddings.dtype == torch.half               # the at::Half instantiations (hashencoder.cu:778,817)
+        _lib.call("hash_encode_backward_f16" if half else "hash_encode_backward", grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H,
                   int(calc_grad_inputs), dy_dx if calc_grad_inputs else None, grad_inputs if calc_grad_inputs else None)
         ctx.save_for_backward(grad, inputs, embeddings, offsets, dy_dx)
         ctx.dims = (B, D, C, L, S, H)
@@ -72,8 +66,8 @@ class _HashEncodeBackward(Function):
         B, D, C, L, S, H = ctx.dims
         grad_grad = torch.zeros_like(grad)
         grad2_embeddings = torch.zeros_like(embeddings)
-        _lib.call("hash_encode_second_backward", grad, inputs, embeddings, offsets, B, D, C, L, S, H, int(ctx.calc_grad_inputs),
-                  dy_dx, grad_grad_inputs.contiguous(), grad_grad, grad2_embeddings)
+        _lib.call("hash_encode_second_backward_f16" if embeddings.dtype == torch.half else "hash_encode_second_backward", grad, inputs, embeddings,
+                  offsets, B, D, C, L, S, H, int(ctx.calc_grad_inputs), dy_dx, grad_grad_inputs.to(embeddings.dtype).contiguous(), grad_grad, grad2_embeddings)
         return grad_grad, None, grad2_embeddings, None, None, None, None, None, None, None, None, None, None
 
 

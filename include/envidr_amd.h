@@ -188,9 +188,10 @@ int envidr_sh_encode_backward(const float* grad, const float* inputs, uint32_t B
  * `hashencoder/hashgrid.py:19` (custom_fwd(cast_inputs=torch.half)) and `gridencoder/grid.py:37-40` (half table under autocast)
  * dispatch to.  uint16_t* = IEEE binary16 storage (torch.half `data_ptr()`).  hashencoder narrows inputs, table, outputs,
  * dy_dx and gradients; gridencoder keeps fp32 inputs (its kernels take `const float* inputs`).  Arithmetic narrows where
- * c10::Half narrows (csrc/grid_half.hip); same argument order as the fp32 entry points.  Not provided in half: the second
- * backward, freq / SH / raymarching (the reference's Python wrappers force fp32 there: shencoder/sphere_harmonics.py:16
- * `cast_inputs=torch.float32`, raymarching.py `.float()`, freqencoder.cu `data_ptr<float>()`).
+ * c10::Half narrows (csrc/grid_half.hip); same argument order as the fp32 entry points.  hash_encode_second_backward_f16
+ * (hashencoder.cu:817; all tensors fp16) completes the hash encoder.  Not provided in half: freq / SH / raymarching (the
+ * reference's Python wrappers force fp32 there: shencoder/sphere_harmonics.py:16 `cast_inputs=torch.float32`,
+ * raymarching.py `.float()`, freqencoder.cu `data_ptr<float>()`).
  * ------------------------------------------------------------------------------------------ */
 int envidr_hash_encode_forward_f16(const uint16_t* inputs, const uint16_t* embeddings, const int32_t* offsets,
                                    uint16_t* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
@@ -200,6 +201,11 @@ int envidr_hash_encode_backward_f16(const uint16_t* grad, const uint16_t* inputs
                                     const int32_t* offsets, uint16_t* grad_embeddings, uint32_t B, uint32_t D,
                                     uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs,
                                     const uint16_t* dy_dx, uint16_t* grad_inputs, envidr_stream_t stream);
+int envidr_hash_encode_second_backward_f16(const uint16_t* grad, const uint16_t* inputs, const uint16_t* embeddings,
+                                           const int32_t* offsets, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                           uint32_t H, int calc_grad_inputs, const uint16_t* dy_dx,
+                                           const uint16_t* grad_grad_inputs, uint16_t* grad_grad,
+                                           uint16_t* grad2_embeddings, envidr_stream_t stream);
 int envidr_grid_encode_forward_f16(const float* inputs, const uint16_t* embeddings, const int32_t* offsets,
                                    uint16_t* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
                                    float S, uint32_t H, uint16_t* dy_dx, uint32_t gridtype, int align_corners,

@@ -954,6 +954,68 @@ API int oracle_hash_encode_backward_f16(const uint16_t* grad, const uint16_t* in
     if (D != 2 && D != 3) return -1;
     return grid_backward_h(grad, inputs, 1, offsets, grad_embeddings, B, D, C, L, S, H_, calc_grad_inputs ? dy_dx : NULL, grad_inputs, 1, 0, 0);
 }
+/* hash_encode_second_backward<at::Half> (hashencoder.cu:375-428 grad_grad, :431-595 table): Half products and sums in the first
+ * kernel; in the second the corner cache is Half -- `cache +-= w * grad * ggx[gd] * smoothstep'` narrows the float product, then adds /
+ * subtracts in Half -- and `(__half)(1.0 * cache)` is exact; the scatter is an fp16 (pair) atomic add, serial here */
+API int oracle_hash_encode_second_backward_f16(const uint16_t* grad, const uint16_t* inputs, const uint16_t* embeddings, const int32_t* offsets,
+                                               uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H_, int calc_grad_inputs,
+                                               const uint16_t* dy_dx, const uint16_t* ggx, uint16_t* grad_grad, uint16_t* grad2_emb) {
+    (void)embeddings; (void)calc_grad_inputs;
+    if ((D != 2 && D != 3) || C == 1 || C > MAXC) return -1;
+    for (uint32_t l = 0; l < L; ++l)
+        for (uint32_t b = 0; b < B; ++b)
+            for (uint32_t c = 0; c < C; ++c) {
+                uint16_t r = H(0.0f);
+                for (uint32_t d = 0; d < D; ++d) r = H(F(r) + F(H(F(ggx[(size_t)b * D + d]) * F(dy_dx[((size_t)b * L + l) * D * C + d * C + c]))));
+                grad_grad[((size_t)l * B + b) * C + c] = r;
+            }
+    for (uint32_t l = 0; l < L; ++l) {
+        const float scale = exp2f(l * S) * H_ - 1.0f;
+        const uint32_t resolution = (uint32_t)ceilf(scale) + 1;
+        const uint32_t size = (uint32_t)(offsets[l + 1] - offsets[l]);
+        uint16_t* table = grad2_emb + (size_t)offsets[l] * C;
+        for (uint32_t b = 0; b < B; ++b) {
+            float x[MAXD];
+            int oob = 0;
+            for (uint32_t d = 0; d < D; ++d) { x[d] = F(inputs[(size_t)b * D + d]); if (x[d] < 0 || x[d] > 1) oob = 1; }
+            if (oob) continue;
+            float pos[MAXD], dpos[MAXD]; uint32_t cell[MAXD];
+            for (uint32_t d = 0; d < D; ++d) {
+                pos[d] = x[d] * scale;
+                cell[d] = (uint32_t)floorf(pos[d]);
+                pos[d] -= (float)cell[d];
+                dpos[d] = 6 * pos[d] * (1.0f - pos[d]);
+                pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
+            }
+            for (uint32_t ch = 0; ch < C; ch += 2) {
+                uint16_t cache[8][2];
+                for (int i = 0; i < 8; ++i) cache[i][0] = cache[i][1] = H(0.0f);
+                for (uint32_t gd = 0; gd < D; ++gd)
+                    for (uint32_t idx = 0; idx < (1u << (D - 1)); ++idx) {
+                        float w = scale; uint32_t lo = 0;
+                        for (uint32_t nd = 0; nd < D - 1; ++nd) {
+                            const uint32_t d = nd >= gd ? nd + 1 : nd;
+                            if ((idx & (1u << nd)) == 0) w *= 1 - pos[d];
+                            else { w *= pos[d]; lo |= 1u << d; }
+                        }
+                        const uint32_t hi = lo | (1u << gd);
+                        for (uint32_t c = 0; c < 2; ++c) {
+                            const uint16_t v = H(w * F(grad[((size_t)l * B + b) * C + ch + c]) * F(ggx[(size_t)b * D + gd]) * dpos[gd]);
+                            cache[hi][c] = H(F(cache[hi][c]) + F(v));
+                            cache[lo][c] = H(F(cache[lo][c]) - F(v));
+                        }
+                    }
+                for (uint32_t idx = 0; idx < (1u << D); ++idx) {
+                    uint32_t q[MAXD];
+                    for (uint32_t d = 0; d < D; ++d) q[d] = cell[d] + ((idx >> d) & 1u);
+                    const uint32_t row = grid_row(q, D, size, resolution, 1);
+                    for (uint32_t c = 0; c < 2; ++c) { uint16_t* t = &table[(size_t)row * C + ch + c]; *t = H(F(*t) + F(cache[idx][c])); }
+                }
+            }
+        }
+    }
+    return 0;
+}
 API int oracle_grid_encode_forward_f16(const float* inputs, const uint16_t* embeddings, const int32_t* offsets, uint16_t* outputs, uint32_t B,
                                        uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H_, uint16_t* dy_dx, uint32_t gridtype, int align_corners) {
     return grid_forward_h(inputs, 0, embeddings, offsets, outputs, B, D, C, L, S, H_, dy_dx, 0, gridtype, align_corners);

@@ -254,6 +254,27 @@ EXPORT int ref_hash_encode_backward_f16(const uint16_t* grad, const uint16_t* in
 #undef F3
     return 0;
 }
+template <uint32_t D, uint32_t C, uint32_t NC>
+static void hash_bwd2_h(const H16* grad, const H16* in, const H16* emb, const int* off, uint32_t B, uint32_t L, float S, uint32_t H,
+                        const H16* dy_dx, const H16* ggi, H16* gg, H16* g2e) {
+    emu_launch(emu_blocks(B * C / NC, 256), L, 256,
+               [&] { ref_hash::kernel_grid_second_backward_grad<H16, D, C, NC>(grad, in, emb, off, ggi, dy_dx, gg, B, L, S, H); });
+    emu_launch(emu_blocks(B * C / NC, 256), L, 256, [&] {
+        ref_hash::kernel_grid_second_backward_embedding<H16, D, C, NC>(grad, in, emb, off, ggi, dy_dx, g2e, B, L, S, H);
+    });
+}
+EXPORT int ref_hash_encode_second_backward_f16(const uint16_t* grad, const uint16_t* inputs, const uint16_t* embeddings, const int32_t* offsets,
+                                               uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, int calc_grad_inputs,
+                                               const uint16_t* dy_dx, const uint16_t* grad_grad_inputs, uint16_t* grad_grad, uint16_t* grad2_embeddings) {
+    (void)calc_grad_inputs;
+    if (C == 1) return -1;
+#define F2(c, nc) hash_bwd2_h<2, c, nc>((const H16*)grad, (const H16*)inputs, (const H16*)embeddings, offsets, B, L, S, H, (const H16*)dy_dx, (const H16*)grad_grad_inputs, (H16*)grad_grad, (H16*)grad2_embeddings)
+#define F3(c, nc) hash_bwd2_h<3, c, nc>((const H16*)grad, (const H16*)inputs, (const H16*)embeddings, offsets, B, L, S, H, (const H16*)dy_dx, (const H16*)grad_grad_inputs, (H16*)grad_grad, (H16*)grad2_embeddings)
+    DC_SWITCH(F2, F3)
+#undef F2
+#undef F3
+    return 0;
+}
 template <uint32_t D, uint32_t C>
 static void grid_fwd_h(const float* in, const H16* emb, const int* off, H16* out, uint32_t B, uint32_t L, float S, uint32_t H, H16* dy_dx,
                        uint32_t gt, bool ac) {

@@ -336,6 +336,11 @@ def half_cases():
         # input gradient: bit-exact; table gradient: order-dependent fp16 sums -> two separate cases
         out.append((cid + "_bwd_inputs", "hash_encode_backward_f16", (grad, h(x), h(table), offsets, None, B, D, C, L, S, base, 1, dy, np.zeros((B, D), np.int16)), None))
         out.append((cid + "_bwd_table", "hash_encode_backward_f16", (grad, h(x), h(table), offsets, np.zeros((int(offsets[-1]), C), np.int16), B, D, C, L, S, base, 0, None, None), "f16"))
+        if C > 1:
+            # second backward (hashencoder.cu:817): grad_grad bit-exact; the table's second gradient is again a sum of fp16 atomics
+            ggx = h(rng.normal(size=(B, D)) * 0.1)
+            out.append((cid + "_bwd2", "hash_encode_second_backward_f16", (grad, h(x), h(table), offsets, B, D, C, L, S, base, 1, dy, ggx,
+                                                                            np.zeros((L, B, C), np.int16), np.zeros((int(offsets[-1]), C), np.int16)), "f16"))
     for D, C, L, log2T, base, desired, gridtype, align in [(3, 2, 8, 16, 16, 512, 0, 0), (2, 4, 4, 10, 4, 40, 1, 1), (1, 2, 4, 8, 4, 64, 0, 1), (4, 2, 3, 10, 2, 8, 0, 0)]:
         offsets, pls = scenes.grid_level_offsets(D, L, base, log2T, desired, bool(align))
         S = float(np.log2(pls))

@@ -52,7 +52,7 @@ VARIANTS = {
          "            if (a.ray_cost) a.ray_cost[id] = (uint16_t)min(st.n_taken, 65535u);\n        }\n"
          "        tm_[6] = __builtin_amdgcn_s_memtime();\n"
          "        if (lane == 0) {\n"
-         "            uint32_t* w_ = a.counters + kCntSpare + 16u * min(a.round, 7u);\n"
+         "            uint32_t* w_ = a.counters + 80u + 16u * min(a.round, 7u);\n"
          "            for (int s_ = 0; s_ < 6; ++s_) { const uint32_t d_ = (uint32_t)((tm_[s_ + 1] - tm_[s_]) >> 6); atomicAdd(w_ + 2 * s_, d_); atomicMax(w_ + 2 * s_ + 1, d_); }\n"
          "            const uint32_t all_ = (uint32_t)((tm_[6] - tm_[0]) >> 6); atomicAdd(w_ + 12, all_); atomicMax(w_ + 13, all_); atomicAdd(w_ + 14, 1u);\n"
          "        }\n"),
