@@ -187,3 +187,31 @@ def test_encoder_modules_take_half_tables_like_the_reference():
         half.embeddings.data.copy_(enc.embeddings.data)
         o2 = half(x.detach())
         assert o2.dtype == torch.float16 and float((o2.float() - ref).detach().abs().max()) <= 1e-2
+
+
+def test_hash_encoder_double_backward_in_half():
+    """the eikonal pattern -- a loss on d(features)/d(x) -- through a half table: the first backward is differentiated again by
+    hash_encode_second_backward_f16 (hashencoder.cu:817 on at::Half); the table's second gradient tracks the fp32 run on the same
+    narrowed operands to fp16 accuracy"""
+    import torch
+    from envidr_amd.hashencoder.hashgrid import hash_encode
+    from envidr_amd.hashencoder import HashEncoder
+    torch.manual_seed(1)
+    enc = HashEncoder(3, num_levels=6, level_dim=2, base_resolution=8, log2_hashmap_size=12, desired_resolution=96).cuda()
+    enc.embeddings.data.uniform_(-1, 1)
+    table32 = enc.embeddings.data.half().float().requires_grad_(True)
+    table16 = table32.detach().half().requires_grad_(True)
+    x01 = torch.rand(1500, 3, device="cuda").half().float()
+    g = torch.randn(1500, enc.output_dim, device="cuda").half().float()
+    grads = {}
+    for name, table in (("f32", table32), ("f16", table16)):
+        x = x01.clone().requires_grad_(True)
+        out = hash_encode(x, table, enc.offsets, enc.per_level_scale, enc.base_resolution, True)
+        assert out.dtype == table.dtype
+        (dx,) = torch.autograd.grad((out.float() * g).sum(), x, create_graph=True)
+        assert dx.requires_grad
+        (dx.float().norm(dim=-1) - 1).pow(2).mean().backward()
+        assert table.grad is not None and table.grad.dtype == table.dtype and torch.isfinite(table.grad).all()
+        grads[name] = table.grad.float()
+    rel = float((grads["f16"] - grads["f32"]).norm() / grads["f32"].norm())
+    assert float(grads["f32"].norm()) > 0 and rel <= 5e-2, rel
