@@ -194,13 +194,19 @@ def run(argv: list[str]) -> None:
     import torch.distributed as dist
 
     stub = args.stub
+    # stdout of a distributed run carries the ONE JSON line of rank 0 and nothing else: the communication libraries print
+    # banners there (RCCL when its first communicator comes up, Gloo at rendezvous), so file descriptor 1 is pointed away before
+    # the process group exists -- at stderr on rank 0 (until _finish() restores it for the JSON line), at /dev/null elsewhere
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    if int(os.environ.get("RANK", "0")) != 0:
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+    elif int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.force_dist:
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
     rank, world, local = parallel.init_from_env(backend="gloo" if stub else None, force=args.force_dist)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if rank != 0:
-        # only rank 0 reports; whatever libraries print on the other ranks' stdout must not land behind its JSON line
-        sys.stdout.flush()
-        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
     dist_on = world > 1 or args.force_dist         # the collective code path (a world of one with --force-dist)
     strong = args.scaling == "strong"
     if stub:
@@ -460,6 +466,9 @@ def run(argv: list[str]) -> None:
     _finish(None, dist_on)
 
 
+_REAL_STDOUT = None          # rank 0 of a distributed run: the saved stdout (see run())
+
+
 def _flush_c_stdio() -> None:
     """RCCL writes a version banner with C stdio (buffered until the process exits, i.e. AFTER anything Python has printed):
     push it out now so that the JSON line is the last thing on stdout"""
@@ -477,8 +486,13 @@ def _finish(result, dist_on: bool) -> None:
     if dist_on and dist.is_initialized():
         dist.destroy_process_group()
     _flush_c_stdio()
+    sys.stdout.flush()
+    global _REAL_STDOUT
+    if _REAL_STDOUT is not None:
+        os.dup2(_REAL_STDOUT, 1)
+        os.close(_REAL_STDOUT)
+        _REAL_STDOUT = None
     if result is not None:
-        sys.stdout.flush()
         print(json.dumps(result), flush=True)
 
 

@@ -16,6 +16,8 @@ def _run(args, env_extra=None):
     env.update(env_extra or {})
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
+    # stdout carries the one JSON line and nothing else (library banners -- RCCL, Gloo -- are routed to stderr)
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     return json.loads(lines[0])
