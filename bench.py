@@ -420,11 +420,11 @@ def run(argv: list[str]) -> None:
                                            "mfma": {"achieved": evaluated * FLOP_PER_SAMPLE_GEOMETRY / (geometry_ms * 1e-3) / 1e12,
                                                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                                     "frac": evaluated * FLOP_PER_SAMPLE_GEOMETRY / (geometry_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}},
-                "geometry_pass_bound_note": ("neither roofline binds this stage: its hash sweep is bound by the rate at which L2 misses come back "
-                                             "(~12-15 missed 64-B lines per sample of the 48.8 MB table, 55-65 G random lines/s measured with "
-                                             "tools/probe/gather_probe.hip, profiles/r02_gather_probe.txt => ~1.95 ms per frame) and its SDF network "
-                                             "costs ~1.5 ms of fp32 MFMA time; kernels with 2, 3 and 4 waves per SIMD all land at 2.75-3.0 ms "
-                                             "(DESIGN.md 3.1)"),
+                "geometry_pass_bound_note": ("neither roofline binds this stage: k_geo_eval32 runs at the SUM of its matrix-pipe time (224 fp32 MFMAs "
+                                             "per 32 samples, 58 %) and its vector issue time (2 497 instructions per batch, 40 %) -- on this chip a wave "
+                                             "issuing MFMAs back to back starves its SIMD partner (tools/probe/cross_wave_probe.hip), so two waves per SIMD "
+                                             "do not overlap the two; without any table load the kernel is 8 % faster, halving its L2 misses (tile order) "
+                                             "bought 2 % (DESIGN.md 3.1)"),
                 "record_bytes_per_sample": 92}
         if world == 1 and not strong and not args.headline_only and pipeline:
             context_legs(result, renderer, dev, args.steps, N_frame)
