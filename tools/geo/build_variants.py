@@ -102,7 +102,6 @@ VARIANTS = {
     "first_chunk12": ("geometry_pass", [("geometry_pass.hip", "std::min(16u, d->max_steps)", "std::min(12u, d->max_steps)")]),
     "first_chunk24": ("geometry_pass", [("geometry_pass.hip", "std::min(16u, d->max_steps)", "std::min(24u, d->max_steps)")]),
     "split_group4": ("shade_split", [("mlp_split.hip.h", "constexpr int kSplitGroup = 2;", "constexpr int kSplitGroup = 4;")]),
-    "split_ahead4": ("shade_split", [("mlp_split.hip.h", "constexpr int kSplitAhead = 8;", "constexpr int kSplitAhead = 4;")]),
     "ring16": ("fused_render", [("fused_render.hip", "constexpr int kRingDepth = 32;", "constexpr int kRingDepth = 16;")]),
 }
 
