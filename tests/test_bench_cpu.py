@@ -52,3 +52,11 @@ def test_force_dist_runs_one_rank_through_the_collective_path():
     assert j["n_gpus"] == 1 and j["dist"]["world"] == 1 and j["dist"]["force_dist"] is True and j["dist"]["gathered_equals_rendered"] is True
     j = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--stub", "--force-dist", "--scaling", "strong"])
     assert j["scaling"] == "strong" and j["dist"]["gathered_equals_rendered"] is True
+
+
+def test_eight_ranks_the_drivers_largest_launch():
+    """`python bench.py --gpus 8` as the driver's scaling run starts it (self-launched ranks), both modes, on gloo"""
+    for mode in ("weak", "strong"):
+        j = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--stub", "--scaling", mode])
+        assert j["n_gpus"] == 8 and j["scaling"] == mode and len(j["per_rank_ms_per_step"]) == 8
+        assert j["dist"]["gathered_equals_rendered"] is True and j["value"] > 0
