@@ -158,3 +158,44 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "nope.so")
     with pytest.raises(_lib.EnvidrError):
         _lib.load()
+
+
+def test_every_operator_takes_an_empty_batch_as_a_no_op():
+    """a zero element count returns ENVIDR_OK before anything is dereferenced or launched (the reference's wrappers can hand
+    their kernels empty tensors: an image whose rays all miss the box has n_alive == 0) -- checkable without a GPU: every
+    pointer is NULL here"""
+    from envidr_amd import _lib
+    P = None
+    empty = {
+        "near_far_from_aabb": (P, P, P, 0, 0.05, P, P),
+        "get_rays": (P, 1.0, 1.0, 0.5, 0.5, 0, 0, 0, P, P),
+        "sph_from_ray": (P, P, 1.0, 0, P),
+        "morton3D": (P, 0, P), "morton3D_invert": (P, 0, P),
+        "packbits": (P, 0, 0.01, P),
+        "get_scatter_idx": (P, 0, P),
+        "march_rays_train": (P, P, P, 1.0, 0.0, 1024, 0, 0, 1, 128, 0, P, P, P, P, P, P, P, P),
+        "composite_rays_train_forward": (P, P, P, P, 0, 0, 1e-4, 1, 0, P, P, P, P),
+        "composite_rays_train_backward": (P, P, P, P, P, P, P, P, P, P, 0, 0, 1e-4, P, P, 1, 0),
+        "march_rays": (0, 4, P, P, P, P, 1.0, 0.0, 1024, 1, 128, P, P, P, P, P, P, P),
+        "composite_rays": (0, 4, 1e-4, 1, 0, P, P, P, P, P, P, P, P),
+        "hash_encode_forward": (P, P, P, P, 0, 3, 2, 16, 0.4, 16, 1, P),
+        "hash_encode_backward": (P, P, P, P, P, 0, 3, 2, 16, 0.4, 16, 1, P, P),
+        "hash_encode_second_backward": (P, P, P, P, 0, 3, 2, 16, 0.4, 16, 1, P, P, P, P),
+        "grid_encode_forward": (P, P, P, P, 0, 3, 2, 8, 0.4, 16, P, 0, 0),
+        "grid_encode_backward": (P, P, P, P, P, 0, 3, 2, 8, 0.4, 16, P, P, 0, 0),
+        "hash_encode_forward_f16": (P, P, P, P, 0, 3, 2, 16, 0.4, 16, 1, P),
+        "hash_encode_backward_f16": (P, P, P, P, P, 0, 3, 2, 16, 0.4, 16, 1, P, P),
+        "hash_encode_second_backward_f16": (P, P, P, P, 0, 3, 2, 16, 0.4, 16, 1, P, P, P, P),
+        "grid_encode_forward_f16": (P, P, P, P, 0, 3, 2, 8, 0.4, 16, P, 0, 0),
+        "grid_encode_backward_f16": (P, P, P, P, P, 0, 3, 2, 8, 0.4, 16, P, P, 0, 0),
+        "freq_encode_forward": (P, 0, 3, 4, 27, P),
+        "freq_encode_backward": (P, P, 0, 3, 4, 27, P),
+        "sh_encode_forward": (P, P, 0, 3, 4, P),
+        "sh_encode_backward": (P, P, 0, 3, 4, P, P),
+        "ide_encode_forward": (P, P, 0.5, 0, 5, P),
+        "ide_encode_backward": (P, P, P, 0.5, 0, 5, P, P),
+    }
+    # (compact_alive is the exception: with nothing alive it still writes *out_count = 0 -- tests/test_ops_gpu.py)
+    assert set(empty) | {"compact_alive"} == set(_lib.SIGNATURES), set(_lib.SIGNATURES) ^ set(empty)
+    for name, args in empty.items():
+        _lib.call(name, *args, stream=0)          # raises EnvidrError on any non-zero return code
