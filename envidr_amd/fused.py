@@ -722,6 +722,19 @@ class FusedRenderer:
         rays_d = rays_d.contiguous().view(-1, 3).float()
         N, dev = rays_o.shape[0], rays_o.device
         res = out if out is not None else {}
+        if N == 0:
+            # no rays (a rank whose tile shard is empty, a masked batch that came out empty): an empty result, nothing enqueued
+            for name, shape in (("depth", (0,)), ("weights_sum", (0,)), ("normal_image", (0, 3)), ("roughness_image", (0,)), ("image", (0, 3)),
+                                ("diffuse_image", (0, 3)), ("specular_image", (0, 3))):
+                if geometry_only and name in ("diffuse_image", "specular_image"):
+                    continue
+                res[name] = torch.empty(*shape, device=dev)
+            res["ray_cost"] = torch.empty(0, dtype=torch.int16, device=dev)
+            res["n_records"] = res["n_samples"] = 0
+            if events:
+                for e in events:
+                    e.record()
+            return res
         for attempt in range(3):
             st = self._frame_buffers(N, dev, max(samples_per_ray_hint, self.__dict__.get("_frame_hints", {}).get(N, 0.0)))
             cap = st["cap"]

@@ -272,6 +272,13 @@ def test_frame_edge_cases(renderer):
     g = renderer.render_frame(torch.from_numpy(ro_).cuda(), torch.from_numpy(rd_).cuda(), geometry_only=True)
     torch.cuda.synchronize()
     assert torch.equal(g["depth"], a["depth"]) and torch.equal(g["normal_image"], a["normal_image"])
+    # a frame of ZERO rays (a tile shard of a rank that got no tile; a masked batch that came out empty) is an empty result, not an error
+    z = renderer.render_frame(o[:0], d[:0])
+    torch.cuda.synchronize()
+    assert z["image"].shape == (0, 3) and z["depth"].shape == (0,) and z["n_records"] == 0
+    again = renderer.render_frame(torch.from_numpy(ro_).cuda(), torch.from_numpy(rd_).cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(again["image"], img)
 
 
 def test_no_environment_family_on_the_pipeline():
