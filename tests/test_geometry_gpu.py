@@ -345,3 +345,33 @@ def test_image_width_hint_changes_the_block_layout_not_the_frame(renderer):
     odd = renderer.render_frame(ro_[: 90 * W], rd_[: 90 * W], 0.3, image_width=W)         # 90 rows: not a multiple of 8 -> list order
     ref = renderer.render_frame(ro_[: 90 * W], rd_[: 90 * W], 0.3)
     assert torch.equal(odd["image"], ref["image"])
+
+
+def test_two_cascades_and_growing_steps_on_the_pipeline():
+    """the general marcher of the pipeline (MODE 0: two occupancy cascades; with dt_gamma > 0 the step grows along the ray) and render
+    knobs away from the toaster defaults, against the oracle on the reference schedule with n_step = 1 -- and the same integer
+    trace as the persistent kernel (per-ray sample counts)"""
+    import torch
+    from envidr_amd.fused import FusedOptions, FusedRenderer
+    from oracle.py import render_oracle as ro
+    rng = np.random.default_rng(12)
+    offsets, pls = scenes.hash_level_offsets(desired_resolution=2 * 2048)
+    base = scenes.toaster_scene(seed=12)
+    scene2 = scenes.SceneParams(bitfield=scenes.occupancy_bitfield(scenes.shell(1.1, 0.12), bound=2.0, cascades=2), offsets=offsets,
+                                per_level_scale=pls, table=rng.uniform(-0.1, 0.1, size=(int(offsets[-1]), 2)).astype(np.float32),
+                                mlps=base.mlps, beta=0.02, bound=2.0, cascades=2)
+    knobs = dict(bound=2.0, min_near=0.05, max_steps=384, dt_gamma=1 / 128, T_thresh=1e-3, enabled_levels=8, intensity_scale=0.7,
+                 roughness_scale=1.5)
+    r = FusedRenderer.from_scene(scene2, FusedOptions(**knobs))
+    rays_o, rays_d = scenes.camera_rays(40, 40, theta=140.0, phi=-30.0, radius=4.0, scale=1.2)
+    want = ro.render_rays(scene2, rays_o, rays_d, ro.RenderOptions(cascades=2, ide_mode="exact", **knobs), None, force_n_step=1)
+    out = _frame(r, rays_o, rays_d)
+    assert want["n_samples"] > 5000 and out["n_records"] == want["n_samples"]
+    for key in KEYS:
+        err = rel_l2(out[key], want[key].reshape(out[key].shape))
+        assert err <= 2e-5, f"{key}: rel-L2 {err:.3e}"
+    o, d = torch.from_numpy(rays_o).cuda(), torch.from_numpy(rays_d).cuda()
+    cost = torch.zeros(rays_o.shape[0], dtype=torch.int16, device="cuda")
+    r.render(o, d, None, ray_cost=cost)
+    torch.cuda.synchronize()
+    assert torch.equal(cost, r.render_frame(o, d)["ray_cost"])
