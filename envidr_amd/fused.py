@@ -718,6 +718,8 @@ class FusedRenderer:
         `image_width`: the rays are the pixels of a row-major image this wide (layout hint: blocks of 64 rays are then 8x8-pixel
         tiles; same outputs, bit for bit; ignored unless width and height are multiples of 8)."""
         self.check_frames(block=False)
+        if not (rays_o.is_cuda and rays_d.is_cuda):
+            raise _lib.EnvidrError("render_frame: rays_o / rays_d must be CUDA tensors (envidr_amd has no CPU path)")      # the reference's CHECK_CUDA
         rays_o = rays_o.contiguous().view(-1, 3).float()
         rays_d = rays_d.contiguous().view(-1, 3).float()
         N, dev = rays_o.shape[0], rays_o.device
