@@ -235,7 +235,8 @@ class NeRFRenderer(nn.Module):
 
     def render(self, rays_o, rays_d, staged=False, max_ray_batch=4096, get_normal_image=False, use_specular_color=True,
                env_net_index=None, material=None, r_images=None, env_rot_radian=None, fused=True, **kwargs):
-        """rays_o, rays_d: [B, N, 3] (B == 1).  Returns the reference's result dict: image [B,N,3],
+        """rays_o, rays_d: [B, N, 3] (any B: the leading shape is flattened and restored like the reference's `prefix`,
+        cuda_ray.py:30-33).  Returns the reference's result dict: image [B,N,3],
         depth [B,N], weights_sum [B,N] and, per configuration, normal_image / diffuse_image /
         specular_image / roughness_image."""
         if not self.cuda_ray:
