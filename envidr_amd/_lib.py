@@ -52,6 +52,8 @@ SIGNATURES: dict[str, str] = {
     # shencoder (shencoder.h:9-10)
     "sh_encode_forward": "ppuuup",
     "sh_encode_backward": "ppuuupp",
+    "sh_encode_forward_f16": "ppuuup",
+    "sh_encode_backward_f16": "ppuuupp",
     # ide_encoder (ide_encoder.py:98-130)
     "ide_encode_forward": "ppfuup",
     "ide_encode_backward": "pppfuupp",

@@ -29,7 +29,8 @@ _OPTIONAL = {"grid_encode_forward": {10}, "grid_encode_backward": {11, 12}, "sh_
 _IGNORED_WHEN_OFF = {"hash_encode_forward": (10, [11]), "hash_encode_backward": (11, [12, 13])}
 # AT_DISPATCH_FLOATING_TYPES_AND_HALF: the argument whose scalar type selects the instantiation (hashencoder.cu:747,778,817 inputs /
 # grad / grad; gridencoder.cu:443,474 embeddings / grad) -> a half tensor there routes to the `_f16` entry point
-_DISPATCH_ARG = {"hash_encode_forward": 0, "hash_encode_backward": 0, "hash_encode_second_backward": 0, "grid_encode_forward": 1, "grid_encode_backward": 0}
+_DISPATCH_ARG = {"hash_encode_forward": 0, "hash_encode_backward": 0, "hash_encode_second_backward": 0, "grid_encode_forward": 1, "grid_encode_backward": 0,
+                 "sh_encode_forward": 0, "sh_encode_backward": 0}
 
 
 def _make_fn(name: str):

@@ -189,9 +189,9 @@ int envidr_sh_encode_backward(const float* grad, const float* inputs, uint32_t B
  * dispatch to.  uint16_t* = IEEE binary16 storage (torch.half `data_ptr()`).  hashencoder narrows inputs, table, outputs,
  * dy_dx and gradients; gridencoder keeps fp32 inputs (its kernels take `const float* inputs`).  Arithmetic narrows where
  * c10::Half narrows (csrc/grid_half.hip); same argument order as the fp32 entry points.  hash_encode_second_backward_f16
- * (hashencoder.cu:817; all tensors fp16) completes the hash encoder.  Not provided in half: freq / SH / raymarching (the
- * reference's Python wrappers force fp32 there: shencoder/sphere_harmonics.py:16 `cast_inputs=torch.float32`,
- * raymarching.py `.float()`, freqencoder.cu `data_ptr<float>()`).
+ * (hashencoder.cu:817; all tensors fp16) completes the hash encoder; sh_encode_*_f16 below.  Not provided in half: freq (freqencoder.cu takes
+ * `data_ptr<float>()`) and raymarching (raymarching.py `.float()`s every input; raymarching.cu:90 "scalar_t should always be
+ * float in use").
  * ------------------------------------------------------------------------------------------ */
 int envidr_hash_encode_forward_f16(const uint16_t* inputs, const uint16_t* embeddings, const int32_t* offsets,
                                    uint16_t* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
@@ -206,6 +206,13 @@ int envidr_hash_encode_second_backward_f16(const uint16_t* grad, const uint16_t*
                                            uint32_t H, int calc_grad_inputs, const uint16_t* dy_dx,
                                            const uint16_t* grad_grad_inputs, uint16_t* grad_grad,
                                            uint16_t* grad2_embeddings, envidr_stream_t stream);
+/* shencoder.cu:413,435 on at::Half: half inputs / outputs / dy_dx / gradients.  The forward evaluates the basis in fp32 and rounds once
+ * (within a few fp16 ulp of the reference's half instantiation, which rounds every monomial; not bit-identical); the backward is the
+ * reference's Half arithmetic exactly.  The reference's own wrapper casts to float32 (sphere_harmonics.py:16) and never calls these. */
+int envidr_sh_encode_forward_f16(const uint16_t* inputs, uint16_t* outputs, uint32_t B, uint32_t D, uint32_t C, uint16_t* dy_dx,
+                                 envidr_stream_t stream);
+int envidr_sh_encode_backward_f16(const uint16_t* grad, const uint16_t* inputs, uint32_t B, uint32_t D, uint32_t C,
+                                  const uint16_t* dy_dx, uint16_t* grad_inputs, envidr_stream_t stream);
 int envidr_grid_encode_forward_f16(const float* inputs, const uint16_t* embeddings, const int32_t* offsets,
                                    uint16_t* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
                                    float S, uint32_t H, uint16_t* dy_dx, uint32_t gridtype, int align_corners,

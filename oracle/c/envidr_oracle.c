@@ -1016,6 +1016,35 @@ API int oracle_hash_encode_second_backward_f16(const uint16_t* grad, const uint1
     }
     return 0;
 }
+/* shencoder.cu:413,435 on at::Half.  Forward: the exact basis (the double evaluation above) of the widened direction, rounded to
+ * fp32 and then to fp16 -- NOT the reference's half arithmetic, which rounds every monomial (x2 = H(x*x), x4 = H(x2*x2) ...) and so
+ * sits a few fp16 ulp from the exact basis; tests/test_oracle_pinning.py measures that distance against the reference's own
+ * template.  Backward: `grad_inputs[t] += grad[ch] * dy_dx[ch]` in Half, term by term, as the reference (shencoder.cu:359-379). */
+API int oracle_sh_encode_forward_f16(const uint16_t* inputs, uint16_t* outputs, uint32_t B, uint32_t D, uint32_t C, uint16_t* dy_dx) {
+    if (D != 3 || C < 1 || C > 8) return -1;
+    const uint32_t C2 = C * C;
+    float* in = (float*)malloc(sizeof(float) * 3 * (size_t)(B ? B : 1));
+    float* out = (float*)malloc(sizeof(float) * C2 * (size_t)(B ? B : 1));
+    float* dy = dy_dx ? (float*)malloc(sizeof(float) * 3 * C2 * (size_t)(B ? B : 1)) : NULL;
+    for (size_t i = 0; i < (size_t)B * 3; ++i) in[i] = F(inputs[i]);
+    const int rc = oracle_sh_encode_forward(in, out, B, D, C, dy);
+    for (size_t i = 0; i < (size_t)B * C2; ++i) outputs[i] = H(out[i]);
+    if (dy) for (size_t i = 0; i < (size_t)B * 3 * C2; ++i) dy_dx[i] = H(dy[i]);
+    free(in); free(out); free(dy);
+    return rc;
+}
+API int oracle_sh_encode_backward_f16(const uint16_t* grad, const uint16_t* inputs, uint32_t B, uint32_t D, uint32_t C, const uint16_t* dy_dx,
+                                      uint16_t* grad_inputs) {
+    (void)inputs;
+    const uint32_t C2 = C * C;
+    for (int64_t t = 0; t < (int64_t)B * D; ++t) {
+        const uint32_t b = (uint32_t)(t / D), d = (uint32_t)(t - (int64_t)b * D);
+        uint16_t acc = grad_inputs[t];
+        for (uint32_t ch = 0; ch < C2; ++ch) acc = H(F(acc) + F(H(F(grad[(size_t)b * C2 + ch]) * F(dy_dx[(size_t)b * D * C2 + d * C2 + ch]))));
+        grad_inputs[t] = acc;
+    }
+    return 0;
+}
 API int oracle_grid_encode_forward_f16(const float* inputs, const uint16_t* embeddings, const int32_t* offsets, uint16_t* outputs, uint32_t B,
                                        uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H_, uint16_t* dy_dx, uint32_t gridtype, int align_corners) {
     return grid_forward_h(inputs, 0, embeddings, offsets, outputs, B, D, C, L, S, H_, dy_dx, 0, gridtype, align_corners);

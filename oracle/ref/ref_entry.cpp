@@ -323,3 +323,15 @@ EXPORT int ref_sh_encode_backward(const float* grad, const float* inputs, uint32
     emu_launch(emu_blocks(B * D, 256), 1, 256, [&] { ref_sh::kernel_sh_backward<float>(grad, inputs, B, D, C, dy_dx, grad_inputs); });
     return 0;
 }
+
+/* ---- shencoder on at::Half (the dispatch of shencoder.cu:413,435) ---- */
+EXPORT int ref_sh_encode_forward_f16(const uint16_t* inputs, uint16_t* outputs, uint32_t B, uint32_t D, uint32_t C, uint16_t* dy_dx) {
+    emu_launch(emu_blocks(B, 256), 1, 256, [&] { ref_sh::kernel_sh<H16>((const H16*)inputs, (H16*)outputs, B, D, C, (H16*)dy_dx); });
+    return 0;
+}
+EXPORT int ref_sh_encode_backward_f16(const uint16_t* grad, const uint16_t* inputs, uint32_t B, uint32_t D, uint32_t C,
+                                      const uint16_t* dy_dx, uint16_t* grad_inputs) {
+    emu_launch(emu_blocks(B * D, 256), 1, 256,
+               [&] { ref_sh::kernel_sh_backward<H16>((const H16*)grad, (const H16*)inputs, B, D, C, (const H16*)dy_dx, (H16*)grad_inputs); });
+    return 0;
+}

@@ -341,6 +341,19 @@ def half_cases():
             ggx = h(rng.normal(size=(B, D)) * 0.1)
             out.append((cid + "_bwd2", "hash_encode_second_backward_f16", (grad, h(x), h(table), offsets, B, D, C, L, S, base, 1, dy, ggx,
                                                                             np.zeros((L, B, C), np.int16), np.zeros((int(offsets[-1]), C), np.int16)), "f16"))
+    # shencoder on at::Half: the forward is the exact basis rounded once ("hulp": compared in fp16 ulp -- GPU vs oracle 1 ulp of
+    # double rounding; oracle vs the reference's half template, which rounds every monomial, a few ulp: tests/test_oracle_pinning.py);
+    # the backward is the reference's Half arithmetic, bit for bit
+    for degree in (1, 2, 4, 6, 8):
+        B = 200
+        d16 = _unit_dirs(rng, B).astype(np.float16)
+        C2 = degree * degree
+        out.append((f"sh16_deg{degree}", "sh_encode_forward_f16", (h(d16), np.zeros((B, C2), np.int16), B, 3, degree, None), "hulp"))
+        dy = np.zeros((B, 3 * C2), np.int16)
+        out.append((f"sh16_deg{degree}_grad", "sh_encode_forward_f16", (h(d16), np.zeros((B, C2), np.int16), B, 3, degree, dy), "hulp"))
+        dy = dy.copy()
+        clib.oracle().call("sh_encode_forward_f16", h(d16), np.zeros((B, C2), np.int16), B, 3, degree, dy)
+        out.append((f"sh16_deg{degree}_bwd", "sh_encode_backward_f16", (h(rng.normal(size=(B, C2)) * 0.3), h(d16), B, 3, degree, dy, h(rng.normal(size=(B, 3)))), None))
     for D, C, L, log2T, base, desired, gridtype, align in [(3, 2, 8, 16, 16, 512, 0, 0), (2, 4, 4, 10, 4, 40, 1, 1), (1, 2, 4, 8, 4, 64, 0, 1), (4, 2, 3, 10, 2, 8, 0, 0)]:
         offsets, pls = scenes.grid_level_offsets(D, L, base, log2T, desired, bool(align))
         S = float(np.log2(pls))

@@ -192,6 +192,8 @@ def test_every_operator_takes_an_empty_batch_as_a_no_op():
         "freq_encode_backward": (P, P, 0, 3, 4, 27, P),
         "sh_encode_forward": (P, P, 0, 3, 4, P),
         "sh_encode_backward": (P, P, 0, 3, 4, P, P),
+        "sh_encode_forward_f16": (P, P, 0, 3, 4, P),
+        "sh_encode_backward_f16": (P, P, 0, 3, 4, P, P),
         "ide_encode_forward": (P, P, 0.5, 0, 5, P),
         "ide_encode_backward": (P, P, P, 0.5, 0, 5, P, P),
     }

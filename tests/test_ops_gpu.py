@@ -20,6 +20,12 @@ def _compare(cid, op, got, want, tol):
     for k, (g, w) in enumerate(zip(got, want)):
         if g is None:
             continue
+        if tol == "hulp":
+            if g.dtype == np.int16:          # fp32 result rounded to fp16 (GPU) against double -> fp32 -> fp16 (oracle): the fp32 results differ by
+                from tests.util import half_ulp_distance        # ~1e-7 relative, which moves a rounding to fp16 by at most one value
+                dist = half_ulp_distance(g, w)
+                assert dist.max() <= 1 and (dist > 0).mean() <= 2e-3, f"{cid}: arg {k}: {int(dist.max())} fp16 ulp, {(dist > 0).mean():.2e} of the values differ"
+            continue
         if tol == "f16" and g.dtype == np.int16:
             # int16 views of fp16 sums built by atomic adds in arrival order: every add rounds the running sum to 11 bits, so n adds
             # into one entry random-walk ~sqrt(n) * 2^-12 of it away from the oracle's (serial-order) sum -- the small tables of the

@@ -27,6 +27,21 @@ def test_oracle_matches_reference_bodies(cid, op, args, tol, ref_lib):
     for k, (g, w) in enumerate(zip(got, want)):
         if g is None:
             continue
+        if tol == "hulp":
+            # The oracle's half SH forward is the EXACT basis rounded once.  The reference's at::Half instantiation rounds every monomial it
+            # forms (x2, x4, x6, xy, xyz ... each H(.)) before its polynomial expressions cancel them against each other: measured
+            # here, it is bit-identical up to degree 2 and then drifts from the exact basis -- rel-L2 3.3e-4 / 6.0e-4 / 1.4e-3 and up to
+            # 4.9e-4 / 2.4e-3 / 9.3e-3 absolute at degree 4 / 6 / 8 (which is why its own wrapper casts to float32, sphere_harmonics.py:16).
+            # Parity with it can therefore only be asserted to that noise.
+            if g.dtype == np.int16 and g.size:
+                a, b = g.view(np.float16).astype(np.float64), w.view(np.float16).astype(np.float64)
+                degree = int(args[4])
+                if degree <= 2:
+                    assert np.array_equal(a, b), f"{cid}: pointer arg {k} differs at degree {degree}"          # (value equality: +0 / -0 derivatives)
+                else:
+                    assert np.linalg.norm(a - b) <= 3e-3 * np.linalg.norm(b), f"{cid}: pointer arg {k}: rel-L2 {np.linalg.norm(a - b) / np.linalg.norm(b):.2e}"
+                    assert np.abs(a - b).max() <= 2e-2 * max(1.0, np.abs(b).max()), f"{cid}: pointer arg {k}: max abs {np.abs(a - b).max():.3e}"
+            continue
         if tol == "f16":
             tol = None          # serial on both sides: the fp16 sums are built in the same order, bit for bit
         if op in DERIVED:

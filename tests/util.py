@@ -51,3 +51,12 @@ def bits_equal(a: np.ndarray, b: np.ndarray) -> bool:
     """bitwise equality for float arrays (distinguishes -0/+0, matches NaN payloads)."""
     a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
     return a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes()
+
+
+def half_ulp_distance(a16: np.ndarray, b16: np.ndarray) -> np.ndarray:
+    """distance of two int16-viewed fp16 arrays in units of fp16 ulp: both mapped to the integer line on which consecutive
+    halves are consecutive integers (sign-magnitude -> offset), so the result counts representable values between them"""
+    def line(v):
+        u = v.view(np.uint16).astype(np.int64)
+        return np.where(u & 0x8000, -(u & 0x7fff), u & 0x7fff)
+    return np.abs(line(np.ascontiguousarray(a16)) - line(np.ascontiguousarray(b16)))
