@@ -547,6 +547,15 @@ class FusedRenderer:
         rays_d = rays_d.contiguous().view(-1, 3).float()
         N, dev = rays_o.shape[0], rays_o.device
         res = out if out is not None else {}
+        if N == 0:                      # no rays: an empty result, nothing enqueued
+            for name, shape in (("image", (0, 3)), ("depth", (0,)), ("weights_sum", (0,)), ("normal_image", (0, 3)), ("diffuse_image", (0, 3)),
+                                ("specular_image", (0, 3)), ("roughness_image", (0,))):
+                res[name] = torch.empty(*shape, device=dev)
+            res["n_records"] = 0
+            if events:
+                for e in events:
+                    e.record()
+            return res
         st = self.__dict__.setdefault("_two_phase", {})
         if ray_cost is None:
             if st.get("cost_n") != N:
@@ -830,12 +839,18 @@ class FusedRenderer:
         render() of the same rays with the same environment rotation"""
         dev = cache.w.device
         res = out if out is not None else {}
-        shaded = _shade(self.lib, self.desc, cache.normals, cache.dirs, cache.geo_feat, cache.roughness, env_rot_radian,
-                        res.setdefault("_shaded", {}))
         N = cache.n_rays
         for name in ("image", "diffuse_image", "specular_image"):
             if name not in res or res[name].shape != (N, 3):
                 res[name] = torch.empty(N, 3, device=dev)
+        if cache.w.shape[0] == 0:       # no ray of this camera hits anything (or no rays): background only, nothing to shade
+            res["image"].fill_(float(self.desc.bg_color))
+            res["diffuse_image"].zero_()
+            res["specular_image"].zero_()
+            res.update(depth=cache.depth, weights_sum=cache.weights_sum, normal_image=cache.normal_image)
+            return res
+        shaded = _shade(self.lib, self.desc, cache.normals, cache.dirs, cache.geo_feat, cache.roughness, env_rot_radian,
+                        res.setdefault("_shaded", {}))
         rc = self.lib.envidr_composite_shaded(cache.offsets.data_ptr(), cache.w.data_ptr(), shaded["c_diffuse"].data_ptr(),
                                               shaded["c_specular"].data_ptr(), cache.weights_sum.data_ptr(), N,
                                               float(self.desc.intensity_scale), float(self.desc.bg_color), res["image"].data_ptr(),

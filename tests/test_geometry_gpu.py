@@ -279,6 +279,13 @@ def test_frame_edge_cases(renderer):
     again = renderer.render_frame(torch.from_numpy(ro_).cuda(), torch.from_numpy(rd_).cuda())
     torch.cuda.synchronize()
     assert torch.equal(again["image"], img)
+    # the other frame schedules on the same degenerate inputs: zero rays, and a geometry cache that holds no sample
+    assert renderer.render_two_phase(o[:0], d[:0])["image"].shape == (0, 3) and renderer.render(o[:0], d[:0])["image"].shape == (0, 3)
+    cache = renderer.cache_geometry(o, d)                 # every ray misses
+    lit = renderer.render_cached(cache, 0.3)
+    torch.cuda.synchronize()
+    assert int(cache.offsets[-1]) == 0 and torch.all(lit["image"] == 1.0) and torch.all(lit["weights_sum"] == 0)
+    assert torch.equal(renderer.render_cached(renderer.cache_geometry(o[:0], d[:0]))["image"], torch.empty(0, 3, device="cuda"))
 
 
 def test_no_environment_family_on_the_pipeline():
