@@ -22,7 +22,14 @@ typedef _Float16 h16;
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float F(h16 v) { return (float)v; }
-__device__ __forceinline__ h16 H(float v) { return (h16)v; }
+// narrow a float that EXISTS as a float: c10::Half narrows the fp32 result of `w * grid[i]` (two roundings).  Left alone, the compiler
+// folds `(h16)(a * b)` into v_fma_mixlo_f16 -- the exact product rounded ONCE to fp16 -- which differs from the reference where the
+// fp32 rounding moves the product across an fp16 rounding boundary (seen on ~1 value in 2 000, tools/fuzz_ops.py); the empty asm makes
+// the fp32 value materialise first.  (Sums and differences of two halves are immune: fp32 holds them with 2 * 11 + 2 bits to spare.)
+__device__ __forceinline__ h16 H(float v) {
+    asm volatile("" : "+v"(v));
+    return (h16)v;
+}
 __device__ __forceinline__ h16 add_f(h16 a, float b) { return H(F(a) + F(H(b))); }       // Half += float
 
 template <typename IN> __device__ __forceinline__ float widen(IN v) { return (float)v; }

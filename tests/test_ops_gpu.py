@@ -21,10 +21,15 @@ def _compare(cid, op, got, want, tol):
         if g is None:
             continue
         if tol == "hulp":
-            if g.dtype == np.int16:          # fp32 result rounded to fp16 (GPU) against double -> fp32 -> fp16 (oracle): the fp32 results differ by
-                from tests.util import half_ulp_distance        # ~1e-7 relative, which moves a rounding to fp16 by at most one value
+            if g.dtype == np.int16:
+                # fp32 result rounded to fp16 (GPU) against double -> fp32 -> fp16 (oracle).  The fp32 evaluation carries ~1e-7 of the
+                # basis' SCALE (up to ~30 for the degree-8 derivatives), so a value is off by at most one fp16 rounding -- or, where the
+                # polynomial cancels to something small, by that absolute noise (a few ulp of a small value: seen with other seeds)
+                from tests.util import half_ulp_distance
                 dist = half_ulp_distance(g, w)
-                assert dist.max() <= 1 and (dist > 0).mean() <= 2e-3, f"{cid}: arg {k}: {int(dist.max())} fp16 ulp, {(dist > 0).mean():.2e} of the values differ"
+                a, b = g.view(np.float16).astype(np.float64), w.view(np.float16).astype(np.float64)
+                ok = (dist <= 1) | (np.abs(a - b) <= 2e-6 * max(1.0, np.abs(b).max()))
+                assert ok.all() and (dist > 0).mean() <= 2e-3, f"{cid}: arg {k}: {int(dist.max())} fp16 ulp, {(dist > 0).mean():.2e} of the values differ"
             continue
         if tol == "f16" and g.dtype == np.int16:
             # int16 views of fp16 sums built by atomic adds in arrival order: every add rounds the running sum to 11 bits, so n adds
