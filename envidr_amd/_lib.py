@@ -103,6 +103,27 @@ def exported_symbols() -> dict[str, bool]:
     return {name: hasattr(lib, "envidr_" + name) for name in SIGNATURES}
 
 
+_ELEMENT_DTYPES = {"float": (torch.float32,), "int32_t": (torch.int32,), "uint8_t": (torch.uint8, torch.bool),
+                   "uint16_t": (torch.float16, torch.int16) + ((torch.uint16,) if hasattr(torch, "uint16") else ())}
+_pointer_types: dict[str, list[str]] | None = None
+
+
+def pointer_types() -> dict[str, list[str]]:
+    """operator -> C element type of each of its arguments ('' for scalars), read from include/envidr_amd.h: what the reference's
+    CHECK_IS_FLOATING / CHECK_IS_INT guard (a tensor of another dtype would be read as garbage through a raw pointer)"""
+    global _pointer_types
+    if _pointer_types is None:
+        import re
+        _pointer_types = {}
+        header = _PKG.parent / "include" / "envidr_amd.h"
+        if header.exists():
+            text = re.sub(r"/\*.*?\*/", "", header.read_text(), flags=re.S)
+            for m in re.finditer(r"\bint\s+envidr_([a-zA-Z0-9_]+)\s*\((.*?)\)\s*;", text, flags=re.S):
+                params = [" ".join(p.split()) for p in m.group(2).split(",")][:-1]          # the stream is last
+                _pointer_types[m.group(1)] = [p.replace("const ", "").split("*")[0].strip() if "*" in p else "" for p in params]
+    return _pointer_types
+
+
 def _ptr(x, name: str, pos: int):
     if x is None:
         return None
@@ -111,6 +132,10 @@ def _ptr(x, name: str, pos: int):
             raise EnvidrError(f"{name}: argument {pos} must live on the GPU (got a {x.device} tensor)")
         if not x.is_contiguous():
             raise EnvidrError(f"{name}: argument {pos} must be contiguous")
+        elem = pointer_types().get(name, [])
+        if pos < len(elem) and elem[pos] in _ELEMENT_DTYPES and x.dtype not in _ELEMENT_DTYPES[elem[pos]]:
+            raise EnvidrError(f"{name}: argument {pos} must be a {elem[pos]} tensor ({' / '.join(str(d) for d in _ELEMENT_DTYPES[elem[pos]])}), "
+                              f"not {x.dtype}")
         return x.data_ptr()
     if isinstance(x, int):
         return x

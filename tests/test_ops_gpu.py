@@ -159,6 +159,29 @@ def test_errors_are_reported_not_swallowed():
         _lib.call("near_far_from_aabb", x.cpu(), x, x, 4, 0.2, x, x)                  # host tensor
 
 
+def test_wrong_element_types_are_refused_not_reinterpreted():
+    """the reference's CHECK_IS_INT / CHECK_IS_FLOATING: an int64 offsets tensor (numpy's default integer), a double table or an int32
+    bitfield would otherwise be read through a raw pointer as something else"""
+    import torch
+    from envidr_amd import _lib
+    from envidr_amd.compat import make_backend
+    x = torch.rand(8, 3, device="cuda")
+    table = torch.rand(100, 2, device="cuda")
+    out = torch.empty(1, 8, 2, device="cuda")
+    good = torch.tensor([0, 100], dtype=torch.int32, device="cuda")
+    _lib.call("hash_encode_forward", x, table, good, out, 8, 3, 2, 1, 1.0, 4, 0, None)
+    with pytest.raises(_lib.EnvidrError, match="int32_t"):
+        _lib.call("hash_encode_forward", x, table, good.long(), out, 8, 3, 2, 1, 1.0, 4, 0, None)
+    with pytest.raises(_lib.EnvidrError, match="float"):
+        _lib.call("hash_encode_forward", x, table.double(), good, out, 8, 3, 2, 1, 1.0, 4, 0, None)
+    be = make_backend("hashencoder")
+    with pytest.raises(RuntimeError, match="int32_t"):
+        be.hash_encode_forward(x, table, good.long(), out, 8, 3, 2, 1, 1.0, 4, False, None)
+    rm = make_backend("raymarching")
+    with pytest.raises(RuntimeError, match="uint8_t"):
+        rm.packbits(torch.rand(64, device="cuda"), 64, 0.5, torch.zeros(8, dtype=torch.int32, device="cuda"))
+
+
 def test_encoder_modules_take_half_tables_like_the_reference():
     """GridEncoder / HashEncoder with fp16 tables: the reference narrows the table under autocast (grid.py:37-40, even C) or takes
     half inputs + table (hashgrid.py:19); outputs come back in half, gradients flow to the table, values track an fp32 run on the
