@@ -176,8 +176,9 @@ def load_scene(rank: int, world: int, dist_on: bool, dev):
     instead of every rank generating its own copy; the MLP weights (< 1 MB, milliseconds) are generated from the seed everywhere."""
     import torch.distributed as dist
     from envidr_amd import scenes
-    if not dist_on or world == 1:
+    if not dist_on:
         return scenes.toaster_scene()
+    # (a forced world of one goes through the same calls: the broadcasts are then trivial, but the code that runs on N ranks has run)
     sc = scenes.toaster_scene(arrays=(rank == 0))
     rows = int(sc.offsets[-1])
     table = torch.from_numpy(sc.table).to(dev) if rank == 0 else torch.empty(rows, 2, dtype=torch.float32, device=dev)
@@ -396,7 +397,7 @@ def run(argv: list[str]) -> None:
         }
         if dist_on:
             result["dist"] = {"backend": dist.get_backend(), "world": world, "force_dist": bool(args.force_dist), "gathered_equals_rendered": delivered_ok,
-                              "scene": "none (stub)" if stub else ("generated on rank 0, table + bitfield broadcast" if world > 1 else "generated locally")}
+                              "scene": "none (stub)" if stub else ("generated on rank 0, table + bitfield broadcast" if dist_on else "generated locally")}
         if stub:
             result["config"]["workload"] = "STUB (CPU plumbing test)"
             _finish(result, dist_on)
