@@ -1,0 +1,82 @@
+"""Standalone operators of the C ABI at headline-like sizes (640 k rays, ~7.7 M samples, the 48.8 MB hash table): time per call, algorithmic
+bytes moved and the fraction of the 8 TB/s HBM peak.  These are the kernels of the operator loop (`fused=False`) and of the training branch;
+the frame pipeline does not call them.  Run on the GPU box:  python tools/ops_bench.py"""
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import numpy as np, torch
+from envidr_amd import _lib, scenes
+
+dev = torch.device("cuda:0")
+sc = scenes.toaster_scene()
+ro_, rd_ = scenes.camera_rays(800, 800)
+ro, rd = torch.from_numpy(ro_).to(dev), torch.from_numpy(rd_).to(dev)
+N = ro.shape[0]
+bitfield = torch.from_numpy(sc.bitfield).to(dev)
+table = torch.from_numpy(sc.table).to(dev)
+offsets = torch.from_numpy(np.ascontiguousarray(sc.offsets, np.int32)).to(dev)
+S = float(np.log2(sc.per_level_scale))
+aabb = torch.tensor([-1, -1, -1, 1, 1, 1.0], device=dev)
+rows = []
+def bench(name, fn, bytes_, reps=10, note=""):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    rows.append((name, ms, bytes_, note))
+    print(f"{name:44s} {ms:8.3f} ms   {bytes_ / 1e6:9.1f} MB   {bytes_ / ms / 1e6:8.1f} GB/s  ({100 * bytes_ / ms / 1e6 / 8000:4.1f} % of 8 TB/s)  {note}")
+
+nears, fars = torch.empty(N, device=dev), torch.empty(N, device=dev)
+bench("near_far_from_aabb (640 k rays)", lambda: _lib.call("near_far_from_aabb", ro, rd, aabb, N, 0.2, nears, fars), N * 32)
+alive = torch.arange(N, dtype=torch.int32, device=dev)
+rays_t = nears.clone()
+for n_step in (1, 8):
+    M = N * n_step
+    xyzs, dirs, deltas = torch.zeros(M, 3, device=dev), torch.zeros(M, 3, device=dev), torch.zeros(M, 2, device=dev)
+    noises = torch.zeros(N, device=dev)
+    def f(n_step=n_step, xyzs=xyzs, dirs=dirs, deltas=deltas):
+        _lib.call("march_rays", N, n_step, alive, rays_t, ro, rd, 1.0, 0.0, 1024, 1, 128, bitfield, nears, fars, xyzs, dirs, deltas, noises)
+    bench(f"march_rays (640 k rays, n_step {n_step})", f, N * 40 + M * 32, note="writes only for samples found; walks empty cells")
+M = 7_700_000
+x01 = torch.rand(M, 3, device=dev)
+out = torch.empty(16, M, 2, device=dev)
+dy = torch.empty(M, 16 * 3 * 2, device=dev)
+bench("hash_encode_forward (7.7 M, no dy_dx)", lambda: _lib.call("hash_encode_forward", x01, table, offsets, out, M, 3, 2, 16, S, 16, 0, None), M * (1024 + 12 + 128),
+      note="random points: no locality between neighbours")
+bench("hash_encode_forward (7.7 M, + dy_dx)", lambda: _lib.call("hash_encode_forward", x01, table, offsets, out, M, 3, 2, 16, S, 16, 1, dy), M * (1024 + 12 + 128 + 384))
+grad = torch.randn(16, M, 2, device=dev)
+gin = torch.zeros(M, 3, device=dev)
+bench("hash_encode_backward (7.7 M, inputs only)", lambda: _lib.call("hash_encode_backward", grad, x01, table, offsets, None, M, 3, 2, 16, S, 16, 1, dy, gin), M * (128 + 384 + 12))
+gtab = torch.zeros_like(table)
+bench("hash_encode_backward (7.7 M, + table scatter)", lambda: _lib.call("hash_encode_backward", grad, x01, table, offsets, gtab, M, 3, 2, 16, S, 16, 1, dy, gin),
+      M * (128 + 384 + 12 + 12 + 1024), reps=3, note="8 x 16 fp32 atomics per sample")
+ggx = torch.randn(M, 3, device=dev); gg = torch.zeros(16, M, 2, device=dev); g2 = torch.zeros_like(table)
+bench("hash_encode_second_backward (7.7 M)", lambda: _lib.call("hash_encode_second_backward", grad, x01, table, offsets, M, 3, 2, 16, S, 16, 1, dy, ggx, gg, g2),
+      M * (128 + 384 + 12 + 12 + 128 + 1024), reps=3)
+d = torch.nn.functional.normalize(torch.randn(M, 3, device=dev), dim=-1)
+o16 = torch.empty(M, 16, device=dev)
+bench("sh_encode_forward (7.7 M, degree 4)", lambda: _lib.call("sh_encode_forward", d, o16, M, 3, 4, None), M * (12 + 64))
+o27 = torch.empty(M, 27, device=dev)
+bench("freq_encode_forward (7.7 M, degree 4)", lambda: _lib.call("freq_encode_forward", d, M, 3, 4, 27, o27), M * (12 + 108))
+o72 = torch.empty(M, 72, device=dev); rough = torch.rand(M, device=dev)
+bench("ide_encode_forward (7.7 M, degree 5)", lambda: _lib.call("ide_encode_forward", d, rough, 0.0, M, 5, o72), M * (16 + 288))
+n_step = 8
+Mc = N * n_step
+sig = torch.rand(Mc, device=dev) * 50; rgb = torch.rand(Mc, 3, device=dev)
+al = torch.arange(N, dtype=torch.int32, device=dev); rt = torch.zeros(N, device=dev)
+dl = torch.full((Mc, 2), 0.0034, device=dev)
+ws, dp, im = torch.zeros(N, device=dev), torch.zeros(N, device=dev), torch.zeros(N, 3, device=dev)
+def comp():
+    al.copy_(torch.arange(N, dtype=torch.int32, device=dev))          # the compositor tombstones finished rays (-1): restore the list
+    _lib.call("composite_rays", N, n_step, 1e-4, 1, 0, al, rt, sig, rgb, dl, ws, dp, im)
+bench("composite_rays (640 k rays x 8 samples)", comp, N * (n_step * 24 + 8 + 40), note="incl. a 2.6 MB list refill per call")
+grid = torch.rand(128 ** 3, device=dev); bits = torch.zeros(128 ** 3 // 8, dtype=torch.uint8, device=dev)
+bench("packbits (128^3 cells)", lambda: _lib.call("packbits", grid, 128 ** 3 // 8, 0.01, bits), 128 ** 3 * 4 + 128 ** 3 // 8, note="N counts bytes of the bitfield, like the reference")
+print()
+print("| operator | ms | algorithmic MB | GB/s | of 8 TB/s |")
+print("|---|---|---|---|---|")
+for name, ms, b, note in rows:
+    print(f"| {name} | {ms:.3f} | {b / 1e6:.0f} | {b / ms / 1e6:.0f} | {100 * b / ms / 1e6 / 8000:.1f} % |")
