@@ -14,6 +14,10 @@
 // One lane per (point, level); these instantiations exist for interface completeness, the fp32 kernels are the tuned ones.
 #include "grid_core.hip.h"
 
+// (the opaque statement in H() keeps the largest instantiation -- D = 5, C = 8: 32 corners x 8 channels -- from being fully unrolled;
+//  that is a missed optimisation in a kernel that exists for interface completeness, not something to be warned about on every build)
+#pragma clang diagnostic ignored "-Wpass-failed"
+
 using namespace envidr;
 
 namespace {
@@ -27,7 +31,7 @@ __device__ __forceinline__ float F(h16 v) { return (float)v; }
 // fp32 rounding moves the product across an fp16 rounding boundary (seen on ~1 value in 2 000, tools/fuzz_ops.py); the empty asm makes
 // the fp32 value materialise first.  (Sums and differences of two halves are immune: fp32 holds them with 2 * 11 + 2 bits to spare.)
 __device__ __forceinline__ h16 H(float v) {
-    asm volatile("" : "+v"(v));
+    asm("" : "+v"(v));          // (not volatile: it only has to be opaque, and a volatile statement keeps the big instantiations from unrolling)
     return (h16)v;
 }
 __device__ __forceinline__ h16 add_f(h16 a, float b) { return H(F(a) + F(H(b))); }       // Half += float

@@ -86,9 +86,14 @@ __global__ void __launch_bounds__(kBlock) k_grid_backward_table(const float* __r
     uint32_t level, chunk;
     if (!xcd_level_chunk(L, chunks, level, chunk)) return;
     const uint32_t b = chunk * blockDim.x + threadIdx.x;
-    if (b >= B) return;
     float x[D];
-    if (!load_point<D>(inputs, b, x)) return;
+#pragma unroll
+    for (int d = 0; d < D; ++d) x[d] = 0.5f;
+    const bool on = b < B && load_point<D>(inputs, b, x);          // (no early exit per lane: RunScatter combines across the wave)
+    if (!on) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) x[d] = 0.5f;
+    }
 
     const uint32_t row0 = (uint32_t)offsets[level];
     const uint32_t size = (uint32_t)offsets[level + 1] - row0;
@@ -106,9 +111,11 @@ __global__ void __launch_bounds__(kBlock) k_grid_backward_table(const float* __r
     }
     float gcur[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) gcur[c] = grad[((size_t)level * B + b) * C + c];
+    for (int c = 0; c < C; ++c) gcur[c] = on ? grad[((size_t)level * B + b) * C + c] : 0.0f;
 
     float* t = grad_table + (size_t)row0 * C;
+    const RunScatter rs(on);
+    bool combine = false;
 #pragma unroll
     for (int i = 0; i < (1 << D); ++i) {
         float w = 1;
@@ -120,8 +127,11 @@ __global__ void __launch_bounds__(kBlock) k_grid_backward_table(const float* __r
             q[d] = cell[d] + bit;
         }
         const uint32_t row = cell_row<D>(g, q);
+        if (i == 0) combine = rs.worth(row, on);
+        float v[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) unsafeAtomicAdd(&t[(size_t)row * C + c], w * gcur[c]);
+        for (int c = 0; c < C; ++c) v[c] = w * gcur[c];
+        rs.template add<C>(t, row, on, v, combine);
     }
 }
 
