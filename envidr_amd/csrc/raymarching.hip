@@ -282,6 +282,13 @@ __global__ void __launch_bounds__(kBlock) k_march_rays_train(const float* __rest
                                                              float* __restrict__ deltas, int32_t* __restrict__ rays,
                                                              int32_t* __restrict__ counter,
                                                              const float* __restrict__ noises) {
+    // A training batch is a few thousand rays: sixteen workgroups on 256 CUs, so the kernel's run time is the LATENCY of one ray's
+    // walk (a dependent bitfield load per cell), and the reference's second pass walks it all again.  The ray times of the first
+    // kTimeCache samples found by the counting pass stay in LDS ([sample][thread]: conflict-free); position and step are pure
+    // functions of that time (march_visit), so the write pass replays them -- same statements, same bits -- and only marches on
+    // from where the cache ends.
+    constexpr uint32_t kTimeCache = 48;
+    __shared__ float s_time[kTimeCache][kBlock];
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const RayGeom r = load_ray(rays_o, rays_d, n);
@@ -293,7 +300,19 @@ __global__ void __launch_bounds__(kBlock) k_march_rays_train(const float* __rest
     // pass 1: count occupied steps
     float t = t0, x, y, z, dt;
     uint32_t num_steps = 0;
-    while (num_steps < early_stop_steps && march_next(k, r, far, t, x, y, z, dt)) ++num_steps;
+    // (a FLAT loop, one cell visit per iteration: with `while (march_next(...))` -- a walk to the next sample inside a loop over samples
+    //  -- a wave pays, at every sample index, the longest walk any of its lanes takes there; the visits are the same statements in
+    //  the same order for every lane, march_core.hip.h)
+    auto count = [&](auto pow2) {
+        while (t < far && num_steps < early_stop_steps) {
+            if (march_visit<decltype(pow2)::value>(k, r, t, x, y, z, dt)) {
+                if (num_steps < kTimeCache) s_time[num_steps][threadIdx.x] = t;
+                ++num_steps;
+                t += dt;
+            }
+        }
+    };
+    if (k.H_pow2) count(std::true_type{}); else count(std::false_type{});
 
     // reserve output ranges (the compiler folds these into one atomic per wave)
     const uint32_t point_index = (uint32_t)atomicAdd(counter, (int32_t)num_steps);
@@ -310,7 +329,14 @@ __global__ void __launch_bounds__(kBlock) k_march_rays_train(const float* __rest
     t = t0;
     float last_t = near;
     for (uint32_t s = 0; s < num_steps; ++s) {
-        if (!march_next(k, r, far, t, x, y, z, dt)) break;
+        if (s < kTimeCache) {
+            const float ts = s_time[s][threadIdx.x];
+            x = clampf(r.ox + ts * r.dx, -k.bound, k.bound);          // the statements of march_visit at the sample's time
+            y = clampf(r.oy + ts * r.dy, -k.bound, k.bound);
+            z = clampf(r.oz + ts * r.dz, -k.bound, k.bound);
+            dt = step_size(k, ts);
+            t = ts + dt;
+        } else if (!march_next(k, r, far, t, x, y, z, dt)) break;
         px[0] = x; px[1] = y; px[2] = z;
         pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
         pl[0] = dt;

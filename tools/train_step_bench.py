@@ -1,0 +1,31 @@
+"""One training step of the toaster network (run_cuda's training branch: 4 096 rays, eikonal loss on) -- wall time per step and, under
+rocprofv3 --kernel-trace --stats, where it goes.  Run on the GPU box:  python tools/train_step_bench.py [steps]"""
+import sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import numpy as np, torch
+from envidr_amd import scenes
+from tests.test_dropin_gpu import build_model
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+model, opt = build_model(scenes.toaster_scene())
+model.train(); opt.eikonal_loss = True
+ro_, rd_ = scenes.camera_rays(800, 800)
+pick = np.random.default_rng(0).choice(ro_.shape[0], 4096, replace=False)
+ro, rd = torch.from_numpy(ro_[pick]).cuda()[None], torch.from_numpy(rd_[pick]).cuda()[None]
+target = torch.rand(1, 4096, 3, device="cuda")
+optim = torch.optim.Adam(model.parameters(), lr=1e-4)
+def step():
+    optim.zero_grad(set_to_none=True)
+    res = model.render(ro, rd, staged=False, bg_color=1, perturb=True, force_all_rays=False, max_steps=opt.max_steps, T_thresh=opt.T_thresh, dt_gamma=opt.dt_gamma)
+    loss = (res["image"] - target).pow(2).mean() + 0.1 * (res["sdf_gradients"].norm(dim=-1) - 1).pow(2).mean()
+    loss.backward()
+    optim.step()
+    return res
+for _ in range(3):
+    res = step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(steps):
+    res = step()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+print(f"training step: 4096 rays, {int(res['sigmas'].shape[0])} samples: {dt * 1e3:.2f} ms per step ({4096 / dt / 1e6:.2f} M rays/s)")
