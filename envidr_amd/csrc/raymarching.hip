@@ -144,16 +144,26 @@ __global__ void __launch_bounds__(kBlock) k_march_rays(uint32_t n_alive, uint32_
     float* px = xyzs + base * 3;
     float* pd = dirs + base * 3;
     float* pl = deltas + base * 2;
-    for (uint32_t s = 0; s < n_step; ++s) {
-        float x, y, z, dt;
-        if (!march_next(k, r, far, t, x, y, z, dt)) break;
-        px[0] = x; px[1] = y; px[2] = z;
-        pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
-        pl[0] = dt;
-        pl[1] = t - last_t;
-        last_t = t;
-        px += 3; pd += 3; pl += 2;
-    }
+    // a FLAT loop, one cell visit per iteration (the statements of `for (s < n_step) if (!march_next(...)) break;`, per lane in the same
+    // order): with the walk to the next sample nested inside the loop over samples a wave pays, at every sample index, the longest walk
+    // of any of its lanes
+    auto walk = [&](auto pow2) {
+        uint32_t s = 0;
+        while (s < n_step && t < far) {
+            float x, y, z, dt;
+            if (march_visit<decltype(pow2)::value>(k, r, t, x, y, z, dt)) {
+                t += dt;
+                px[0] = x; px[1] = y; px[2] = z;
+                pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
+                pl[0] = dt;
+                pl[1] = t - last_t;
+                last_t = t;
+                px += 3; pd += 3; pl += 2;
+                ++s;
+            }
+        }
+    };
+    if (k.H_pow2) walk(std::true_type{}); else walk(std::false_type{});
 }
 
 // ---------------------------------------------------------------------------------------------
