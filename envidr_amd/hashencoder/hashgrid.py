@@ -102,9 +102,14 @@ class HashEncoder(nn.Module):
         return (f"HashEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
                 f"base_resolution={self.base_resolution} per_level_scale={self.per_level_scale} params={tuple(self.embeddings.shape)}")
 
-    def forward(self, inputs, bound=1):
+    def forward(self, inputs, bound=1, table_grad=True):
+        """`table_grad=False` (not a reference argument): the table takes no part in the graph -- for callers that differentiate the
+        features w.r.t. the POSITIONS only (normals at inference): autograd hands a custom Function `needs_input_grad` from the inputs'
+        `requires_grad`, not from what `autograd.grad(..., inputs=xyz)` asked for, so with the Parameter in the graph every backward also
+        zero-fills and scatters a 48.8 MB table gradient nobody reads (the reference does: SURVEY.md 8 a6 "wastefully")."""
         inputs = (inputs + bound) / (2 * bound)
         prefix = list(inputs.shape[:-1])
         inputs = inputs.view(-1, self.input_dim)
-        out = hash_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution, inputs.requires_grad)
+        table = self.embeddings if table_grad else self.embeddings.detach()
+        out = hash_encode(inputs, table, self.offsets, self.per_level_scale, self.base_resolution, inputs.requires_grad)
         return out.view(prefix + [self.output_dim])

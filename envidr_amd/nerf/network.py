@@ -158,7 +158,10 @@ class NeRFNetwork(NeRFRenderer):
 
     # ---- geometry ---------------------------------------------------------------------------------
     def forward_geometry(self, xyz, material=None):
-        x = self.encoder(xyz, bound=self.bound)
+        from ..hashencoder import HashEncoder
+        # eval mode: the features are differentiated w.r.t. the positions only (normals): keep the table out of the graph
+        kw = {"table_grad": False} if (not self.training and isinstance(self.encoder, HashEncoder)) else {}
+        x = self.encoder(xyz, bound=self.bound, **kw)
         if self.opt.enabled_levels > 0:
             mask = torch.zeros(self.opt.num_levels, self.opt.level_dim, device=x.device)
             mask[: self.opt.enabled_levels] += 1
