@@ -649,6 +649,7 @@ class FusedRenderer:
         frames = self.__dict__.setdefault("_frames", {})
         st = frames.get(N)
         cap = max(int(N * samples_per_ray), 4096)
+        cap = min(cap, N * int(self.desc.max_steps) + 4096)          # a ray never marches more than max_steps samples
         # trim: buffers more than twice the PEAK any frame of this ray count has needed so far (evaluated samples or records,
         # + 25 %) are given back after 64 frames and re-made at that size -- the first guess of 20 samples per ray is ~0.9 GB at
         # 800^2, harmless on 288 GB, but a long-lived renderer should converge on what it uses.  The peak never decreases, so a
@@ -703,7 +704,9 @@ class FusedRenderer:
             if not overflow:
                 st["peak"] = max(st.get("peak", 0), samples, records)
             if overflow:
-                self.__dict__.setdefault("_frame_hints", {})[N] = max(2.0 * st["cap"] / N, 1.5 * max(samples, records) / N)
+                # (the device stops counting where a frame stops fitting, so the need is only known to exceed what was seen: grow
+                #  geometrically; a ray never has more than max_steps samples, which bounds the search)
+                self.__dict__.setdefault("_frame_hints", {})[N] = max(4.0 * st["cap"] / N, 1.5 * max(samples, records) / N)
                 del self.__dict__["_frames"][N]
                 overflowed = st["cap"]
         if overflowed is not None:
@@ -746,7 +749,7 @@ class FusedRenderer:
                 for e in events:
                     e.record()
             return res
-        for attempt in range(3):
+        for attempt in range(8):          # capacities 20, 80, 320, 1280 ... samples per ray: max_steps (<= 65535) is reached within eight
             st = self._frame_buffers(N, dev, max(samples_per_ray_hint, self.__dict__.get("_frame_hints", {}).get(N, 0.0)))
             cap = st["cap"]
             stream = torch.cuda.current_stream(dev).cuda_stream
@@ -832,7 +835,7 @@ class FusedRenderer:
             res["n_records"] = st["last"][1]
             res["n_samples"] = st["last"][0]
             return res
-        raise _lib.EnvidrError("render_frame: the frame did not fit its buffers after two enlargements")
+        raise _lib.EnvidrError("render_frame: the frame did not fit its buffers after seven enlargements")
 
     def render_cached(self, cache: GeometryCache, env_rot_radian: float | None = None, out: dict | None = None) -> dict:
         """re-light a cached frame: envidr_shade_samples over its samples + envidr_composite_shaded; bit-identical to

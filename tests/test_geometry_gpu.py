@@ -384,6 +384,24 @@ def test_two_cascades_and_growing_steps_on_the_pipeline():
     assert torch.equal(cost, r.render_frame(o, d)["ray_cost"])
 
 
+def test_a_frame_far_denser_than_the_first_guess_is_regrown_until_it_fits():
+    """a solid ball with T_thresh = 0: ~300 samples per ray hitting it against a first guess of 20 -- the buffers grow geometrically
+    (the device only knows that a frame did not fit, not by how much) until the frame fits; found by tools/geo/fuzz_frames.py"""
+    import torch
+    from envidr_amd.fused import FusedOptions, FusedRenderer
+    r = FusedRenderer.from_scene(scenes.lego_scene(shape=scenes.ball(), seed=5), FusedOptions(T_thresh=0.0, dir_sh_degree=4))
+    ro_, rd_ = scenes.camera_rays(100, 100)
+    ro, rd = torch.from_numpy(ro_).cuda(), torch.from_numpy(rd_).cuda()
+    out = r.render_frame(ro, rd)
+    torch.cuda.synchronize()
+    hit = out["weights_sum"] > 0
+    assert out["n_records"] > 100 * int(hit.sum()) and torch.isfinite(out["image"]).all()
+    cost = torch.zeros(ro.shape[0], dtype=torch.int16, device="cuda")
+    r.render(ro, rd, None, ray_cost=cost)
+    torch.cuda.synchronize()
+    assert torch.equal(cost, out["ray_cost"])
+
+
 def test_random_batches_and_knobs_pipeline_against_the_persistent_kernel():
     """a short run of tools/geo/fuzz_frames.py (random ray batches: 1 .. 20 k rays, ragged tails, random cameras, model boxes, max_steps 1 .. 1024,
     T_thresh 0 .. 0.5, constant and growing steps, near planes, environment rotations, layout hints, random masks, garbage count hints):

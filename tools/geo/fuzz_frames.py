@@ -15,11 +15,19 @@ def run(iters: int, seed: int, verbose: bool = True):
     """-> (iterations with findings, summary line)"""
     rng = np.random.default_rng(seed)
     dev = torch.device("cuda:0")
-    scene = scenes.toaster_scene()
+    # three scenes / network families: the shell with the environment-MLP network (toaster.ini), a torus with the relight-shaped one
+    # (IDE degree 4, 160-wide), a ball with the no-environment family (SH heads, configs[1])
+    scene_list = [scenes.toaster_scene(), scenes.toaster_scene(shape=scenes.torus(), hidden_env=160, ide_deg=4, seed=3, beta=0.02),
+                  scenes.lego_scene(shape=scenes.ball(), seed=5)]
     bad, worst, total_off, total_rays, count_off = 0, 0.0, 0, 0, 0
     for it in range(iters):
         knobs = dict(max_steps=int(rng.choice([1, 2, 7, 16, 17, 64, 333, 1024])), T_thresh=float(rng.choice([0.0, 1e-4, 1e-2, 0.5])),
                      dt_gamma=float(rng.choice([0.0, 0.0, 1 / 256, 1 / 64])), min_near=float(rng.choice([0.05, 0.2, 1.0])))
+        scene = scene_list[int(rng.integers(0, len(scene_list)))]
+        if "env" in scene.mlps:
+            knobs["ide_degree"] = 4 if scene.mlps["env"][0][0].shape[1] == 38 else 5
+        else:
+            knobs["dir_sh_degree"] = 4
         r = FusedRenderer.from_scene(scene, FusedOptions(**knobs), device=dev)
         if rng.random() < 0.3:
             lo = rng.uniform(-1, -0.2, 3); hi = rng.uniform(0.2, 1, 3)
