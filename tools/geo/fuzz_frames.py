@@ -73,6 +73,14 @@ def run(iters: int, seed: int, verbose: bool = True):
         total_rays += N
         if n_off > max(3, 3e-4 * N):
             msg.append(f"{n_off} rays differ by more than 1e-3")
+        if "env" in scene.mlps:
+            # the geometry cache (f4): re-lighting a cached camera gives the persistent kernel's frame bit for bit
+            cache = r.cache_geometry(ro, rd)
+            lit = r.render_cached(cache, rot)
+            torch.cuda.synchronize()
+            for k in ("image", "depth", "weights_sum", "diffuse_image", "specular_image"):
+                if not torch.equal(lit[k].reshape(ref[k].shape), ref[k]):
+                    msg.append(f"cached {k} differs from the persistent kernel's ({int((lit[k].reshape(ref[k].shape) != ref[k]).sum())} values)")
         first = {k: got[k].clone() for k in ("image", "depth", "weights_sum")}
         # garbage hints, then a mask
         st = r._frames[N]
