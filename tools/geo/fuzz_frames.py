@@ -81,6 +81,16 @@ def run(iters: int, seed: int, verbose: bool = True):
             for k in ("image", "depth", "weights_sum", "diffuse_image", "specular_image"):
                 if not torch.equal(lit[k].reshape(ref[k].shape), ref[k]):
                     msg.append(f"cached {k} differs from the persistent kernel's ({int((lit[k].reshape(ref[k].shape) != ref[k]).sum())} values)")
+            # the optional split-precision shading mode on the same frame: fp32-equivalent colours
+            sp = r.render_frame(ro, rd, rot, image_width=iw, env_precision="f16x2")
+            torch.cuda.synchronize()
+            for k in ("image", "specular_image", "diffuse_image"):
+                a, b = sp[k].double(), got[k].double()
+                den = float(torch.linalg.norm(b))
+                if den > 0 and float(torch.linalg.norm(a - b)) / den > 2e-6:
+                    msg.append(f"split-precision {k} rel-L2 {float(torch.linalg.norm(a - b)) / den:.2e} vs the fp32 frame")
+                if not torch.isfinite(a).all():
+                    msg.append(f"split-precision {k} not finite")
         first = {k: got[k].clone() for k in ("image", "depth", "weights_sum")}
         # garbage hints, then a mask
         st = r._frames[N]
