@@ -263,27 +263,24 @@ __device__ __forceinline__ void shade_sample(WP& wp, const uint32_t lane, const 
             float in[TERMS];
 #pragma unroll
             for (int s = 0; s < TERMS; ++s) in[s] = grp ? code[2 * s + 1] : code[2 * s];
-            f32x16 ha[ENV_T], hb[ENV_T], o[1];
+            f32x16 ha[ENV_T], hb[ENV_T], o;
             const bool last = enc == 1 && grp == 1;
             wp.begin_pass(c.env_blob, kEnvChunks, last ? c.head_blob : c.env_blob, last ? kHeadChunks : kEnvChunks);
             pipe_layer_from_lanes<TERMS, ENV_T, kEnv0, kEnvN>(wp, lane, in, ha);
             pipe_layer_from_tiles<ENV_T, ENV_T, kEnv1, kEnvN, true>(wp, lane, ha, hb);
             pipe_layer_from_tiles<ENV_T, ENV_T, kEnv2, kEnvN, true>(wp, lane, hb, ha);
-            pipe_layer_from_tiles<ENV_T, 1, kEnv3, kEnvN, true>(wp, lane, ha, o);
+            pipe_layer16_from_tiles<ENV_T, kEnv3, kEnvN, true>(wp, lane, ha, o);        // 32 ENV_T -> 12 on 16-row MFMA blocks
             wp.template end_pass<kEnvFrags>();
-            if (grp == 0) outA = o[0]; else outB = o[0];
+            if (grp == 0) outA = o; else outB = o;
         }
         tick(5);   // env mlp
-        float e[16];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            float u = outA[r], v = outB[r];
-            unpack_pair(u, v);
-            e[tile_row(r, 0)] = u; e[tile_row(r, 1)] = v;     // rows 0-3, 8-11 and 4-7, 12-15
-        }
         float e12[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) e12[i] = e[i];
+        {
+            float alo[4], ahi[4], blo[4], bhi[4];
+            fold16(outA, alo, ahi);
+            fold16(outB, blo, bhi);
+            rows_to_lanes<3>(alo, ahi, blo, bhi, e12);
+        }
         normalize_n<12>(e12, 1e-12f);                                               // network.py:541,600
         if (enc == 0) {
 #pragma unroll
@@ -327,25 +324,27 @@ __device__ __forceinline__ void shade_sample(WP& wp, const uint32_t lane, const 
             for (int s = 0; s < kDSteps; ++s) in_d[s] = grp ? din[2 * s + 1] : din[2 * s];
 #pragma unroll
             for (int s = 0; s < kSSteps; ++s) in_s[s] = grp ? sin_[2 * s + 1] : sin_[2 * s];
-            f32x16 d1[1], d2[1], s1[2], s2[2], s3[1];
+            f32x16 d1[1], d2, s1[2], s2[2], s3;
             wp.begin_pass(c.head_blob, kHeadChunks, grp == 0 ? c.head_blob : c.next_blob, grp == 0 ? kHeadChunks : c.next_chunks);
             pipe_layer_from_lanes<kDSteps, 1, kHeadD1, kHeadN>(wp, lane, in_d, d1);
-            pipe_layer_from_tiles<1, 1, kHeadD2, kHeadN, true>(wp, lane, d1, d2);
+            pipe_layer16_from_tiles<1, kHeadD2, kHeadN, true>(wp, lane, d1, d2);
             pipe_layer_from_lanes<kSSteps, 2, kHeadS1, kHeadN>(wp, lane, in_s, s1);
             pipe_layer_from_tiles<2, 2, kHeadS2, kHeadN, true>(wp, lane, s1, s2);
-            pipe_layer_from_tiles<2, 1, kHeadS3, kHeadN, true>(wp, lane, s2, s3);
+            pipe_layer16_from_tiles<2, kHeadS3, kHeadN, true>(wp, lane, s2, s3);
             wp.template end_pass<kHeadFrags>();
-            if (grp == 0) { dA = d2[0]; sA = s3[0]; } else { dB = d2[0]; sB = s3[0]; }
+            if (grp == 0) { dA = d2; sA = s3; } else { dB = d2; sB = s3; }
         }
+        float alo[4], ahi[4], blo[4], bhi[4], rgb[4];
+        fold16(dA, alo, ahi);
+        fold16(dB, blo, bhi);
+        rows_to_lanes<1>(alo, ahi, blo, bhi, rgb);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {      // rows 0..2 live in registers 0..2 of lane half 0
-            float u = dA[r], v = dB[r];
-            unpack_pair(u, v);
-            cd[r] = sigmoidf(u);                                                    // color_act, metallic = 1
-            float p = sA[r], q = sB[r];
-            unpack_pair(p, q);
-            cs[r] = sigmoidf(p);
-        }
+        for (int r = 0; r < 3; ++r) cd[r] = sigmoidf(rgb[r]);                       // color_act, metallic = 1
+        fold16(sA, alo, ahi);
+        fold16(sB, blo, bhi);
+        rows_to_lanes<1>(alo, ahi, blo, bhi, rgb);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) cs[r] = sigmoidf(rgb[r]);
     }
 
 }
@@ -369,25 +368,22 @@ __device__ __forceinline__ void shade_renv(WP& wp, const uint32_t lane, const fl
 #pragma unroll 1
     for (int grp = 0; grp < 2; ++grp) {
         float in[2] = {grp ? rin[1] : rin[0], grp ? rin[3] : rin[2]};
-        f32x16 r1[2], r2[2], r3[1];
+        f32x16 r1[2], r2[2], r3;
         wp.begin_pass(renv_blob, kRenvChunks, grp == 0 ? renv_blob : spec2_blob, grp == 0 ? kRenvChunks : kSpec2Chunks);
         pipe_layer_from_lanes<2, 2, kRenv1, kRenvN>(wp, lane, in, r1);
         pipe_layer_from_tiles<2, 2, kRenv2, kRenvN, true>(wp, lane, r1, r2);
         pipe_layer_from_tiles<2, 2, kRenv3, kRenvN, true>(wp, lane, r2, r1);
-        pipe_layer_from_tiles<2, 1, kRenv4, kRenvN, true>(wp, lane, r1, r3);
+        pipe_layer16_from_tiles<2, kRenv4, kRenvN, true>(wp, lane, r1, r3);
         wp.template end_pass<kRenvFrags>();
-        if (grp == 0) eA = r3[0]; else eB = r3[0];
-    }
-    float e[16];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        float u = eA[r], v = eB[r];
-        unpack_pair(u, v);
-        e[tile_row(r, 0)] = u; e[tile_row(r, 1)] = v;
+        if (grp == 0) eA = r3; else eB = r3;
     }
     float e12[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) e12[i] = e[i];
+    {
+        float alo[4], ahi[4], blo[4], bhi[4];
+        fold16(eA, alo, ahi);
+        fold16(eB, blo, bhi);
+        rows_to_lanes<3>(alo, ahi, blo, bhi, e12);
+    }
     normalize_n<12>(e12, 1e-12f);
     float sin2[28];
 #pragma unroll
@@ -401,21 +397,23 @@ __device__ __forceinline__ void shade_renv(WP& wp, const uint32_t lane, const fl
         float in_s[14];
 #pragma unroll
         for (int s = 0; s < 14; ++s) in_s[s] = grp ? sin2[2 * s + 1] : sin2[2 * s];
-        f32x16 s1[2], s2[2], s3[1];
+        f32x16 s1[2], s2[2], s3;
         wp.begin_pass(spec2_blob, kSpec2Chunks, grp == 0 ? spec2_blob : after_blob, grp == 0 ? kSpec2Chunks : after_chunks);
         pipe_layer_from_lanes<14, 2, kSpec2S1, kSpec2N>(wp, lane, in_s, s1);
         pipe_layer_from_tiles<2, 2, kSpec2S2, kSpec2N, true>(wp, lane, s1, s2);
-        pipe_layer_from_tiles<2, 1, kSpec2S3, kSpec2N, true>(wp, lane, s2, s3);
+        pipe_layer16_from_tiles<2, kSpec2S3, kSpec2N, true>(wp, lane, s2, s3);
         wp.template end_pass<kSpec2Frags>();
-        if (grp == 0) cA = s3[0]; else cB = s3[0];
+        if (grp == 0) cA = s3; else cB = s3;
     }
     const bool masked = rough < indir_rough_thresh && vis > 0.9f;
     const float blend = 0.98f * sigmoidf(blend_logit);                              // learn_indir_blend, network.py:443-446,630
+    float alo[4], ahi[4], blo[4], bhi[4], rgb[4];
+    fold16(cA, alo, ahi);
+    fold16(cB, blo, bhi);
+    rows_to_lanes<1>(alo, ahi, blo, bhi, rgb);
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        float p = cA[r], q = cB[r];
-        unpack_pair(p, q);
-        const float c_renv = sigmoidf(p);
+        const float c_renv = sigmoidf(rgb[r]);
         if (masked) cs[r] = cs[r] * blend + c_renv * (1 - blend);
     }
 }
@@ -1030,12 +1028,19 @@ uint32_t envidr_packed_weight_floats(int k_order, uint32_t k_in, uint32_t m_out)
     return packed_weight_floats(k_order ? kTileOrder : kLaneOrder, k_in, m_out);
 }
 uint32_t envidr_packed_layer_floats(int k_order, uint32_t k_in, uint32_t m_out, int with_bias) {
+    if (k_order == 2) return packed_weight_floats(kTileOrder, k_in, 16, with_bias != 0);     // one fragment per reduction step
     return packed_weight_floats(k_order ? kTileOrder : kLaneOrder, k_in, m_out, with_bias != 0);
 }
 int envidr_pack_layer(const float* W_host, const float* bias_host, uint32_t m_out, uint32_t k_in, int transpose, int k_order,
                       float* dst_host) {
     ENVIDR_REQUIRE(W_host && dst_host && m_out && k_in, "pack_layer: null pointer or empty layer");
     ENVIDR_REQUIRE(!(bias_host && transpose), "pack_layer: a transposed (gradient) layer carries no bias");
+    ENVIDR_REQUIRE(k_order >= 0 && k_order <= 2, "pack_layer: k_order must be 0 (lane), 1 (tile) or 2 (tile order, at most 16 outputs)");
+    if (k_order == 2) {
+        ENVIDR_REQUIRE(m_out <= 16 && !transpose, "pack_layer: k_order 2 packs a layer of at most 16 outputs, not transposed");
+        pack_linear16(W_host, m_out, k_in, dst_host, bias_host);
+        return ENVIDR_OK;
+    }
     pack_linear(W_host, m_out, k_in, transpose != 0, k_order ? kTileOrder : kLaneOrder, dst_host, bias_host);
     return ENVIDR_OK;
 }

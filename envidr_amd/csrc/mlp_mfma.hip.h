@@ -85,6 +85,30 @@ inline void pack_rowvec(const float* v, uint32_t m_out, float* dst) {
             }
 }
 
+// ---- layers with at most 16 outputs ------------------------------------------------------------
+// A layer like env 256 -> 12 or a head's 64 -> 3 fills 12 (3) of a 32-feature tile's rows.  It runs on
+// v_mfma_f32_16x16x1_4B_f32 instead (four independent 16x16x1 blocks in one 32-cycle instruction; lane l belongs to
+// block l >> 4 and holds one A entry (row l & 15) and one B entry (column l & 15) of it).  Accumulator register r of a
+// 32x32 input tile, read as that instruction's B operand, IS four such blocks:
+//     block 0: feature tile_row(r, 0) of samples  0-15      block 1: the same feature of samples 16-31
+//     block 2: feature tile_row(r, 1) of samples  0-15      block 3: the same feature of samples 16-31
+// so with A = W[l & 15][the feature the lane's block sees] the 16 outputs of 32 samples cost one 32-cycle MFMA per input
+// register -- half the time of a 32x32x2 step.  D register 4 b + q of lane l is block b's row 4 (l >> 4) + q, column l & 15;
+// a sample's output is the sum of its two blocks (fold16).  Fragment = 64 floats per reduction step as for a one-tile layer,
+// so the pass blobs keep their sizes; k_order 2 in envidr_pack_layer.
+inline void pack_linear16(const float* W, uint32_t m_out, uint32_t k_in, float* dst, const float* bias = nullptr) {
+    const uint32_t steps = steps_for(kTileOrder, k_in);
+    if (bias) {
+        for (uint32_t lane = 0; lane < 64; ++lane) dst[lane] = (lane < 32 && (lane & 15) < m_out) ? bias[lane & 15] : 0.0f;
+        dst += 64;
+    }
+    for (uint32_t s = 0; s < steps; ++s)
+        for (uint32_t lane = 0; lane < 64; ++lane) {
+            const uint32_t i = lane & 15, k = (uint32_t)k_of_step(kTileOrder, (int)s, (int)(lane >> 5));
+            dst[(size_t)s * 64 + lane] = (i < m_out && k < k_in) ? W[(size_t)i * k_in + k] : 0.0f;
+        }
+}
+
 // ---- device side ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
@@ -240,25 +264,165 @@ __device__ __forceinline__ float relu1(float x) {
     return y;
 }
 
+// one reduction step: MT MFMAs (one per output tile) sharing the B operand `bv`; FI = index of the step's first fragment
+template <int MT, int FI, int FRAGS, typename Src>
+__device__ __forceinline__ void pipe_one_step(Src& wp, f32x16 (&acc)[MT], const float bv) {
+    [&]<int... T>(std::integer_sequence<int, T...>) {
+        ((acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp.template take<FI + T, FRAGS>(), bv, acc[T], 0, 0, 0)), ...);
+    }(std::make_integer_sequence<int, MT>{});
+}
+
+// B operands R0 .. R1-1 of input tile K: accumulator read (+ ReLU)
+template <int K, int R0, int R1, bool RELU, int KT>
+__device__ __forceinline__ void stage_operands(const f32x16 (&in)[KT], float (&bq)[16]) {
+#pragma unroll
+    for (int r = R0; r < R1; ++r) bq[r] = RELU ? relu1(in[K][r]) : in[K][r];
+}
+// after which step of tile K clump c (of CLUMPS) of tile K+1's operands is staged
+constexpr int clump_of_step(int clumps, int s) {
+    const int per = 16 / clumps;
+    return (s % per == (per - 1) / 2) ? s / per : -1;
+}
+
+// ---- ReLU in the LDS atomic unit --------------------------------------------------------------------------------------
+// A wave's own vector-ALU instructions stall its matrix pipe (above), LDS instructions do not.  ds_max_f32 on a zero-filled
+// slot IS ReLU, and its data operand may be an accumulator register: tile K+1's 16 operands go  acc --ds_max_f32--> LDS
+// --ds_read--> VGPR, then the slot is zeroed again, all issued between tile K's MFMAs; no v_accvgpr_read, no v_max.
+// `slot`: this lane's column of a [16][64] float area private to the wave (slot[r * 64]), zero on entry and on exit.
+constexpr int kLdsStageFloats = 16 * 64;
+template <int K, int KT>
+__device__ __forceinline__ void lds_stage_put(const f32x16 (&in)[KT], float* slot) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) __hip_atomic_fetch_max(slot + r * 64, in[K][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_stage_get(float* slot, float (&bq)[16]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bq[r] = slot[r * 64];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) slot[r * 64] = 0.0f;
+}
+template <int K, int S, int KT, int MT, int W0, int FRAGS, typename Src>
+__device__ __forceinline__ void pipe_tile_step_lds(Src& wp, const f32x16 (&in)[KT], f32x16 (&acc)[MT], float (&bq)[2][16], float* slot) {
+    pipe_one_step<MT, W0 + (K * 16 + S) * MT, FRAGS>(wp, acc, bq[K & 1][S]);
+    if constexpr (K + 1 < KT && S == 1) lds_stage_put<(K + 1 < KT ? K + 1 : K)>(in, slot);
+    if constexpr (K + 1 < KT && S == 4) lds_stage_get(slot, bq[(K + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// step S of input tile K in the software-pipelined form: the step's MFMAs, then (at a clump point) part of tile K+1's operands
+template <int K, int S, int KT, int MT, int W0, int FRAGS, bool RELU_IN, int CLUMPS, typename Src>
+__device__ __forceinline__ void pipe_tile_step(Src& wp, const f32x16 (&in)[KT], f32x16 (&acc)[MT], float (&bq)[2][16]) {
+    pipe_one_step<MT, W0 + (K * 16 + S) * MT, FRAGS>(wp, acc, bq[K & 1][S]);
+    constexpr int c = clump_of_step(CLUMPS, S);
+    if constexpr (K + 1 < KT && c >= 0)
+        stage_operands<(K + 1 < KT ? K + 1 : K), c * (16 / CLUMPS), (c + 1) * (16 / CLUMPS), RELU_IN>(in, bq[(K + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int K, int S, int KT, int W0, int FRAGS, bool RELU_IN, int CLUMPS, typename Src>
+__device__ __forceinline__ void pipe_tile_step16(Src& wp, const f32x16 (&in)[KT], f32x16& a0, f32x16& a1, float (&bq)[2][16]) {
+    if constexpr (S % 2 == 0) a0 = __builtin_amdgcn_mfma_f32_16x16x1f32(wp.template take<W0 + K * 16 + S, FRAGS>(), bq[K & 1][S], a0, 0, 0, 0);
+    else a1 = __builtin_amdgcn_mfma_f32_16x16x1f32(wp.template take<W0 + K * 16 + S, FRAGS>(), bq[K & 1][S], a1, 0, 0, 0);
+    constexpr int c = clump_of_step(CLUMPS, S);
+    if constexpr (K + 1 < KT && c >= 0)
+        stage_operands<(K + 1 < KT ? K + 1 : K), c * (16 / CLUMPS), (c + 1) * (16 / CLUMPS), RELU_IN>(in, bq[(K + 1) & 1]);
+    if constexpr (is_weight_ring<Src>::value) __builtin_amdgcn_sched_barrier(0);
+}
+
 // layer whose input is KT accumulator tiles of the previous layer.
-// The 16 B operands of one input tile are produced (accumulator read + ReLU) as ONE cluster of vector-ALU
-// instructions ahead of that tile's 16 x MT MFMAs.  Measured on gfx950 (tools/probe/valu_overlap_probe.hip,
-// env_pass_probe.hip): a wave's own vector-ALU instruction between two of its MFMAs costs ~10 cycles of matrix-pipe
-// idle time plus ~20 more when the MFMA consumes its result, so ReLU "as the operand is fetched" (one small VALU
-// chain per step) cost 30 cycles per step = 8 % of an environment pass; one cluster per tile costs < 1 %.
-template <int KT, int MT, int F0, int FRAGS, bool RELU_IN = false, bool BIAS = true, typename Src>
-__device__ __forceinline__ void pipe_layer_from_tiles(Src& wp, uint32_t lane, const f32x16 (&in)[KT], f32x16 (&acc)[MT]) {
+// A wave's own vector-ALU instructions do not hide under its own fp32 MFMAs (tools/probe/valu_overlap_probe.hip,
+// env_pass_probe.hip): an accumulator read + ReLU "as the operand is fetched" cost ~30 cycles per step = 8 % of an
+// environment pass.  CLUMPS == 0: the 16 operands of an input tile are produced as ONE cluster of vector-ALU instructions
+// ahead of that tile's 16 x MT MFMAs (< 3 %).  CLUMPS > 0: software-pipelined -- tile K+1's operands are staged in CLUMPS
+// small clumps between tile K's steps into a second register set, so that only the first tile's cluster of a layer sits
+// in front of MFMAs that wait for it.
+template <int KT, int MT, int F0, int FRAGS, bool RELU_IN = false, bool BIAS = true, int CLUMPS = 0, typename Src>
+__device__ __forceinline__ void pipe_layer_from_tiles(Src& wp, uint32_t lane, const f32x16 (&in)[KT], f32x16 (&acc)[MT], float* lds_slot = nullptr) {
     zero_acc<MT>(acc);
     if constexpr (BIAS) bias_step<MT, F0, FRAGS>(wp, lane, acc);
-    [&]<int... K>(std::integer_sequence<int, K...>) {
-        ([&] {
-            float bq[16];
+    constexpr int W0 = F0 + (BIAS ? MT : 0);
+    if constexpr (CLUMPS == -1) {
+        // CLUMPS == -1: ReLU through the LDS atomic unit for tiles 1 .. KT-1 (the first tile's operands have nothing to hide under)
+        static_assert(RELU_IN, "LDS staging is a ReLU");
+        float bq[2][16];
+        stage_operands<0, 0, 16, true>(in, bq[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        [&]<int... KS>(std::integer_sequence<int, KS...>) {
+            (pipe_tile_step_lds<KS / 16, KS % 16, KT, MT, W0, FRAGS>(wp, in, acc, bq, lds_slot), ...);
+        }(std::make_integer_sequence<int, 16 * KT>{});
+    } else if constexpr (CLUMPS == 0) {
+        [&]<int... K>(std::integer_sequence<int, K...>) {
+            ([&] {
+                float bq[16];
+                stage_operands<K, 0, 16, RELU_IN>(in, bq);
+                if constexpr (is_weight_ring<Src>::value) __builtin_amdgcn_sched_barrier(0);
+                pipe_steps<16, MT, W0 + K * 16 * MT, FRAGS>(wp, acc, [&](int s) { return bq[s]; });
+            }(), ...);
+        }(std::make_integer_sequence<int, KT>{});
+    } else {
+        static_assert(16 % CLUMPS == 0, "CLUMPS must divide 16");
+        float bq[2][16];
+        stage_operands<0, 0, 16, RELU_IN>(in, bq[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        [&]<int... KS>(std::integer_sequence<int, KS...>) {
+            (pipe_tile_step<KS / 16, KS % 16, KT, MT, W0, FRAGS, RELU_IN, CLUMPS>(wp, in, acc, bq), ...);
+        }(std::make_integer_sequence<int, 16 * KT>{});
+    }
+}
+
+// ---- layers with at most 16 outputs (pack_linear16) -----------------------------------------------------------------
+// d: the v_mfma_f32_16x16x1_4B_f32 accumulator of the layer for one 32-sample group (see pack_linear16).  Two accumulators
+// alternate (a 16x16 MFMA issues every 32 cycles but its result is ready after 40) and are added at the end.
+template <int KT, int F0, int FRAGS, bool RELU_IN = true, bool BIAS = true, int CLUMPS = 0, typename Src>
+__device__ __forceinline__ void pipe_layer16_from_tiles(Src& wp, uint32_t lane, const f32x16 (&in)[KT], f32x16& d) {
+    f32x16 a0, a1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) bq[r] = RELU_IN ? relu1(in[K][r]) : in[K][r];
-            if constexpr (is_weight_ring<Src>::value) __builtin_amdgcn_sched_barrier(0);
-            pipe_steps<16, MT, F0 + (BIAS ? MT : 0) + K * 16 * MT, FRAGS>(wp, acc, [&](int s) { return bq[s]; });
-        }(), ...);
-    }(std::make_integer_sequence<int, KT>{});
+    for (int r = 0; r < 16; ++r) { a0[r] = 0.0f; a1[r] = 0.0f; }
+    if constexpr (BIAS) {     // A = bias[l & 15] in lanes 0-31 (blocks 0 and 1: every sample once), B = 1 there
+        a1 = __builtin_amdgcn_mfma_f32_16x16x1f32(wp.template take<F0, FRAGS>(), lane < 32 ? 1.0f : 0.0f, a1, 0, 0, 0);
+        if constexpr (is_weight_ring<Src>::value) __builtin_amdgcn_sched_barrier(0);
+    }
+    constexpr int W0 = F0 + (BIAS ? 1 : 0);
+    constexpr int kClumps = CLUMPS ? CLUMPS : 1;
+    float bq[2][16];
+    stage_operands<0, 0, 16, RELU_IN>(in, bq[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    [&]<int... KS>(std::integer_sequence<int, KS...>) {
+        (pipe_tile_step16<KS / 16, KS % 16, KT, W0, FRAGS, RELU_IN, kClumps>(wp, in, a0, a1, bq), ...);
+    }(std::make_integer_sequence<int, 16 * KT>{});
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[r] = a0[r] + a1[r];
+}
+// lane (Q = l >> 4, j = l & 15): lo[q] = output row 4 Q + q of the group's sample j, hi[q] = of its sample 16 + j
+__device__ __forceinline__ void fold16(const f32x16& d, float (&lo)[4], float (&hi)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { lo[q] = d[q] + d[8 + q]; hi[q] = d[4 + q] + d[12 + q]; }
+}
+// Quarter exchange across the wave (v_permlane16_swap; a quarter = 16 lanes): afterwards
+//   a = [a.q0 | b.q0 | a.q2 | b.q2],  b = [a.q1 | b.q1 | a.q3 | b.q3]
+__device__ __forceinline__ void swap_quarters(float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+// fold16 outputs of group A (samples of lanes 0-31) and group B (lanes 32-63)  ->  for every lane, rows 0 .. 4 NQ - 1 of its own
+// sample: a 4 x 4 transpose between "which of (A lo, A hi, B lo, B hi)" and "which lane quarter", two swaps per stage
+template <int NQ>
+__device__ __forceinline__ void rows_to_lanes(const float (&alo)[4], const float (&ahi)[4], const float (&blo)[4], const float (&bhi)[4],
+                                              float (&out)[4 * NQ]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float x0 = alo[q], x1 = ahi[q], x2 = blo[q], x3 = bhi[q];
+        swap_halves(x0, x2);          // x0 = [A lo.q0, A lo.q1, B lo.q0, B lo.q1]   x2 = [A lo.q2, A lo.q3, B lo.q2, B lo.q3]
+        swap_halves(x1, x3);          // x1 = [A hi.q0, A hi.q1, B hi.q0, B hi.q1]   x3 = [A hi.q2, ...]
+        swap_quarters(x0, x1);        // x0 = [A lo.q0, A hi.q0, B lo.q0, B hi.q0]: every lane's own sample, rows 0-3;  x1: rows 4-7
+        out[q] = x0;
+        if constexpr (NQ > 1) out[4 + q] = x1;
+        if constexpr (NQ > 2) {
+            swap_quarters(x2, x3);    // x2: rows 8-11, x3: rows 12-15
+            out[8 + q] = x2;
+            if constexpr (NQ > 3) out[12 + q] = x3;
+        }
+    }
 }
 
 constexpr int pass_chunks(int frags) { return (frags + kChunkFrags - 1) / kChunkFrags; }

@@ -316,8 +316,8 @@ class FusedShader:
 
         L = lambda Wb, order: pack_layer(Wb[0], Wb[1], order)
         d = RenderDesc()
-        d.env_blob = blob([L(env[0], 0)] + [L(env[i], 1) for i in (1, 2, 3)])
-        d.head_blob = blob([L(dif[0], 0), L(dif[1], 1), L(spc[0], 0), L(spc[1], 1), L(spc[2], 1)])
+        d.env_blob = blob([L(env[0], 0), L(env[1], 1), L(env[2], 1), L(env[3], 2)])
+        d.head_blob = blob([L(dif[0], 0), L(dif[1], 2), L(spc[0], 0), L(spc[1], 1), L(spc[2], 2)])
         d.ide_degree, d.env_hidden = ide_degree, _np32(env[0][0]).shape[0]
         d.diffuse_kappa_inv, d.light_intensity_scale, d.intensity_scale = diffuse_kappa_inv, light_intensity_scale, 1.0
         self.desc = d
@@ -405,15 +405,15 @@ class FusedRenderer:
         L = lambda Wb, order: pack_layer(Wb[0], Wb[1], order)
         d.sdf_blob = blob([L(sdf[0], 0), L(sdf[1], 1), L(sdf[2], 1),
                            pack_layer(sdf[1][0], None, 1, transpose=True), pack_layer(sdf[0][0], None, 1, transpose=True)])
-        d.env_blob = blob([L(env[0], 0)] + [L(env[i], 1) for i in (1, 2, 3)]) if env is not None else None
+        d.env_blob = blob([L(env[0], 0), L(env[1], 1), L(env[2], 1), L(env[3], 2)]) if env is not None else None
         d.dir_sh_degree = sh_degree
-        d.head_blob = blob([L(dif[0], 0), L(dif[1], 1), L(spc[0], 0), L(spc[1], 1), L(spc[2], 1)])
+        d.head_blob = blob([L(dif[0], 0), L(dif[1], 2), L(spc[0], 0), L(spc[1], 1), L(spc[2], 2)])
         renv = mlps.get("renv")
         if renv is not None and env is not None:
             if len(renv) != 4 or _np32(renv[0][0]).shape != (64, 4) or _np32(renv[3][0]).shape != (12, 64):
                 raise _lib.EnvidrError("fused renderer expects the renv MLP 4 -> 64 -> 64 -> 64 -> 12")
-            d.renv_blob = blob([L(renv[0], 0)] + [L(renv[i], 1) for i in (1, 2, 3)])
-            d.spec2_blob = blob([L(spc[0], 0), L(spc[1], 1), L(spc[2], 1)])
+            d.renv_blob = blob([L(renv[0], 0), L(renv[1], 1), L(renv[2], 1), L(renv[3], 2)])
+            d.spec2_blob = blob([L(spc[0], 0), L(spc[1], 1), L(spc[2], 2)])
         d.indir_roughness_thresh = self.opt.indir_roughness_thresh
         d.sdf_w3_row0 = up(pack_rowvec(_np32(sdf[2][0])[0])).data_ptr()
         if self.opt.geometry_kernel not in ("32", "16"):

@@ -33,7 +33,9 @@ extern "C" {
  * (envidr_amd/csrc/mlp_mfma.hip.h).  These helpers convert a torch-style row-major
  * nn.Linear.weight [out, in] (HOST pointers) into that layout.
  *   k_order: 0 = the layer's input is per-sample features written by scalar code ("lane order"),
- *            1 = the layer's input is the previous layer's output tiles       ("tile order").
+ *            1 = the layer's input is the previous layer's output tiles       ("tile order"),
+ *            2 = tile order for a layer of AT MOST 16 OUTPUTS (envidr_pack_layer only): the layer runs on
+ *                16-row MFMA blocks, one 64-float fragment per reduction step (ABI 7; E4, D2, S3, renv R4).
  *   transpose != 0 packs W^T (the input-gradient layers of the SDF network). */
 uint32_t envidr_packed_weight_floats(int k_order, uint32_t k_in, uint32_t m_out);
 uint32_t envidr_packed_rowvec_floats(uint32_t m_out);
@@ -111,8 +113,9 @@ typedef struct envidr_render_desc {
      * waves of a workgroup stream a blob through LDS once per pass (envidr_amd/csrc/mlp_mfma.hip.h).
      * Every forward layer is packed WITH its bias (envidr_pack_layer), the two gradient layers without.
      *   sdf_blob  : W1+b (lane order, 32->64) | W2+b (tile, 64->64) | W3+b (tile, 64->15) | W2^T (tile) | W1^T (tile, 64->32)
-     *   env_blob  : E1+b (lane, ide_dim->H) | E2+b (tile, H->H) | E3+b (tile, H->H) | E4+b (tile, H->12)
-     *   head_blob : D1+b (lane, 24->32) | D2+b (tile, 32->3) | S1+b (lane, 28->64) | S2+b (tile, 64->64) | S3+b (tile, 64->3) */
+     *   env_blob  : E1+b (lane, ide_dim->H) | E2+b (tile, H->H) | E3+b (tile, H->H) | E4+b (k_order 2, H->12)
+     *   head_blob : D1+b (lane, 24->32) | D2+b (k_order 2, 32->3) | S1+b (lane, 28->64) | S2+b (tile, 64->64) | S3+b (k_order 2, 64->3)
+     *   renv_blob : R1+b (lane) | R2+b | R3+b (tile) | R4+b (k_order 2, 64->12);  spec2_blob : S1+b (lane) | S2+b (tile) | S3+b (k_order 2) */
     const float* sdf_blob;
     const float* env_blob;
     const float* head_blob;
