@@ -6,6 +6,7 @@
 #include "grid_core.hip.h"
 #include "march_core.hip.h"
 #include "mlp_mfma.hip.h"
+#include "env_pass.hip.h"
 
 #include "../../include/envidr_render.h"
 

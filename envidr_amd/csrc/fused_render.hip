@@ -220,7 +220,7 @@ template <int IDE_DEG, int ENV_T, int SH_DEG, bool PRE_ENV = false, class WP, cl
 __device__ __forceinline__ void shade_sample(WP& wp, const uint32_t lane, const ShadeConsts c, const float (&nrm)[3],
                                              const float (&nenv)[3], const float (&wr)[3], const float (&vd)[3], const float ndot,
                                              const float (&geo)[12], const float rough, float (&cd)[3], float (&cs)[3], float (&env_r)[12], Tick&& tick,
-                                             const float* env_pre = nullptr) {
+                                             const EnvAux& aux, const float* env_pre = nullptr) {
     constexpr bool kEnvNet = SH_DEG == 0;
     constexpr int kShDim = SH_DEG * SH_DEG;
     constexpr int kDiffIn = kEnvNet ? 24 : 12, kSpecIn = kEnvNet ? 28 : 2 * kShDim + 13;
@@ -229,8 +229,7 @@ __device__ __forceinline__ void shade_sample(WP& wp, const uint32_t lane, const 
     constexpr int kHeadD1 = Head::D1, kHeadD2 = Head::D2, kHeadS1 = Head::S1, kHeadS2 = Head::S2, kHeadS3 = Head::S3,
                   kHeadFrags = Head::Frags;
     constexpr int TERMS = ide_terms(IDE_DEG);
-    constexpr int kEnv0 = 0, kEnv1 = kEnv0 + lane_layer_frags(TERMS, ENV_T, true), kEnv2 = kEnv1 + tile_layer_frags(ENV_T, ENV_T, true),
-                  kEnv3 = kEnv2 + tile_layer_frags(ENV_T, ENV_T, true), kEnvFrags = kEnv3 + tile_layer_frags(ENV_T, 1, true);
+    constexpr int kEnvFrags = EnvLayout<TERMS, (ENV_T ? ENV_T : 1)>::Frags;
     constexpr uint32_t kEnvChunks = pass_chunks(kEnvFrags), kHeadChunks = pass_chunks(kHeadFrags);
     constexpr int kEnvN = ring_padded(kEnvFrags), kHeadN = ring_padded(kHeadFrags);
     // ================= environment MLP on IDE(normal) and IDE(reflection) =====================
@@ -263,14 +262,10 @@ __device__ __forceinline__ void shade_sample(WP& wp, const uint32_t lane, const 
             float in[TERMS];
 #pragma unroll
             for (int s = 0; s < TERMS; ++s) in[s] = grp ? code[2 * s + 1] : code[2 * s];
-            f32x16 ha[ENV_T], hb[ENV_T], o;
+            f32x16 o;
             const bool last = enc == 1 && grp == 1;
             wp.begin_pass(c.env_blob, kEnvChunks, last ? c.head_blob : c.env_blob, last ? kHeadChunks : kEnvChunks);
-            pipe_layer_from_lanes<TERMS, ENV_T, kEnv0, kEnvN>(wp, lane, in, ha);
-            pipe_layer_from_tiles<ENV_T, ENV_T, kEnv1, kEnvN, true>(wp, lane, ha, hb);
-            pipe_layer_from_tiles<ENV_T, ENV_T, kEnv2, kEnvN, true>(wp, lane, hb, ha);
-            pipe_layer16_from_tiles<ENV_T, kEnv3, kEnvN, true>(wp, lane, ha, o);        // 32 ENV_T -> 12 on 16-row MFMA blocks
-            wp.template end_pass<kEnvFrags>();
+            env_pass<TERMS, ENV_T, kEnvN>(wp, lane, aux, in, o);                        // env_pass.hip.h
             if (grp == 0) outA = o; else outB = o;
         }
         tick(5);   // env mlp
@@ -443,6 +438,11 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
     // otherwise sit in -- or be spilled from -- registers the 256-wide layers need)
     constexpr int kParked = 26;
     __shared__ float s_park[kParked * 64];
+    // environment pass: ReLU staging slot + bias tiles (env_pass.hip.h)
+    constexpr bool kEnvLds = SH_DEG == 0 && !GEOM;
+    __shared__ __attribute__((aligned(16))) float s_env[kEnvLds ? EnvLayout<ide_terms(IDE_DEG), (ENV_T ? ENV_T : 1)>::kLdsFloats : 4];
+    EnvAux aux = {nullptr, nullptr};
+    if constexpr (kEnvLds) aux = env_lds_init<ide_terms(IDE_DEG), ENV_T>(a.env_blob, s_env, lane);
     WeightRing<kRingDepth> wp;
     wp.start(lane, a.sdf_blob, kSdfChunks);
     // fragments per pass as the weight source sees them (the ring pads every pass to a multiple of its depth)
@@ -756,7 +756,7 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
                                     a.kappa_diffuse, a.light_scale};
             const float vd[3] = {rg.dx, rg.dy, rg.dz};
             float env_r[12];
-            shade_sample<IDE_DEG, ENV_T, SH_DEG>(wp, lane, sc, nrm, nenv, wr, vd, ndot, geo, rough, cd, cs, env_r, [](int) {});
+            shade_sample<IDE_DEG, ENV_T, SH_DEG>(wp, lane, sc, nrm, nenv, wr, vd, ndot, geo, rough, cd, cs, env_r, [](int) {}, aux);
             if constexpr (kEnvNet) if (renv)
                 shade_renv(wp, lane, a.renv_blob, a.spec2_blob, a.sdf_blob, kSdfChunks, rimg, rough, a.rough_scale, a.indir_rough_thresh,
                            h3[14], geo, nrm, ndot, cs);
@@ -887,6 +887,10 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_shade_samples(const ShadeA
     constexpr uint32_t kRenvChunks = pass_chunks(kRenvFrags);
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr bool kEnvLds = kEnvNet && !PRE_ENV;
+    __shared__ __attribute__((aligned(16))) float s_env[kEnvLds ? EnvLayout<TERMS, (ENV_T ? ENV_T : 1)>::kLdsFloats : 4];
+    EnvAux aux = {nullptr, nullptr};
+    if constexpr (kEnvLds) aux = env_lds_init<TERMS, ENV_T>(a.env_blob, s_env, lane);
     WeightRing<kRingDepth> wp;
     // the first blob a round streams: the environment MLP, or the heads when there is none
     const float* first_blob = (kEnvNet && !PRE_ENV) ? a.env_blob : a.head_blob;
@@ -926,7 +930,7 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_shade_samples(const ShadeA
             }
         }
         float cd[3], cs[3], env_r[12];
-        shade_sample<IDE_DEG, ENV_T, SH_DEG, PRE_ENV>(wp, lane, sc, nrm, nenv, wr, vd, ndot, geo, rough, cd, cs, env_r, [](int) {},
+        shade_sample<IDE_DEG, ENV_T, SH_DEG, PRE_ENV>(wp, lane, sc, nrm, nenv, wr, vd, ndot, geo, rough, cd, cs, env_r, [](int) {}, aux,
                                                       PRE_ENV ? a.env_pre + 24 * i : nullptr);
         if constexpr (RENV) {
             float rimg[4];

@@ -7,7 +7,7 @@
 //   RELU    off = the floor without any operand staging work
 // plus a numerical self-test of the 16-wide layer against the host (layout of the 4-block MFMA, v_permlane16_swap).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++20 -ffp-contract=off -I../../envidr_amd/csrc -I../../include -o env_pass_probe env_pass_probe.hip
-#include "mlp_mfma.hip.h"
+#include "env_pass.hip.h"
 #include <cmath>
 #include <cstdio>
 #include <vector>
@@ -17,6 +17,44 @@ namespace envidr { void set_error(const char*, ...) {} }
 
 constexpr int kPF = 32;
 constexpr int ring_padded(int frags) { return (frags + kPF - 1) / kPF * kPF; }
+
+// the pass as the kernels run it now (env_pass.hip.h): biases from LDS, ReLU in the LDS atomic unit, 16-row output blocks
+template <int TERMS, int ENV_T>
+__global__ void __launch_bounds__(64, 1) probe_env_pass(const float* __restrict__ blob, float* out, unsigned long long* cyc, int iters) {
+    using L = EnvLayout<TERMS, ENV_T>;
+    constexpr uint32_t kEnvChunks = pass_chunks(L::Frags);
+    constexpr int kEnvN = ring_padded(L::Frags);
+    const uint32_t lane = lane_id();
+    __shared__ __attribute__((aligned(16))) float s_env[L::kLdsFloats];
+    const EnvAux aux = env_lds_init<TERMS, ENV_T>(blob, s_env, lane);
+    WeightRing<kPF> wp;
+    wp.start(lane, blob, kEnvChunks);
+    float code[2 * TERMS];
+#pragma unroll
+    for (int s = 0; s < 2 * TERMS; ++s) code[s] = (float)(lane + s) * 1e-3f;
+    float acc_out = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        f32x16 outA, outB;
+#pragma unroll 1
+        for (int grp = 0; grp < 2; ++grp) {
+            float in[TERMS];
+#pragma unroll
+            for (int s = 0; s < TERMS; ++s) in[s] = grp ? code[2 * s + 1] : code[2 * s];
+            f32x16 o;
+            wp.begin_pass(blob, kEnvChunks, blob, kEnvChunks);
+            env_pass<TERMS, ENV_T, kEnvN>(wp, lane, aux, in, o);
+            if (grp == 0) outA = o; else outB = o;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc_out += outA[r] + outB[r]; }
+#pragma unroll
+        for (int s = 0; s < 2 * TERMS; ++s) code[s] += acc_out * 1e-9f;
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * 64 + lane] = acc_out;
+    if (lane == 0) cyc[blockIdx.x] = t1 - t0;
+}
 
 template <int TERMS, int ENV_T, int CLUMPS, bool OUT16, bool RELU>
 __global__ void __launch_bounds__(64, 1) probe(const float* __restrict__ blob, float* out, unsigned long long* cyc, int iters) {
@@ -49,7 +87,7 @@ __global__ void __launch_bounds__(64, 1) probe(const float* __restrict__ blob, f
             pipe_layer_from_tiles<ENV_T, ENV_T, kEnv1, kEnvN, RELU, true, CLUMPS>(wp, lane, ha, hb, slot);
             pipe_layer_from_tiles<ENV_T, ENV_T, kEnv2, kEnvN, RELU, true, CLUMPS>(wp, lane, hb, ha, slot);
             if constexpr (OUT16) pipe_layer16_from_tiles<ENV_T, kEnv3, kEnvN, RELU, true, (CLUMPS < 0 ? 0 : CLUMPS)>(wp, lane, ha, o[0]);
-            else pipe_layer_from_tiles<ENV_T, 1, kEnv3, kEnvN, RELU, true, CLUMPS>(wp, lane, ha, o);
+            else pipe_layer_from_tiles<ENV_T, 1, kEnv3, kEnvN, RELU, true, CLUMPS>(wp, lane, ha, o, slot);
             wp.template end_pass<kEnvFrags>();
             if (grp == 0) outA = o[0]; else outB = o[0];
         }
@@ -61,6 +99,22 @@ __global__ void __launch_bounds__(64, 1) probe(const float* __restrict__ blob, f
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     out[blockIdx.x * 64 + lane] = acc_out;
     if (lane == 0) { cyc[blockIdx.x] = t1 - t0; cyc[gridDim.x] = kEnvFrags; }
+}
+
+void run_env_pass(int blocks) {
+    const int iters = 50;
+    float *blob, *out; unsigned long long* cyc;
+    (void)hipMalloc(&blob, 4 << 20); (void)hipMemset(blob, 0, 4 << 20);
+    (void)hipMalloc(&out, blocks * 64 * 4); (void)hipMalloc(&cyc, (blocks + 1) * 8);
+    for (int rep = 0; rep < 2; ++rep) {
+        probe_env_pass<36, 8><<<blocks, 64>>>(blob, out, cyc, iters);
+        (void)hipDeviceSynchronize();
+        std::vector<unsigned long long> h(blocks + 1);
+        (void)hipMemcpy(h.data(), cyc, (blocks + 1) * 8, hipMemcpyDeviceToHost);
+        double avg = 0; for (int i = 0; i < blocks; ++i) avg += h[i]; avg /= blocks;
+        if (rep) printf("env_pass() of env_pass.hip.h, %4d waves: %.0f ticks per pass (MFMA issue time 64 x 2368 + 32 x 129 = 155680)\n", blocks, avg / (iters * 2));
+    }
+    (void)hipFree(blob); (void)hipFree(out); (void)hipFree(cyc);
 }
 
 template <int CLUMPS, bool OUT16, bool RELU>
@@ -132,6 +186,7 @@ int run_selftest() {
 
 int main() {
     const int rc = run_selftest();
+    run_env_pass(1024);
     run<0, false, true>(1024);      // the kernel of rounds 1-3
     run<0, false, false>(1024);     // floor without operand staging
     run<2, false, true>(1024);
