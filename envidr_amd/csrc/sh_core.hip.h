@@ -4,6 +4,7 @@
 #pragma once
 #include "common.hip.h"
 #include "sh_ide_tables.inc"
+#include <utility>
 
 namespace envidr {
 
@@ -57,6 +58,61 @@ __device__ __forceinline__ void sh_eval(float x, float y, float z, float* __rest
 // the SAME fp32-rounded coefficient table in fp64 Horner (in z^2, the polynomials have parity), which
 // costs ~120 DFMA per call and is exact to fp32 rounding.
 // emit(j, re_part, im_part) receives term j = 0 .. n_terms-1 in the reference's (l, m) order.
+// An fp64 constant as two scalar moves issued where it is used.  Left to itself the compiler hoists the 121 coefficient
+// pairs out of the kernels' loops, runs out of scalar registers and parks them in VGPR lanes: ~350 v_writelane / v_readlane
+// per call, vector-ALU instructions all of them (a third of the call).  `asm volatile` can be neither hoisted nor merged.
+template <uint64_t BITS>
+__device__ __forceinline__ double sgpr_f64() {
+    uint32_t lo, hi;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(lo) : "n"((int)(uint32_t)(BITS & 0xffffffffull)));
+    asm volatile("s_mov_b32 %0, %1" : "=s"(hi) : "n"((int)(uint32_t)(BITS >> 32)));
+    return __hiloint2double((int)hi, (int)lo);
+}
+template <int IDX>
+__device__ __forceinline__ double ide_coef() { return sgpr_f64<__builtin_bit_cast(uint64_t, kIdeCoef[IDX])>(); }
+// P(z) = sum_k coef[START + k] z^(D - 2k) as a sum of (scalar coefficient) x (power of z) fused multiply-adds.  The
+// coefficient is a MULTIPLICAND on purpose: as the addend of a Horner step a scalar operand has to be copied into the vector
+// register the fused multiply-add accumulates in (two v_mov per coefficient).
+template <int START, int K, int CNT, int D, int LMAX>
+__device__ __forceinline__ double ide_poly(const double p, const double (&zp)[LMAX + 1]) {
+    if constexpr (K < CNT) {
+        constexpr int n = D - 2 * K;
+        if constexpr (n == 0) return ide_poly<START, K + 1, CNT, D, LMAX>(__builtin_fma(ide_coef<START + K>(), 1.0, p), zp);
+        else return ide_poly<START, K + 1, CNT, D, LMAX>(__builtin_fma(ide_coef<START + K>(), zp[n], p), zp);
+    } else return p;
+}
+// (x + i y)^m for m = 0..M-1 in fp64, two multiplies + two fused multiply-adds per power
+template <int M>
+__device__ __forceinline__ void complex_powers_f64(double x, double y, double (&re)[M], double (&im)[M]) {
+    re[0] = 1; im[0] = 0;
+    if constexpr (M > 1) { re[1] = x; im[1] = y; }
+#pragma unroll
+    for (int m = 2; m < M; ++m) {
+        re[m] = __builtin_fma(re[m - 1], x, -(im[m - 1] * y));
+        im[m] = __builtin_fma(re[m - 1], y, im[m - 1] * x);
+    }
+}
+template <int I, int M, int LMAX, typename Emit>
+__device__ __forceinline__ void ide_term(const double (&re)[LMAX + 1], const double (&im)[LMAX + 1], const double (&zp)[LMAX + 1], const float att,
+                                         Emit&& emit) {
+    constexpr int l = 1 << I, j = l - 1 + I + M, start = kIdeStart[j], cnt = kIdeCount[j], d = l - M;
+    static_assert(cnt == d / 2 + 1, "IDE table: a polynomial of degree l - m with parity");
+    if constexpr (d == 0) {
+        emit(j, (float)(re[M] * ide_coef<start>()) * att, (float)(im[M] * ide_coef<start>()) * att);
+    } else {
+        const double p = ide_poly<start, 1, cnt, d, LMAX>(ide_coef<start>() * zp[d], zp);
+        emit(j, (float)(re[M] * p) * att, (float)(im[M] * p) * att);
+    }
+}
+template <int I, int LMAX, typename Emit>
+__device__ __forceinline__ void ide_level(const double (&re)[LMAX + 1], const double (&im)[LMAX + 1], const double (&zp)[LMAX + 1],
+                                          const float kappa_inv, Emit&& emit) {
+    constexpr int l = 1 << I;
+    const float att = expf(-(0.5f * (float)(l * (l + 1))) * kappa_inv);
+    [&]<int... M>(std::integer_sequence<int, M...>) {
+        (ide_term<I, M, LMAX>(re, im, zp, att, emit), ...);
+    }(std::make_integer_sequence<int, l + 1>{});
+}
 template <int DEG_VIEW, typename Emit>
 __device__ __forceinline__ void ide_eval(float xf, float yf, float zf, float kappa_inv, Emit&& emit) {
     constexpr int LMAX = 1 << (DEG_VIEW - 1);
@@ -64,23 +120,14 @@ __device__ __forceinline__ void ide_eval(float xf, float yf, float zf, float kap
     const double z = zf;
     if (xf == 0.0f && yf == 0.0f) y += 1.0;   // reference: y = y + (x == 0 & y == 0)
     double re[LMAX + 1], im[LMAX + 1];
-    complex_powers<LMAX + 1, double>(x, y, re, im);
-    const double z2 = z * z;
-    int j = 0;
+    complex_powers_f64<LMAX + 1>(x, y, re, im);
+    double zp[LMAX + 1];                      // z^n
+    zp[0] = 1; zp[1] = z;
 #pragma unroll
-    for (int i = 0; i < DEG_VIEW; ++i) {
-        const int l = 1 << i;
-        const float att = expf(-(0.5f * (float)(l * (l + 1))) * kappa_inv);
-#pragma unroll
-        for (int m = 0; m <= l; ++m, ++j) {
-            const int start = kIdeStart[j], cnt = kIdeCount[j];
-            double p = kIdeCoef[start];
-#pragma unroll
-            for (int k = 1; k < cnt; ++k) p = p * z2 + kIdeCoef[start + k];
-            if ((l - m) & 1) p *= z;
-            emit(j, (float)(re[m] * p) * att, (float)(im[m] * p) * att);
-        }
-    }
+    for (int n = 2; n <= LMAX; ++n) zp[n] = (n & 1) ? zp[n - 1] * z : zp[n / 2] * zp[n / 2];
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+        (ide_level<I, LMAX>(re, im, zp, kappa_inv, emit), ...);
+    }(std::make_integer_sequence<int, DEG_VIEW>{});
 }
 
 __host__ __device__ constexpr int ide_terms(int deg_view) { return (1 << deg_view) - 1 + deg_view; }
