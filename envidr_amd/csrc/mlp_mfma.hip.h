@@ -182,8 +182,14 @@ struct WeightRing {
     __amdgpu_buffer_rsrc_t cur_rsrc, next_rsrc;
     uint32_t lane_off;
     float ring[PF];
+    // The descriptor's inputs go through readfirstlane: they ARE wave-uniform (kernel arguments), but once the compiler
+    // cannot prove it -- a lambda capture, a struct copy in the caller is enough -- it wraps EVERY buffer load of the stream in
+    // a waterfall loop (v_readfirstlane x 4, compare, s_and_saveexec ...: 2.5x the kernel time, seen in round 4).
     __device__ __forceinline__ static __amdgpu_buffer_rsrc_t rsrc_of(const float* blob, uint32_t chunks) {
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(blob), 0, (int)(chunks * kChunkBytes), 0x00020000);
+        const uint64_t v = reinterpret_cast<uint64_t>(blob);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        float* p = reinterpret_cast<float*>(((uint64_t)hi << 32) | lo);
+        return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)(__builtin_amdgcn_readfirstlane(chunks) * kChunkBytes), 0x00020000);
     }
     __device__ __forceinline__ void start(uint32_t lane, const float* first_blob, uint32_t first_chunks) {
         cur_rsrc = next_rsrc = rsrc_of(first_blob, first_chunks);
