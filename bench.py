@@ -150,6 +150,8 @@ def parse(argv: list[str]):
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak: one full view per rank per step (default); "
                     "strong: ONE view per step, its 8x8-pixel tiles interleaved over the ranks, gathered and assembled on rank 0")
     ap.add_argument("--cold", action="store_true", help="headline frames without the per-ray hint (profiling the cold frame)")
+    ap.add_argument("--corrupt-rank", type=int, default=-1, help="test hook: this rank damages one pixel of the LAST step's image before "
+                    "sending it; dist.gathered_equals_rendered must then come out false for that rank (tests/test_bench_cpu.py)")
     ap.add_argument("--stub", action="store_true", help="CPU plumbing test: gloo, a stand-in renderer, tiny frames "
                     "(tests/test_bench_cpu.py); exercises launch, view partition, overlapped gather and the JSON line")
     return ap.parse_args(argv)
@@ -234,6 +236,7 @@ def run(argv: list[str]) -> None:
         rays_o, rays_d = (torch.from_numpy(a).to(dev) for a in scenes.camera_rays(H, W))
     # strong scaling: this rank's interleaved 8x8-pixel tiles of THE frame; weak: the whole frame (its own view)
     sizes = parallel.shard_sizes(n_side, n_side, world) if strong else [N_frame] * world
+    full_rays = (rays_o, rays_d)                 # rank 0 re-renders what the others sent after the timed region (all N_frame rays)
     if strong:
         mine = parallel.tile_shard(n_side, n_side, rank, world).to(dev)
         rays_o, rays_d = rays_o[mine].contiguous(), rays_d[mine].contiguous()
@@ -265,9 +268,14 @@ def run(argv: list[str]) -> None:
 
     slot_sent = [None, None]     # event on the side stream: the gather that reads this output set has finished
 
-    def deliver(res, slot, timed):
+    last_step = args.warmup + args.steps - 1
+
+    def deliver(res, slot, timed, i):
         """the finished image -> rank 0 (+ assembly of the tile shards there); runs on the side stream when there is one"""
         img = res["image"]
+        if i == last_step and rank == args.corrupt_rank:
+            img = img.clone()
+            img[0, 0] += 1.0
         if send_pad is not None:
             send_pad[slot][:N].copy_(img)
             img = send_pad[slot]
@@ -288,13 +296,13 @@ def run(argv: list[str]) -> None:
         res = frame(i if strong else i * world + rank, slot, events)
         if dist_on:
             if comm is None:
-                deliver(res, slot, timed)
+                deliver(res, slot, timed, i)
             else:
                 done = torch.cuda.Event()
                 done.record()
                 with torch.cuda.stream(comm):
                     comm.wait_event(done)
-                    deliver(res, slot, timed)
+                    deliver(res, slot, timed, i)
                     slot_sent[slot] = torch.cuda.Event()
                     slot_sent[slot].record()
         return res
@@ -323,24 +331,37 @@ def run(argv: list[str]) -> None:
     fence()
     dt_local = time.perf_counter() - t0
     renderer.check_frames()
-    last = args.warmup + args.steps - 1
-    delivered_ok = None
+    last = last_step
+    delivered_ok = delivered_per_rank = None
     if dist_on and rank == 0 and args.steps > 0:
-        # what arrived is what was rendered: the last step's gathered image(s) against the senders' own
-        if stub:
+        # What arrived is what every sender should have rendered -- for EVERY rank, not only the root's own shard: rank 0 renders
+        # the last step again itself (weak: rank r's view, one frame each; strong: the whole frame, all ranks' tiles) into fresh
+        # buffers and requires the gathered pixels to be bit-identical (rays are independent and the kernels deterministic: a
+        # rank's shard of a frame equals those rays of the whole frame, tests/test_fullsize_gpu.py).
+        def render_again(view):
+            ro, rd = full_rays
+            if pipeline:
+                r2 = renderer.render_frame(ro, rd, env_rot(view) if not stub else float(view), out={}, wait=False,
+                                           use_cost_hint=False, image_width=n_side)
+            else:
+                r2 = renderer.render(ro, rd, env_rot(view), extras=True, stats=True, out={})
+            return r2["image"]
+        delivered_per_rank = []
+        if strong:
+            want = render_again(last)
+            first = 0
             for r in range(world):
-                if sizes[r] == 0:          # more ranks than 8x8 tiles (only the 16x16 stub image can be that small): an empty shard
-                    continue
-                want_view = float(last if strong else last * world + r)
-                assert float(gather_lists[last & 1][r][0, 0]) == want_view, "gather delivered the wrong view"
-            if strong:
-                ids = torch.arange(N_frame, dtype=torch.float32)
-                assert torch.equal(frames[last & 1][:, 1], ids) and torch.equal(frames[last & 1][:, 2], 2 * ids), "tiles assembled in the wrong place"
-            delivered_ok = True
-        elif strong:
-            delivered_ok = bool(torch.equal(frames[last & 1][place[:N]], outs[last & 1]["image"]))
+                shard = place[first:first + sizes[r]]
+                first += sizes[r]
+                delivered_per_rank.append(bool(torch.equal(gather_lists[last & 1][r][:sizes[r]], want[shard])))
+            assembled = bool(torch.equal(frames[last & 1], want))                    # ... and the tiles went to the right pixels
+            delivered_ok = assembled and all(delivered_per_rank)
         else:
-            delivered_ok = bool(torch.equal(gather_lists[last & 1][0][:N], outs[last & 1]["image"]))
+            for r in range(world):
+                delivered_per_rank.append(bool(torch.equal(gather_lists[last & 1][r][:N], render_again(last * world + r))))
+            delivered_ok = all(delivered_per_rank)
+        if not stub:
+            renderer.check_frames()
     samples = 0 if res is None else int(res.get("n_records", 0))
     geometry_ms = kernel_ms = composite_ms = 0.0
     if not stub:
@@ -397,6 +418,8 @@ def run(argv: list[str]) -> None:
         }
         if dist_on:
             result["dist"] = {"backend": dist.get_backend(), "world": world, "force_dist": bool(args.force_dist), "gathered_equals_rendered": delivered_ok,
+                              "gathered_equals_rendered_per_rank": delivered_per_rank,
+                              "gathered_check": "rank 0 re-rendered every rank's last view / the whole last frame and compared the gathered pixels bit for bit",
                               "scene": "none (stub)" if stub else ("generated on rank 0, table + bitfield broadcast" if dist_on else "generated locally")}
         if stub:
             result["config"]["workload"] = "STUB (CPU plumbing test)"

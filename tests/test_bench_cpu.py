@@ -60,3 +60,15 @@ def test_eight_ranks_the_drivers_largest_launch():
         j = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--stub", "--scaling", mode])
         assert j["n_gpus"] == 8 and j["scaling"] == mode and len(j["per_rank_ms_per_step"]) == 8
         assert j["dist"]["gathered_equals_rendered"] is True and j["value"] > 0
+
+
+def test_a_damaged_shard_of_any_rank_is_noticed():
+    """dist.gathered_equals_rendered covers EVERY rank's payload: rank 0 renders the last step again and compares what the
+    gather delivered for each sender.  --corrupt-rank damages one pixel of one rank's last image before it is sent."""
+    for mode in ("weak", "strong"):
+        j = _run(["--gpus", "3", "--steps", "3", "--warmup", "1", "--stub", "--scaling", mode])
+        assert j["dist"]["gathered_equals_rendered"] is True and j["dist"]["gathered_equals_rendered_per_rank"] == [True, True, True]
+        for bad in (1, 2, 0):
+            j = _run(["--gpus", "3", "--steps", "3", "--warmup", "1", "--stub", "--scaling", mode, "--corrupt-rank", str(bad)])
+            assert j["dist"]["gathered_equals_rendered"] is False
+            assert j["dist"]["gathered_equals_rendered_per_rank"] == [r != bad for r in range(3)], (mode, bad, j["dist"])
