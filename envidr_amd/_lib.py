@@ -105,23 +105,24 @@ def exported_symbols() -> dict[str, bool]:
 
 _ELEMENT_DTYPES = {"float": (torch.float32,), "int32_t": (torch.int32,), "uint8_t": (torch.uint8, torch.bool),
                    "uint16_t": (torch.float16, torch.int16) + ((torch.uint16,) if hasattr(torch, "uint16") else ())}
-_pointer_types: dict[str, list[str]] | None = None
+def parse_header_types(header: Path | None = None) -> dict[str, list[str]]:
+    """include/envidr_amd.h -> {operator: C element type of each argument ('' for scalars)}; the generator of _abi_types.py"""
+    import re
+    header = header or (_PKG.parent / "include" / "envidr_amd.h")
+    text = re.sub(r"/\*.*?\*/", "", header.read_text(), flags=re.S)
+    types = {}
+    for m in re.finditer(r"\bint\s+envidr_([a-zA-Z0-9_]+)\s*\((.*?)\)\s*;", text, flags=re.S):
+        params = [" ".join(p.split()) for p in m.group(2).split(",")][:-1]          # the stream is last
+        types[m.group(1)] = [p.replace("const ", "").split("*")[0].strip() if "*" in p else "" for p in params]
+    return types
 
 
 def pointer_types() -> dict[str, list[str]]:
-    """operator -> C element type of each of its arguments ('' for scalars), read from include/envidr_amd.h: what the reference's
-    CHECK_IS_FLOATING / CHECK_IS_INT guard (a tensor of another dtype would be read as garbage through a raw pointer)"""
-    global _pointer_types
-    if _pointer_types is None:
-        import re
-        _pointer_types = {}
-        header = _PKG.parent / "include" / "envidr_amd.h"
-        if header.exists():
-            text = re.sub(r"/\*.*?\*/", "", header.read_text(), flags=re.S)
-            for m in re.finditer(r"\bint\s+envidr_([a-zA-Z0-9_]+)\s*\((.*?)\)\s*;", text, flags=re.S):
-                params = [" ".join(p.split()) for p in m.group(2).split(",")][:-1]          # the stream is last
-                _pointer_types[m.group(1)] = [p.replace("const ", "").split("*")[0].strip() if "*" in p else "" for p in params]
-    return _pointer_types
+    """operator -> C element type of each of its arguments ('' for scalars): what the reference's CHECK_IS_FLOATING /
+    CHECK_IS_INT guard (a tensor of another dtype would be read as garbage through a raw pointer).  The table ships inside the
+    package (_abi_types.py, generated from include/envidr_amd.h), so the guard also works where the header is not installed."""
+    from ._abi_types import ELEMENT_TYPES
+    return ELEMENT_TYPES
 
 
 def _ptr(x, name: str, pos: int):

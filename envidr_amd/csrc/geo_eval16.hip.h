@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(kE16Threads, 1) k_geo_eval16(const GeoEvalArgs
     constexpr int kAhead = kGeoAhead < kE16LevelSteps ? kGeoAhead : kE16LevelSteps - 1;
     const __amdgpu_buffer_rsrc_t table = table_rsrc(a.table, a.table_bytes);
     const uint32_t stride = per_xcd_blocks * kE16Waves;
-    typedef float f32x3 __attribute__((ext_vector_type(3)));
+    typedef float f32x3 __attribute__((ext_vector_type(3), aligned(4)));   // 12-byte stride arrays: NOT 16-byte aligned
 
     for (uint32_t b = b_lo + in_xcd * kE16Waves + wave; b < b_hi; b += stride) {
         const uint32_t sidx = b * 16u + sl;

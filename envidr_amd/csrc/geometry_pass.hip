@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(kE32Threads, 2) k_geo_eval32(const GeoEvalArgs
         float xc[3];
         bool inside;
         {
-            typedef float f32x3 __attribute__((ext_vector_type(3)));
+            typedef float f32x3 __attribute__((ext_vector_type(3), aligned(4)));   // 12-byte stride arrays: NOT 16-byte aligned
             f32x3 pv = {0.0f, 0.0f, 0.0f};
             if (on) pv = *reinterpret_cast<const f32x3*>(a.xyz + 3 * slot);
             const float x01[3] = {(pv[0] + a.bound) / a.bound2, (pv[1] + a.bound) / a.bound2, (pv[2] + a.bound) / a.bound2};
@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(kE32Threads, 2) k_geo_eval32(const GeoEvalArgs
             if (a.rough) a.rough[slot] = rough;
             if (a.blend) a.blend[slot] = h3[14];
             if (a.normal) {
-                typedef float f32x3 __attribute__((ext_vector_type(3)));
+                typedef float f32x3 __attribute__((ext_vector_type(3), aligned(4)));   // 12-byte stride arrays: NOT 16-byte aligned
                 const f32x3 nv = {nrm[0], nrm[1], nrm[2]};
                 *reinterpret_cast<f32x3*>(a.normal + 3 * slot) = nv;
             }
@@ -667,7 +667,7 @@ __global__ void __launch_bounds__(kBlock) k_geo_rays(const GeoRayArgs a) {
             const bool fits = rec_base + wave_records <= a.rec_cap;
             if (!fits && lane == 0) a.counters[kCntOverflow] = 1u;
             {
-                typedef float f32x3 __attribute__((ext_vector_type(3)));
+                typedef float f32x3 __attribute__((ext_vector_type(3), aligned(4)));   // 12-byte stride arrays: NOT 16-byte aligned
                 constexpr uint32_t kGroup2 = 4;
                 uint32_t off = 0, roff = 0;
                 for (uint32_t c0 = 0;; c0 += kGroup2) {            // pass 2: the recurrence itself + the records

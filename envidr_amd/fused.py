@@ -665,18 +665,26 @@ class FusedRenderer:
                 carry = (st["costs"], st["peak"])
                 frames.pop(N)
                 st, cap = None, need
+                # the growth hint of an earlier overflow decays with the buffers it grew: what these rays need is now known
+                self.__dict__.get("_frame_hints", {}).pop(N, None)
         if st is None or st["cap"] < cap:
             if st is None and len(frames) >= 4:
                 frames.pop(next(iter(frames)))
             need = int(self.lib.envidr_geometry_workspace_bytes(N, cap))
-            st = dict(N=N, cap=cap, ws=torch.empty(need, dtype=torch.uint8, device=dev), counter=torch.zeros(1, dtype=torch.int32, device=dev),
-                      ray=torch.empty(cap, dtype=torch.int32, device=dev), idx=torch.empty(cap, dtype=torch.int32, device=dev),
-                      w=torch.empty(cap, device=dev), slot=torch.empty(cap, dtype=torch.int32, device=dev),
-                      perm=torch.empty(cap, dtype=torch.int32, device=dev), cd=torch.empty(cap, 3, device=dev), cs=torch.empty(cap, 3, device=dev),
-                      cost=torch.zeros(N, dtype=torch.int16, device=dev), costs={}, offsets=torch.zeros(N + 1, dtype=torch.int32, device=dev),
-                      stats=torch.zeros(3, dtype=torch.int64, device=dev), worst=torch.zeros(3, dtype=torch.int64, device=dev),
-                      host=torch.zeros(6, dtype=torch.int64).pin_memory(),
-                      event=torch.cuda.Event(), pending=False, hint=samples_per_ray, peak=0)
+            try:
+                st = dict(N=N, cap=cap, ws=torch.empty(need, dtype=torch.uint8, device=dev), counter=torch.zeros(1, dtype=torch.int32, device=dev),
+                          ray=torch.empty(cap, dtype=torch.int32, device=dev), idx=torch.empty(cap, dtype=torch.int32, device=dev),
+                          w=torch.empty(cap, device=dev), slot=torch.empty(cap, dtype=torch.int32, device=dev),
+                          perm=torch.empty(cap, dtype=torch.int32, device=dev), cd=torch.empty(cap, 3, device=dev), cs=torch.empty(cap, 3, device=dev),
+                          cost=torch.zeros(N, dtype=torch.int16, device=dev), costs={}, offsets=torch.zeros(N + 1, dtype=torch.int32, device=dev),
+                          stats=torch.zeros(3, dtype=torch.int64, device=dev), worst=torch.zeros(3, dtype=torch.int64, device=dev),
+                          host=torch.zeros(6, dtype=torch.int64).pin_memory(),
+                          event=torch.cuda.Event(), pending=False, hint=samples_per_ray, peak=0)
+            except torch.OutOfMemoryError as e:
+                # (regrowth after an overflow quadruples the capacity up to N * max_steps: on a small device that can end here)
+                raise _lib.EnvidrError(f"render_frame: the frame buffers for {N} rays x {cap / max(N, 1):.1f} samples per ray ({cap} sample / record "
+                                       f"slots) need {(need + 44 * cap) / 2 ** 30:.2f} GiB of device memory, which is not available; render fewer "
+                                       "rays per call (opt.max_ray_batch_cuda)") from e
             if carry is not None:
                 st["costs"], st["peak"] = carry
             frames[N] = st

@@ -26,7 +26,7 @@ class _HashEncode(Function):
         dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=dtype) if calc_grad_inputs else None
         _lib.call("hash_encode_forward_f16" if half else "hash_encode_forward", inputs, embeddings, offsets, outputs, B, D, C, L, S, H,
                   int(calc_grad_inputs), dy_dx)
-        ctx.save_for_backward(inputs, embeddings, offsets, dy_dx if dy_dx is not None else torch.empty(1, device=inputs.device))
+        ctx.save_for_backward(inputs, embeddings, offsets, dy_dx if dy_dx is not None else torch.empty(1, device=inputs.device, dtype=dtype))
         ctx.dims = (B, D, C, L, S, H)
         ctx.calc_grad_inputs, ctx.half = calc_grad_inputs, half
         return outputs.permute(1, 0, 2).reshape(B, L * C)
@@ -64,6 +64,15 @@ class _HashEncodeBackward(Function):
     def backward(ctx, grad_grad_inputs, grad_grad_embeddings):
         grad, inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
         B, D, C, L, S, H = ctx.dims
+        # The second-order kernel (reference hashencoder.cu:375-595) propagates through grad_inputs only; the reference's
+        # Function ignores grad_grad_embeddings the same way (hashgrid.py:91-107).  Without grad_inputs there is nothing it can
+        # do: the saved dy_dx is then the 1-element dummy of the forward pass, which the reference's kernel would read as
+        # [B, L*D*C] (undefined behaviour there; refused here).
+        if grad_grad_inputs is None:
+            return (None,) * 13
+        if not ctx.calc_grad_inputs:
+            raise RuntimeError("double backward through the hash encoding needs the input gradient: the forward pass ran with "
+                               "inputs.requires_grad == False, so no dy_dx was kept")
         grad_grad = torch.zeros_like(grad)
         grad2_embeddings = torch.zeros_like(embeddings)
         _lib.call("hash_encode_second_backward_f16" if embeddings.dtype == torch.half else "hash_encode_second_backward", grad, inputs, embeddings,

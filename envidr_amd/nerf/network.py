@@ -159,8 +159,11 @@ class NeRFNetwork(NeRFRenderer):
     # ---- geometry ---------------------------------------------------------------------------------
     def forward_geometry(self, xyz, material=None):
         from ..hashencoder import HashEncoder
-        # eval mode: the features are differentiated w.r.t. the positions only (normals): keep the table out of the graph
-        kw = {"table_grad": False} if (not self.training and isinstance(self.encoder, HashEncoder)) else {}
+        # Only when the caller says that nothing but the input gradient (normals) will be taken -- run_cuda's inference loop,
+        # which detaches everything it gets back, sets `_normals_only` around its call -- is the table kept out of the graph
+        # (autograd would otherwise zero-fill and scatter a 48.8 MB table gradient nobody reads, every loop iteration).  Any other
+        # caller, in train() or eval() mode, gets the reference's graph: embeddings included.
+        kw = {"table_grad": False} if (getattr(self, "_normals_only", False) and isinstance(self.encoder, HashEncoder)) else {}
         x = self.encoder(xyz, bound=self.bound, **kw)
         if self.opt.enabled_levels > 0:
             mask = torch.zeros(self.opt.num_levels, self.opt.level_dim, device=x.device)

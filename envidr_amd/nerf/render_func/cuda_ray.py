@@ -179,7 +179,9 @@ def run_cuda(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, fo
         fr.desc.bg_color = 0.0 if tensor_bg is not None else float(bg_color)
         fr.desc.min_near = float(self.min_near)
         # per-call march parameters (the reflected pass of indirect rendering has its own max_steps; callers may pass their own
-        # T_thresh / dt_gamma): plain descriptor fields, read by the kernels at launch
+        # T_thresh / dt_gamma): plain descriptor fields, read by the kernels at launch -- and put back when the launches are
+        # enqueued, so that direct users of model.fused_renderer() keep seeing opt's values, not the last call's
+        saved_march = (fr.desc.max_steps, fr.desc.T_thresh, fr.desc.dt_gamma)
         fr.desc.max_steps, fr.desc.T_thresh, fr.desc.dt_gamma = int(max_steps), float(T_thresh), float(dt_gamma)
         fr.set_aabb(self.aabb_infer)               # the operator loop's near_far_from_aabb box, not just +-bound
         # The geometry pipeline (march rounds + sample-parallel hash / SDF kernel -> record shading -> composite;
@@ -187,24 +189,27 @@ def run_cuda(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, fo
         # and the reflected-radiance third pass of indirect rendering.  It keeps, per batch size, the per-ray sample counts of
         # the previous render as a sizing hint (video frames share their rays; outputs never depend on it).
         # `two_phase=False` asks for the single persistent kernel instead (envidr_render_rays).
-        pipeline = two_phase is not False
-        if pipeline:
-            # `image_width` (not a reference argument; optional): the rays are a row-major image this wide -- a layout hint that
-            # lets the pipeline form its blocks from 8x8-pixel tiles (same outputs)
-            res = fr.render_frame(rays_o, rays_d, env_rot_radian, geometry_only=geometry_only,
-                                  r_images=None if r_images is None else r_images[0], ray_mask=ray_mask, tag=frame_tag, wait=wait,
-                                  image_width=int(kwargs.get("image_width", 0) or 0))
-        else:
-            if ray_mask is not None:
-                raise NotImplementedError("ray_mask is a feature of the geometry pipeline (two_phase)")
-            hints = self.__dict__.setdefault("_ray_cost_hints", {})
-            key = (N, bool(geometry_only), r_images is not None)
-            if key not in hints or hints[key].device != device:
-                if len(hints) > 8:
-                    hints.clear()
-                hints[key] = torch.zeros(N, dtype=torch.int16, device=device)
-            res = fr.render(rays_o, rays_d, env_rot_radian, extras=True, geometry_only=geometry_only,
-                            r_images=None if r_images is None else r_images[0], ray_cost=hints[key])
+        try:
+            pipeline = two_phase is not False
+            if pipeline:
+                # `image_width` (not a reference argument; optional): the rays are a row-major image this wide -- a layout hint that
+                # lets the pipeline form its blocks from 8x8-pixel tiles (same outputs)
+                res = fr.render_frame(rays_o, rays_d, env_rot_radian, geometry_only=geometry_only,
+                                      r_images=None if r_images is None else r_images[0], ray_mask=ray_mask, tag=frame_tag, wait=wait,
+                                      image_width=int(kwargs.get("image_width", 0) or 0))
+            else:
+                if ray_mask is not None:
+                    raise NotImplementedError("ray_mask is a feature of the geometry pipeline (two_phase)")
+                hints = self.__dict__.setdefault("_ray_cost_hints", {})
+                key = (N, bool(geometry_only), r_images is not None)
+                if key not in hints or hints[key].device != device:
+                    if len(hints) > 8:
+                        hints.clear()
+                    hints[key] = torch.zeros(N, dtype=torch.int16, device=device)
+                res = fr.render(rays_o, rays_d, env_rot_radian, extras=True, geometry_only=geometry_only,
+                                r_images=None if r_images is None else r_images[0], ray_cost=hints[key])
+        finally:
+            fr.desc.max_steps, fr.desc.T_thresh, fr.desc.dt_gamma = saved_march
         image = res["image"] if tensor_bg is None else res["image"] + (1 - res["weights_sum"])[:, None] * tensor_bg
         out = {"image": image.view(*prefix, 3), "depth": res["depth"].view(*prefix), "weights_sum": res["weights_sum"].view(*prefix)}
         if sphere_bg is not None:
@@ -268,7 +273,11 @@ def run_cuda(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, fo
                                                     perturb if step == 0 else False, dt_gamma, max_steps)
         with torch.enable_grad():
             xyzs.requires_grad_(True)
-            sdfs, sigmas, geo_feats, normals, _ = self.forward_sigma(xyzs, use_sdf_sigma_grad=True, dirs=dirs, dists=deltas[..., 0])
+            self._normals_only = True          # everything below is detached: only d sdf / d xyz is taken (network.py forward_geometry)
+            try:
+                sdfs, sigmas, geo_feats, normals, _ = self.forward_sigma(xyzs, use_sdf_sigma_grad=True, dirs=dirs, dists=deltas[..., 0])
+            finally:
+                self._normals_only = False
         roughness = self.roughness
         sigmas = (self.density_scale * sigmas).detach()
         normals = normals.detach()

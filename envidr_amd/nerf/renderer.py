@@ -33,6 +33,13 @@ class NeRFRenderer(nn.Module):
                  use_sdf=True, opt=None, env_opt=None, **kwargs):
         super().__init__()
         self.opt, self.env_opt = opt, env_opt
+        # options that select code of the reference this package does not carry are refused here, never ignored:
+        # error_bound_sample -> the VolSDF sampler (reference renderer.py:373-375); env_sph_mode / render_env_on_sphere ->
+        # run_sph's volume renderer (:376-377); unwrap_env_sphere -> main_nerf.py's environment-map export; plot_roughness ->
+        # matplotlib debugging inside forward_geometry (network.py:336,402,452)
+        for name in ("error_bound_sample", "env_sph_mode", "render_env_on_sphere", "unwrap_env_sphere", "plot_roughness"):
+            if getattr(opt, name, False):
+                raise NotImplementedError(f"opt.{name} selects a part of the reference outside the render hot path (DESIGN.md section 7)")
         self.bound = bound
         self.cascade = 1 + math.ceil(math.log2(bound))
         self.grid_size = 128
@@ -47,7 +54,16 @@ class NeRFRenderer(nn.Module):
             aabb = torch.tensor([-bound] * 3 + [bound] * 3, dtype=torch.float32)
         self.register_buffer("aabb_train", aabb)
         self.register_buffer("aabb_infer", aabb.clone())
-        self.obj_aabb = None
+        # reference renderer.py:91-97: the object's box (opt.obj_aabb * scale, clamped to the bound cube).  It masks the
+        # reflected rays of indirect rendering (renderer.py:458-460) and the samples of the relative-sdf term (cuda_ray.py:191-192)
+        obj_aabb = getattr(opt, "obj_aabb", None)
+        if obj_aabb is not None and len(obj_aabb) > 0:
+            if len(obj_aabb) != 6:
+                raise ValueError(f"obj_aabb takes 6 numbers (p min, p max), got {len(obj_aabb)}")
+            self.register_buffer("obj_aabb", (torch.tensor(list(obj_aabb), dtype=torch.float32) * opt.scale).clamp(min=-bound, max=bound),
+                                 persistent=False)
+        else:
+            self.obj_aabb = None
         self.use_sdf = use_sdf
         self.use_normal_with_mlp = opt.normal_with_mlp
         self.use_reflected_dir = opt.use_reflected_dir
@@ -300,6 +316,8 @@ class NeRFRenderer(nn.Module):
         ray_mask = (depth != 0) & (ws > 0.3)
         ref_o = rays_o + depth[..., None] * rays_d
         ref_d = reflect_dir(-rays_d, normals)
+        if self.obj_aabb is not None:                       # reflected rays start inside the object's box (reference renderer.py:458-460)
+            ref_mask = ref_mask & (ref_o > self.obj_aabb[:3]).all(-1) & (ref_o < self.obj_aabb[3:]).all(-1)
         saved_bg, saved_near = kwargs.get("bg_color"), self.min_near
         bg = 0 if saved_bg is None else saved_bg
         if geo.get("sphere_bg") is not None:
@@ -309,8 +327,8 @@ class NeRFRenderer(nn.Module):
                    force_all_rays=True)
         try:
             ref = self._run(ref_o, ref_d, get_normal_image=get_normal_image, use_specular_color=use_specular_color,
-                            env_net_index=env_net_index, main_pass=False, bg_sphere=False, env_rot_radian=env_rot_radian, fused=True,
-                            ray_mask=ref_mask, frame_tag="indirect-reflected", **kw2)
+                            env_net_index=env_net_index, main_pass=False, grad_ray=getattr(self.opt, "grad_rays", False), bg_sphere=False,
+                            env_rot_radian=env_rot_radian, fused=True, ray_mask=ref_mask, frame_tag="indirect-reflected", **kw2)
         finally:
             self.min_near = saved_near
         # reflected radiance + visibility per primary ray; zero where no reflected ray was traced (the reference's new_zeros +
@@ -354,6 +372,8 @@ class NeRFRenderer(nn.Module):
         ray_mask = (depth != 0) & (ws > 0.3)
         ref_o = rays_o + depth[None, ..., None] * rays_d
         ref_d = reflect_dir(-rays_d, normals)
+        if self.obj_aabb is not None:                       # reference renderer.py:458-460
+            ref_mask = ref_mask & (ref_o[0] > self.obj_aabb[:3]).all(-1) & (ref_o[0] < self.obj_aabb[3:]).all(-1)
         saved_bg, saved_near = kwargs.get("bg_color"), self.min_near
         bg = 0 if saved_bg is None else saved_bg
         if geo.get("sphere_bg") is not None:
@@ -364,7 +384,7 @@ class NeRFRenderer(nn.Module):
         try:
             ref = self._run(ref_o[:, ref_mask, :], ref_d[:, ref_mask, :], get_normal_image=get_normal_image,
                             use_specular_color=use_specular_color, env_net_index=env_net_index, main_pass=False,
-                            bg_sphere=False, env_rot_radian=env_rot_radian, fused=fused, **kw2)
+                            grad_ray=getattr(self.opt, "grad_rays", False), bg_sphere=False, env_rot_radian=env_rot_radian, fused=fused, **kw2)
         finally:
             self.min_near = saved_near
         ref_image = torch.cat([ref["image"], ref["weights_sum"][..., None]], -1)

@@ -245,6 +245,19 @@ def golden_frame(model, opt, tag, H, W, env_rot=None, theta=30.0, phi=-20.0, ext
           f"hit fraction {float((res['weights_sum'] > 0).float().mean()):.3f}, mean rgb {res['image'].mean(dim=(0, 1)).tolist()}")
 
 
+OBJ_AABB = [-1.5, -1.5, -0.12, 0.35, 1.5, 1.5]      # in dataset units (x scale 0.65): cuts through the torus
+
+
+def golden_indirect_aabb():
+    """config #4 with `--obj_aabb`: reflected rays are only traced from points inside the object's box (reference
+    renderer.py:91-97, 458-460); the box cuts the torus so that both sides of the mask occur among the hit pixels"""
+    scene4 = scenes.toaster_scene(shape=scenes.torus(), seed=3)
+    model, opt = build_reference_model(scene4, extra_argv=["--indir_ref", "--obj_aabb", *map(str, OBJ_AABB)])
+    assert opt.indir_ref and model.obj_aabb is not None
+    golden_frame(model, opt, "toaster_indir_aabb_40", 40, 40, theta=40.0, phi=-50.0,
+                 extra={"obj_aabb": np.array(OBJ_AABB, F), "obj_aabb_scaled": model.obj_aabb.numpy().astype(F)})
+
+
 def golden_background():
     """run_cuda's background-sphere branch (cuda_ray.py:56-62, network.py:343-367,727-742): toaster.ini + `--bg_radius 3`.
     The background model's parameters (2-D hash grid table, bias-free MLP) are the reference's own seeded initialisation
@@ -528,6 +541,9 @@ def main():
     if sys.argv[1:] == ["ide"]:
         golden_ide()
         return
+    if sys.argv[1:] == ["indir_aabb"]:         # only the obj_aabb variant of the three-pass frame
+        golden_indirect_aabb()
+        return
     if sys.argv[1:] == ["train"]:              # only the training-branch fixtures
         golden_train("toaster", scenes.toaster_scene())
         golden_train("lego", scenes.lego_scene(seed=8), config=OUT / "lego_like.ini", theta=110.0, phi=-40.0)
@@ -548,6 +564,7 @@ def main():
     model4, opt4 = build_reference_model(scene4, extra_argv=["--indir_ref"])
     assert opt4.indir_ref and opt4.use_renv
     golden_frame(model4, opt4, "toaster_indir_40", 40, 40, theta=40.0, phi=-50.0)
+    golden_indirect_aabb()
     golden_relight()
     golden_background()
     golden_grid()

@@ -70,6 +70,13 @@ VARIANTS = {
                                          "        st.pair[j] = u32x4{r0[j], r1[j], base[j], lv.row0_bytes};"),
                                         ("hash_lean.hip.h", "            st.solo[j] = __builtin_amdgcn_raw_buffer_load_b64(table, r1[j] * 8u + (LANE_LEVEL ? lv.row0_bytes : 0u), LANE_LEVEL ? 0u : lv.row0_bytes, AUX);",
                                          "            st.solo[j] = u32x2{r1[j], base[j]};")]),
+    # ablations of the record-shading kernel (timing only: results are wrong): where does a round's time go besides the MFMAs?
+    "shade_noide": ("fused_render", [("fused_render.hip", "        ide_eval<IDE_DEG>(vx, vy, vz, kinv, [&](int j, float re, float im) {\n            code[j] = re * c.light_scale;\n            code[TERMS + j] = im * c.light_scale;\n        });\n",
+                                      "        for (int j = 0; j < TERMS; ++j) { code[j] = vx * kinv + (float)j; code[TERMS + j] = vy * vz - (float)j; }\n")]),
+    "shade_noenv": ("fused_render", [("fused_render.hip", "            env_pass<TERMS, ENV_T, kEnvN>(wp, lane, aux, in, o);                        // env_pass.hip.h\n",
+                                      "            for (int r_ = 0; r_ < 16; ++r_) o[r_] = in[r_] + in[r_ + 16];\n")]),
+    "shade_noheads": ("fused_render", [("fused_render.hip", "            pipe_layer_from_lanes<kDSteps, 1, kHeadD1, kHeadN>(wp, lane, in_d, d1);\n            pipe_layer16_from_tiles<1, kHeadD2, kHeadN, true>(wp, lane, d1, d2);\n            pipe_layer_from_lanes<kSSteps, 2, kHeadS1, kHeadN>(wp, lane, in_s, s1);\n            pipe_layer_from_tiles<2, 2, kHeadS2, kHeadN, true>(wp, lane, s1, s2);\n            pipe_layer16_from_tiles<2, kHeadS3, kHeadN, true>(wp, lane, s2, s3);\n            wp.template end_pass<kHeadFrags>();\n",
+                                        "            for (int r_ = 0; r_ < 16; ++r_) { d2[r_] = in_d[r_ % kDSteps]; s3[r_] = in_s[r_ % kSSteps]; }\n")]),
     # ablations / parameters of k_env_split (timing only where marked: results are wrong)
     "split_base": ("shade_split", []),
     "split_nodma": ("shade_split", [("mlp_split.hip.h", "            if constexpr (c == kSplitMeetAt + 1) dma_piece<0>();\n            if constexpr (c == kSplitMeetAt + 3) dma_piece<1>();\n", "")]),       # timing only
