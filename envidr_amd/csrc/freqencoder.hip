@@ -4,6 +4,7 @@
 // in fp32, exactly the reference's formulation.  One lane per output element:
 // consecutive lanes write consecutive floats.
 #include "common.hip.h"
+#include "rowio.hip.h"
 
 using namespace envidr;
 
@@ -40,6 +41,48 @@ __global__ void __launch_bounds__(kBlock) k_freq_backward(const float* __restric
     grad_inputs[t] = r;
 }
 
+// D = 3 (every use in the reference's networks): one lane per point, rows of C = 3 + 6 deg floats through LDS (rowio.hip.h) --
+// no integer division per output element, 16-byte stores.  Same expressions, element for element, as the generic kernels above.
+template <int DEG, bool ALIGNED>
+__global__ void __launch_bounds__(64) k_freq_forward3(const float* __restrict__ inputs, uint32_t B, float* __restrict__ outputs) {
+    constexpr int D = 3, C = D + 2 * D * DEG;
+    __shared__ float s_tile[wave_tile_floats<C>()];
+    const uint32_t lane = threadIdx.x, row0 = blockIdx.x * 64u;
+    const uint32_t b = min(row0 + lane, B - 1);
+    float x[D], v[C];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { x[d] = inputs[(size_t)b * D + d]; v[d] = x[d]; }
+#pragma unroll
+    for (int c = D; c < C; ++c) {
+        const int col = c / D - 1, d = c % D;
+        const float phase = (col & 1) * (3.141592653589793f / 2);
+        v[c] = sinf(scalbnf(x[d], col >> 1) + phase);
+    }
+    wave_store_rows<C, ALIGNED>(s_tile, v, outputs + (size_t)row0 * C, min(64u, B - row0), lane);
+}
+
+template <int DEG, bool ALIGNED>
+__global__ void __launch_bounds__(64) k_freq_backward3(const float* __restrict__ grad, const float* __restrict__ outputs, uint32_t B,
+                                                       float* __restrict__ grad_inputs) {
+    constexpr int D = 3, C = D + 2 * D * DEG;
+    __shared__ float s_tile[wave_tile_floats<C>()];
+    const uint32_t lane = threadIdx.x, row0 = blockIdx.x * 64u, rows = min(64u, B - row0);
+    float g[C], o[C];
+    wave_load_rows<C, ALIGNED>(s_tile, g, grad + (size_t)row0 * C, rows, lane);
+    wave_load_rows<C, ALIGNED>(s_tile, o, outputs + (size_t)row0 * C, rows, lane);
+    float r[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        r[d] = g[d];
+#pragma unroll
+        for (int f = 0; f < DEG; ++f) {
+            const int at = D + 2 * D * f;
+            r[d] += scalbnf(1.0f, f) * (g[at + d] * o[at + D + d] - g[at + D + d] * o[at + d]);
+        }
+    }
+    wave_store_rows<D, ALIGNED>(s_tile, r, grad_inputs + (size_t)row0 * D, rows, lane);
+}
+
 extern "C" {
 
 int envidr_freq_encode_forward(const float* inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float* outputs,
@@ -47,6 +90,19 @@ int envidr_freq_encode_forward(const float* inputs, uint32_t B, uint32_t D, uint
     ENVIDR_REQUIRE(C == D + 2 * D * deg, "freq_encode_forward: C=%u must equal D + 2*D*deg = %u", C, D + 2 * D * deg);
     if (B == 0) return ENVIDR_OK;
     ENVIDR_REQUIRE(inputs && outputs && D >= 1, "freq_encode_forward: null pointer or D = 0");
+    if (D == 3 && deg >= 1 && deg <= 10) {
+        const dim3 grid(ceil_div(B, 64)), block(64);
+        hipStream_t s = as_stream(stream);
+        const bool al = aligned16(outputs);
+#define ENVIDR_FREQ(DEG)                                                                                    \
+    case DEG:                                                                                               \
+        if (al) hipLaunchKernelGGL((k_freq_forward3<DEG, true>), grid, block, 0, s, inputs, B, outputs);      \
+        else hipLaunchKernelGGL((k_freq_forward3<DEG, false>), grid, block, 0, s, inputs, B, outputs);        \
+        break;
+        switch (deg) { ENVIDR_FREQ(1) ENVIDR_FREQ(2) ENVIDR_FREQ(3) ENVIDR_FREQ(4) ENVIDR_FREQ(5) ENVIDR_FREQ(6) ENVIDR_FREQ(7) ENVIDR_FREQ(8) ENVIDR_FREQ(9) ENVIDR_FREQ(10) }
+#undef ENVIDR_FREQ
+        return check_launch("k_freq_forward3");
+    }
     hipLaunchKernelGGL(k_freq_forward, dim3(ceil_div(B * C, kBlock)), dim3(kBlock), 0, as_stream(stream), inputs, B, D, C,
                        outputs);
     return check_launch("k_freq_forward");
@@ -57,6 +113,19 @@ int envidr_freq_encode_backward(const float* grad, const float* outputs, uint32_
     ENVIDR_REQUIRE(C == D + 2 * D * deg, "freq_encode_backward: C=%u must equal D + 2*D*deg", C);
     if (B == 0) return ENVIDR_OK;
     ENVIDR_REQUIRE(grad && outputs && grad_inputs && D >= 1, "freq_encode_backward: null pointer or D = 0");
+    if (D == 3 && deg >= 1 && deg <= 10) {
+        const dim3 grid(ceil_div(B, 64)), block(64);
+        hipStream_t s = as_stream(stream);
+        const bool al = aligned16(grad) && aligned16(outputs) && aligned16(grad_inputs);
+#define ENVIDR_FREQ(DEG)                                                                                                  \
+    case DEG:                                                                                                             \
+        if (al) hipLaunchKernelGGL((k_freq_backward3<DEG, true>), grid, block, 0, s, grad, outputs, B, grad_inputs);        \
+        else hipLaunchKernelGGL((k_freq_backward3<DEG, false>), grid, block, 0, s, grad, outputs, B, grad_inputs);          \
+        break;
+        switch (deg) { ENVIDR_FREQ(1) ENVIDR_FREQ(2) ENVIDR_FREQ(3) ENVIDR_FREQ(4) ENVIDR_FREQ(5) ENVIDR_FREQ(6) ENVIDR_FREQ(7) ENVIDR_FREQ(8) ENVIDR_FREQ(9) ENVIDR_FREQ(10) }
+#undef ENVIDR_FREQ
+        return check_launch("k_freq_backward3");
+    }
     hipLaunchKernelGGL(k_freq_backward, dim3(ceil_div(B * D, kBlock)), dim3(kBlock), 0, as_stream(stream), grad, outputs,
                        B, D, deg, C, grad_inputs);
     return check_launch("k_freq_backward");

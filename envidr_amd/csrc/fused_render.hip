@@ -249,7 +249,7 @@ __device__ __forceinline__ void shade_sample(WP& wp, const uint32_t lane, const 
         const float vx = enc ? wr[0] : nenv[0], vy = enc ? wr[1] : nenv[1], vz = enc ? wr[2] : nenv[2];
         const float kinv = enc ? rough : c.kappa_diffuse;
         float code[2 * TERMS];
-        ide_eval<IDE_DEG>(vx, vy, vz, kinv, [&](int j, float re, float im) {
+        ide_eval<IDE_DEG, true>(vx, vy, vz, kinv, [&](int j, float re, float im) {
             code[j] = re * c.light_scale;
             code[TERMS + j] = im * c.light_scale;
         });

@@ -2,20 +2,24 @@
 // (ide_encoder/ide_encoder.py:98-130: complex pow + a [.,17]x[17,36] matmul + exp).  One lane per
 // direction, output row [Re(all terms) | Im(all terms)].
 #include "sh_core.hip.h"
+#include "rowio.hip.h"
 
 using namespace envidr;
 
-template <int DEG_VIEW>
-__global__ void __launch_bounds__(kBlock) k_ide_forward(const float* __restrict__ dirs,
-                                                        const float* __restrict__ roughness, float roughness_scalar,
-                                                        uint32_t B, float* __restrict__ outputs) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+// One lane per direction, one wave per workgroup; the wave's 64 x 2N tile of outputs leaves through LDS as 16-byte stores
+// (rowio.hip.h): written from the lanes, each of the 2N store instructions would touch 64 different cache lines.
+template <int DEG_VIEW, bool ALIGNED>
+__global__ void __launch_bounds__(64) k_ide_forward(const float* __restrict__ dirs, const float* __restrict__ roughness, float roughness_scalar,
+                                                    uint32_t B, float* __restrict__ outputs) {
     constexpr int N = ide_terms(DEG_VIEW);
+    __shared__ float s_tile[wave_tile_floats<2 * N>()];
+    const uint32_t lane = threadIdx.x, row0 = blockIdx.x * 64u;
+    const uint32_t b = min(row0 + lane, B - 1);
     const float kinv = roughness ? roughness[b] : roughness_scalar;
-    float* o = outputs + (size_t)b * 2 * N;
+    float v[2 * N];
     ide_eval<DEG_VIEW>(dirs[3 * (size_t)b], dirs[3 * (size_t)b + 1], dirs[3 * (size_t)b + 2], kinv,
-                       [&](int j, float re, float im) { o[j] = re; o[N + j] = im; });
+                       [&](int j, float re, float im) { v[j] = re; v[N + j] = im; });
+    wave_store_rows<2 * N, ALIGNED>(s_tile, v, outputs + (size_t)row0 * 2 * N, min(64u, B - row0), lane);
 }
 
 extern "C" int envidr_ide_encode_forward(const float* dirs, const float* roughness_ptr, float roughness_scalar, uint32_t B,
@@ -24,15 +28,16 @@ extern "C" int envidr_ide_encode_forward(const float* dirs, const float* roughne
                    "ide_encode_forward: deg_view must be in [1, 5] (the reference raises ValueError above 5)");
     if (B == 0) return ENVIDR_OK;
     ENVIDR_REQUIRE(dirs && outputs, "ide_encode_forward: null pointer");
-    const dim3 grid(ceil_div(B, kBlock)), block(kBlock);
+    const dim3 grid(ceil_div(B, 64)), block(64);
     hipStream_t s = as_stream(stream);
-    switch (deg_view) {
-        case 1: hipLaunchKernelGGL(k_ide_forward<1>, grid, block, 0, s, dirs, roughness_ptr, roughness_scalar, B, outputs); break;
-        case 2: hipLaunchKernelGGL(k_ide_forward<2>, grid, block, 0, s, dirs, roughness_ptr, roughness_scalar, B, outputs); break;
-        case 3: hipLaunchKernelGGL(k_ide_forward<3>, grid, block, 0, s, dirs, roughness_ptr, roughness_scalar, B, outputs); break;
-        case 4: hipLaunchKernelGGL(k_ide_forward<4>, grid, block, 0, s, dirs, roughness_ptr, roughness_scalar, B, outputs); break;
-        case 5: hipLaunchKernelGGL(k_ide_forward<5>, grid, block, 0, s, dirs, roughness_ptr, roughness_scalar, B, outputs); break;
-    }
+    const bool al = aligned16(outputs);
+#define ENVIDR_IDE(DEG)                                                                                                             \
+    case DEG:                                                                                                                       \
+        if (al) hipLaunchKernelGGL((k_ide_forward<DEG, true>), grid, block, 0, s, dirs, roughness_ptr, roughness_scalar, B, outputs); \
+        else hipLaunchKernelGGL((k_ide_forward<DEG, false>), grid, block, 0, s, dirs, roughness_ptr, roughness_scalar, B, outputs);   \
+        break;
+    switch (deg_view) { ENVIDR_IDE(1) ENVIDR_IDE(2) ENVIDR_IDE(3) ENVIDR_IDE(4) ENVIDR_IDE(5) }
+#undef ENVIDR_IDE
     return check_launch("k_ide_forward");
 }
 

@@ -68,17 +68,22 @@ __device__ __forceinline__ double sgpr_f64() {
     asm volatile("s_mov_b32 %0, %1" : "=s"(hi) : "n"((int)(uint32_t)(BITS >> 32)));
     return __hiloint2double((int)hi, (int)lo);
 }
-template <int IDX>
-__device__ __forceinline__ double ide_coef() { return sgpr_f64<__builtin_bit_cast(uint64_t, kIdeCoef[IDX])>(); }
+// PIN: the asm form above (the fused kernels, where the call sits inside loops); without it a plain constant -- in the
+// standalone operator there is no loop to hoist out of and many waves per SIMD, which the pinned scalar moves only slow down
+template <int IDX, bool PIN>
+__device__ __forceinline__ double ide_coef() {
+    if constexpr (PIN) return sgpr_f64<__builtin_bit_cast(uint64_t, kIdeCoef[IDX])>();
+    else return kIdeCoef[IDX];
+}
 // P(z) = sum_k coef[START + k] z^(D - 2k) as a sum of (scalar coefficient) x (power of z) fused multiply-adds.  The
 // coefficient is a MULTIPLICAND on purpose: as the addend of a Horner step a scalar operand has to be copied into the vector
 // register the fused multiply-add accumulates in (two v_mov per coefficient).
-template <int START, int K, int CNT, int D, int LMAX>
+template <int START, int K, int CNT, int D, int LMAX, bool PIN>
 __device__ __forceinline__ double ide_poly(const double p, const double (&zp)[LMAX + 1]) {
     if constexpr (K < CNT) {
         constexpr int n = D - 2 * K;
-        if constexpr (n == 0) return ide_poly<START, K + 1, CNT, D, LMAX>(__builtin_fma(ide_coef<START + K>(), 1.0, p), zp);
-        else return ide_poly<START, K + 1, CNT, D, LMAX>(__builtin_fma(ide_coef<START + K>(), zp[n], p), zp);
+        if constexpr (n == 0) return ide_poly<START, K + 1, CNT, D, LMAX, PIN>(__builtin_fma(ide_coef<START + K, PIN>(), 1.0, p), zp);
+        else return ide_poly<START, K + 1, CNT, D, LMAX, PIN>(__builtin_fma(ide_coef<START + K, PIN>(), zp[n], p), zp);
     } else return p;
 }
 // (x + i y)^m for m = 0..M-1 in fp64, two multiplies + two fused multiply-adds per power
@@ -92,28 +97,28 @@ __device__ __forceinline__ void complex_powers_f64(double x, double y, double (&
         im[m] = __builtin_fma(re[m - 1], y, im[m - 1] * x);
     }
 }
-template <int I, int M, int LMAX, typename Emit>
+template <int I, int M, int LMAX, bool PIN, typename Emit>
 __device__ __forceinline__ void ide_term(const double (&re)[LMAX + 1], const double (&im)[LMAX + 1], const double (&zp)[LMAX + 1], const float att,
                                          Emit&& emit) {
     constexpr int l = 1 << I, j = l - 1 + I + M, start = kIdeStart[j], cnt = kIdeCount[j], d = l - M;
     static_assert(cnt == d / 2 + 1, "IDE table: a polynomial of degree l - m with parity");
     if constexpr (d == 0) {
-        emit(j, (float)(re[M] * ide_coef<start>()) * att, (float)(im[M] * ide_coef<start>()) * att);
+        emit(j, (float)(re[M] * ide_coef<start, PIN>()) * att, (float)(im[M] * ide_coef<start, PIN>()) * att);
     } else {
-        const double p = ide_poly<start, 1, cnt, d, LMAX>(ide_coef<start>() * zp[d], zp);
+        const double p = ide_poly<start, 1, cnt, d, LMAX, PIN>(ide_coef<start, PIN>() * zp[d], zp);
         emit(j, (float)(re[M] * p) * att, (float)(im[M] * p) * att);
     }
 }
-template <int I, int LMAX, typename Emit>
+template <int I, int LMAX, bool PIN, typename Emit>
 __device__ __forceinline__ void ide_level(const double (&re)[LMAX + 1], const double (&im)[LMAX + 1], const double (&zp)[LMAX + 1],
                                           const float kappa_inv, Emit&& emit) {
     constexpr int l = 1 << I;
     const float att = expf(-(0.5f * (float)(l * (l + 1))) * kappa_inv);
     [&]<int... M>(std::integer_sequence<int, M...>) {
-        (ide_term<I, M, LMAX>(re, im, zp, att, emit), ...);
+        (ide_term<I, M, LMAX, PIN>(re, im, zp, att, emit), ...);
     }(std::make_integer_sequence<int, l + 1>{});
 }
-template <int DEG_VIEW, typename Emit>
+template <int DEG_VIEW, bool PIN = false, typename Emit>
 __device__ __forceinline__ void ide_eval(float xf, float yf, float zf, float kappa_inv, Emit&& emit) {
     constexpr int LMAX = 1 << (DEG_VIEW - 1);
     double x = xf, y = yf;
@@ -126,7 +131,7 @@ __device__ __forceinline__ void ide_eval(float xf, float yf, float zf, float kap
 #pragma unroll
     for (int n = 2; n <= LMAX; ++n) zp[n] = (n & 1) ? zp[n - 1] * z : zp[n / 2] * zp[n / 2];
     [&]<int... I>(std::integer_sequence<int, I...>) {
-        (ide_level<I, LMAX>(re, im, zp, kappa_inv, emit), ...);
+        (ide_level<I, LMAX, PIN>(re, im, zp, kappa_inv, emit), ...);
     }(std::make_integer_sequence<int, DEG_VIEW>{});
 }
 

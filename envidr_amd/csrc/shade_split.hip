@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(kSplitThreads, 1) k_env_split(const ShadeArgs 
         float f[16 * S1];
 #pragma unroll
         for (int k = 2 * TERMS; k < 16 * S1; ++k) f[k] = 0.0f;
-        ide_eval<IDE_DEG>(enc ? wr[0] : nenv[0], enc ? wr[1] : nenv[1], enc ? wr[2] : nenv[2], enc ? rough : a.kappa_diffuse,
+        ide_eval<IDE_DEG, true>(enc ? wr[0] : nenv[0], enc ? wr[1] : nenv[1], enc ? wr[2] : nenv[2], enc ? rough : a.kappa_diffuse,
                           [&](int j, float re, float im) {
                               f[j] = re * a.light_scale;
                               f[TERMS + j] = im * a.light_scale;

@@ -77,6 +77,11 @@ VARIANTS = {
                                       "            for (int r_ = 0; r_ < 16; ++r_) o[r_] = in[r_] + in[r_ + 16];\n")]),
     "shade_noheads": ("fused_render", [("fused_render.hip", "            pipe_layer_from_lanes<kDSteps, 1, kHeadD1, kHeadN>(wp, lane, in_d, d1);\n            pipe_layer16_from_tiles<1, kHeadD2, kHeadN, true>(wp, lane, d1, d2);\n            pipe_layer_from_lanes<kSSteps, 2, kHeadS1, kHeadN>(wp, lane, in_s, s1);\n            pipe_layer_from_tiles<2, 2, kHeadS2, kHeadN, true>(wp, lane, s1, s2);\n            pipe_layer16_from_tiles<2, kHeadS3, kHeadN, true>(wp, lane, s2, s3);\n            wp.template end_pass<kHeadFrags>();\n",
                                         "            for (int r_ = 0; r_ < 16; ++r_) { d2[r_] = in_d[r_ % kDSteps]; s3[r_] = in_s[r_ % kSSteps]; }\n")]),
+    "shade_noload": ("fused_render", [
+        ("fused_render.hip", "        const size_t gi = a.slot ? (size_t)a.slot[i] : i;          // where this record's geometry lives\n        float nrm[3], vd[3], geo[12];\n        const size_t ray = a.ray_ids ? (size_t)a.ray_ids[i] : 0;\n",
+         "        const size_t gi = i;\n        float nrm[3], vd[3], geo[12];\n        const size_t ray = 0;\n"),
+        ("fused_render.hip", "        for (int d = 0; d < 3; ++d) { nrm[d] = on ? a.normals[3 * gi + d] : 0.0f; vd[d] = on ? dir[d] : 0.0f; }\n#pragma unroll\n        for (int j = 0; j < 12; ++j) geo[j] = a.geo_feat[(size_t)a.geo_stride * gi + j];\n        const float rough = a.roughness[(size_t)a.rough_stride * gi];\n",
+         "        for (int d = 0; d < 3; ++d) { nrm[d] = 0.577f + 1e-9f * (float)(gi + d); vd[d] = -0.577f + 1e-9f * (float)(gi & 255); }\n#pragma unroll\n        for (int j = 0; j < 12; ++j) geo[j] = 0.288f + 1e-9f * (float)(gi + j);\n        const float rough = 0.1f + 1e-9f * (float)(gi & 1023); (void)dir;\n")]),
     # ablations / parameters of k_env_split (timing only where marked: results are wrong)
     "split_base": ("shade_split", []),
     "split_nodma": ("shade_split", [("mlp_split.hip.h", "            if constexpr (c == kSplitMeetAt + 1) dma_piece<0>();\n            if constexpr (c == kSplitMeetAt + 3) dma_piece<1>();\n", "")]),       # timing only

@@ -27,7 +27,8 @@ def bench(name, fn, bytes_, reps=10, note=""):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     rows.append((name, ms, bytes_, note))
-    print(f"{name:44s} {ms:8.3f} ms   {bytes_ / 1e6:9.1f} MB   {bytes_ / ms / 1e6:8.1f} GB/s  ({100 * bytes_ / ms / 1e6 / 8000:4.1f} % of 8 TB/s)  {note}")
+    print(f"{name:44s} {ms:8.3f} ms   {bytes_ / 1e6:9.1f} MB   {bytes_ / ms / 1e6:8.1f} GB/s  ({100 * bytes_ / ms / 1e6 / 8000:4.1f} % of 8 TB/s, "
+          f"{100 * bytes_ / ms / 1e6 / 6300:4.1f} % of the 6.3 TB/s a copy reaches)  {note}")
 
 nears, fars = torch.empty(N, device=dev), torch.empty(N, device=dev)
 bench("near_far_from_aabb (640 k rays)", lambda: _lib.call("near_far_from_aabb", ro, rd, aabb, N, 0.2, nears, fars), N * 32)
@@ -69,14 +70,20 @@ sig = torch.rand(Mc, device=dev) * 50; rgb = torch.rand(Mc, 3, device=dev)
 al = torch.arange(N, dtype=torch.int32, device=dev); rt = torch.zeros(N, device=dev)
 dl = torch.full((Mc, 2), 0.0034, device=dev)
 ws, dp, im = torch.zeros(N, device=dev), torch.zeros(N, device=dev), torch.zeros(N, 3, device=dev)
-def comp():
-    al.copy_(torch.arange(N, dtype=torch.int32, device=dev))          # the compositor tombstones finished rays (-1): restore the list
-    _lib.call("composite_rays", N, n_step, 1e-4, 1, 0, al, rt, sig, rgb, dl, ws, dp, im)
-bench("composite_rays (640 k rays x 8 samples)", comp, N * (n_step * 24 + 8 + 40), note="incl. a 2.6 MB list refill per call")
+als = [torch.arange(N, dtype=torch.int32, device=dev) for _ in range(12)]      # the compositor tombstones finished rays (-1): a fresh list per call
+it = iter(als)
+bench("composite_rays (640 k rays x 8 samples)", lambda: _lib.call("composite_rays", N, n_step, 1e-4, 1, 0, next(it), rt, sig, rgb, dl, ws, dp, im),
+      N * (n_step * 24 + 8 + 40))
+g27 = torch.randn(M, 27, device=dev); gi3 = torch.zeros(M, 3, device=dev)
+bench("freq_encode_backward (7.7 M, degree 4)", lambda: _lib.call("freq_encode_backward", g27, o27, M, 3, 4, 27, gi3), M * (108 + 108 + 12))
+dy48 = torch.empty(M, 48, device=dev)
+bench("sh_encode_forward (7.7 M, degree 4, + dy_dx)", lambda: _lib.call("sh_encode_forward", d, o16, M, 3, 4, dy48), M * (12 + 64 + 192))
+g16 = torch.randn(M, 16, device=dev)
+bench("sh_encode_backward (7.7 M, degree 4)", lambda: _lib.call("sh_encode_backward", g16, d, M, 3, 4, dy48, gi3), M * (64 + 192 + 24))
 grid = torch.rand(128 ** 3, device=dev); bits = torch.zeros(128 ** 3 // 8, dtype=torch.uint8, device=dev)
 bench("packbits (128^3 cells)", lambda: _lib.call("packbits", grid, 128 ** 3 // 8, 0.01, bits), 128 ** 3 * 4 + 128 ** 3 // 8, note="N counts bytes of the bitfield, like the reference")
 print()
-print("| operator | ms | algorithmic MB | GB/s | of 8 TB/s |")
-print("|---|---|---|---|---|")
+print("| operator | ms | algorithmic MB | GB/s | of 8 TB/s (HBM roofline) | of the 6.3 TB/s a copy reaches |")
+print("|---|---|---|---|---|---|")
 for name, ms, b, note in rows:
-    print(f"| {name} | {ms:.3f} | {b / 1e6:.0f} | {b / ms / 1e6:.0f} | {100 * b / ms / 1e6 / 8000:.1f} % |")
+    print(f"| {name} | {ms:.3f} | {b / 1e6:.0f} | {b / ms / 1e6:.0f} | {100 * b / ms / 1e6 / 8000:.1f} % | {100 * b / ms / 1e6 / 6300:.1f} % |")
