@@ -7,12 +7,14 @@
 // XCD's L2, so the random 8-byte gathers of that level stay L2-resident on the XCD that owns it
 // instead of every XCD thrashing all 16 tables.
 #include "grid_core.hip.h"
+#include <algorithm>
 
 using namespace envidr;
 
 namespace {
 
 constexpr uint32_t kXcds = 8;
+__host__ __device__ constexpr uint32_t ceil_div_u(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 // block -> (level, chunk) such that blocks resident on one XCD (block % 8) sweep one level after
 // another.  Returns false for padding blocks.
@@ -266,6 +268,214 @@ __global__ void __launch_bounds__(kBlock) k_second_backward_table(const float* _
 }
 
 // ------------------------------------------------------------------------------------------
+// Table gradients of LARGE batches: range-owned accumulation in LDS.
+//
+// Global fp32 atomics run at ~20 G/s on this chip whatever their addresses and however many XCDs issue them (measured:
+// 6.2 ms per level and 7.7 M points, linear in the number of levels although every level runs on its own XCD) -- 2 x 10^9 of
+// them are the 98 ms of the scatter kernels above.  A level's table has far fewer rows (<= 2^19) than a large batch has
+// contributions (8 B), so the sums are formed in LDS instead: a workgroup OWNS a range of kLdsRows rows of one level (128 KiB
+// of accumulators), walks the points, recomputes every point's corner rows and adds those that fall into its range with LDS
+// atomics; at the end the range is flushed with one global atomic per non-zero entry.  The index arithmetic is redone by the
+// (up to 32) range owners of a level; the 32 CUs of an XCD take the 32 ranges of one level at the same time and stream the
+// same points, so the inputs come out of that XCD's L2.  Point ranges are split into `parts` to even out the rounds.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kLdsScatterThreads = 1024;
+constexpr uint32_t kLdsScatterFloats = 32768;          // 128 KiB of accumulators per workgroup
+constexpr uint32_t kLdsScatterSlots = 32;              // range slots per (level, part) group = CUs per XCD
+constexpr uint32_t kLdsAhead = 4;                      // points per lane whose loads are in flight together
+
+// Work distribution.  The launch is 256 persistent workgroups: 8 XCDs x 32 slots (blockIdx % 8 is the XCD).  In step n the 32
+// slots of XCD x take "super-group" 8 n + x together.  A super-group belongs to one level and holds k = 32 / ranges groups of
+// `ranges` slots each (ranges = row ranges of the level, at most 32 per pass); a group is one part of the level's points, its
+// slots that part's row ranges -- so the slots of a group stream the same points at the same time (out of their XCD's L2), and
+// a level with few ranges (the dense ones: 1, 1, 2, 5, 13) still keeps ~kLdsBlocksPerLevel workgroups busy instead of doing all
+// its LDS atomics on a handful (level 0 on three workgroups took 51 ms).  The plan is recomputed from `offsets` by every
+// workgroup (scalar work; the sizes live on the device).
+constexpr uint32_t kLdsBlocksPerLevel = 96;
+struct LevelPlan { uint32_t ranges, per_sg, parts, sgs; };
+__device__ __forceinline__ LevelPlan level_plan(uint32_t size, uint32_t rows_per_range) {
+    LevelPlan p;
+    p.ranges = min(kLdsScatterSlots, max(1u, ceil_div_u(size, rows_per_range)));
+    p.per_sg = kLdsScatterSlots / p.ranges;
+    p.parts = ceil_div_u(ceil_div_u(kLdsBlocksPerLevel, p.ranges), p.per_sg) * p.per_sg;
+    p.sgs = p.parts / p.per_sg;
+    return p;
+}
+
+template <int D, int C, bool SECOND>
+__global__ void __launch_bounds__(kLdsScatterThreads) k_table_scatter_lds(const float* __restrict__ grad, const float* __restrict__ inputs,
+                                                                          const int32_t* __restrict__ offsets, const float* __restrict__ ggx,
+                                                                          float* __restrict__ grad_table, uint32_t B, uint32_t L, LevelScale ls) {
+    constexpr uint32_t kRows = kLdsScatterFloats / C;
+    __shared__ float s_acc[kLdsScatterFloats];
+    // block -> (group, range slot): the blocks of one XCD (blockIdx % 8) take the 32 ranges of one group at a time
+    const uint32_t xcd = blockIdx.x % kXcds, slot = (blockIdx.x / kXcds) % kLdsScatterSlots;
+  for (uint32_t step = 0;; ++step) {
+    const uint32_t sg = step * kXcds + xcd;
+    uint32_t level = 0, first = 0;
+    LevelPlan plan = {};
+    for (; level < L; ++level) {
+        plan = level_plan((uint32_t)(offsets[level + 1] - offsets[level]), kRows);
+        if (sg < first + plan.sgs) break;
+        first += plan.sgs;
+    }
+    if (level >= L) break;                                   // past the last super-group (uniform over the workgroup)
+    const uint32_t sub = slot / plan.ranges;
+    if (sub >= plan.per_sg) continue;                        // 32 is not a multiple of this level's range count: a spare slot
+    const uint32_t parts = plan.parts, part = (sg - first) * plan.per_sg + sub, first_range = slot - sub * plan.ranges;
+    const uint32_t row0 = (uint32_t)offsets[level];
+    const uint32_t size = (uint32_t)offsets[level + 1] - row0;
+    const uint32_t ranges = ceil_div_u(size, kRows);
+    // a level with more than 32 ranges (a table beyond 2^19 x 2 floats per level) wraps around: a slot owns ranges r, r + 32, ...
+    const LevelGeom<D> g = make_level_geom<D>(size, ls.resolution[level], true);
+    const float scale = ls.scale[level];
+    const uint32_t p0 = (uint32_t)(((unsigned long long)B * part) / parts), p1 = (uint32_t)(((unsigned long long)B * (part + 1)) / parts);
+    for (uint32_t range = first_range; range < ranges; range += kLdsScatterSlots) {
+        const uint32_t base = range * kRows;
+        for (uint32_t i = threadIdx.x; i < kLdsScatterFloats; i += kLdsScatterThreads) s_acc[i] = 0.0f;
+        __syncthreads();
+        // kLdsAhead points per lane and iteration, every load issued before the first is used: with four waves per SIMD and
+        // nothing else to switch to, one point per iteration ran at the latency of its loads (53 ms for 7.7 M points)
+        for (uint32_t b0 = p0; b0 < p1; b0 += kLdsScatterThreads * kLdsAhead) {
+            float xs[kLdsAhead][D], gs[kLdsAhead][C], ggs[kLdsAhead][D];
+            bool ons[kLdsAhead];
+#pragma unroll
+            for (uint32_t u = 0; u < kLdsAhead; ++u) {
+                const uint32_t bu = b0 + u * kLdsScatterThreads + threadIdx.x;
+                const uint32_t b = min(bu, p1 - 1);
+                ons[u] = bu < p1;
+#pragma unroll
+                for (int d = 0; d < D; ++d) xs[u][d] = inputs[(size_t)b * D + d];
+#pragma unroll
+                for (int c = 0; c < C; ++c) gs[u][c] = grad[((size_t)level * B + b) * C + c];
+                if constexpr (SECOND) {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) ggs[u][d] = ggx[(size_t)b * D + d];
+                }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kLdsAhead; ++u) {
+                float x[D];
+                bool on = ons[u];
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    x[d] = xs[u][d];
+                    if (x[d] < 0 || x[d] > 1) on = false;           // outside the cube: nothing to add
+                }
+                if (!on) {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) x[d] = 0.5f;
+                }
+                float w1[D], dw[D];
+                uint32_t cell[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    float p = x[d] * scale;
+                    cell[d] = (uint32_t)floorf(p);
+                    p -= (float)cell[d];
+                    dw[d] = 6 * p * (1.0f - p);
+                    w1[d] = p * p * (3.0f - 2.0f * p);
+                }
+                uint32_t local[1 << D];
+                bool mine = false;
+#pragma unroll
+                for (int i = 0; i < (1 << D); ++i) {
+                    uint32_t q[D];
+#pragma unroll
+                    for (int d = 0; d < D; ++d) q[d] = cell[d] + ((i >> d) & 1);
+                    local[i] = cell_row<D>(g, q) - base;
+                    mine |= on && local[i] < kRows;
+                }
+                if (!__ballot(mine)) continue;          // nothing of this wave's 64 points lands in the range
+                float gcur[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) gcur[c] = on ? gs[u][c] : 0.0f;
+                float corner[1 << D][C];
+                if constexpr (SECOND) {
+                    // +/- w * grad * ggx[gd] * smoothstep'(frac_gd) on the corner pairs along gd (k_second_backward_table's statements)
+                    float gg[D];
+#pragma unroll
+                    for (int d = 0; d < D; ++d) gg[d] = on ? ggs[u][d] : 0.0f;
+#pragma unroll
+                    for (int i = 0; i < (1 << D); ++i)
+#pragma unroll
+                        for (int c = 0; c < C; ++c) corner[i][c] = 0;
+#pragma unroll
+                    for (int gd = 0; gd < D; ++gd) {
+#pragma unroll
+                        for (int jj = 0; jj < (1 << (D - 1)); ++jj) {
+                            float w = scale;
+                            int lo = 0;
+#pragma unroll
+                            for (int nd = 0; nd < D - 1; ++nd) {
+                                const int d = nd >= gd ? nd + 1 : nd;
+                                const int bit = (jj >> nd) & 1;
+                                w *= bit ? w1[d] : 1 - w1[d];
+                                lo |= bit << d;
+                            }
+                            const int hi = lo | (1 << gd);
+#pragma unroll
+                            for (int c = 0; c < C; ++c) {
+                                const float v = w * gcur[c] * gg[gd] * dw[gd];
+                                corner[hi][c] += v;
+                                corner[lo][c] -= v;
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < (1 << D); ++i) {
+                        float w = 1;
+#pragma unroll
+                        for (int d = 0; d < D; ++d) w *= ((i >> d) & 1) ? w1[d] : 1 - w1[d];
+#pragma unroll
+                        for (int c = 0; c < C; ++c) corner[i][c] = w * gcur[c];
+                    }
+                }
+                // A range owns 1/32 of a hashed level's rows, so per wave ~16 of the 512 (lane, corner) pairs are in range: one
+                // predicated LDS atomic per corner would issue 8 C instructions with ~2 active lanes each (a returnless fp32 LDS
+                // atomic costs ~40 cycles of the CU's LDS pipe however few lanes take part).  Instead every lane picks ITS next
+                // in-range corner and the wave issues one atomic per channel and round; two rounds cover almost every wave.
+                uint32_t pending = 0;
+#pragma unroll
+                for (int i = 0; i < (1 << D); ++i) pending |= (on && local[i] < kRows) ? (1u << i) : 0u;
+                while (__ballot(pending != 0)) {
+                    const int pick = pending ? __ffs((int)pending) - 1 : 0;
+                    uint32_t at = local[0];
+                    float v[C];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) v[c] = corner[0][c];
+#pragma unroll
+                    for (int i = 1; i < (1 << D); ++i) {
+                        if (pick == i) {
+                            at = local[i];
+#pragma unroll
+                            for (int c = 0; c < C; ++c) v[c] = corner[i][c];
+                        }
+                    }
+                    if (pending) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) __hip_atomic_fetch_add(&s_acc[at * C + c], v[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        pending &= pending - 1;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        float* t = grad_table + ((size_t)row0 + base) * C;
+        const uint32_t valid = min(kRows, size - base) * C;
+        for (uint32_t i = threadIdx.x; i < valid; i += kLdsScatterThreads) {
+            const float v = s_acc[i];
+            if (v != 0.0f) unsafeAtomicAdd(&t[i], v);
+        }
+        __syncthreads();
+    }
+  }
+}
+
+constexpr uint32_t kLdsScatterMinPoints = 1u << 19;    // below this the per-point atomics (combined inside the wave) are faster
+
+// ------------------------------------------------------------------------------------------
 // dispatch helpers
 // ------------------------------------------------------------------------------------------
 template <typename F>
@@ -318,7 +528,12 @@ int envidr_hash_encode_backward(const float* grad, const float* inputs, const fl
     const uint32_t chunks = ceil_div(B, kBlock);
     return dispatch_dc(D, C, "hash_encode_backward", [&](auto d, auto c) {
         constexpr int DD = decltype(d)::value, CC = decltype(c)::value;
-        if (grad_embeddings) {
+        if (grad_embeddings && B >= kLdsScatterMinPoints) {
+            hipLaunchKernelGGL((k_table_scatter_lds<DD, CC, false>), dim3(kXcds * kLdsScatterSlots), dim3(kLdsScatterThreads), 0,
+                               as_stream(stream), grad, inputs, offsets, (const float*)nullptr, grad_embeddings, B, L, ls);
+            const int rc = check_launch("k_table_scatter_lds");
+            if (rc) return rc;
+        } else if (grad_embeddings) {
             hipLaunchKernelGGL((k_hash_backward_table<DD, CC>), dim3(xcd_grid_blocks(L, chunks)), dim3(kBlock), 0,
                                as_stream(stream), grad, inputs, offsets, grad_embeddings, B, L, ls, chunks);
             const int rc = check_launch("k_hash_backward_table");
@@ -352,6 +567,11 @@ int envidr_hash_encode_second_backward(const float* grad, const float* inputs, c
                            grad_grad_inputs, dy_dx, grad_grad, B, L);
         int rc = check_launch("k_second_backward_grad");
         if (rc) return rc;
+        if (B >= kLdsScatterMinPoints) {
+            hipLaunchKernelGGL((k_table_scatter_lds<DD, CC, true>), dim3(kXcds * kLdsScatterSlots), dim3(kLdsScatterThreads), 0,
+                               as_stream(stream), grad, inputs, offsets, grad_grad_inputs, grad2_embeddings, B, L, ls);
+            return check_launch("k_table_scatter_lds");
+        }
         hipLaunchKernelGGL((k_second_backward_table<DD, CC>), dim3(xcd_grid_blocks(L, chunks)), dim3(kBlock), 0,
                            as_stream(stream), grad, inputs, offsets, grad_grad_inputs, grad2_embeddings, B, L, ls,
                            chunks);
