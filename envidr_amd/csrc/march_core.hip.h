@@ -6,7 +6,7 @@
 // scene cube, pick the cascade level, truncate to a voxel, test one bit of the Morton-ordered
 // bitfield, then either emit a sample and advance by dt or hop to the voxel's exit face.
 //
-// Bit-exactness contract (tests/test_raymarching_gpu.py): every float op below is a single IEEE
+// Bit-exactness contract (tests/test_ops_gpu.py): every float op below is a single IEEE
 // fp32 (or, where the reference's expression promotes, fp64) operation in the reference's order;
 // this TU is built with -ffp-contract=off and HIP's correctly rounded fp32 division.
 #pragma once

@@ -133,3 +133,91 @@ def test_operators_bit_exact_at_full_size():
     grid = np.random.default_rng(0).uniform(-1, 30, size=cells).astype(np.float32)
     args = ("packbits", grid, cells // 8, 10.0, np.zeros(cells // 8, np.uint8))
     assert np.array_equal(run_op("hip", *args)[-1], run_op("oracle", *args)[-1])
+
+
+# ---- BASELINE configs[1] and [3] at 800 x 800: the same size-independent properties as for the toaster network ----------------
+KEYS7 = ("image", "depth", "weights_sum", "normal_image", "diffuse_image", "specular_image", "roughness_image")
+
+
+def _shard_reassembly(render, ro, rd, full_image):
+    """the frame as 8 interleaved tile shards (the strong-scaling decomposition of parallel.tile_shard) == the whole frame"""
+    import torch
+    parts = [render(ro[idx], rd[idx])["image"].clone() for idx in (parallel.tile_shard(H, W, rank, 8).cuda() for rank in range(8))]
+    torch.cuda.synchronize()
+    assert torch.equal(parallel.assemble_frame(parts, H, W), full_image)
+
+
+def test_configs1_no_env_network_at_full_size():
+    """configs[1] (hash-grid SDF + diffuse / specular heads on SH encodings, no environment MLP) through the frame pipeline bench.py
+    runs: invariants, permutation / subset / tile-shard independence bit for bit, and 5 000 rays against the operator loop"""
+    import torch
+    from envidr_amd.fused import FusedOptions, FusedRenderer
+    from envidr_amd.nerf.network import NeRFNetwork
+    scene = scenes.lego_scene()
+    r = FusedRenderer.from_scene(scene, FusedOptions(dir_sh_degree=4))
+    ro, rd = (torch.from_numpy(a).cuda() for a in scenes.camera_rays(H, W))
+    res = {k: v.clone() for k, v in r.render_frame(ro, rd, None, out={}, image_width=W).items() if torch.is_tensor(v)}
+    for k in KEYS7:
+        assert torch.isfinite(res[k]).all(), k
+    ws = res["weights_sum"]
+    miss = ws == 0
+    assert 0.3 < float(miss.float().mean()) < 0.8 and torch.all(res["image"][miss] == 1.0)
+    assert float(ws.max()) <= 1 + 1e-6 and 3_000_000 < int(r._frame["last"][1]) < 20_000_000
+    g = torch.Generator().manual_seed(4)
+    perm = torch.randperm(N, generator=g).cuda()
+    out = r.render_frame(ro[perm], rd[perm], None, out={})
+    for k in KEYS7:
+        assert torch.equal(out[k], res[k][perm]), f"permutation: {k}"
+    sub = perm[:5003]
+    out = r.render_frame(ro[sub], rd[sub], None, out={})
+    for k in KEYS7:
+        assert torch.equal(out[k], res[k][sub]), f"subset: {k}"
+    _shard_reassembly(lambda o, d: r.render_frame(o, d, None, out={}), ro, rd, res["image"])
+    # 5 000 rays through the reference-shaped operator loop
+    from envidr_amd.nerf.options import toaster_options
+    from tests.test_dropin_gpu import LEGO
+    opt = toaster_options(**LEGO)
+    model = NeRFNetwork.from_scene(scene, opt)
+    idx = perm[:5000]
+    loop = model.render(ro[idx][None], rd[idx][None], staged=True, bg_color=1, perturb=False, get_normal_image=False, env_rot_radian=None,
+                        fused=False, max_steps=opt.max_steps, T_thresh=opt.T_thresh, dt_gamma=opt.dt_gamma)
+    torch.cuda.synchronize()
+    for k in ("image", "depth", "weights_sum", "diffuse_image", "specular_image"):
+        a, b = loop[k].reshape(5000, -1).cpu().numpy(), res[k][idx].reshape(5000, -1).cpu().numpy()
+        assert rel_l2(a, b) <= 2e-5, f"{k}: {rel_l2(a, b):.3e}"
+
+
+def test_configs3_indirect_three_pass_at_full_size():
+    """configs[3] (use_renv + indir_ref on the concave torus scene) through NeRFRenderer.render: the masked three-pass form at
+    800 x 800 -- invariants, tile-shard reassembly bit for bit, and 5 000 rays against the reference-shaped form (boolean-mask
+    gathers + operator loop)"""
+    import torch
+    from envidr_amd.nerf.network import NeRFNetwork
+    from envidr_amd.nerf.options import toaster_options
+    opt = toaster_options(indir_ref=True)
+    model = NeRFNetwork.from_scene(scenes.toaster_scene(shape=scenes.torus(), seed=3), opt)
+    ro, rd = (torch.from_numpy(a).cuda() for a in scenes.camera_rays(H, W))
+    kw = dict(staged=True, bg_color=1, perturb=False, get_normal_image=True, env_rot_radian=0.4, max_steps=opt.max_steps, T_thresh=opt.T_thresh,
+              dt_gamma=opt.dt_gamma, early_stop_steps=-1)
+
+    def render(o, d, **more):
+        out = model.render(o[None], d[None], fused=True, **kw, **more)
+        return {k: v.reshape(o.shape[0], -1).squeeze(-1).clone() for k, v in out.items() if torch.is_tensor(v)}
+    res = render(ro, rd, image_width=W)
+    torch.cuda.synchronize()
+    for k in KEYS7:
+        assert torch.isfinite(res[k]).all(), k
+    ws = res["weights_sum"]
+    assert 0.2 < float((ws > 0.3).float().mean()) < 0.9 and float(ws.max()) <= 1 + 1e-6
+    assert torch.all(res["image"][ws == 0] == 1.0)
+    _shard_reassembly(lambda o, d: render(o, d), ro, rd, res["image"].reshape(N, 3))
+    g = torch.Generator().manual_seed(6)
+    idx = torch.randperm(N, generator=g)[:5000].cuda()
+    sub = render(ro[idx], rd[idx])
+    for k in KEYS7:
+        assert torch.equal(sub[k], res[k][idx]), f"subset: {k}"
+    loop = model.render(ro[idx][None], rd[idx][None], fused=False, **kw)
+    torch.cuda.synchronize()
+    for k in ("image", "depth", "weights_sum", "diffuse_image", "specular_image"):
+        a, b = loop[k].reshape(5000, -1).cpu().numpy(), res[k][idx].reshape(5000, -1).cpu().numpy()
+        assert rel_l2(a, b) <= 5e-5, f"{k}: {rel_l2(a, b):.3e}"
