@@ -397,9 +397,13 @@ def run(argv: list[str]) -> None:
             "metric": "rendered rays/s at 800x800, 1024 max samples/ray", "value": rays_per_s, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]/[4] network (toaster.ini: hash L16xC2 + SDF 32-64-64-15 + IDE deg5 + env MLP "
-                                   "72-256-256-256-12 x2 + diffuse/specular heads) on a synthetic shell scene, 800x800 view per "
-                                   + ("step, sharded by 8x8-pixel tiles" if strong else "GPU per step, env-rotation video frames sharded by view")
+            # (the first ~120 characters carry what a truncated record must still show: the scene's samples per ray -- rays/s scales
+            #  inversely with it -- and whether the frames had the previous frame's per-ray counts as a hint)
+            "config": {"workload": f"toaster.ini network 800x800, {samples / max(N, 1):.2f} samples/ray (thin synthetic shell), "
+                                   + ("COLD frames (no per-ray hint); " if args.cold else "HINTED frames (fixed camera: exact per-ray counts); ")
+                                   + "BASELINE configs[2]/[4]: hash L16xC2 + SDF 32-64-64-15 + IDE deg5 + env MLP "
+                                   "72-256-256-256-12 x2 + diffuse/specular heads, one view per "
+                                   + ("step sharded by 8x8-pixel tiles" if strong else "GPU per step, env-rotation video frames sharded by view")
                                    + ", normal/diffuse/specular/roughness images on",
                        "rays_per_step_per_gpu": N, "samples_per_frame": samples, "samples_evaluated_per_frame": evaluated,
                        "samples_per_ray": samples / max(N, 1), "max_steps": 1024, "T_thresh": 1e-4, "parallelism": par,
@@ -599,7 +603,7 @@ def other_configs(result, dev, rays_o, rays_d, N) -> None:
     plain.check_frames()
     psamples = int(plain._frame["last"][1])
     oc["configs[1] hash-grid SDF + diffuse/specular MLPs (SH view dir, no env MLP), 800x800, 1 GPU"] = {
-        "rays_per_s": N / pdt, "ms_per_frame": pdt * 1e3, "samples_per_s": psamples / pdt, "samples_per_frame": psamples,
+        "rays_per_s": N / pdt, "ms_per_frame": pdt * 1e3, "samples_per_s": psamples / pdt, "samples_per_frame": psamples, "samples_per_ray": psamples / N,
         "roofline": _both_rooflines(psamples, pdt, FLOP_PER_SAMPLE_PLAIN)}
     # the headline frames through the single persistent kernel (envidr_render_rays)
     one = FusedRenderer.from_scene(scenes.toaster_scene(), device=dev)
@@ -619,7 +623,7 @@ def other_configs(result, dev, rays_o, rays_d, N) -> None:
     relight.check_frames()
     rs = int(relight._frame["last"][1])
     oc["configs[2] relight variant: IDE deg 4 + env MLP 38-160-160-160-12 x2 (shape of the shipped env nets), 800x800, 1 GPU"] = {
-        "rays_per_s": N / rdt, "ms_per_frame": rdt * 1e3, "samples_per_frame": rs, "roofline": _both_rooflines(rs, rdt, FLOP_PER_SAMPLE_RELIGHT)}
+        "rays_per_s": N / rdt, "ms_per_frame": rdt * 1e3, "samples_per_frame": rs, "samples_per_ray": rs / N, "roofline": _both_rooflines(rs, rdt, FLOP_PER_SAMPLE_RELIGHT)}
     # BASELINE configs[4] with the geometry cache (NOT the headline): fixed camera, rotating environment
     headline = FusedRenderer.from_scene(scenes.toaster_scene(), device=dev)
     torch.cuda.synchronize(dev)
@@ -630,7 +634,8 @@ def other_configs(result, dev, rays_o, rays_d, N) -> None:
     cout: dict = {}
     cdt = _time(lambda: headline.render_cached(cache, 0.1, out=cout), 5, dev)
     oc["configs[4] env-rotation video of a FIXED camera with the geometry cache (bit-identical frames), 800x800, 1 GPU"] = {
-        "rays_per_s": N / cdt, "ms_per_frame": cdt * 1e3, "cache_build_ms": build_ms, "cached_samples": cache.n_samples}
+        "rays_per_s": N / cdt, "ms_per_frame": cdt * 1e3, "cache_build_ms": build_ms, "cached_samples": cache.n_samples,
+        "samples_per_ray": cache.n_samples / N}
     # split-precision shading mode (env MLP on the fp16 matrix cores with (hi, lo) operand pairs, heads fp32): reported here
     # only, NEVER the headline (whose dtype is f32 throughout); error measured against the fp32 frame of the same view
     ref = {k_: v.clone() for k_, v in headline.render_frame(rays_o, rays_d, 0.1, out={}).items() if k_ in ("image", "specular_image")}
@@ -665,6 +670,9 @@ def other_configs(result, dev, rays_o, rays_d, N) -> None:
     ddt = _time(lambda: direct.render(rays_o[None], rays_d[None], **ikw), 3, dev)
     oc["configs[3] toaster network + use_renv + indir_ref (3 passes per frame), torus scene, 800x800, 1 GPU"] = {
         "primary_rays_per_s": N / idt, "ms_per_frame": idt * 1e3, "direct_frame_of_the_same_scene_ms": ddt * 1e3, "ratio_to_direct": idt / ddt,
+        "samples_per_primary_ray": ilog.get("indirect-geometry", [0, 0])[1] / N,
+        "passes": "geometry of the primary rays (march + SDF network) -> reflected rays (a full frame of their own) -> main pass = shading + "
+                  "composite of the FIRST pass's records with the reflected radiance (same rays, same samples: not marched or evaluated again)",
         "samples_evaluated_and_records_per_pass": {t: v[:2] for t, v in ilog.items()},
         "roofline": {"hbm": {"achieved": isamples * HASH_BYTES_PER_SAMPLE / idt / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                              "frac": isamples * HASH_BYTES_PER_SAMPLE / idt / 1e9 / PEAK_HBM_GBPS},

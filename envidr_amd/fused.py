@@ -643,11 +643,13 @@ class FusedRenderer:
             raise _lib.EnvidrError(f"envidr_geometry_probe failed ({rc}): {self.lib.envidr_last_error().decode()}")
         return out
 
-    def _frame_buffers(self, N: int, dev, samples_per_ray: float) -> dict:
+    def _frame_buffers(self, N: int, dev, samples_per_ray: float, buffers: str = "") -> dict:
         """workspace, record arrays, per-ray count hint and status words of the frames with N rays (a few ray counts are
-        kept: the three passes of indirect rendering alternate between theirs)"""
+        kept: the three passes of indirect rendering alternate between theirs).  `buffers` names a separate set for the same N:
+        the reflected pass of an indirect frame must not overwrite the primary rays' records, which the main pass shades again."""
         frames = self.__dict__.setdefault("_frames", {})
-        st = frames.get(N)
+        key = (N, buffers) if buffers else N
+        st = frames.get(key)
         cap = max(int(N * samples_per_ray), 4096)
         cap = min(cap, N * int(self.desc.max_steps) + 4096)          # a ray never marches more than max_steps samples
         # trim: buffers more than twice the PEAK any frame of this ray count has needed so far (evaluated samples or records,
@@ -663,12 +665,12 @@ class FusedRenderer:
             st["slack"] = st.get("slack", 0) + 1 if st["cap"] > 2 * need else 0
             if st["slack"] >= 64:
                 carry = (st["costs"], st["peak"])
-                frames.pop(N)
+                frames.pop(key)
                 st, cap = None, need
                 # the growth hint of an earlier overflow decays with the buffers it grew: what these rays need is now known
                 self.__dict__.get("_frame_hints", {}).pop(N, None)
         if st is None or st["cap"] < cap:
-            if st is None and len(frames) >= 4:
+            if st is None and len(frames) >= 6:
                 frames.pop(next(iter(frames)))
             need = int(self.lib.envidr_geometry_workspace_bytes(N, cap))
             try:
@@ -687,7 +689,7 @@ class FusedRenderer:
                                        "rays per call (opt.max_ray_batch_cuda)") from e
             if carry is not None:
                 st["costs"], st["peak"] = carry
-            frames[N] = st
+            frames[key] = st
         self.__dict__["_frame"] = st
         return st
 
@@ -698,7 +700,8 @@ class FusedRenderer:
         has finished, so that the host can enqueue a frame ahead of the device) at the start of every frame, and with
         block=True by anyone who needs the answer now."""
         overflowed = None
-        for N, st in list(self.__dict__.get("_frames", {}).items()):
+        for key, st in list(self.__dict__.get("_frames", {}).items()):
+            N = st["N"]
             if not st["pending"]:
                 continue
             if not block and not st["event"].query():
@@ -715,7 +718,7 @@ class FusedRenderer:
                 # (the device stops counting where a frame stops fitting, so the need is only known to exceed what was seen: grow
                 #  geometrically; a ray never has more than max_steps samples, which bounds the search)
                 self.__dict__.setdefault("_frame_hints", {})[N] = max(4.0 * st["cap"] / N, 1.5 * max(samples, records) / N)
-                del self.__dict__["_frames"][N]
+                del self.__dict__["_frames"][key]
                 overflowed = st["cap"]
         if overflowed is not None:
             raise FrameOverflow(f"a frame needed more than the {overflowed} sample / record slots it was given; its buffers were dropped, render it again")
@@ -723,7 +726,8 @@ class FusedRenderer:
     def render_frame(self, rays_o: torch.Tensor, rays_d: torch.Tensor, env_rot_radian: float | None = None, out: dict | None = None,
                      samples_per_ray_hint: float = 20.0, events: list | None = None, geometry_only: bool = False, wait: bool = True,
                      use_cost_hint: bool = True, r_images: torch.Tensor | None = None, ray_mask: torch.Tensor | None = None,
-                     tag: str = "", env_precision: str | None = None, image_width: int = 0) -> dict:
+                     tag: str = "", env_precision: str | None = None, image_width: int = 0, buffers: str = "",
+                     reuse_geometry: dict | None = None) -> dict:
         """One frame as: geometry pipeline (envidr_geometry_pass: march rounds + per-sample hash grid / SDF network, one record
         per composited sample) -> shading of the records (k_shade_samples) -> per-ray composite.  Both network families
         (environment MLP; SH heads without one); `r_images` [N,4] (reflected radiance + visibility per ray) selects the
@@ -736,7 +740,11 @@ class FusedRenderer:
         `events`: four torch.cuda.Event(enable_timing=True) recorded at the pass boundaries (geometry | shading | composite).
         `env_precision`: "fp32" / "f16x2" for this frame (default: FusedOptions.env_precision).
         `image_width`: the rays are the pixels of a row-major image this wide (layout hint: blocks of 64 rays are then 8x8-pixel
-        tiles; same outputs, bit for bit; ignored unless width and height are multiples of 8)."""
+        tiles; same outputs, bit for bit; ignored unless width and height are multiples of 8).
+        `buffers`: name of the buffer set (default: one per N).
+        `reuse_geometry`: the result of the previous render_frame of THESE rays in THIS buffer set (a geometry_only frame): its
+        records are shaded and composited again -- no marching, no hash grid, no SDF network; `ray_mask` then zeroes the
+        masked-out rays' outputs.  Main pass of indirect rendering: same rays, same samples as the first pass."""
         self.check_frames(block=False)
         if not (rays_o.is_cuda and rays_d.is_cuda):
             raise _lib.EnvidrError("render_frame: rays_o / rays_d must be CUDA tensors (envidr_amd has no CPU path)")      # the reference's CHECK_CUDA
@@ -757,8 +765,15 @@ class FusedRenderer:
                 for e in events:
                     e.record()
             return res
+        if reuse_geometry is not None:
+            st = self.__dict__.get("_frames", {}).get((N, buffers) if buffers else N)
+            if (geometry_only or st is None or st.get("records_of") != (rays_o.data_ptr(), rays_d.data_ptr(), N)
+                    or reuse_geometry.get("_records_serial") != st.get("records_serial")):
+                reuse_geometry = None                      # not the frame these buffers hold: render from scratch
+        if reuse_geometry is not None:
+            return self._reshade_records(st, reuse_geometry, rays_d, N, dev, env_rot_radian, res, events, r_images, ray_mask, env_precision, tag)
         for attempt in range(8):          # capacities 20, 80, 320, 1280 ... samples per ray: max_steps (<= 65535) is reached within eight
-            st = self._frame_buffers(N, dev, max(samples_per_ray_hint, self.__dict__.get("_frame_hints", {}).get(N, 0.0)))
+            st = self._frame_buffers(N, dev, max(samples_per_ray_hint, self.__dict__.get("_frame_hints", {}).get(N, 0.0)), buffers)
             cap = st["cap"]
             stream = torch.cuda.current_stream(dev).cuda_stream
             for name, shape in (("depth", (N,)), ("weights_sum", (N,)), ("normal_image", (N, 3)), ("roughness_image", (N,))):
@@ -834,6 +849,10 @@ class FusedRenderer:
             if self.__dict__.get("frame_log") is not None:       # measurement hook: (samples evaluated, records, overflow) per tag, on the device
                 self.frame_log[tag] = st["stats"].clone()
             res["ray_cost"] = st["cost"]
+            # what these buffers hold now (reuse_geometry asks for exactly this frame's records)
+            st["records_of"] = (rays_o.data_ptr(), rays_d.data_ptr(), N)
+            st["records_serial"] = res["_records_serial"] = st.get("records_serial", 0) + 1
+            st["records_cost"], st["records_ex"] = st["cost"], ex       # (envidr_geometry_pass filled in where the per-sample arrays live)
             if not wait:
                 return res
             try:
@@ -844,6 +863,61 @@ class FusedRenderer:
             res["n_samples"] = st["last"][0]
             return res
         raise _lib.EnvidrError("render_frame: the frame did not fit its buffers after seven enlargements")
+
+    def _reshade_records(self, st, prev, rays_d, N, dev, env_rot_radian, res, events, r_images, ray_mask, env_precision, tag) -> dict:
+        """shading + composite over the records a geometry frame left in `st` (render_frame's reuse_geometry): the per-ray outputs
+        of that frame are taken over (masked), every record is shaded with this call's environment / reflected radiance"""
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        ev = events
+        if ev: ev[0].record()
+        keep = None
+        if ray_mask is not None:
+            keep = ray_mask.reshape(-1).to(torch.float32)
+            if keep.shape[0] != N or not keep.is_cuda:
+                raise _lib.EnvidrError("render_frame: ray_mask must be [N] on the GPU")
+        for name in ("depth", "weights_sum", "roughness_image"):
+            res[name] = prev[name] if keep is None else prev[name] * keep
+        res["normal_image"] = prev["normal_image"] if keep is None else prev["normal_image"] * keep[:, None]
+        if ev: ev[1].record()
+        ex = st["records_ex"]
+        _set_env_rotation(self.desc, env_rot_radian)
+        self.desc.geometry_only, self.desc.r_images, self.desc.geometry_export = 0, None, None
+        if r_images is not None:
+            if not self.desc.renv_blob:
+                raise _lib.EnvidrError("render_frame: r_images given but the model has no renv MLP")
+            r_images = r_images.contiguous().view(-1, 4).float()
+            if r_images.shape[0] != N or not r_images.is_cuda:
+                raise _lib.EnvidrError("render_frame: r_images must be [N,4] on the GPU")
+            self.desc.r_images = r_images.data_ptr()
+        self._set_precision("fp32" if r_images is not None or self._env_layers is None else env_precision, st["cap"])
+        rc = self.lib.envidr_shade_records(ctypes.byref(self.desc), ctypes.byref(ex), rays_d.data_ptr(), st["cd"].data_ptr(), st["cs"].data_ptr(), stream)
+        self.desc.r_images = None
+        self._set_precision("fp32", 0)
+        if rc:
+            raise _lib.EnvidrError(f"envidr_shade_records failed ({rc}): {self.lib.envidr_last_error().decode()}")
+        if ev: ev[2].record()
+        torch.cumsum(st["records_cost"], 0, dtype=torch.int32, out=st["offsets"][1:])
+        for name in ("image", "diffuse_image", "specular_image"):
+            if name not in res or res[name].shape != (N, 3):
+                res[name] = torch.empty(N, 3, device=dev)
+        # (composited with the UNMASKED weights: a masked-out ray's pixel is then replaced below, everybody else's is what a
+        #  from-scratch frame with this mask computes, bit for bit)
+        rc = self.lib.envidr_composite_records(ctypes.byref(ex), st["offsets"].data_ptr(), st["perm"].data_ptr(), st["cd"].data_ptr(),
+                                               st["cs"].data_ptr(), prev["weights_sum"].data_ptr(), N, float(self.desc.intensity_scale),
+                                               float(self.desc.bg_color), res["image"].data_ptr(), res["diffuse_image"].data_ptr(),
+                                               res["specular_image"].data_ptr(), stream)
+        if rc:
+            raise _lib.EnvidrError(f"envidr_composite_records failed ({rc}): {self.lib.envidr_last_error().decode()}")
+        if keep is not None:
+            k3 = keep[:, None]
+            res["image"] = res["image"] * k3 + (1 - k3) * float(self.desc.bg_color)
+            res["diffuse_image"] = res["diffuse_image"] * k3
+            res["specular_image"] = res["specular_image"] * k3
+        if ev: ev[3].record()
+        if self.__dict__.get("frame_log") is not None:       # (samples evaluated: none; records shaded: the geometry frame's; overflow: its)
+            self.frame_log[tag] = st["stats"] * torch.tensor([0, 1, 1], dtype=st["stats"].dtype, device=dev)
+        res["ray_cost"] = st["records_cost"]
+        return res
 
     def render_cached(self, cache: GeometryCache, env_rot_radian: float | None = None, out: dict | None = None) -> dict:
         """re-light a cached frame: envidr_shade_samples over its samples + envidr_composite_shaded; bit-identical to

@@ -146,7 +146,7 @@ def _run_cuda_train(self, rays_o, rays_d, prefix, dt_gamma, bg_color, perturb, f
 def run_cuda(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024,
              T_thresh=1e-4, get_normal_image=False, use_specular_color=True, early_stop_steps=-1, ray_depth=None,
              main_pass=True, r_images=None, geometry_only=False, grad_ray=False, bg_sphere=True, env_rot_radian=None,
-             fused=True, two_phase=None, ray_mask=None, frame_tag="", wait=True, **kwargs):
+             fused=True, two_phase=None, ray_mask=None, frame_tag="", wait=True, frame_buffers="", reuse_geometry=None, **kwargs):
     self = model
     prefix = rays_o.shape[:-1]
     rays_o = rays_o.contiguous().view(-1, 3)
@@ -196,7 +196,7 @@ def run_cuda(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, fo
                 # lets the pipeline form its blocks from 8x8-pixel tiles (same outputs)
                 res = fr.render_frame(rays_o, rays_d, env_rot_radian, geometry_only=geometry_only,
                                       r_images=None if r_images is None else r_images[0], ray_mask=ray_mask, tag=frame_tag, wait=wait,
-                                      image_width=int(kwargs.get("image_width", 0) or 0))
+                                      image_width=int(kwargs.get("image_width", 0) or 0), buffers=frame_buffers, reuse_geometry=reuse_geometry)
             else:
                 if ray_mask is not None:
                     raise NotImplementedError("ray_mask is a feature of the geometry pipeline (two_phase)")
@@ -217,6 +217,7 @@ def run_cuda(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, fo
         if geometry_only:
             out["image"] = None
             out["normal_image"] = res["normal_image"].view(*prefix, 3)
+            out["_frame"] = res            # the raw frame: render_frame(reuse_geometry=...) shades its records again (indirect main pass)
             return out
         if get_normal_image:
             out["normal_image"] = res["normal_image"].view(*prefix, 3)

@@ -308,7 +308,7 @@ class NeRFRenderer(nn.Module):
         dt = 2 * SQRT3 / self.opt.indir_max_steps
         kwargs = dict(kwargs, wait=False)
         geo = self._run(rays_o, rays_d, get_normal_image=get_normal_image, main_pass=False, geometry_only=True,
-                        env_rot_radian=env_rot_radian, fused=True, frame_tag="indirect-geometry", **kwargs)
+                        env_rot_radian=env_rot_radian, fused=True, frame_tag="indirect-geometry", frame_buffers="indirect-primary", **kwargs)
         normals = geo["normal_image"]                       # [1,N,3]
         depth = geo["depth"] - dt                           # [1,N]
         ws = geo["weights_sum"]
@@ -335,9 +335,15 @@ class NeRFRenderer(nn.Module):
         # masked_scatter, renderer.py:483-486)
         r_images = torch.cat([ref["image"], ref["weights_sum"][..., None]], -1) * ref_mask[..., None]
         kw3 = dict(kwargs, bg_color=0)
+        # The main pass marches the same rays with the same parameters as the first: same samples, same compositing weights.  The
+        # first pass's records are still in their buffer set (the reflected pass has its own), so the main pass only shades and
+        # composites them again -- with the reflected radiance this time -- instead of marching and evaluating the SDF network a
+        # second time; ray_mask zeroes the rays the reference would not have gathered (renderer.py:490-492).  (Chunked renders
+        # -- max_ray_batch_cuda -- do not take this form: _render_indirect sends them through the gather path.)
         res = self._run(rays_o, rays_d, get_normal_image=get_normal_image, use_specular_color=use_specular_color,
                         env_net_index=env_net_index, main_pass=True, r_images=r_images, bg_sphere=False, env_rot_radian=env_rot_radian,
-                        fused=True, ray_mask=ray_mask, frame_tag="indirect-main", **kw3)
+                        fused=True, ray_mask=ray_mask, frame_tag="indirect-main", frame_buffers="indirect-primary",
+                        reuse_geometry=geo.get("_frame"), **kw3)
         res["normal_image"] = normals
         res["depth"] = depth
         for k in ("specular_image", "diffuse_image", "roughness_image"):

@@ -12,9 +12,9 @@ if [ "$2" != "quick" ]; then
 fi
 timeout 1500 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" >> $OUT/bench.err
 # kernel trace + stats of the same command (CPU leg skipped: it launches no kernels)
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --headline-only > $OUT/trace.log 2>&1 )
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --headline-only > $OUT/trace.log 2>&1 )
 # the same for COLD frames (no per-ray hint): kernel trace + stats
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cold -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --headline-only --cold > $OUT/trace_cold.log 2>&1 )
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cold -o trace -- python $GRAFT_REPO_ROOT/bench.py --headline-only --cold > $OUT/trace_cold.log 2>&1 )
 # the multi-GPU code path on this one GPU (RCCL world of one) and the strong-scaling mode
 timeout 600 python bench.py --headline-only --force-dist > $OUT/bench_force_dist.json 2> $OUT/bench_force_dist.err
 timeout 600 python bench.py --headline-only --force-dist --scaling strong > $OUT/bench_strong.json 2> $OUT/bench_strong.err
