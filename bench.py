@@ -647,6 +647,21 @@ def other_configs(result, dev, rays_o, rays_d, N) -> None:
     oc["headline workload in the optional split-precision shading mode (env MLP: fp16 MFMA on (hi, lo) pairs; NOT f32, not comparable to value), 800x800, 1 GPU"] = {
         "rays_per_s": N / sdt, "ms_per_frame": sdt * 1e3, "dtype": "f16x2 pairs (env MLP) + f32 (everything else)",
         "rel_l2_vs_f32_frame": srel, "parity_tests": "tests/test_split_gpu.py: <= 1e-4 rel-L2 vs the reference's chains and frames"}
+    # A "trained-like" scene (sharp Laplace density, beta = 1e-3; sdf mostly positive in front of the surface): most
+    # samples inside the occupancy shell then have alpha = 1 - exp(-sigma dt) == 0 EXACTLY in fp32.  The reference shades them all;
+    # the pipeline composites them (they are records) but gathers only the records with a non-zero weight for shading.
+    tl_scene = scenes.toaster_scene(beta=1e-3, sdf_bias=0.065)
+    tl = {}
+    for skip in (True, False):
+        fr_tl = FusedRenderer.from_scene(tl_scene, FusedOptions(skip_zero_weight=skip), device=dev)
+        tout: dict = {}
+        tdt = _time(lambda: fr_tl.render_frame(rays_o, rays_d, 0.2, out=tout, wait=False, image_width=W), 5, dev)
+        fr_tl.check_frames()
+        tl[skip] = (tdt, int(fr_tl._frame["last"][1]), int(fr_tl._frame["shade_list"][0].item()) if skip else None, tout["image"].clone())
+    oc["trained-like scene (beta 1e-3: exact-zero compositing weights), toaster network, 800x800, 1 GPU"] = {
+        "rays_per_s": N / tl[True][0], "ms_per_frame": tl[True][0] * 1e3, "samples_per_ray": tl[True][1] / N, "records": tl[True][1],
+        "records_shaded": tl[True][2], "ms_per_frame_shading_every_record": tl[False][0] * 1e3,
+        "frames_identical": bool(torch.equal(tl[True][3], tl[False][3]))}
     # BASELINE configs[3]: use_renv + indir_ref, three passes per frame through the NeRFRenderer.render() drop-in surface
     from envidr_amd.nerf.network import NeRFNetwork
     from envidr_amd.nerf.options import toaster_options

@@ -208,6 +208,8 @@ struct ShadeArgs {
     const float* rays_d;
     const uint32_t* m_dev;
     const uint32_t* slot;       // record mode, optional: normals / geo_feat / roughness of record i live at index slot[i]
+    const uint32_t* list;       // record mode, optional: the records to shade (the i-th shaded record is list[i]; m_dev counts the list)
+    const uint32_t* m_all;      // with list: the number of records; when the list holds them all it is the identity and is not read
     // reflected-radiance branch (record mode): per-ray (rgb, visibility), the learnt blend logit per sample, the two extra blobs
     const float* r_images; const float* blend; const float* renv_blob; const float* spec2_blob;
     float rough_scale, indir_rough_thresh;

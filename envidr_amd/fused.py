@@ -24,7 +24,8 @@ _FP = ctypes.c_void_p
 class GeometryExport(ctypes.Structure):
     """mirror of `envidr_geometry_export`"""
     _fields_ = [("counter", _FP), ("capacity", ctypes.c_uint32), ("ray", _FP), ("idx", _FP), ("w", _FP), ("normal", _FP),
-                ("geo_feat", _FP), ("roughness", _FP), ("slot", _FP), ("blend", _FP), ("image_width", ctypes.c_uint32)]
+                ("geo_feat", _FP), ("roughness", _FP), ("slot", _FP), ("blend", _FP), ("image_width", ctypes.c_uint32),
+                ("shade_list", _FP)]
 
 
 class SamplesOut(ctypes.Structure):
@@ -88,6 +89,9 @@ class FusedOptions:
     # arithmetic of the environment MLP: "fp32" (default, what every headline number uses) or "f16x2" -- fp16 matrix cores
     # with every operand carried as a (hi, lo) fp16 pair, fp32 accumulation (csrc/mlp_split.hip.h); the heads stay fp32
     env_precision: str = "fp32"
+    # records whose compositing weight alpha * T is exactly 0 in fp32 are not shaded (they contribute w * c = 0 whatever c is; the
+    # reference shades them all): nothing on the synthetic benchmark scene, most of the samples of a trained scene (beta ~ 1e-3)
+    skip_zero_weight: bool = True
     # per-sample geometry kernel: "32" = k_geo_eval32 (32 samples per wave, two waves per SIMD: the default, and the faster),
     # "16" = k_geo_eval16 (16-column MFMAs, three waves per SIMD; kept as a measured alternative, csrc/geo_eval16.hip.h)
     geometry_kernel: str = "32"
@@ -678,6 +682,7 @@ class FusedRenderer:
                           ray=torch.empty(cap, dtype=torch.int32, device=dev), idx=torch.empty(cap, dtype=torch.int32, device=dev),
                           w=torch.empty(cap, device=dev), slot=torch.empty(cap, dtype=torch.int32, device=dev),
                           perm=torch.empty(cap, dtype=torch.int32, device=dev), cd=torch.empty(cap, 3, device=dev), cs=torch.empty(cap, 3, device=dev),
+                          shade_list=torch.empty(cap + cap // 1024 + 3, dtype=torch.int32, device=dev),
                           cost=torch.zeros(N, dtype=torch.int16, device=dev), costs={}, offsets=torch.zeros(N + 1, dtype=torch.int32, device=dev),
                           stats=torch.zeros(3, dtype=torch.int64, device=dev), worst=torch.zeros(3, dtype=torch.int64, device=dev),
                           host=torch.zeros(6, dtype=torch.int64).pin_memory(),
@@ -785,6 +790,8 @@ class FusedRenderer:
             o.stats = st["stats"].data_ptr()
             ex = GeometryExport(st["counter"].data_ptr(), cap, st["ray"].data_ptr(), st["idx"].data_ptr(), st["w"].data_ptr(), None, None, None,
                                 st["slot"].data_ptr(), None)
+            if self.opt.skip_zero_weight:          # records whose compositing weight is exactly 0 are not shaded (same outputs)
+                ex.shade_list = st["shade_list"].data_ptr()
             if tag not in st["costs"]:
                 st["costs"][tag] = torch.zeros(N, dtype=torch.int16, device=dev)
             st["cost"] = st["costs"][tag]

@@ -84,6 +84,12 @@ typedef struct envidr_geometry_export {
     /* ABI 6: set by envidr_geometry_pass when it laid its blocks out as 8x8-pixel tiles (desc.image_width), else 0; lets
      * envidr_composite_records walk the rays in the same order, so that a wave's records are again one contiguous run */
     uint32_t image_width;
+    /* ABI 7, optional scratch: device uint32 [capacity + capacity / 1024 + 3], or NULL.  With it envidr_shade_records first gathers the
+     * records whose compositing weight is NOT exactly zero (shade_list[0] = their number, shade_list[1..] = their indices, ascending) and shades
+     * only those; envidr_composite_records skips zero-weight records (w * c = 0 whatever c is).  On a trained scene (beta ~ 1e-3)
+     * most samples inside the occupancy shell have alpha = 1 - exp(-sigma * dt) == 0 exactly in fp32; the reference shades them
+     * all.  Outputs are unchanged bit for bit.  Ignored by the split-precision mode. */
+    uint32_t* shade_list;
 } envidr_geometry_export;
 
 /* ---- scene / model description ---------------------------------------------------------------- */
