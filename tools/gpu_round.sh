@@ -26,6 +26,9 @@ for pr in mfma_f16_fill_probe mfma_f32_fill_probe mfma_vmem_probe cross_wave_pro
 timeout 300 python tools/geo/shard_probe.py 1 2 4 8 16 > $OUT/shard_probe.txt 2>&1
 # the standalone operators at headline-like sizes
 PYTHONUNBUFFERED=1 timeout 300 python tools/ops_bench.py > $OUT/ops_bench.txt 2>&1
+# the reference-shaped operator loop on the headline frame, and one training step
+timeout 300 python tools/loop_frame_bench.py > $OUT/loop_frame_bench.txt 2>&1
+timeout 300 python tools/train_step_bench.py > $OUT/train_step_bench.txt 2>&1
 # every operator case group re-generated with other seeds, HIP against oracle
 timeout 900 python tools/fuzz_ops.py 1 8 > $OUT/fuzz_ops.txt 2>&1
 # randomised differential run of the two frame implementations
@@ -78,7 +81,7 @@ tail -3 $OUT/pytest_gpu.log $OUT/smoke.log 2>/dev/null; cat $OUT/bench.json | cu
 # what gets committed under profiles/<tag>/
 P=$OUT/profile; mkdir -p $P
 cp $OUT/bench.json $OUT/summary.json $P/ 2>/dev/null
-cp $OUT/bench_force_dist.json $OUT/bench_strong.json $OUT/bench_torchrun.json $OUT/gather_probe.txt $OUT/mfma_f16_fill_probe.txt $OUT/mfma_f32_fill_probe.txt $OUT/mfma_vmem_probe.txt $OUT/cross_wave_probe.txt $OUT/shard_probe.txt $OUT/fuzz_frames.txt $OUT/fuzz_ops.txt $OUT/ops_bench.txt $P/ 2>/dev/null
+cp $OUT/bench_force_dist.json $OUT/bench_strong.json $OUT/bench_torchrun.json $OUT/gather_probe.txt $OUT/mfma_f16_fill_probe.txt $OUT/mfma_f32_fill_probe.txt $OUT/mfma_vmem_probe.txt $OUT/cross_wave_probe.txt $OUT/shard_probe.txt $OUT/fuzz_frames.txt $OUT/fuzz_ops.txt $OUT/ops_bench.txt $OUT/loop_frame_bench.txt $OUT/train_step_bench.txt $P/ 2>/dev/null
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $P/kernel_stats.csv \;
 find $OUT/trace_cold -name "*kernel_stats.csv" -exec cp {} $P/kernel_stats_cold.csv \;
 for d in $OUT/pmc_*/; do n=$(basename $d); find $d -name "*counter_collection.csv" -exec cp {} $P/$n.csv \; ; done
