@@ -14,6 +14,7 @@ using namespace envidr;
 namespace {
 
 constexpr uint32_t kXcds = 8;
+__device__ constexpr uint32_t kCellPrimes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};   // grid_core.hip.h cell_row()
 __host__ __device__ constexpr uint32_t ceil_div_u(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 // block -> (level, chunk) such that blocks resident on one XCD (block % 8) sweep one level after
@@ -282,7 +283,7 @@ __global__ void __launch_bounds__(kBlock) k_second_backward_table(const float* _
 constexpr uint32_t kLdsScatterThreads = 1024;
 constexpr uint32_t kLdsScatterFloats = 32768;          // 128 KiB of accumulators per workgroup
 constexpr uint32_t kLdsScatterSlots = 32;              // range slots per (level, part) group = CUs per XCD
-constexpr uint32_t kLdsAhead = 4;                      // points per lane whose loads are in flight together
+constexpr uint32_t kLdsAhead = 8;                      // points per lane whose loads are in flight together
 
 // Work distribution.  The launch is 256 persistent workgroups: 8 XCDs x 32 slots (blockIdx % 8 is the XCD).  In step n the 32
 // slots of XCD x take "super-group" 8 n + x together.  A super-group belongs to one level and holds k = 32 / ranges groups of
@@ -376,14 +377,26 @@ __global__ void __launch_bounds__(kLdsScatterThreads) k_table_scatter_lds(const 
                     dw[d] = 6 * p * (1.0f - p);
                     w1[d] = p * p * (3.0f - 2.0f * p);
                 }
+                // rows of the 2^D corners: cell_row()'s arithmetic with the per-dimension products formed once -- (c + 1) * m is
+                // c * m + m in uint32 arithmetic -- instead of D multiplies per corner (quarter-rate instructions: 16 of them were a
+                // third of the range owners' index work)
+                uint32_t term[D][2];
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const uint32_t m = g.hashed ? kCellPrimes[d] : g.stride[d];
+                    term[d][0] = cell[d] * m;
+                    term[d][1] = term[d][0] + m;
+                }
                 uint32_t local[1 << D];
                 bool mine = false;
 #pragma unroll
                 for (int i = 0; i < (1 << D); ++i) {
-                    uint32_t q[D];
+                    uint32_t idx = 0;
 #pragma unroll
-                    for (int d = 0; d < D; ++d) q[d] = cell[d] + ((i >> d) & 1);
-                    local[i] = cell_row<D>(g, q) - base;
+                    for (int d = 0; d < D; ++d) idx = g.hashed ? (idx ^ term[d][(i >> d) & 1]) : (idx + term[d][(i >> d) & 1]);
+                    if (g.pow2) idx &= g.size - 1;
+                    else if (idx >= g.size) idx %= g.size;          // dense levels: only the cube's far faces reach past the last row
+                    local[i] = idx - base;
                     mine |= on && local[i] < kRows;
                 }
                 if (!__ballot(mine)) continue;          // nothing of this wave's 64 points lands in the range
@@ -422,16 +435,7 @@ __global__ void __launch_bounds__(kLdsScatterThreads) k_table_scatter_lds(const 
                             }
                         }
                     }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < (1 << D); ++i) {
-                        float w = 1;
-#pragma unroll
-                        for (int d = 0; d < D; ++d) w *= ((i >> d) & 1) ? w1[d] : 1 - w1[d];
-#pragma unroll
-                        for (int c = 0; c < C; ++c) corner[i][c] = w * gcur[c];
-                    }
-                }
+                }          // (first order: the picked corner's value is formed in the loop below -- ~0.25 corners per point are in range)
                 // A range owns 1/32 of a hashed level's rows, so per wave ~16 of the 512 (lane, corner) pairs are in range: one
                 // predicated LDS atomic per corner would issue 8 C instructions with ~2 active lanes each (a returnless fp32 LDS
                 // atomic costs ~40 cycles of the CU's LDS pipe however few lanes take part).  Instead every lane picks ITS next
@@ -443,15 +447,33 @@ __global__ void __launch_bounds__(kLdsScatterThreads) k_table_scatter_lds(const 
                     const int pick = pending ? __ffs((int)pending) - 1 : 0;
                     uint32_t at = local[0];
                     float v[C];
+                    if constexpr (SECOND) {
 #pragma unroll
-                    for (int c = 0; c < C; ++c) v[c] = corner[0][c];
+                        for (int c = 0; c < C; ++c) v[c] = corner[0][c];
 #pragma unroll
-                    for (int i = 1; i < (1 << D); ++i) {
-                        if (pick == i) {
-                            at = local[i];
+                        for (int i = 1; i < (1 << D); ++i) {
+                            if (pick == i) {
+                                at = local[i];
 #pragma unroll
-                            for (int c = 0; c < C; ++c) v[c] = corner[i][c];
+                                for (int c = 0; c < C; ++c) v[c] = corner[i][c];
+                            }
                         }
+                    } else {
+                        // the picked corner's row and weight from its bits: D selects each, instead of 2^D-way select chains
+                        uint32_t idx = 0;
+                        float w = 1;
+#pragma unroll
+                        for (int d = 0; d < D; ++d) {
+                            const bool bit = (pick >> d) & 1;
+                            const uint32_t t = bit ? term[d][1] : term[d][0];
+                            idx = g.hashed ? (idx ^ t) : (idx + t);
+                            w *= bit ? w1[d] : 1 - w1[d];
+                        }
+                        if (g.pow2) idx &= g.size - 1;
+                        else if (idx >= g.size) idx %= g.size;
+                        at = idx - base;
+#pragma unroll
+                        for (int c = 0; c < C; ++c) v[c] = w * gcur[c];
                     }
                     if (pending) {
 #pragma unroll
