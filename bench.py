@@ -572,6 +572,17 @@ def context_legs(result, renderer, dev, steps: int, N: int) -> None:
     result["moving_camera"] = dict(leg(moving, True, 2),
                                    note="camera orbit advanced 2 degrees per frame; envidr_get_rays inside the timed region; the per-ray hint is "
                                         "the previous pose's sample counts (wrong for rays near silhouettes: extra rounds / zero-filled slots)")
+    # rays/s scales inversely with the scene's samples per ray, and the headline shell is thin (12 per ray).  The same network, camera
+    # and pipeline on the density SURVEY.md 8(d) proposed (mean sdf slightly positive inside the shell: ~28 samples per ray at the
+    # same 37 % hit rate): the portable figure is samples/s, which should not move.
+    from envidr_amd.fused import FusedRenderer
+    headline_renderer = renderer
+    renderer = FusedRenderer.from_scene(scenes.toaster_scene(sdf_bias=0.065), device=dev)
+    thick = leg(lambda i: fixed, True, 2)
+    renderer = headline_renderer
+    result["survey_density_scene"] = dict(thick, samples_per_ray=thick["samples_composited_per_frame"] / N,
+                                          samples_per_s=thick["samples_composited_per_frame"] / (thick["ms_per_frame"] * 1e-3),
+                                          note="toaster_scene(sdf_bias=0.065): the density of SURVEY.md 8(d) (~28 samples per ray), hinted frames like the headline")
 
 
 def _time(fn, reps: int, dev) -> float:

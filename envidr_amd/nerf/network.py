@@ -54,11 +54,15 @@ def _run_mlp(net, h):
 
 
 def _feat_act(x, kind):
+    """geo_feat_act / env_feat_act (reference nerf/network.py:432-440, 538-546, 597-605, 646-654); any other name leaves the
+    features as they are, as the reference's if / elif chains do"""
     if kind == "unitNorm":
         return F.normalize(x, dim=-1)
     if kind == "tanh":
         return torch.tanh(x)
-    raise NotImplementedError(f"feature activation {kind!r}")
+    if kind == "instanceNorm":
+        return (x - x.mean(dim=-1, keepdim=True)) / torch.sqrt(x.var(dim=-1, keepdim=True) + 1e-5)      # torch.var: unbiased
+    return x
 
 
 class NeRFNetwork(NeRFRenderer):

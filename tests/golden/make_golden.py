@@ -245,6 +245,14 @@ def golden_frame(model, opt, tag, H, W, env_rot=None, theta=30.0, phi=-20.0, ext
           f"hit fraction {float((res['weights_sum'] > 0).float().mean()):.3f}, mean rgb {res['image'].mean(dim=(0, 1)).tolist()}")
 
 
+def golden_instance_norm():
+    """geo_feat_act = env_feat_act = instanceNorm (reference network.py:436-440, 542-546, 601-605): the per-sample chain and a frame"""
+    model, opt = build_reference_model(scenes.toaster_scene(seed=2), extra_argv=["--geo_feat_act", "instanceNorm", "--env_feat_act", "instanceNorm"])
+    assert opt.geo_feat_act == "instanceNorm" and opt.env_feat_act == "instanceNorm"
+    golden_shading(model, opt, "toaster_inorm", n=1024)
+    golden_frame(model, opt, "toaster_inorm_32", 32, 32, theta=75.0, phi=-30.0)
+
+
 OBJ_AABB = [-1.5, -1.5, -0.12, 0.35, 1.5, 1.5]      # in dataset units (x scale 0.65): cuts through the torus
 
 
@@ -541,6 +549,9 @@ def main():
     if sys.argv[1:] == ["ide"]:
         golden_ide()
         return
+    if sys.argv[1:] == ["inorm"]:              # only the instanceNorm feature-activation chain
+        golden_instance_norm()
+        return
     if sys.argv[1:] == ["indir_aabb"]:         # only the obj_aabb variant of the three-pass frame
         golden_indirect_aabb()
         return
@@ -565,6 +576,7 @@ def main():
     assert opt4.indir_ref and opt4.use_renv
     golden_frame(model4, opt4, "toaster_indir_40", 40, 40, theta=40.0, phi=-50.0)
     golden_indirect_aabb()
+    golden_instance_norm()
     golden_relight()
     golden_background()
     golden_grid()
