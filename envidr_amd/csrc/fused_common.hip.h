@@ -209,6 +209,7 @@ struct ShadeArgs {
     const uint32_t* m_dev;
     const uint32_t* slot;       // record mode, optional: normals / geo_feat / roughness of record i live at index slot[i]
     const uint32_t* list;       // record mode, optional: the records to shade (the i-th shaded record is list[i]; m_dev counts the list)
+    uint32_t* work;             // device word, zero at launch: the next unclaimed record (waves claim 64 at a time; null: static grid stride)
     const uint32_t* m_all;      // with list: the number of records; when the list holds them all it is the identity and is not read
     // reflected-radiance branch (record mode): per-ray (rgb, visibility), the learnt blend logit per sample, the two extra blobs
     const float* r_images; const float* blend; const float* renv_blob; const float* spec2_blob;

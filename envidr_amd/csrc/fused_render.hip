@@ -902,8 +902,22 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_shade_samples(const ShadeA
     uint32_t M = a.M;
     if (a.m_dev) { const uint32_t md = __builtin_amdgcn_readfirstlane(*a.m_dev); M = md > a.M ? 0u : md; }
     const uint32_t* list = (a.list && __builtin_amdgcn_readfirstlane(*a.m_all) != M) ? a.list : nullptr;
-    for (uint32_t base = (blockIdx.x * (kBlockThreads / 64)) * 64; base < M; base += waves * 64) {
-        const uint32_t id = base + wave * 64 + lane;
+    // Rounds are CLAIMED, not assigned: a wave takes the next 64 records off a device counter when it starts a round (the claim for
+    // the round after is issued at once, so its latency hides behind 280 us of work).  With a static grid stride every wave does
+    // 117 or 118 rounds of the headline frame and the kernel lasts as long as its slowest wave -- the waves of the odd XCDs are
+    // 1.35 % slower than those of the even ones on this chip (tools/probe/wave_times.py: mean wave 32.99 ms, kernel 33.42 ms);
+    // claimed rounds end within one round of each other.  Which wave shades a record changes nothing about its result.
+    // (claiming the tail in half rounds -- one 32-sample group -- was measured: the run-time group count costs the whole kernel more
+    //  than the half round it saves at the end, 33.46 against 33.25 ms)
+    auto claim = [&]() -> uint32_t {
+        uint32_t b = 0;
+        if (lane == 0) b = atomicAdd(a.work, 64u);
+        return __builtin_amdgcn_readfirstlane(b);
+    };
+    uint32_t base = a.work ? claim() : (blockIdx.x * (kBlockThreads / 64) + wave) * 64;
+    uint32_t ahead = a.work ? claim() : base + waves * 64;
+    for (; base < M; base = ahead, ahead = a.work ? claim() : ahead + waves * 64) {
+        const uint32_t id = base + lane;
         const bool on = id < M;
         const size_t i = on ? (list ? (size_t)list[id] : (size_t)id) : 0;
         const size_t gi = a.slot ? (size_t)a.slot[i] : i;          // where this record's geometry lives
@@ -1257,6 +1271,18 @@ int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const f
     return check_launch("k_render_persistent");
 }
 
+// one zero-initialised work counter per (device, stream): launches on different streams never share it
+static uint32_t* shade_work_counter(hipStream_t s) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, uint32_t*> pool;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    uint32_t*& p = pool[{dev, s}];
+    if (!p && hipMalloc(reinterpret_cast<void**>(&p), 256) != hipSuccess) p = nullptr;
+    return p;
+}
+
 static int launch_shade(const envidr_render_desc* d, ShadeArgs& a, envidr_stream_t stream, const char* who) {
     ENVIDR_REQUIRE(d->head_blob && (d->env_blob || d->dir_sh_degree), "%s: null weight blob", who);
     a.env_blob = d->env_blob; a.head_blob = d->head_blob;
@@ -1272,6 +1298,8 @@ static int launch_shade(const envidr_render_desc* d, ShadeArgs& a, envidr_stream
     const uint32_t waves_per_block = kBlockThreads / 64;
     const uint32_t blocks = std::min((uint32_t)device_cu_count() * ((heads_only ? 8 : 4) / waves_per_block), ceil_div(a.M, kBlockThreads));
     const dim3 grid(blocks), block(kBlockThreads);
+    a.work = shade_work_counter(s);
+    if (a.work && hipMemsetAsync(a.work, 0, sizeof(uint32_t), s) != hipSuccess) return check_launch("shade work counter");
     // split-precision mode: the environment features come from the fp16-pair kernel (shade_split.hip), the heads stay fp32
     const bool split = d->env_split_blob != nullptr && !d->dir_sh_degree;
     if (split) {

@@ -77,6 +77,16 @@ VARIANTS = {
                                       "            for (int r_ = 0; r_ < 16; ++r_) o[r_] = in[r_] + in[r_ + 16];\n")]),
     "shade_noheads": ("fused_render", [("fused_render.hip", "            pipe_layer_from_lanes<kDSteps, 1, kHeadD1, kHeadN>(wp, lane, in_d, d1);\n            pipe_layer16_from_tiles<1, kHeadD2, kHeadN, true>(wp, lane, d1, d2);\n            pipe_layer_from_lanes<kSSteps, 2, kHeadS1, kHeadN>(wp, lane, in_s, s1);\n            pipe_layer_from_tiles<2, 2, kHeadS2, kHeadN, true>(wp, lane, s1, s2);\n            pipe_layer16_from_tiles<2, kHeadS3, kHeadN, true>(wp, lane, s2, s3);\n            wp.template end_pass<kHeadFrags>();\n",
                                         "            for (int r_ = 0; r_ < 16; ++r_) { d2[r_] = in_d[r_ % kDSteps]; s3[r_] = in_s[r_ % kSSteps]; }\n")]),
+    # per-wave start / end clocks of the record-shading kernel -> the unused tail of c_diffuse (tools/probe/wave_times.py reads them):
+    # do all waves take the same time for the same number of rounds?
+    "shade_wavetime": ("fused_render", [
+        ("fused_render.hip", "    const uint32_t waves = gridDim.x * (kBlockThreads / 64);\n    // a frame whose records did not fit",
+         "    const unsigned long long t_start_ = __builtin_amdgcn_s_memrealtime();\n    const unsigned long long c_start_ = __builtin_amdgcn_s_memtime();\n    const uint32_t waves = gridDim.x * (kBlockThreads / 64);\n    // a frame whose records did not fit"),
+        ("fused_render.hip", "        if (on) {\n#pragma unroll\n            for (int d = 0; d < 3; ++d) { a.c_diffuse[3 * i + d] = cd[d]; a.c_specular[3 * i + d] = cs[d]; }\n        }\n    }\n}\n",
+         "        if (on) {\n#pragma unroll\n            for (int d = 0; d < 3; ++d) { a.c_diffuse[3 * i + d] = cd[d]; a.c_specular[3 * i + d] = cs[d]; }\n        }\n    }\n"
+         "    if (lane == 0) { unsigned long long* o_ = reinterpret_cast<unsigned long long*>(a.c_diffuse + 3 * (size_t)(a.M - 8192)) + 4 * (size_t)blockIdx.x;\n"
+         "        o_[0] = t_start_; o_[1] = __builtin_amdgcn_s_memrealtime(); o_[2] = __builtin_amdgcn_s_memtime() - c_start_; o_[3] = __builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 8); }\n}\n"),
+    ]),
     "shade_noload": ("fused_render", [
         ("fused_render.hip", "        const size_t gi = a.slot ? (size_t)a.slot[i] : i;          // where this record's geometry lives\n        float nrm[3], vd[3], geo[12];\n        const size_t ray = a.ray_ids ? (size_t)a.ray_ids[i] : 0;\n",
          "        const size_t gi = i;\n        float nrm[3], vd[3], geo[12];\n        const size_t ray = 0;\n"),
