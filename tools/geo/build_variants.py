@@ -71,7 +71,7 @@ VARIANTS = {
                                         ("hash_lean.hip.h", "            st.solo[j] = __builtin_amdgcn_raw_buffer_load_b64(table, r1[j] * 8u + (LANE_LEVEL ? lv.row0_bytes : 0u), LANE_LEVEL ? 0u : lv.row0_bytes, AUX);",
                                          "            st.solo[j] = u32x2{r1[j], base[j]};")]),
     # ablations of the record-shading kernel (timing only: results are wrong): where does a round's time go besides the MFMAs?
-    "shade_noide": ("fused_render", [("fused_render.hip", "        ide_eval<IDE_DEG>(vx, vy, vz, kinv, [&](int j, float re, float im) {\n            code[j] = re * c.light_scale;\n            code[TERMS + j] = im * c.light_scale;\n        });\n",
+    "shade_noide": ("fused_render", [("fused_render.hip", "        ide_eval<IDE_DEG, true>(vx, vy, vz, kinv, [&](int j, float re, float im) {\n            code[j] = re * c.light_scale;\n            code[TERMS + j] = im * c.light_scale;\n        });\n",
                                       "        for (int j = 0; j < TERMS; ++j) { code[j] = vx * kinv + (float)j; code[TERMS + j] = vy * vz - (float)j; }\n")]),
     "shade_noenv": ("fused_render", [("fused_render.hip", "            env_pass<TERMS, ENV_T, kEnvN>(wp, lane, aux, in, o);                        // env_pass.hip.h\n",
                                       "            for (int r_ = 0; r_ < 16; ++r_) o[r_] = in[r_] + in[r_ + 16];\n")]),
