@@ -126,40 +126,77 @@ __device__ __forceinline__ void env_step_out16(Src& wp, const f32x16 (&in)[KT], 
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// which widths run the hand-over form (an even number of 32-feature tiles); the host packs E1 with k_order 4 and E2, E3 with 3 for
+// exactly these (envidr_amd/fused.py: env_orders)
+constexpr bool env_handoff(int env_t) { return env_t >= 4 && env_t % 2 == 0; }
+
+// ---- hand-over of a layer's first input tile ---------------------------------------------------------------------------
+// The operands of a layer's FIRST input tile have nothing of that layer to hide under; staged with the vector ALU they sit in
+// front of its MFMAs (174 cycles, three times per pass).  The layer BEFORE can stage them if its output tile 0 is finished early:
+// its last input tile (E1: its last 16 steps) runs tile-major -- all 16 steps of output tile 0, then of tile 1 ... (the packed
+// fragments of that stretch are laid out in this order, envidr_pack_layer k_order 3 / 4) -- and while tiles 1 .. MT-1 are being
+// finished, tile 0 goes through the LDS round trip into bq[0], which the last input tile (odd index) does not use.
+template <int T, int S, int MT, int W0, int FRAGS, bool NEXT_BIAS, int KT, typename Src>
+__device__ __forceinline__ void env_step_tail(Src& wp, f32x16 (&in)[KT], f32x16 (&acc)[MT], const float bv, float (&bq0)[16], const EnvAux& aux, int next_tile0) {
+    acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp.template take<W0 + T * 16 + S, FRAGS>(), bv, acc[T], 0, 0, 0);
+    constexpr int J = (T - 1) * 16 + S;            // pieces ride behind the MFMAs of tiles 1 and 2
+    if constexpr (T >= 1 && J < 32) lds_stage_piece<(J >= 0 && J < 32 ? J : 32), 0>(acc, aux.slot, bq0);
+    if constexpr (NEXT_BIAS && T == MT / 2 && S == 0) in[KT - 1] = lds_bias_tile(aux.bias, next_tile0 + KT - 1);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // FRAGS: the pass's fragment count padded to the weight ring's depth.  out16: see pipe_layer16_from_tiles / fold16.
-template <int TERMS, int ENV_T, int FRAGS, typename Src>
+template <int TERMS, int ENV_T, int FRAGS, bool HANDOFF = false, typename Src>
 __device__ __forceinline__ void env_pass(Src& wp, const uint32_t lane, const EnvAux& aux, const float (&in)[TERMS], f32x16& out16) {
     using L = EnvLayout<TERMS, ENV_T>;
     f32x16 ha[ENV_T], hb[ENV_T];
     float bq[2][16];
+    static_assert(!HANDOFF || (ENV_T % 2 == 0 && ENV_T >= 4 && TERMS >= 16), "hand-over needs an even tile count (the last tile uses bq[1])");
     // ---- E1: 2 TERMS -> 32 ENV_T
 #pragma unroll
     for (int t = 0; t < ENV_T; ++t) ha[t] = lds_bias_tile(aux.bias, t);
     skip_frags<L::E1, ENV_T, FRAGS>(wp);
     __builtin_amdgcn_sched_barrier(0);
+    constexpr int kHead = HANDOFF ? TERMS - 16 : TERMS;        // E1's step-major steps
     [&]<int... S>(std::integer_sequence<int, S...>) {
         (env_step_lanes<S, TERMS, ENV_T, L::E1 + ENV_T, FRAGS>(wp, in, ha, hb, aux.bias, ENV_T), ...);
-    }(std::make_integer_sequence<int, TERMS>{});
+    }(std::make_integer_sequence<int, kHead>{});
+    if constexpr (HANDOFF) {
+        [&]<int... TS>(std::integer_sequence<int, TS...>) {
+            (env_step_tail<TS / 16, TS % 16, ENV_T, L::E1 + ENV_T + kHead * ENV_T, FRAGS, false>(wp, hb, ha, in[kHead + TS % 16], bq[0], aux, 0), ...);
+        }(std::make_integer_sequence<int, 16 * ENV_T>{});
+    }
     // ---- E2: ha -> hb, ha reloaded with E3's bias
     skip_frags<L::E2, ENV_T, FRAGS>(wp);
-    stage_operands<0, 0, 16, true>(ha, bq[0]);
+    if constexpr (!HANDOFF) stage_operands<0, 0, 16, true>(ha, bq[0]);
     __builtin_amdgcn_sched_barrier(0);
+    constexpr int kTiles = HANDOFF ? ENV_T - 1 : ENV_T;        // step-major input tiles of E2 / E3
     [&]<int... KS>(std::integer_sequence<int, KS...>) {
         (env_step_tiles<KS / 16, KS % 16, ENV_T, ENV_T, L::E2 + ENV_T, FRAGS, true>(wp, ha, hb, bq, aux, 2 * ENV_T), ...);
-    }(std::make_integer_sequence<int, 16 * ENV_T>{});
+    }(std::make_integer_sequence<int, 16 * kTiles>{});
+    if constexpr (HANDOFF) {
+        [&]<int... TS>(std::integer_sequence<int, TS...>) {
+            (env_step_tail<TS / 16, TS % 16, ENV_T, L::E2 + ENV_T + kTiles * 16 * ENV_T, FRAGS, true>(wp, ha, hb, bq[1][TS % 16], bq[0], aux, 2 * ENV_T), ...);
+        }(std::make_integer_sequence<int, 16 * ENV_T>{});
+    }
     // ---- E3: hb -> ha
     skip_frags<L::E3, ENV_T, FRAGS>(wp);
-    stage_operands<0, 0, 16, true>(hb, bq[0]);
+    if constexpr (!HANDOFF) stage_operands<0, 0, 16, true>(hb, bq[0]);
     __builtin_amdgcn_sched_barrier(0);
     [&]<int... KS>(std::integer_sequence<int, KS...>) {
         (env_step_tiles<KS / 16, KS % 16, ENV_T, ENV_T, L::E3 + ENV_T, FRAGS, false>(wp, hb, ha, bq, aux, 0), ...);
-    }(std::make_integer_sequence<int, 16 * ENV_T>{});
+    }(std::make_integer_sequence<int, 16 * kTiles>{});
+    if constexpr (HANDOFF) {
+        [&]<int... TS>(std::integer_sequence<int, TS...>) {
+            (env_step_tail<TS / 16, TS % 16, ENV_T, L::E3 + ENV_T + kTiles * 16 * ENV_T, FRAGS, false>(wp, hb, ha, bq[1][TS % 16], bq[0], aux, 0), ...);
+        }(std::make_integer_sequence<int, 16 * ENV_T>{});
+    }
     // ---- E4: ha -> 12 outputs (bias through the stream: one 32-cycle MFMA)
     f32x16 a0, a1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a0[r] = 0.0f; a1[r] = 0.0f; }
     a1 = __builtin_amdgcn_mfma_f32_16x16x1f32(wp.template take<L::E4, FRAGS>(), lane < 32 ? 1.0f : 0.0f, a1, 0, 0, 0);
-    stage_operands<0, 0, 16, true>(ha, bq[0]);
+    if constexpr (!HANDOFF) stage_operands<0, 0, 16, true>(ha, bq[0]);
     __builtin_amdgcn_sched_barrier(0);
     [&]<int... KS>(std::integer_sequence<int, KS...>) {
         (env_step_out16<KS / 16, KS % 16, ENV_T, L::E4 + 1, FRAGS>(wp, ha, a0, a1, bq, aux), ...);

@@ -265,7 +265,7 @@ __device__ __forceinline__ void shade_sample(WP& wp, const uint32_t lane, const 
             f32x16 o;
             const bool last = enc == 1 && grp == 1;
             wp.begin_pass(c.env_blob, kEnvChunks, last ? c.head_blob : c.env_blob, last ? kHeadChunks : kEnvChunks);
-            env_pass<TERMS, ENV_T, kEnvN>(wp, lane, aux, in, o);                        // env_pass.hip.h
+            env_pass<TERMS, ENV_T, kEnvN, env_handoff(ENV_T)>(wp, lane, aux, in, o);    // env_pass.hip.h
             if (grp == 0) outA = o; else outB = o;
         }
         tick(5);   // env mlp
@@ -1113,19 +1113,25 @@ uint32_t envidr_packed_weight_floats(int k_order, uint32_t k_in, uint32_t m_out)
 }
 uint32_t envidr_packed_layer_floats(int k_order, uint32_t k_in, uint32_t m_out, int with_bias) {
     if (k_order == 2) return packed_weight_floats(kTileOrder, k_in, 16, with_bias != 0);     // one fragment per reduction step
-    return packed_weight_floats(k_order ? kTileOrder : kLaneOrder, k_in, m_out, with_bias != 0);
+    return packed_weight_floats((k_order == 1 || k_order == 3) ? kTileOrder : kLaneOrder, k_in, m_out, with_bias != 0);
 }
 int envidr_pack_layer(const float* W_host, const float* bias_host, uint32_t m_out, uint32_t k_in, int transpose, int k_order,
                       float* dst_host) {
     ENVIDR_REQUIRE(W_host && dst_host && m_out && k_in, "pack_layer: null pointer or empty layer");
     ENVIDR_REQUIRE(!(bias_host && transpose), "pack_layer: a transposed (gradient) layer carries no bias");
-    ENVIDR_REQUIRE(k_order >= 0 && k_order <= 2, "pack_layer: k_order must be 0 (lane), 1 (tile) or 2 (tile order, at most 16 outputs)");
+    ENVIDR_REQUIRE(k_order >= 0 && k_order <= 4, "pack_layer: k_order must be 0 (lane), 1 (tile), 2 (tile order, at most 16 outputs), 3 / 4 (tile / lane order, tail tile-major)");
     if (k_order == 2) {
         ENVIDR_REQUIRE(m_out <= 16 && !transpose, "pack_layer: k_order 2 packs a layer of at most 16 outputs, not transposed");
         pack_linear16(W_host, m_out, k_in, dst_host, bias_host);
         return ENVIDR_OK;
     }
-    pack_linear(W_host, m_out, k_in, transpose != 0, k_order ? kTileOrder : kLaneOrder, dst_host, bias_host);
+    const KOrder order = (k_order == 1 || k_order == 3) ? kTileOrder : kLaneOrder;
+    pack_linear(W_host, m_out, k_in, transpose != 0, order, dst_host, bias_host);
+    if (k_order >= 3) {
+        ENVIDR_REQUIRE(!transpose, "pack_layer: k_order 3 / 4 is for forward layers");
+        const uint32_t mt = round_up(m_out, 32) / 32;
+        retile_tail(dst_host + (bias_host ? (size_t)mt * 64 : 0), steps_for(order, k_in), mt);
+    }
     return ENVIDR_OK;
 }
 uint32_t envidr_packed_rowvec_floats(uint32_t m_out) { return packed_bias_floats(m_out); }

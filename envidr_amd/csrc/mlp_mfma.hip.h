@@ -85,6 +85,20 @@ inline void pack_rowvec(const float* v, uint32_t m_out, float* dst) {
             }
 }
 
+// The LAST 16 reduction steps of a packed layer in tile-major order ([tile][step] instead of [step][tile]): the environment pass
+// finishes output tile 0 first there and stages it for the next layer while the other tiles are completed (env_pass.hip.h
+// "hand-over"; k_order 3 = tile order + this, 4 = lane order + this).  `w`: the layer's weight fragments (behind the bias step).
+inline void retile_tail(float* w, uint32_t steps, uint32_t mt) {
+    if (steps < 16) return;
+    const uint32_t s0 = steps - 16;
+    float* tail = w + (size_t)s0 * mt * 64;
+    float* tmp = new float[(size_t)16 * mt * 64];
+    memcpy(tmp, tail, sizeof(float) * 16 * mt * 64);
+    for (uint32_t t = 0; t < mt; ++t)
+        for (uint32_t q = 0; q < 16; ++q) memcpy(tail + ((size_t)t * 16 + q) * 64, tmp + ((size_t)q * mt + t) * 64, sizeof(float) * 64);
+    delete[] tmp;
+}
+
 // ---- layers with at most 16 outputs ------------------------------------------------------------
 // A layer like env 256 -> 12 or a head's 64 -> 3 fills 12 (3) of a 32-feature tile's rows.  It runs on
 // v_mfma_f32_16x16x1_4B_f32 instead (four independent 16x16x1 blocks in one 32-cycle instruction; lane l belongs to

@@ -182,6 +182,14 @@ def pack_layer(W, bias, k_order: int, transpose: bool = False) -> np.ndarray:
     return dst
 
 
+def env_orders(hidden: int) -> tuple[int, int, int, int]:
+    """k_order of the four environment-MLP layers: widths with an even number of 32-feature tiles run the hand-over form of the
+    pass (csrc/env_pass.hip.h env_handoff): E1 lane order with a tile-major tail (4), E2 / E3 tile order with one (3); the others the
+    plain orders.  E4 (H -> 12) is always packed for 16-row blocks (2)."""
+    tiles = (hidden + 31) // 32
+    return (4, 3, 3, 2) if (tiles >= 4 and tiles % 2 == 0) else (0, 1, 1, 2)
+
+
 def pack_sdf_geometry(sdf) -> np.ndarray:
     """the SDF network 2L -> 64 -> 64 -> 15 for the 16-column geometry kernel (csrc/geo_eval16.hip.h)"""
     lib = _lib.load()
@@ -320,7 +328,7 @@ class FusedShader:
 
         L = lambda Wb, order: pack_layer(Wb[0], Wb[1], order)
         d = RenderDesc()
-        d.env_blob = blob([L(env[0], 0), L(env[1], 1), L(env[2], 1), L(env[3], 2)])
+        d.env_blob = blob([L(env[i], o) for i, o in enumerate(env_orders(_np32(env[0][0]).shape[0]))])
         d.head_blob = blob([L(dif[0], 0), L(dif[1], 2), L(spc[0], 0), L(spc[1], 1), L(spc[2], 2)])
         d.ide_degree, d.env_hidden = ide_degree, _np32(env[0][0]).shape[0]
         d.diffuse_kappa_inv, d.light_intensity_scale, d.intensity_scale = diffuse_kappa_inv, light_intensity_scale, 1.0
@@ -409,7 +417,7 @@ class FusedRenderer:
         L = lambda Wb, order: pack_layer(Wb[0], Wb[1], order)
         d.sdf_blob = blob([L(sdf[0], 0), L(sdf[1], 1), L(sdf[2], 1),
                            pack_layer(sdf[1][0], None, 1, transpose=True), pack_layer(sdf[0][0], None, 1, transpose=True)])
-        d.env_blob = blob([L(env[0], 0), L(env[1], 1), L(env[2], 1), L(env[3], 2)]) if env is not None else None
+        d.env_blob = blob([L(env[i], o) for i, o in enumerate(env_orders(_np32(env[0][0]).shape[0]))]) if env is not None else None
         d.dir_sh_degree = sh_degree
         d.head_blob = blob([L(dif[0], 0), L(dif[1], 2), L(spc[0], 0), L(spc[1], 1), L(spc[2], 2)])
         renv = mlps.get("renv")

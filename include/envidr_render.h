@@ -36,6 +36,10 @@ extern "C" {
  *            1 = the layer's input is the previous layer's output tiles       ("tile order"),
  *            2 = tile order for a layer of AT MOST 16 OUTPUTS (envidr_pack_layer only): the layer runs on
  *                16-row MFMA blocks, one 64-float fragment per reduction step (ABI 7; E4, D2, S3, renv R4).
+ *            3 = tile order, 4 = lane order, each with the layer's LAST 16 reduction steps laid out tile-major (envidr_pack_layer
+ *                only).  ABI 7: when env_hidden / 32 is even (256, 128) the environment pass stages a layer's first input tile
+ *                inside the layer before it, and its blob must then be E1 (k_order 4) | E2 (3) | E3 (3) | E4 (2); for the other
+ *                widths (160) E1 (0) | E2 (1) | E3 (1) | E4 (2).
  *   transpose != 0 packs W^T (the input-gradient layers of the SDF network). */
 uint32_t envidr_packed_weight_floats(int k_order, uint32_t k_in, uint32_t m_out);
 uint32_t envidr_packed_rowvec_floats(uint32_t m_out);

@@ -19,7 +19,7 @@ constexpr int kPF = 32;
 constexpr int ring_padded(int frags) { return (frags + kPF - 1) / kPF * kPF; }
 
 // the pass as the kernels run it now (env_pass.hip.h): biases from LDS, ReLU in the LDS atomic unit, 16-row output blocks
-template <int TERMS, int ENV_T>
+template <int TERMS, int ENV_T, bool HANDOFF>
 __global__ void __launch_bounds__(64, 1) probe_env_pass(const float* __restrict__ blob, float* out, unsigned long long* cyc, int iters) {
     using L = EnvLayout<TERMS, ENV_T>;
     constexpr uint32_t kEnvChunks = pass_chunks(L::Frags);
@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(64, 1) probe_env_pass(const float* __restrict_
             for (int s = 0; s < TERMS; ++s) in[s] = grp ? code[2 * s + 1] : code[2 * s];
             f32x16 o;
             wp.begin_pass(blob, kEnvChunks, blob, kEnvChunks);
-            env_pass<TERMS, ENV_T, kEnvN>(wp, lane, aux, in, o);
+            env_pass<TERMS, ENV_T, kEnvN, HANDOFF>(wp, lane, aux, in, o);
             if (grp == 0) outA = o; else outB = o;
         }
 #pragma unroll
@@ -101,18 +101,19 @@ __global__ void __launch_bounds__(64, 1) probe(const float* __restrict__ blob, f
     if (lane == 0) { cyc[blockIdx.x] = t1 - t0; cyc[gridDim.x] = kEnvFrags; }
 }
 
+template <bool HANDOFF>
 void run_env_pass(int blocks) {
     const int iters = 50;
     float *blob, *out; unsigned long long* cyc;
     (void)hipMalloc(&blob, 4 << 20); (void)hipMemset(blob, 0, 4 << 20);
     (void)hipMalloc(&out, blocks * 64 * 4); (void)hipMalloc(&cyc, (blocks + 1) * 8);
     for (int rep = 0; rep < 2; ++rep) {
-        probe_env_pass<36, 8><<<blocks, 64>>>(blob, out, cyc, iters);
+        probe_env_pass<36, 8, HANDOFF><<<blocks, 64>>>(blob, out, cyc, iters);
         (void)hipDeviceSynchronize();
         std::vector<unsigned long long> h(blocks + 1);
         (void)hipMemcpy(h.data(), cyc, (blocks + 1) * 8, hipMemcpyDeviceToHost);
         double avg = 0; for (int i = 0; i < blocks; ++i) avg += h[i]; avg /= blocks;
-        if (rep) printf("env_pass() of env_pass.hip.h, %4d waves: %.0f ticks per pass (MFMA issue time 64 x 2368 + 32 x 129 = 155680)\n", blocks, avg / (iters * 2));
+        if (rep) printf("env_pass() of env_pass.hip.h, hand-over %d, %4d waves: %.0f ticks per pass (MFMA issue time 64 x 2368 + 32 x 129 = 155680)\n", (int)HANDOFF, blocks, avg / (iters * 2));
     }
     (void)hipFree(blob); (void)hipFree(out); (void)hipFree(cyc);
 }
@@ -186,7 +187,10 @@ int run_selftest() {
 
 int main() {
     const int rc = run_selftest();
-    run_env_pass(1024);
+    run_env_pass<false>(1024);
+    run_env_pass<true>(1024);
+    run_env_pass<false>(1024);
+    run_env_pass<true>(1024);
     run<0, false, true>(1024);      // the kernel of rounds 1-3
     run<0, false, false>(1024);     // floor without operand staging
     run<2, false, true>(1024);
