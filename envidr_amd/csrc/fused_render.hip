@@ -655,7 +655,7 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
                 float in[kLevels];
 #pragma unroll
                 for (int s = 0; s < kLevels; ++s) in[s] = grp ? inB[s] : inA[s];
-                f32x16 h1[2], h2[2], o3[1];
+                f32x16 h1[2], h2[2], o3;
                 const bool to_sdf = grp == 0 || GEOM || a.geometry_only;       // geometry-only: the SDF blob is the only one streamed
                 wp.begin_pass(a.sdf_blob, kSdfChunks, to_sdf ? a.sdf_blob : (kEnvNet ? a.env_blob : a.head_blob),
                               to_sdf ? kSdfChunks : (kEnvNet ? kEnvChunks : kHeadChunks));
@@ -673,7 +673,7 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) pos2 |= (h2[t][r] > 0 ? 1u : 0u) << (16 * t + r);
-                pipe_layer_from_tiles<2, 1, kSdfW3, kSdfN, true>(wp, lane, h2, o3);
+                pipe_layer16_from_tiles<2, kSdfW3, kSdfN, true>(wp, lane, h2, o3);       // 64 -> 15 on 16-row MFMA blocks (k_order 2)
                 // backward of sdf = o3[row 0]:  g2 = W3[0,:] * [h2 > 0];  g1 = (W2^T g2) * [h1 > 0];  gfeat = W1^T g1
                 f32x16 g2[2], g1[2], gf[1];
                 const ParamBuf w3r0 = make_param_buf(a.sdf_w3r0, 2 * 128u, lane);
@@ -690,13 +690,19 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_render_persistent(const Re
                     for (int r = 0; r < 16; ++r) g1[t][r] = (pos1 >> (16 * t + r)) & 1u ? g1[t][r] : 0.0f;
                 pipe_layer_from_tiles<2, 1, kSdfW1t, kSdfN, false, false>(wp, lane, g1, gf);
                 wp.template end_pass<kSdfFrags>();
-                if (grp == 0) { outA = o3[0]; gfA = gf[0]; } else { outB = o3[0]; gfB = gf[0]; }
+                if (grp == 0) { outA = o3; gfA = gf[0]; } else { outB = o3; gfB = gf[0]; }
+            }
+            {
+                float alo[4], ahi[4], blo[4], bhi[4];
+                fold16(outA, alo, ahi);
+                fold16(outB, blo, bhi);
+                float h16[16];
+                rows_to_lanes<4>(alo, ahi, blo, bhi, h16);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h3[r] = h16[r];
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float u = outA[r], v = outB[r];
-                unpack_pair(u, v);
-                h3[tile_row(r, 0)] = u; h3[tile_row(r, 1)] = v;
                 float p = gfA[r], q = gfB[r];
                 unpack_pair(p, q);
                 gfeat[tile_row(r, 0)] = p; gfeat[tile_row(r, 1)] = q;

@@ -241,12 +241,12 @@ __global__ void __launch_bounds__(kE32Threads, 2) k_geo_eval32(const GeoEvalArgs
         // (the hidden pre-activations h1, h2 stay in their accumulator tiles until the backward pass has used their signs: a ReLU
         //  mask is then one compare + one select per value where it is needed; packing the signs into bit words and unpacking
         //  them again cost ~450 of the ~2900 vector instructions of a batch, and this kernel is issue-bound)
-        f32x16 o3[1], gf[1];
+        f32x16 o3, gf[1];
         {
             f32x16 h1[2], h2[2];
             pipe_layer_from_lanes<kLevels, 2, kSdfW1, kSdfN>(wp, lane, in, h1);
             pipe_layer_from_tiles<2, 2, kSdfW2, kSdfN, true>(wp, lane, h1, h2);
-            pipe_layer_from_tiles<2, 1, kSdfW3, kSdfN, true>(wp, lane, h2, o3);
+            pipe_layer16_from_tiles<2, kSdfW3, kSdfN, true>(wp, lane, h2, o3);        // 64 -> 15 on 16-row MFMA blocks (k_order 2)
             f32x16 g2[2], g1[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -299,11 +299,12 @@ __global__ void __launch_bounds__(kE32Threads, 2) k_geo_eval32(const GeoEvalArgs
         normalize_n<3>(nrm, 1e-10f);                                                    // renderer.py:192
         // raw outputs 0..15 of the last layer: rows 0-3, 8-11 in the lower lanes' registers 0..7, rows 4-7, 12-15 in the upper lanes'
         float h3[16];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            float lo = o3[0][r], hi = o3[0][r];
-            swap_halves(lo, hi);
-            h3[tile_row(r, 0)] = lo; h3[tile_row(r, 1)] = hi;
+        {
+            // the 16-row blocks hold rows 4 Q + q of sample (lane & 15) [+ 16] in lane quarter Q; both lane halves hold the same 32
+            // samples here, so "group A" and "group B" of the transpose are the same accumulator
+            float lo[4], hi[4];
+            fold16(o3, lo, hi);
+            rows_to_lanes<4>(lo, hi, lo, hi, h3);
         }
         if constexpr (PROBE) {
             if (on && half == 0 && a.probe_raw) {

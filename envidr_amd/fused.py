@@ -415,7 +415,7 @@ class FusedRenderer:
             return up(np.concatenate([flat, np.zeros(pad, np.float32)])).data_ptr()
 
         L = lambda Wb, order: pack_layer(Wb[0], Wb[1], order)
-        d.sdf_blob = blob([L(sdf[0], 0), L(sdf[1], 1), L(sdf[2], 1),
+        d.sdf_blob = blob([L(sdf[0], 0), L(sdf[1], 1), L(sdf[2], 2),
                            pack_layer(sdf[1][0], None, 1, transpose=True), pack_layer(sdf[0][0], None, 1, transpose=True)])
         d.env_blob = blob([L(env[i], o) for i, o in enumerate(env_orders(_np32(env[0][0]).shape[0]))]) if env is not None else None
         d.dir_sh_degree = sh_degree

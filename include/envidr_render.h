@@ -122,7 +122,7 @@ typedef struct envidr_render_desc {
      * per pass, each blob zero-padded to a multiple of 4096 floats (one 16 KiB LDS chunk).  The four
      * waves of a workgroup stream a blob through LDS once per pass (envidr_amd/csrc/mlp_mfma.hip.h).
      * Every forward layer is packed WITH its bias (envidr_pack_layer), the two gradient layers without.
-     *   sdf_blob  : W1+b (lane order, 32->64) | W2+b (tile, 64->64) | W3+b (tile, 64->15) | W2^T (tile) | W1^T (tile, 64->32)
+     *   sdf_blob  : W1+b (lane order, 32->64) | W2+b (tile, 64->64) | W3+b (k_order 2, 64->15) | W2^T (tile) | W1^T (tile, 64->32)
      *   env_blob  : E1+b (lane, ide_dim->H) | E2+b (tile, H->H) | E3+b (tile, H->H) | E4+b (k_order 2, H->12)
      *   head_blob : D1+b (lane, 24->32) | D2+b (k_order 2, 32->3) | S1+b (lane, 28->64) | S2+b (tile, 64->64) | S3+b (k_order 2, 64->3)
      *   renv_blob : R1+b (lane) | R2+b | R3+b (tile) | R4+b (k_order 2, 64->12);  spec2_blob : S1+b (lane) | S2+b (tile) | S3+b (k_order 2) */
