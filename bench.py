@@ -533,10 +533,13 @@ def context_legs(result, renderer, dev, steps: int, N: int) -> None:
     from envidr_amd.nerf.utils import get_rays
     steps = max(steps, 4)
 
-    def leg(make_rays, use_hint: bool, warm: int) -> dict:
+    def leg(make_rays, use_hint: bool, warm: int, sizing_hint: float = 20.0) -> dict:
         out: dict = {}
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
         log = []
+        # one blocking frame first: it sizes the renderer's sample / record buffers (a frame that does not fit is rendered again
+        # with larger ones), so that none of the asynchronous frames below can overflow
+        renderer.render_frame(*make_rays(0), 0.1, out=out, wait=True, use_cost_hint=False, image_width=W, samples_per_ray_hint=sizing_hint)
         renderer.frame_log = {}
         for i in range(warm):
             o, d = make_rays(i)
@@ -578,7 +581,7 @@ def context_legs(result, renderer, dev, steps: int, N: int) -> None:
     from envidr_amd.fused import FusedRenderer
     headline_renderer = renderer
     renderer = FusedRenderer.from_scene(scenes.toaster_scene(sdf_bias=0.065), device=dev)
-    thick = leg(lambda i: fixed, True, 2)
+    thick = leg(lambda i: fixed, True, 2, sizing_hint=40.0)
     renderer = headline_renderer
     result["survey_density_scene"] = dict(thick, samples_per_ray=thick["samples_composited_per_frame"] / N,
                                           samples_per_s=thick["samples_composited_per_frame"] / (thick["ms_per_frame"] * 1e-3),

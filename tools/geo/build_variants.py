@@ -19,6 +19,9 @@ sys.path.insert(0, str(ROOT))
 from envidr_amd import build as B  # noqa: E402
 
 # name -> (translation unit, [(file, old, new), ...])
+P1 = "        // ================= phase 1: this lane's eight levels: values + Jacobian -> LDS ============================\n"
+P2 = '        f32x16 o3, gf[1];\n'
+P3 = '            wp.template end_pass<kSdfFrags>();\n        }\n\n        // ================= phase 3'
 VARIANTS = {
     "base": ("geometry_pass", []),
     "geo_ahead1": ("geometry_pass", [("geometry_pass.hip", "constexpr int kGeoAhead = 2;", "constexpr int kGeoAhead = 1;")]),
@@ -62,8 +65,8 @@ VARIANTS = {
     "grid_full_tcache16": ("geometry_pass", [("geometry_pass.hip", "const dim3 grid(r == 0 ? ray_blocks : std::min(ray_blocks, 1024u));", "const dim3 grid(ray_blocks);"),
                                              ("geometry_pass.hip", "constexpr uint32_t kTimeCache = 32;", "constexpr uint32_t kTimeCache = 16;")]),
     # ablations of k_geo_eval32 (what bounds it?): no matrix phase / no table gathers / neither
-    "eval_nomlp": ("geometry_pass", [("geometry_pass.hip", "            pipe_layer_from_lanes<kLevels, 2, kSdfW1, kSdfN>(wp, lane, in, h1);\n            pipe_layer_from_tiles<2, 2, kSdfW2, kSdfN, true>(wp, lane, h1, h2);\n            pipe_layer_from_tiles<2, 1, kSdfW3, kSdfN, true>(wp, lane, h2, o3);\n",
-                                      "            for (int r_ = 0; r_ < 16; ++r_) { h1[0][r_] = in[r_]; h1[1][r_] = in[r_]; h2[0][r_] = in[r_]; h2[1][r_] = in[r_]; o3[0][r_] = in[r_]; }\n"),
+    "eval_nomlp": ("geometry_pass", [("geometry_pass.hip", "            pipe_layer_from_lanes<kLevels, 2, kSdfW1, kSdfN>(wp, lane, in, h1);\n            pipe_layer_from_tiles<2, 2, kSdfW2, kSdfN, true>(wp, lane, h1, h2);\n            pipe_layer16_from_tiles<2, kSdfW3, kSdfN, true>(wp, lane, h2, o3);        // 64 -> 15 on 16-row MFMA blocks (k_order 2)\n",
+                                      "            for (int r_ = 0; r_ < 16; ++r_) { h1[0][r_] = in[r_]; h1[1][r_] = in[r_]; h2[0][r_] = in[r_]; h2[1][r_] = in[r_]; o3[r_] = in[r_]; }\n"),
                                      ("geometry_pass.hip", "            pipe_layer_from_tiles<2, 2, kSdfW2t, kSdfN, false, false>(wp, lane, g2, g1);\n", "            g1[0] = g2[1]; g1[1] = g2[0];\n"),
                                      ("geometry_pass.hip", "            pipe_layer_from_tiles<2, 1, kSdfW1t, kSdfN, false, false>(wp, lane, g1, gf);\n            wp.template end_pass<kSdfFrags>();\n", "            gf[0] = g1[0] + g1[1];\n")]),
     "eval_nogather": ("geometry_pass", [("hash_lean.hip.h", "        st.pair[j] = __builtin_amdgcn_raw_buffer_load_b128(table, base[j] * 8u + (LANE_LEVEL ? lv.row0_bytes : 0u), LANE_LEVEL ? 0u : lv.row0_bytes, AUX);",
@@ -128,6 +131,15 @@ VARIANTS = {
     "first_chunk24": ("geometry_pass", [("geometry_pass.hip", "std::min(16u, d->max_steps)", "std::min(24u, d->max_steps)")]),
     "split_group4": ("shade_split", [("mlp_split.hip.h", "constexpr int kSplitGroup = 2;", "constexpr int kSplitGroup = 4;")]),
     "ring16": ("fused_render", [("fused_render.hip", "constexpr int kRingDepth = 32;", "constexpr int kRingDepth = 16;")]),
+    # issue priority by phase (MI355X_MICROARCH.md "Two waves per SIMD": VALU issue is arbitrated by priority, then age): does the SIMD
+    # partner's hash arithmetic advance under this wave's MFMAs when the hash phase outranks the matrix phase?
+    "eval_prio_hash": ("geometry_pass", [("geometry_pass.hip", P1, "        __builtin_amdgcn_s_setprio(2);\n" + P1),
+                                         ("geometry_pass.hip", P2, "        __builtin_amdgcn_s_setprio(0);\n" + P2)]),
+    "eval_prio_hash3": ("geometry_pass", [("geometry_pass.hip", P1, "        __builtin_amdgcn_s_setprio(2);\n" + P1),
+                                          ("geometry_pass.hip", P2, "        __builtin_amdgcn_s_setprio(0);\n" + P2),
+                                          ("geometry_pass.hip", P3, "            wp.template end_pass<kSdfFrags>();\n            __builtin_amdgcn_s_setprio(2);\n        }\n\n        // ================= phase 3")]),
+    "eval_prio_mfma": ("geometry_pass", [("geometry_pass.hip", P1, "        __builtin_amdgcn_s_setprio(0);\n" + P1),
+                                         ("geometry_pass.hip", P2, "        __builtin_amdgcn_s_setprio(2);\n" + P2)]),
 }
 
 

@@ -54,7 +54,13 @@ __global__ void __launch_bounds__(512, 1) probe(float* out, unsigned long long* 
         if (MODE == 3) { mfma_section(acc, a, b); valu_section(x, k1, k2); }
         if (MODE == 4) { if (role == 0) { mfma_section(acc, a, b); valu_section(x, k1, k2); } else { valu_section(x, k1, k2); mfma_section(acc, a, b); } }
         if (MODE >= 10 && MODE < 20) { if (role == 0) mfma_section_yield<MODE - 10>(acc, a, b); else valu_section(x, k1, k2); }
-        if (MODE >= 20) { if (role == 0) { mfma_section_yield<MODE - 20>(acc, a, b); valu_section(x, k1, k2); } else { valu_section(x, k1, k2); mfma_section_yield<MODE - 20>(acc, a, b); } }
+        if (MODE == 32) { if (role == 0) mfma_section(acc, a, b); else { __builtin_amdgcn_s_setprio(3); valu_section(x, k1, k2); } }
+        if (MODE == 33) { if (role == 0) { __builtin_amdgcn_s_setprio(3); mfma_section(acc, a, b); } else valu_section(x, k1, k2); }
+        if (MODE == 34) {          // anti-phase sections, the VALU section outranks the MFMA section
+            if (role == 0) { __builtin_amdgcn_s_setprio(0); mfma_section(acc, a, b); __builtin_amdgcn_s_setprio(3); valu_section(x, k1, k2); }
+            else { __builtin_amdgcn_s_setprio(3); valu_section(x, k1, k2); __builtin_amdgcn_s_setprio(0); mfma_section(acc, a, b); }
+        }
+        if (MODE >= 20 && MODE < 30) { if (role == 0) { mfma_section_yield<MODE - 20>(acc, a, b); valu_section(x, k1, k2); } else { valu_section(x, k1, k2); mfma_section_yield<MODE - 20>(acc, a, b); } }
         __builtin_amdgcn_sched_barrier(0);
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -98,5 +104,8 @@ int main() {
     run<14>("A: MFMA stream + 4 x s_nop 15 after each, B: VALU stream");
     run<22>("both alternate sections (MFMAs + 2 x s_nop 15), anti-phase");
     run<23>("both alternate sections (MFMAs + 3 x s_nop 15), anti-phase");
+    run<32>("A: MFMA stream, B: VALU stream at s_setprio 3");
+    run<33>("A: MFMA stream at s_setprio 3, B: VALU stream");
+    run<34>("both alternate sections, anti-phase, VALU sections at s_setprio 3");
     return 0;
 }
