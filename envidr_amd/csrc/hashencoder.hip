@@ -8,6 +8,8 @@
 // instead of every XCD thrashing all 16 tables.
 #include "grid_core.hip.h"
 #include <algorithm>
+#include <map>
+#include <mutex>
 
 using namespace envidr;
 
@@ -275,15 +277,28 @@ __global__ void __launch_bounds__(kBlock) k_second_backward_table(const float* _
 // 6.2 ms per level and 7.7 M points, linear in the number of levels although every level runs on its own XCD) -- 2 x 10^9 of
 // them are the 98 ms of the scatter kernels above.  A level's table has far fewer rows (<= 2^19) than a large batch has
 // contributions (8 B), so the sums are formed in LDS instead: a workgroup OWNS a range of kLdsRows rows of one level (128 KiB
-// of accumulators), walks the points, recomputes every point's corner rows and adds those that fall into its range with LDS
-// atomics; at the end the range is flushed with one global atomic per non-zero entry.  The index arithmetic is redone by the
-// (up to 32) range owners of a level; the 32 CUs of an XCD take the 32 ranges of one level at the same time and stream the
-// same points, so the inputs come out of that XCD's L2.  Point ranges are split into `parts` to even out the rounds.
+// of accumulators) and adds the corner contributions that fall into its range with LDS atomics; at the end the range is
+// flushed with one global atomic per non-zero entry.  The 32 CUs of an XCD take the 32 ranges of one level at the same time.
+//
+// Which points does a range owner look at?  A hashed level scatters a point's 2^D corners over the whole table: a given
+// range (1/32 of the rows) holds a corner of ~22 % of the points, and a first version in which every owner recomputed
+// every point's corner rows to find out spent its time in that index arithmetic (1.1e10 vector instructions, 20.9 ms for
+// 7.7 M points).  So a pre-pass (k_table_range_masks, 0.34 ms) forms the rows once per (point, level) and leaves a 32-bit
+// word: bit r = "a corner lies in a range owned by slot r".  An owner streams the words of its points (16 bytes per lane
+// and load), ballots "selected", and every lane finds the point it is to work on from the ballots alone (nth_set_bit), so
+// the index and weight arithmetic runs on the selected points only: 1.9e9 vector instructions, 12.9 ms.
+// What bounds it now (tools/probe/lds_atomic_probe.hip, scatter_timers / scatter_phases variants): an fp32 LDS atomic
+// takes 1.9 cycles of the CU's LDS pipe PER LANE (120 for a full wave, whatever the banks), i.e. 2 x 10^9 lane-atomics =
+// 6.0 ms if the pipe never idled; it is busy 48 % of the kernel -- the waves of a workgroup spend their time one behind the
+// other in the atomic section while the pipe serves them in turn, and the other half of the time all of them compute.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kLdsScatterThreads = 1024;
+constexpr uint32_t kLdsScatterWaves = kLdsScatterThreads / 64;
 constexpr uint32_t kLdsScatterFloats = 32768;          // 128 KiB of accumulators per workgroup
 constexpr uint32_t kLdsScatterSlots = 32;              // range slots per (level, part) group = CUs per XCD
-constexpr uint32_t kLdsAhead = 8;                      // points per lane whose loads are in flight together
+constexpr uint32_t kLdsBatch = 2;                      // mask loads (256 points each) a wave works on side by side: points per lane in flight
+constexpr uint32_t kLdsStagger = 10;                   // x 64 cycles x wave index: the waves of a workgroup start a pass out of step
+constexpr uint32_t kMaskGrain = 256;                   // points per wave and mask load (4 per lane); point parts start at multiples of it
 
 // Work distribution.  The launch is 256 persistent workgroups: 8 XCDs x 32 slots (blockIdx % 8 is the XCD).  In step n the 32
 // slots of XCD x take "super-group" 8 n + x together.  A super-group belongs to one level and holds k = 32 / ranges groups of
@@ -303,12 +318,84 @@ __device__ __forceinline__ LevelPlan level_plan(uint32_t size, uint32_t rows_per
     return p;
 }
 
+// position of the r-th (0-based) set bit of a wave-uniform 64-bit mask, r < popcount(mask): five popcount steps per lane
+__device__ __forceinline__ uint32_t nth_set_bit(unsigned long long mask, uint32_t r) {
+    const uint32_t lo = (uint32_t)mask, hi = (uint32_t)(mask >> 32);
+    const uint32_t pl = (uint32_t)__popc(lo);
+    const bool up = r >= pl;
+    uint32_t w = up ? hi : lo;
+    r = up ? r - pl : r;
+    uint32_t pos = up ? 32u : 0u;
+#pragma unroll
+    for (uint32_t width = 16; width >= 1; width >>= 1) {
+        const uint32_t c = (uint32_t)__popc(w & ((1u << width) - 1u));
+        const bool go = r >= c;
+        r = go ? r - c : r;
+        w = go ? (w >> width) : w;
+        pos += go ? width : 0u;
+    }
+    return pos;
+}
+
+// a point's position inside its cell and the per-dimension products of cell_row(): (c + 1) * m is c * m + m in uint32
+// arithmetic, so the rows of the 2^D corners are D multiplies (quarter-rate instructions), not D per corner
+// (lo / hi in separate arrays: a run-time choice between term[d][0] and term[d][1] of ONE array becomes an indexed access, i.e. the
+//  array goes to scratch memory and every round of the atomic loop waits for a scratch load and everything else in flight)
+template <int D> struct CornerTerms { float w1[D], dw[D]; uint32_t lo[D], hi[D]; };
+template <int D>
+__device__ __forceinline__ void corner_terms(const LevelGeom<D>& g, float scale, const float (&x)[D], CornerTerms<D>& t) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        float p = x[d] * scale;
+        const uint32_t cell = (uint32_t)floorf(p);
+        p -= (float)cell;
+        t.dw[d] = 6 * p * (1.0f - p);
+        t.w1[d] = p * p * (3.0f - 2.0f * p);
+        const uint32_t m = g.hashed ? kCellPrimes[d] : g.stride[d];
+        t.lo[d] = cell * m;
+        t.hi[d] = t.lo[d] + m;
+    }
+}
+template <int D>
+__device__ __forceinline__ uint32_t corner_row(const LevelGeom<D>& g, const CornerTerms<D>& t, int i) {
+    uint32_t idx = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { const uint32_t tm = ((i >> d) & 1) ? t.hi[d] : t.lo[d]; idx = g.hashed ? (idx ^ tm) : (idx + tm); }
+    if (g.pow2) idx &= g.size - 1;
+    else if (idx >= g.size) idx %= g.size;          // dense levels: only the cube's far faces reach past the last row
+    return idx;
+}
+
+// masks[level * pitch + b]: bit ((row / rows_per_range) % 32) for the 2^D corner rows of point b (0 outside the cube)
+template <int D>
+__global__ void __launch_bounds__(kBlock) k_table_range_masks(const float* __restrict__ inputs, const int32_t* __restrict__ offsets,
+                                                              uint32_t* __restrict__ masks, uint32_t B, uint32_t pitch, uint32_t log2_rows,
+                                                              LevelScale ls) {
+    const uint32_t level = blockIdx.y, b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t row0 = (uint32_t)offsets[level];
+    const uint32_t size = (uint32_t)offsets[level + 1] - row0;
+    const LevelGeom<D> g = make_level_geom<D>(size, ls.resolution[level], true);
+    float x[D];
+    uint32_t mask = 0;
+    if (load_point<D>(inputs, b, x)) {
+        CornerTerms<D> t;
+        corner_terms<D>(g, ls.scale[level], x, t);
+#pragma unroll
+        for (int i = 0; i < (1 << D); ++i) mask |= 1u << ((corner_row<D>(g, t, i) >> log2_rows) & 31u);
+    }
+    masks[(size_t)level * pitch + b] = mask;
+}
+
 template <int D, int C, bool SECOND>
 __global__ void __launch_bounds__(kLdsScatterThreads) k_table_scatter_lds(const float* __restrict__ grad, const float* __restrict__ inputs,
                                                                           const int32_t* __restrict__ offsets, const float* __restrict__ ggx,
+                                                                          const uint32_t* __restrict__ masks, uint32_t pitch,
                                                                           float* __restrict__ grad_table, uint32_t B, uint32_t L, LevelScale ls) {
     constexpr uint32_t kRows = kLdsScatterFloats / C;
     __shared__ float s_acc[kLdsScatterFloats];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // block -> (group, range slot): the blocks of one XCD (blockIdx % 8) take the 32 ranges of one group at a time
     const uint32_t xcd = blockIdx.x % kXcds, slot = (blockIdx.x / kXcds) % kLdsScatterSlots;
   for (uint32_t step = 0;; ++step) {
@@ -328,171 +415,231 @@ __global__ void __launch_bounds__(kLdsScatterThreads) k_table_scatter_lds(const 
     const uint32_t size = (uint32_t)offsets[level + 1] - row0;
     const uint32_t ranges = ceil_div_u(size, kRows);
     // a level with more than 32 ranges (a table beyond 2^19 x 2 floats per level) wraps around: a slot owns ranges r, r + 32, ...
+    // (all of them share the slot's mask bit)
     const LevelGeom<D> g = make_level_geom<D>(size, ls.resolution[level], true);
     const float scale = ls.scale[level];
-    const uint32_t p0 = (uint32_t)(((unsigned long long)B * part) / parts), p1 = (uint32_t)(((unsigned long long)B * (part + 1)) / parts);
+    // point parts start at multiples of the mask grain (16-byte aligned mask loads)
+    const uint32_t p0 = (uint32_t)(((unsigned long long)B * part) / parts) / kMaskGrain * kMaskGrain;
+    const uint32_t p1 = part + 1 == parts ? B : (uint32_t)(((unsigned long long)B * (part + 1)) / parts) / kMaskGrain * kMaskGrain;
+    const uint32_t* mrow = masks + (size_t)level * pitch;
     for (uint32_t range = first_range; range < ranges; range += kLdsScatterSlots) {
         const uint32_t base = range * kRows;
         for (uint32_t i = threadIdx.x; i < kLdsScatterFloats; i += kLdsScatterThreads) s_acc[i] = 0.0f;
         __syncthreads();
-        // kLdsAhead points per lane and iteration, every load issued before the first is used: with four waves per SIMD and
-        // nothing else to switch to, one point per iteration ran at the latency of its loads (53 ms for 7.7 M points)
-        for (uint32_t b0 = p0; b0 < p1; b0 += kLdsScatterThreads * kLdsAhead) {
-            float xs[kLdsAhead][D], gs[kLdsAhead][C], ggs[kLdsAhead][D];
-            bool ons[kLdsAhead];
+
+        // A batch is kLdsBatch points per lane: loads, index and weight arithmetic, LDS atomics.  NOTHING else here may touch LDS:
+        // the CU's LDS pipe takes ~1.9 cycles per lane of an fp32 atomic (120 per full wave) and serves plain LDS reads and writes of
+        // ANY wave only behind the atomics in flight (tools/probe/lds_atomic_probe.hip: a wave of sparse ds_writes beside atomic waves
+        // finishes when the atomics do) -- with the selected points queued through LDS the kernel took the SUM of its atomics (7.4 ms)
+        // and of everything else (5.4 ms); vector-ALU work and global loads do overlap the atomics.
+        struct Batch { uint32_t b[kLdsBatch]; bool on[kLdsBatch]; float xs[kLdsBatch][D], gs[kLdsBatch][C], ggs[kLdsBatch][D]; };
+        struct Prepared { CornerTerms<D> t; uint32_t pending; float gcur[C]; float corner[SECOND ? (1 << D) : 1][C]; };
+        auto issue_loads = [&](Batch& q) {
 #pragma unroll
-            for (uint32_t u = 0; u < kLdsAhead; ++u) {
-                const uint32_t bu = b0 + u * kLdsScatterThreads + threadIdx.x;
-                const uint32_t b = min(bu, p1 - 1);
-                ons[u] = bu < p1;
+            for (uint32_t u = 0; u < kLdsBatch; ++u) {
+                const uint32_t b = q.b[u];
 #pragma unroll
-                for (int d = 0; d < D; ++d) xs[u][d] = inputs[(size_t)b * D + d];
+                for (int d = 0; d < D; ++d) q.xs[u][d] = inputs[(size_t)b * D + d];
 #pragma unroll
-                for (int c = 0; c < C; ++c) gs[u][c] = grad[((size_t)level * B + b) * C + c];
+                for (int c = 0; c < C; ++c) q.gs[u][c] = grad[((size_t)level * B + b) * C + c];
                 if constexpr (SECOND) {
 #pragma unroll
-                    for (int d = 0; d < D; ++d) ggs[u][d] = ggx[(size_t)b * D + d];
+                    for (int d = 0; d < D; ++d) q.ggs[u][d] = ggx[(size_t)b * D + d];
                 }
             }
+        };
+        auto prepare = [&](const Batch& q, uint32_t u, Prepared& r) {
+            const bool on = q.on[u];          // (a queued point is inside the cube: its mask would be 0 otherwise)
+            float x[D];
 #pragma unroll
-            for (uint32_t u = 0; u < kLdsAhead; ++u) {
-                float x[D];
-                bool on = ons[u];
+            for (int d = 0; d < D; ++d) x[d] = on ? q.xs[u][d] : 0.5f;
+            corner_terms<D>(g, scale, x, r.t);
+            r.pending = 0;
+#pragma unroll
+            for (int i = 0; i < (1 << D); ++i) r.pending |= (on && corner_row<D>(g, r.t, i) - base < kRows) ? (1u << i) : 0u;
+#pragma unroll
+            for (int c = 0; c < C; ++c) r.gcur[c] = on ? q.gs[u][c] : 0.0f;
+            if constexpr (SECOND) {
+                // +/- w * grad * ggx[gd] * smoothstep'(frac_gd) on the corner pairs along gd (k_second_backward_table's statements)
+                float gg[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) gg[d] = on ? q.ggs[u][d] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < (1 << D); ++i)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) r.corner[i][c] = 0;
+#pragma unroll
+                for (int gd = 0; gd < D; ++gd) {
+#pragma unroll
+                    for (int jj = 0; jj < (1 << (D - 1)); ++jj) {
+                        float w = scale;
+                        int lo = 0;
+#pragma unroll
+                        for (int nd = 0; nd < D - 1; ++nd) {
+                            const int d = nd >= gd ? nd + 1 : nd;
+                            const int bit = (jj >> nd) & 1;
+                            w *= bit ? r.t.w1[d] : 1 - r.t.w1[d];
+                            lo |= bit << d;
+                        }
+                        const int hi = lo | (1 << gd);
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            const float v = w * r.gcur[c] * gg[gd] * r.t.dw[gd];
+                            r.corner[hi][c] += v;
+                            r.corner[lo][c] -= v;
+                        }
+                    }
+                }
+            }
+        };
+        // Every lane picks ITS next in-range corner and the wave issues one atomic per channel and round; a queued point has at
+        // least one corner in range, so the first round is a full wave; ~1.1 corners per point are in range on a hashed level.
+        auto add = [&](Prepared& r) {
+            uint32_t pending = r.pending;
+            while (__ballot(pending != 0)) {
+                const int pick = pending ? __ffs((int)pending) - 1 : 0;
+                // the picked corner's row and weight from its bits: D selects each, instead of 2^D-way select chains
+                uint32_t idx = 0;
+                float w = 1;
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-                    x[d] = xs[u][d];
-                    if (x[d] < 0 || x[d] > 1) on = false;           // outside the cube: nothing to add
+                    const bool bit = (pick >> d) & 1;
+                    const uint32_t tm = bit ? r.t.hi[d] : r.t.lo[d];
+                    idx = g.hashed ? (idx ^ tm) : (idx + tm);
+                    w *= bit ? r.t.w1[d] : 1 - r.t.w1[d];
                 }
-                if (!on) {
-#pragma unroll
-                    for (int d = 0; d < D; ++d) x[d] = 0.5f;
-                }
-                float w1[D], dw[D];
-                uint32_t cell[D];
-#pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    float p = x[d] * scale;
-                    cell[d] = (uint32_t)floorf(p);
-                    p -= (float)cell[d];
-                    dw[d] = 6 * p * (1.0f - p);
-                    w1[d] = p * p * (3.0f - 2.0f * p);
-                }
-                // rows of the 2^D corners: cell_row()'s arithmetic with the per-dimension products formed once -- (c + 1) * m is
-                // c * m + m in uint32 arithmetic -- instead of D multiplies per corner (quarter-rate instructions: 16 of them were a
-                // third of the range owners' index work)
-                uint32_t term[D][2];
-#pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    const uint32_t m = g.hashed ? kCellPrimes[d] : g.stride[d];
-                    term[d][0] = cell[d] * m;
-                    term[d][1] = term[d][0] + m;
-                }
-                uint32_t local[1 << D];
-                bool mine = false;
-#pragma unroll
-                for (int i = 0; i < (1 << D); ++i) {
-                    uint32_t idx = 0;
-#pragma unroll
-                    for (int d = 0; d < D; ++d) idx = g.hashed ? (idx ^ term[d][(i >> d) & 1]) : (idx + term[d][(i >> d) & 1]);
-                    if (g.pow2) idx &= g.size - 1;
-                    else if (idx >= g.size) idx %= g.size;          // dense levels: only the cube's far faces reach past the last row
-                    local[i] = idx - base;
-                    mine |= on && local[i] < kRows;
-                }
-                if (!__ballot(mine)) continue;          // nothing of this wave's 64 points lands in the range
-                float gcur[C];
-#pragma unroll
-                for (int c = 0; c < C; ++c) gcur[c] = on ? gs[u][c] : 0.0f;
-                float corner[1 << D][C];
+                if (g.pow2) idx &= g.size - 1;
+                else if (idx >= g.size) idx %= g.size;
+                const uint32_t at = idx - base;
+                float v[C];
                 if constexpr (SECOND) {
-                    // +/- w * grad * ggx[gd] * smoothstep'(frac_gd) on the corner pairs along gd (k_second_backward_table's statements)
-                    float gg[D];
 #pragma unroll
-                    for (int d = 0; d < D; ++d) gg[d] = on ? ggs[u][d] : 0.0f;
+                    for (int c = 0; c < C; ++c) v[c] = r.corner[0][c];
 #pragma unroll
-                    for (int i = 0; i < (1 << D); ++i)
+                    for (int i = 1; i < (1 << D); ++i) {
+                        if (pick == i) {
 #pragma unroll
-                        for (int c = 0; c < C; ++c) corner[i][c] = 0;
-#pragma unroll
-                    for (int gd = 0; gd < D; ++gd) {
-#pragma unroll
-                        for (int jj = 0; jj < (1 << (D - 1)); ++jj) {
-                            float w = scale;
-                            int lo = 0;
-#pragma unroll
-                            for (int nd = 0; nd < D - 1; ++nd) {
-                                const int d = nd >= gd ? nd + 1 : nd;
-                                const int bit = (jj >> nd) & 1;
-                                w *= bit ? w1[d] : 1 - w1[d];
-                                lo |= bit << d;
-                            }
-                            const int hi = lo | (1 << gd);
-#pragma unroll
-                            for (int c = 0; c < C; ++c) {
-                                const float v = w * gcur[c] * gg[gd] * dw[gd];
-                                corner[hi][c] += v;
-                                corner[lo][c] -= v;
-                            }
+                            for (int c = 0; c < C; ++c) v[c] = r.corner[i][c];
                         }
                     }
-                }          // (first order: the picked corner's value is formed in the loop below -- ~0.25 corners per point are in range)
-                // A range owns 1/32 of a hashed level's rows, so per wave ~16 of the 512 (lane, corner) pairs are in range: one
-                // predicated LDS atomic per corner would issue 8 C instructions with ~2 active lanes each (a returnless fp32 LDS
-                // atomic costs ~40 cycles of the CU's LDS pipe however few lanes take part).  Instead every lane picks ITS next
-                // in-range corner and the wave issues one atomic per channel and round; two rounds cover almost every wave.
-                uint32_t pending = 0;
+                } else {
 #pragma unroll
-                for (int i = 0; i < (1 << D); ++i) pending |= (on && local[i] < kRows) ? (1u << i) : 0u;
-                while (__ballot(pending != 0)) {
-                    const int pick = pending ? __ffs((int)pending) - 1 : 0;
-                    uint32_t at = local[0];
-                    float v[C];
-                    if constexpr (SECOND) {
-#pragma unroll
-                        for (int c = 0; c < C; ++c) v[c] = corner[0][c];
-#pragma unroll
-                        for (int i = 1; i < (1 << D); ++i) {
-                            if (pick == i) {
-                                at = local[i];
-#pragma unroll
-                                for (int c = 0; c < C; ++c) v[c] = corner[i][c];
-                            }
-                        }
-                    } else {
-                        // the picked corner's row and weight from its bits: D selects each, instead of 2^D-way select chains
-                        uint32_t idx = 0;
-                        float w = 1;
-#pragma unroll
-                        for (int d = 0; d < D; ++d) {
-                            const bool bit = (pick >> d) & 1;
-                            const uint32_t t = bit ? term[d][1] : term[d][0];
-                            idx = g.hashed ? (idx ^ t) : (idx + t);
-                            w *= bit ? w1[d] : 1 - w1[d];
-                        }
-                        if (g.pow2) idx &= g.size - 1;
-                        else if (idx >= g.size) idx %= g.size;
-                        at = idx - base;
-#pragma unroll
-                        for (int c = 0; c < C; ++c) v[c] = w * gcur[c];
-                    }
-                    if (pending) {
-#pragma unroll
-                        for (int c = 0; c < C; ++c) __hip_atomic_fetch_add(&s_acc[at * C + c], v[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        pending &= pending - 1;
-                    }
+                    for (int c = 0; c < C; ++c) v[c] = w * r.gcur[c];
                 }
+                if (pending) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) __hip_atomic_fetch_add(&s_acc[c * kRows + at], v[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    pending &= pending - 1;
+                }
+            }
+        };
+
+        // Which lane works on which selected point is computed from the ballots alone: the ballot of "point 4 l + k of this load is
+        // selected" (k = 0 .. 3) is wave-uniform, so lane j can find the j-th selected point by itself (rank -> position of the
+        // rank-th set bit: five popcount steps) -- no queue, no cross-lane traffic.  A load of 256 points selects ~56 on a hashed
+        // level, i.e. one round with 7/8 of the lanes busy; kLdsBatch loads are worked on side by side (their point loads in
+        // flight together).
+        const uint32_t bit = first_range;                 // == range % 32
+        constexpr uint32_t kStride = kLdsScatterWaves * kLdsBatch * kMaskGrain;
+        auto load_masks = [&](uint32_t c0, uint4 (&m)[kLdsBatch]) {
+#pragma unroll
+            for (uint32_t u = 0; u < kLdsBatch; ++u) {
+                const uint32_t b = c0 + u * kMaskGrain + lane * 4u;
+                m[u] = make_uint4(0, 0, 0, 0);
+                if (b < p1) m[u] = *reinterpret_cast<const uint4*>(mrow + b);          // (the row's tail is padded: pitch)
+            }
+        };
+        uint4 m_next[kLdsBatch];
+        load_masks(p0 + wave * kLdsBatch * kMaskGrain, m_next);
+        for (uint32_t w = 0; w < wave; ++w) __builtin_amdgcn_s_sleep(kLdsStagger);
+        for (uint32_t c0 = p0 + wave * kLdsBatch * kMaskGrain; c0 < p1; c0 += kStride) {
+            uint4 m[kLdsBatch];
+#pragma unroll
+            for (uint32_t u = 0; u < kLdsBatch; ++u) m[u] = m_next[u];
+            load_masks(c0 + kStride, m_next);          // (the next words are requested before these points are worked on)
+            unsigned long long bal[kLdsBatch][4];
+            uint32_t cum[kLdsBatch][4], most = 0;      // cum[u][k]: selected points of load u with a component below k
+#pragma unroll
+            for (uint32_t u = 0; u < kLdsBatch; ++u) {
+                const uint32_t b = c0 + u * kMaskGrain + lane * 4u;
+                const uint32_t mk[4] = {m[u].x, m[u].y, m[u].z, m[u].w};
+                uint32_t n = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    bal[u][k] = __ballot(((mk[k] >> bit) & 1u) != 0 && b + k < p1);
+                    cum[u][k] = n;
+                    n += (uint32_t)__popcll(bal[u][k]);
+                }
+                most = max(most, n);
+                cum[u][0] = n;                         // (cum[u][0] is 0 by construction: the slot carries the load's total instead)
+            }
+            for (uint32_t r0 = 0; r0 < most; r0 += 64u) {
+                Batch q;
+                const uint32_t j = r0 + lane;
+#pragma unroll
+                for (uint32_t u = 0; u < kLdsBatch; ++u) {
+                    q.on[u] = j < cum[u][0];
+                    const uint32_t k = (j >= cum[u][1] ? 1u : 0u) + (j >= cum[u][2] ? 1u : 0u) + (j >= cum[u][3] ? 1u : 0u);
+                    const unsigned long long mask = k == 0 ? bal[u][0] : k == 1 ? bal[u][1] : k == 2 ? bal[u][2] : bal[u][3];
+                    const uint32_t below = k == 0 ? 0u : k == 1 ? cum[u][1] : k == 2 ? cum[u][2] : cum[u][3];
+                    const uint32_t src = q.on[u] ? nth_set_bit(mask, j - below) : 0u;
+                    q.b[u] = q.on[u] ? c0 + u * kMaskGrain + src * 4u + k : p0;
+                }
+                issue_loads(q);
+                Prepared prep[kLdsBatch];
+#pragma unroll
+                for (uint32_t u = 0; u < kLdsBatch; ++u) prepare(q, u, prep[u]);
+#pragma unroll
+                for (uint32_t u = 0; u < kLdsBatch; ++u) add(prep[u]);
             }
         }
         __syncthreads();
         float* t = grad_table + ((size_t)row0 + base) * C;
         const uint32_t valid = min(kRows, size - base) * C;
         for (uint32_t i = threadIdx.x; i < valid; i += kLdsScatterThreads) {
-            const float v = s_acc[i];
+            const float v = s_acc[(i % C) * kRows + i / C];          // accumulators are channel-major: an atomic's 64 rows spread over all banks
             if (v != 0.0f) unsafeAtomicAdd(&t[i], v);
         }
-        __syncthreads();
+        // (the accumulators may be zeroed again once every wave has READ them: wait for the LDS reads only, not for the global atomics)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
   }
+}
+
+// per-(device, stream) scratch for the range masks: grown on demand and kept
+static uint32_t* range_mask_scratch(hipStream_t s, size_t words) {
+    struct Scratch { void* ptr; size_t bytes; };
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Scratch> pool;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    Scratch& sc = pool[{dev, s}];
+    if (words * 4 > sc.bytes) {
+        if (sc.ptr) (void)hipFree(sc.ptr);
+        sc.bytes = words * 4;
+        if (hipMalloc(&sc.ptr, sc.bytes) != hipSuccess) { sc.ptr = nullptr; sc.bytes = 0; }
+    }
+    return static_cast<uint32_t*>(sc.ptr);
+}
+
+// pre-pass + range owners
+template <int D, int C, bool SECOND>
+static int launch_table_scatter_lds(const float* grad, const float* inputs, const int32_t* offsets, const float* ggx, float* grad_table, uint32_t B,
+                                    uint32_t L, const LevelScale& ls, hipStream_t s) {
+    constexpr uint32_t kRows = kLdsScatterFloats / C;
+    static_assert((kRows & (kRows - 1)) == 0, "rows per range: a power of two");
+    uint32_t log2_rows = 0;
+    while ((1u << log2_rows) < kRows) ++log2_rows;
+    const uint32_t pitch = (B + 3u) / 4u * 4u;
+    uint32_t* masks = range_mask_scratch(s, (size_t)L * pitch + kMaskGrain);
+    if (!masks) { set_error("hash_encode_backward: no memory for %zu bytes of range masks", ((size_t)L * pitch + kMaskGrain) * 4); return ENVIDR_ELAUNCH; }
+    hipLaunchKernelGGL((k_table_range_masks<D>), dim3(ceil_div(B, kBlock), L), dim3(kBlock), 0, s, inputs, offsets, masks, B, pitch, log2_rows, ls);
+    int rc = check_launch("k_table_range_masks");
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_table_scatter_lds<D, C, SECOND>), dim3(kXcds * kLdsScatterSlots), dim3(kLdsScatterThreads), 0, s, grad, inputs, offsets, ggx,
+                       masks, pitch, grad_table, B, L, ls);
+    return check_launch("k_table_scatter_lds");
 }
 
 constexpr uint32_t kLdsScatterMinPoints = 1u << 19;    // below this the per-point atomics (combined inside the wave) are faster
@@ -551,9 +698,7 @@ int envidr_hash_encode_backward(const float* grad, const float* inputs, const fl
     return dispatch_dc(D, C, "hash_encode_backward", [&](auto d, auto c) {
         constexpr int DD = decltype(d)::value, CC = decltype(c)::value;
         if (grad_embeddings && B >= kLdsScatterMinPoints) {
-            hipLaunchKernelGGL((k_table_scatter_lds<DD, CC, false>), dim3(kXcds * kLdsScatterSlots), dim3(kLdsScatterThreads), 0,
-                               as_stream(stream), grad, inputs, offsets, (const float*)nullptr, grad_embeddings, B, L, ls);
-            const int rc = check_launch("k_table_scatter_lds");
+            const int rc = launch_table_scatter_lds<DD, CC, false>(grad, inputs, offsets, nullptr, grad_embeddings, B, L, ls, as_stream(stream));
             if (rc) return rc;
         } else if (grad_embeddings) {
             hipLaunchKernelGGL((k_hash_backward_table<DD, CC>), dim3(xcd_grid_blocks(L, chunks)), dim3(kBlock), 0,
@@ -590,9 +735,7 @@ int envidr_hash_encode_second_backward(const float* grad, const float* inputs, c
         int rc = check_launch("k_second_backward_grad");
         if (rc) return rc;
         if (B >= kLdsScatterMinPoints) {
-            hipLaunchKernelGGL((k_table_scatter_lds<DD, CC, true>), dim3(kXcds * kLdsScatterSlots), dim3(kLdsScatterThreads), 0,
-                               as_stream(stream), grad, inputs, offsets, grad_grad_inputs, grad2_embeddings, B, L, ls);
-            return check_launch("k_table_scatter_lds");
+            return launch_table_scatter_lds<DD, CC, true>(grad, inputs, offsets, grad_grad_inputs, grad2_embeddings, B, L, ls, as_stream(stream));
         }
         hipLaunchKernelGGL((k_second_backward_table<DD, CC>), dim3(xcd_grid_blocks(L, chunks)), dim3(kBlock), 0,
                            as_stream(stream), grad, inputs, offsets, grad_grad_inputs, grad2_embeddings, B, L, ls,

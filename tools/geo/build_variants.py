@@ -140,7 +140,45 @@ VARIANTS = {
                                           ("geometry_pass.hip", P3, "            wp.template end_pass<kSdfFrags>();\n            __builtin_amdgcn_s_setprio(2);\n        }\n\n        // ================= phase 3")]),
     "eval_prio_mfma": ("geometry_pass", [("geometry_pass.hip", P1, "        __builtin_amdgcn_s_setprio(0);\n" + P1),
                                          ("geometry_pass.hip", P2, "        __builtin_amdgcn_s_setprio(2);\n" + P2)]),
+    # ablations of the range-owned table scatter (timing only): without the LDS atomics / without the queued points' work
+    "scatter_noatomic": ("hashencoder", [("hashencoder.hip", "                        for (int c = 0; c < C; ++c) __hip_atomic_fetch_add(&s_acc[c * kRows + at], v[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n",
+                                          "                        for (int c = 0; c < C; ++c) if (v[c] == 123.456f) s_acc[c * kRows + at] = v[c];\n")]),
+    "scatter_nowork": ("hashencoder", [("hashencoder.hip", "                work(bq, onq);\n", "                if (bq[0] == 0xffffffffu) work(bq, onq);\n")]),
+    # per-phase clocks of the range owners (sum over waves, in 64-cycle units) -> the first words of the mask scratch (tools/probe/scatter_only.py --timers)
+    "scatter_timers": ("hashencoder", [
+        ("hashencoder.hip", "            for (uint32_t r0 = 0; r0 < most; r0 += 64u) {\n                Batch q;\n",
+         "            for (uint32_t r0 = 0; r0 < most; r0 += 64u) {\n                Batch q;\n                const unsigned long long T0 = __builtin_amdgcn_s_memtime();\n"),
+        ("hashencoder.hip", "                issue_loads(q);\n                Prepared prep[kLdsBatch];\n",
+         "                const unsigned long long T1 = __builtin_amdgcn_s_memtime();\n                issue_loads(q);\n                __builtin_amdgcn_s_waitcnt(0);\n                const unsigned long long T2 = __builtin_amdgcn_s_memtime();\n                Prepared prep[kLdsBatch];\n"),
+        ("hashencoder.hip", "                for (uint32_t u = 0; u < kLdsBatch; ++u) add(prep[u]);\n            }\n",
+         "                for (uint32_t u = 0; u < kLdsBatch; ++u) if (prep[u].pending == 0xffffffffu) T_acc[3] += 1;\n                __builtin_amdgcn_sched_barrier(0);\n                const unsigned long long T3 = __builtin_amdgcn_s_memtime();\n"
+         "#pragma unroll\n                for (uint32_t u = 0; u < kLdsBatch; ++u) add(prep[u]);\n                __builtin_amdgcn_s_waitcnt(0);\n                const unsigned long long T4 = __builtin_amdgcn_s_memtime();\n"
+         "                T_acc[0] += T1 - T0; T_acc[1] += T2 - T1; T_acc[2] += T3 - T2; T_acc[3] += T4 - T3;\n            }\n"),
+        ("hashencoder.hip", "        uint4 m_next[kLdsBatch];\n", "        unsigned long long T_acc[4] = {0, 0, 0, 0};\n        const unsigned long long T_begin = __builtin_amdgcn_s_memtime();\n        uint4 m_next[kLdsBatch];\n"),
+        ("hashencoder.hip", "        __syncthreads();\n        float* t = grad_table + ((size_t)row0 + base) * C;",
+         "        if (lane == 0) { for (int q_ = 0; q_ < 4; ++q_) atomicAdd(timers + q_, (unsigned long long)(T_acc[q_] >> 6)); atomicAdd(timers + 4, (unsigned long long)((__builtin_amdgcn_s_memtime() - T_begin) >> 6)); }\n"
+         "        __syncthreads();\n        float* t = grad_table + ((size_t)row0 + base) * C;"),
+        ("hashencoder.hip", "    constexpr uint32_t kRows = kLdsScatterFloats / C;\n    __shared__ float s_acc[kLdsScatterFloats];\n",
+         "    constexpr uint32_t kRows = kLdsScatterFloats / C;\n    __shared__ float s_acc[kLdsScatterFloats];\n    unsigned long long* timers = reinterpret_cast<unsigned long long*>(grad_table + (size_t)offsets[L] * C);\n"),
+    ]),
+    # block-level phases of the range owners (thread 0 of every workgroup, 64-cycle units): zeroing, point loop (barrier to barrier), flush, whole kernel
+    "scatter_phases": ("hashencoder", [
+        ("hashencoder.hip", "    constexpr uint32_t kRows = kLdsScatterFloats / C;\n    __shared__ float s_acc[kLdsScatterFloats];\n",
+         "    constexpr uint32_t kRows = kLdsScatterFloats / C;\n    __shared__ float s_acc[kLdsScatterFloats];\n    unsigned long long* timers = reinterpret_cast<unsigned long long*>(grad_table + (size_t)offsets[L] * C);\n    const unsigned long long K0 = __builtin_amdgcn_s_memtime();\n    unsigned long long P_acc[3] = {0, 0, 0};\n"),
+        ("hashencoder.hip", "        const uint32_t base = range * kRows;\n        for (uint32_t i = threadIdx.x; i < kLdsScatterFloats; i += kLdsScatterThreads) s_acc[i] = 0.0f;\n        __syncthreads();\n",
+         "        const uint32_t base = range * kRows;\n        const unsigned long long Q0 = __builtin_amdgcn_s_memtime();\n        for (uint32_t i = threadIdx.x; i < kLdsScatterFloats; i += kLdsScatterThreads) s_acc[i] = 0.0f;\n        __syncthreads();\n        const unsigned long long Q1 = __builtin_amdgcn_s_memtime();\n"),
+        ("hashencoder.hip", "        __syncthreads();\n        float* t = grad_table + ((size_t)row0 + base) * C;",
+         "        __syncthreads();\n        const unsigned long long Q2 = __builtin_amdgcn_s_memtime();\n        float* t = grad_table + ((size_t)row0 + base) * C;"),
+        ("hashencoder.hip", '        asm volatile("s_waitcnt lgkmcnt(0)\\n\\ts_barrier" ::: "memory");\n    }\n',
+         '        asm volatile("s_waitcnt lgkmcnt(0)\\n\\ts_barrier" ::: "memory");\n        P_acc[0] += Q1 - Q0; P_acc[1] += Q2 - Q1; P_acc[2] += __builtin_amdgcn_s_memtime() - Q2;\n    }\n'),
+        ("hashencoder.hip", "    if (level >= L) break;                                   // past the last super-group (uniform over the workgroup)\n",
+         "    if (level >= L) { if (threadIdx.x == 0) { for (int q_ = 0; q_ < 3; ++q_) atomicAdd(timers + q_, (unsigned long long)(P_acc[q_] >> 6)); const unsigned long long all_ = (__builtin_amdgcn_s_memtime() - K0) >> 6; atomicAdd(timers + 3, all_); atomicMax(timers + 4, all_); } break; }\n"),
+    ]),
+    "scatter_waves8": ("hashencoder", [("hashencoder.hip", "constexpr uint32_t kLdsScatterThreads = 1024;", "constexpr uint32_t kLdsScatterThreads = 512;")]),
+    "scatter_batch1": ("hashencoder", [("hashencoder.hip", "constexpr uint32_t kLdsBatch = 2; ", "constexpr uint32_t kLdsBatch = 1; ")]),
+    "scatter_batch4": ("hashencoder", [("hashencoder.hip", "constexpr uint32_t kLdsBatch = 2; ", "constexpr uint32_t kLdsBatch = 4; ")]),
 }
+
 
 
 def main(names):
