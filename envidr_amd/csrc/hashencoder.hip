@@ -286,18 +286,18 @@ __global__ void __launch_bounds__(kBlock) k_second_backward_table(const float* _
 // 7.7 M points).  So a pre-pass (k_table_range_masks, 0.34 ms) forms the rows once per (point, level) and leaves a 32-bit
 // word: bit r = "a corner lies in a range owned by slot r".  An owner streams the words of its points (16 bytes per lane
 // and load), ballots "selected", and every lane finds the point it is to work on from the ballots alone (nth_set_bit), so
-// the index and weight arithmetic runs on the selected points only: 1.9e9 vector instructions, 12.9 ms.
+// the index and weight arithmetic runs on the selected points only: 1.9e9 vector instructions, 12.0 ms.
 // What bounds it now (tools/probe/lds_atomic_probe.hip, scatter_timers / scatter_phases variants): an fp32 LDS atomic
 // takes 1.9 cycles of the CU's LDS pipe PER LANE (120 for a full wave, whatever the banks), i.e. 2 x 10^9 lane-atomics =
 // 6.0 ms if the pipe never idled; it is busy 48 % of the kernel -- the waves of a workgroup spend their time one behind the
-// other in the atomic section while the pipe serves them in turn, and the other half of the time all of them compute.
+// other in the atomic section while the pipe serves them in turn, and the other half of the time all of them compute
+// (starting the waves of a workgroup out of step changes nothing).
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kLdsScatterThreads = 1024;
 constexpr uint32_t kLdsScatterWaves = kLdsScatterThreads / 64;
 constexpr uint32_t kLdsScatterFloats = 32768;          // 128 KiB of accumulators per workgroup
 constexpr uint32_t kLdsScatterSlots = 32;              // range slots per (level, part) group = CUs per XCD
 constexpr uint32_t kLdsBatch = 2;                      // mask loads (256 points each) a wave works on side by side: points per lane in flight
-constexpr uint32_t kLdsStagger = 10;                   // x 64 cycles x wave index: the waves of a workgroup start a pass out of step
 constexpr uint32_t kMaskGrain = 256;                   // points per wave and mask load (4 per lane); point parts start at multiples of it
 
 // Work distribution.  The launch is 256 persistent workgroups: 8 XCDs x 32 slots (blockIdx % 8 is the XCD).  In step n the 32
@@ -307,7 +307,7 @@ constexpr uint32_t kMaskGrain = 256;                   // points per wave and ma
 // a level with few ranges (the dense ones: 1, 1, 2, 5, 13) still keeps ~kLdsBlocksPerLevel workgroups busy instead of doing all
 // its LDS atomics on a handful (level 0 on three workgroups took 51 ms).  The plan is recomputed from `offsets` by every
 // workgroup (scalar work; the sizes live on the device).
-constexpr uint32_t kLdsBlocksPerLevel = 96;
+constexpr uint32_t kLdsBlocksPerLevel = 288;
 struct LevelPlan { uint32_t ranges, per_sg, parts, sgs; };
 __device__ __forceinline__ LevelPlan level_plan(uint32_t size, uint32_t rows_per_range) {
     LevelPlan p;
@@ -551,7 +551,6 @@ __global__ void __launch_bounds__(kLdsScatterThreads) k_table_scatter_lds(const 
         };
         uint4 m_next[kLdsBatch];
         load_masks(p0 + wave * kLdsBatch * kMaskGrain, m_next);
-        for (uint32_t w = 0; w < wave; ++w) __builtin_amdgcn_s_sleep(kLdsStagger);
         for (uint32_t c0 = p0 + wave * kLdsBatch * kMaskGrain; c0 < p1; c0 += kStride) {
             uint4 m[kLdsBatch];
 #pragma unroll

@@ -140,10 +140,6 @@ VARIANTS = {
                                           ("geometry_pass.hip", P3, "            wp.template end_pass<kSdfFrags>();\n            __builtin_amdgcn_s_setprio(2);\n        }\n\n        // ================= phase 3")]),
     "eval_prio_mfma": ("geometry_pass", [("geometry_pass.hip", P1, "        __builtin_amdgcn_s_setprio(0);\n" + P1),
                                          ("geometry_pass.hip", P2, "        __builtin_amdgcn_s_setprio(2);\n" + P2)]),
-    # ablations of the range-owned table scatter (timing only): without the LDS atomics / without the queued points' work
-    "scatter_noatomic": ("hashencoder", [("hashencoder.hip", "                        for (int c = 0; c < C; ++c) __hip_atomic_fetch_add(&s_acc[c * kRows + at], v[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n",
-                                          "                        for (int c = 0; c < C; ++c) if (v[c] == 123.456f) s_acc[c * kRows + at] = v[c];\n")]),
-    "scatter_nowork": ("hashencoder", [("hashencoder.hip", "                work(bq, onq);\n", "                if (bq[0] == 0xffffffffu) work(bq, onq);\n")]),
     # per-phase clocks of the range owners (sum over waves, in 64-cycle units) -> the first words of the mask scratch (tools/probe/scatter_only.py --timers)
     "scatter_timers": ("hashencoder", [
         ("hashencoder.hip", "            for (uint32_t r0 = 0; r0 < most; r0 += 64u) {\n                Batch q;\n",
@@ -177,8 +173,19 @@ VARIANTS = {
     "scatter_waves8": ("hashencoder", [("hashencoder.hip", "constexpr uint32_t kLdsScatterThreads = 1024;", "constexpr uint32_t kLdsScatterThreads = 512;")]),
     "scatter_batch1": ("hashencoder", [("hashencoder.hip", "constexpr uint32_t kLdsBatch = 2; ", "constexpr uint32_t kLdsBatch = 1; ")]),
     "scatter_batch4": ("hashencoder", [("hashencoder.hip", "constexpr uint32_t kLdsBatch = 2; ", "constexpr uint32_t kLdsBatch = 4; ")]),
+    "scatter_parts192": ("hashencoder", [("hashencoder.hip", "constexpr uint32_t kLdsBlocksPerLevel = 288;", "constexpr uint32_t kLdsBlocksPerLevel = 192;")]),
+    "scatter_parts288": ("hashencoder", [("hashencoder.hip", "constexpr uint32_t kLdsBlocksPerLevel = 288;", "constexpr uint32_t kLdsBlocksPerLevel = 288;")]),
+    "scatter_parts512": ("hashencoder", [("hashencoder.hip", "constexpr uint32_t kLdsBlocksPerLevel = 288;", "constexpr uint32_t kLdsBlocksPerLevel = 512;")]),
+    "scatter_parts384": ("hashencoder", [("hashencoder.hip", "constexpr uint32_t kLdsBlocksPerLevel = 288;", "constexpr uint32_t kLdsBlocksPerLevel = 384;")]),
+    # timing only: the LDS atomics as plain LDS writes / as nothing
+    "scatter_plainwrite": ("hashencoder", [("hashencoder.hip", "                    for (int c = 0; c < C; ++c) __hip_atomic_fetch_add(&s_acc[c * kRows + at], v[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n",
+                                            "                    for (int c = 0; c < C; ++c) s_acc[c * kRows + at] = v[c];\n")]),
+    "scatter_noatomic": ("hashencoder", [("hashencoder.hip", "                    for (int c = 0; c < C; ++c) __hip_atomic_fetch_add(&s_acc[c * kRows + at], v[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n",
+                                          "                    for (int c = 0; c < C; ++c) if (v[c] == 123.456f) s_acc[c * kRows + at] = v[c];\n")]),
 }
 
+
+VARIANTS["scatter_timers_noatomic"] = ("hashencoder", VARIANTS["scatter_timers"][1] + VARIANTS["scatter_noatomic"][1])
 
 
 def main(names):
