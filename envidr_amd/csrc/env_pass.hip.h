@@ -128,7 +128,8 @@ __device__ __forceinline__ void env_step_out16(Src& wp, const f32x16 (&in)[KT], 
 
 // which widths run the hand-over form (an even number of 32-feature tiles); the host packs E1 with k_order 4 and E2, E3 with 3 for
 // exactly these (envidr_amd/fused.py: env_orders)
-constexpr bool env_handoff(int env_t) { return env_t >= 4 && env_t % 2 == 0; }
+// (E1 loads the next layer's bias tiles behind its step-major steps 2 .. ENV_T + 1: with the hand-over its first TERMS - 16 steps must cover them)
+constexpr bool env_handoff(int terms, int env_t) { return env_t >= 4 && env_t % 2 == 0 && terms - 16 >= env_t + 2; }
 
 // ---- hand-over of a layer's first input tile ---------------------------------------------------------------------------
 // The operands of a layer's FIRST input tile have nothing of that layer to hide under; staged with the vector ALU they sit in
@@ -151,7 +152,7 @@ __device__ __forceinline__ void env_pass(Src& wp, const uint32_t lane, const Env
     using L = EnvLayout<TERMS, ENV_T>;
     f32x16 ha[ENV_T], hb[ENV_T];
     float bq[2][16];
-    static_assert(!HANDOFF || (ENV_T % 2 == 0 && ENV_T >= 4 && TERMS >= 16), "hand-over needs an even tile count (the last tile uses bq[1])");
+    static_assert(!HANDOFF || env_handoff(TERMS, ENV_T), "hand-over needs an even tile count (the last tile uses bq[1]) and TERMS - 16 >= ENV_T + 2 step-major steps in E1");
     // ---- E1: 2 TERMS -> 32 ENV_T
 #pragma unroll
     for (int t = 0; t < ENV_T; ++t) ha[t] = lds_bias_tile(aux.bias, t);

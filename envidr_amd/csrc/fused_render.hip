@@ -27,6 +27,7 @@
 // deltas (ulp-level), see DESIGN.md.
 #include "fused_common.hip.h"
 #include "sh_core.hip.h"
+#include "rowio.hip.h"
 
 #include <map>
 #include <mutex>
@@ -265,7 +266,7 @@ __device__ __forceinline__ void shade_sample(WP& wp, const uint32_t lane, const 
             f32x16 o;
             const bool last = enc == 1 && grp == 1;
             wp.begin_pass(c.env_blob, kEnvChunks, last ? c.head_blob : c.env_blob, last ? kHeadChunks : kEnvChunks);
-            env_pass<TERMS, ENV_T, kEnvN, env_handoff(ENV_T)>(wp, lane, aux, in, o);    // env_pass.hip.h
+            env_pass<TERMS, ENV_T, kEnvN, env_handoff(TERMS, ENV_T)>(wp, lane, aux, in, o);    // env_pass.hip.h
             if (grp == 0) outA = o; else outB = o;
         }
         tick(5);   // env mlp
@@ -967,6 +968,61 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_shade_samples(const ShadeA
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The environment MLP as a standalone operator: y = env_net(x) for rows of IDE codes (network.py:533-536, 592-595 -- the
+// `for l in range(num_layers_env)` Linear / ReLU chains), 64 rows per wave round, exactly the pass the shading kernels run.
+// For callers that keep the reference's operator loop (encoders and MLPs as separate calls): its torch form is four GEMMs and
+// three ReLU passes over [M, 256] activations.
+// ------------------------------------------------------------------------------------------
+template <int IDE_DEG, int ENV_T>
+__global__ void __launch_bounds__(kBlockThreads, 1) k_env_mlp(const float* __restrict__ env_blob, const float* __restrict__ x, float* __restrict__ y,
+                                                               uint32_t M, uint32_t* __restrict__ work, uint32_t aligned) {
+    constexpr int TERMS = ide_terms(IDE_DEG), IN = 2 * TERMS;
+    using L = EnvLayout<TERMS, ENV_T>;
+    constexpr uint32_t kEnvChunks = pass_chunks(L::Frags);
+    constexpr int kEnvN = ring_padded(L::Frags);
+    const uint32_t lane = lane_id();
+    __shared__ __attribute__((aligned(16))) float s_env[L::kLdsFloats];
+    __shared__ __attribute__((aligned(16))) float s_io[wave_tile_floats<IN>()];
+    const EnvAux aux = env_lds_init<TERMS, ENV_T>(env_blob, s_env, lane);
+    WeightRing<kRingDepth> wp;
+    wp.start(lane, env_blob, kEnvChunks);
+    auto claim = [&]() -> uint32_t {
+        uint32_t b = 0;
+        if (lane == 0) b = atomicAdd(work, 64u);
+        return __builtin_amdgcn_readfirstlane(b);
+    };
+    uint32_t base = claim(), ahead = claim();
+    for (; base < M; base = ahead, ahead = claim()) {
+        const uint32_t rows = min(64u, M - base);
+        float code[IN];
+        if (aligned) wave_load_rows<IN, true>(s_io, code, x + (size_t)base * IN, rows, lane);
+        else wave_load_rows<IN, false>(s_io, code, x + (size_t)base * IN, rows, lane);
+#pragma unroll
+        for (int s = 0; s < TERMS; ++s) pack_pair(code[2 * s], code[2 * s + 1]);
+        f32x16 outA, outB;
+#pragma unroll 1
+        for (int grp = 0; grp < 2; ++grp) {
+            float in[TERMS];
+#pragma unroll
+            for (int s = 0; s < TERMS; ++s) in[s] = grp ? code[2 * s + 1] : code[2 * s];
+            f32x16 o;
+            wp.begin_pass(env_blob, kEnvChunks, env_blob, kEnvChunks);
+            env_pass<TERMS, ENV_T, kEnvN, env_handoff(TERMS, ENV_T)>(wp, lane, aux, in, o);
+            if (grp == 0) outA = o; else outB = o;
+        }
+        float e12[12];
+        {
+            float alo[4], ahi[4], blo[4], bhi[4];
+            fold16(outA, alo, ahi);
+            fold16(outB, blo, bhi);
+            rows_to_lanes<3>(alo, ahi, blo, bhi, e12);
+        }
+        if (aligned) wave_store_rows<12, true>(s_io, e12, y + (size_t)base * 12, rows, lane);
+        else wave_store_rows<12, false>(s_io, e12, y + (size_t)base * 12, rows, lane);
+    }
+}
+
 // Composite shaded colours of cached geometry: one lane per ray, its samples contiguous and in march order, the
 // compositing weights already known (they depend on geometry only).  Same accumulation order and arithmetic as the
 // blend section of the persistent kernel.
@@ -1395,6 +1451,28 @@ int envidr_shade_records(const envidr_render_desc* d, const envidr_geometry_expo
         a.m_dev = rec->shade_list;
     }
     return launch_shade(d, a, stream, "shade_records");
+}
+
+int envidr_env_mlp_forward(const float* env_blob, uint32_t in_dim, uint32_t hidden, const float* x, uint32_t M, float* y, envidr_stream_t stream) {
+    if (M == 0) return ENVIDR_OK;
+    ENVIDR_REQUIRE(env_blob && x && y, "env_mlp_forward: null pointer");
+    hipStream_t s = as_stream(stream);
+    uint32_t* work = shade_work_counter(s);
+    ENVIDR_REQUIRE(work, "env_mlp_forward: no memory for the work counter");
+    if (hipMemsetAsync(work, 0, sizeof(uint32_t), s) != hipSuccess) return check_launch("env_mlp_forward work counter");
+    const uint32_t blocks = std::min((uint32_t)device_cu_count() * 4u, ceil_div(M, 64u));
+    const uint32_t aligned = aligned16(x) && aligned16(y) ? 1u : 0u;
+#define ENVIDR_MLP(DEG, HT) hipLaunchKernelGGL((k_env_mlp<DEG, HT>), dim3(blocks), dim3(kBlockThreads), 0, s, env_blob, x, y, M, work, aligned)
+    if (in_dim == 72 && hidden == 256) ENVIDR_MLP(5, 8);
+    else if (in_dim == 38 && hidden == 160) ENVIDR_MLP(4, 5);
+    else if (in_dim == 72 && hidden == 128) ENVIDR_MLP(5, 4);
+    else if (in_dim == 38 && hidden == 128) ENVIDR_MLP(4, 4);
+    else {
+        set_error("env_mlp_forward: unsupported (in_dim=%u, hidden=%u); built variants: (72,256) (38,160) (72,128) (38,128)", in_dim, hidden);
+        return ENVIDR_EINVAL;
+    }
+#undef ENVIDR_MLP
+    return check_launch("k_env_mlp");
 }
 
 int envidr_composite_records(const envidr_geometry_export* rec, const uint32_t* offsets, uint32_t* perm, const float* c_diffuse,

@@ -144,6 +144,8 @@ def _bind_render(lib):
     lib.envidr_geometry_pass.argtypes = [ctypes.POINTER(RenderDesc), _FP, _FP, ctypes.c_uint32, ctypes.POINTER(RenderOut),
                                          ctypes.POINTER(GeometryExport), _FP, ctypes.c_uint64, ctypes.c_uint32, _FP]
     lib.envidr_geometry_pass.restype = ctypes.c_int
+    lib.envidr_env_mlp_forward.argtypes = [_FP, ctypes.c_uint32, ctypes.c_uint32, _FP, ctypes.c_uint32, _FP, _FP]
+    lib.envidr_env_mlp_forward.restype = ctypes.c_int
     lib._envidr_render_bound = True
 
 
@@ -182,12 +184,53 @@ def pack_layer(W, bias, k_order: int, transpose: bool = False) -> np.ndarray:
     return dst
 
 
-def env_orders(hidden: int) -> tuple[int, int, int, int]:
-    """k_order of the four environment-MLP layers: widths with an even number of 32-feature tiles run the hand-over form of the
-    pass (csrc/env_pass.hip.h env_handoff): E1 lane order with a tile-major tail (4), E2 / E3 tile order with one (3); the others the
-    plain orders.  E4 (H -> 12) is always packed for 16-row blocks (2)."""
+def env_orders(hidden: int, ide_dim: int = 72) -> tuple[int, int, int, int]:
+    """k_order of the four environment-MLP layers (ide_dim -> hidden -> hidden -> hidden -> 12): widths with an even number of
+    32-feature tiles run the hand-over form of the pass (csrc/env_pass.hip.h env_handoff) when the first layer is long enough for
+    it (ide_dim / 2 - 16 >= tiles + 2 step-major steps): E1 lane order with a tile-major tail (4), E2 / E3 tile order with one (3);
+    the others the plain orders.  E4 (H -> 12) is always packed for 16-row blocks (2)."""
     tiles = (hidden + 31) // 32
-    return (4, 3, 3, 2) if (tiles >= 4 and tiles % 2 == 0) else (0, 1, 1, 2)
+    return (4, 3, 3, 2) if (tiles >= 4 and tiles % 2 == 0 and ide_dim // 2 - 16 >= tiles + 2) else (0, 1, 1, 2)
+
+
+ENV_MLP_SHAPES = ((72, 256), (38, 160), (72, 128), (38, 128))      # (IDE code width, hidden width) envidr_env_mlp_forward is built for
+
+
+def env_mlp_supported(layers) -> bool:
+    """layers: four torch.nn.Linear with bias, in -> H -> H -> H -> 12, of a shape the operator is built for"""
+    if len(layers) != 4 or any(getattr(l, "bias", None) is None for l in layers):
+        return False
+    shapes = [tuple(l.weight.shape) for l in layers]
+    k, h = shapes[0][1], shapes[0][0]
+    return (k, h) in ENV_MLP_SHAPES and shapes == [(h, k), (h, h), (h, h), (12, h)] and layers[0].weight.dtype == torch.float32
+
+
+def env_mlp_forward(layers, x: torch.Tensor) -> torch.Tensor:
+    """The environment MLP on [..., in] IDE codes -> [..., 12] through envidr_env_mlp_forward (inference only: no autograd graph).
+    The packed weights are cached on the module list and repacked when a parameter was written (its version counter) or moved."""
+    lib = _lib.load()
+    _bind_render(lib)
+    if not x.is_cuda:
+        raise _lib.EnvidrError("env_mlp_forward needs a GPU tensor; envidr_amd has no CPU path")
+    key = tuple((p.data_ptr(), p._version) for l in layers for p in (l.weight, l.bias))
+    cache = getattr(layers, "_envidr_env_blob", None)
+    if cache is None or cache[0] != key:
+        hidden = layers[0].weight.shape[0]
+        flat = np.concatenate([pack_layer(l.weight, l.bias, o) for l, o in zip(layers, env_orders(hidden, layers[0].weight.shape[1]))])
+        blob = torch.from_numpy(np.concatenate([flat, np.zeros((-flat.size) % 4096, np.float32)])).to(x.device)
+        cache = (key, blob)
+        try:
+            layers._envidr_env_blob = cache
+        except Exception:          # (a plain list of layers: no cache)
+            pass
+    blob = cache[1]
+    k, h = layers[0].weight.shape[1], layers[0].weight.shape[0]
+    x2 = x.detach().reshape(-1, k).to(torch.float32).contiguous()
+    y = torch.empty(x2.shape[0], 12, device=x.device, dtype=torch.float32)
+    rc = lib.envidr_env_mlp_forward(blob.data_ptr(), k, h, x2.data_ptr(), x2.shape[0], y.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream)
+    if rc:
+        raise _lib.EnvidrError(f"envidr_env_mlp_forward failed ({rc}): {lib.envidr_last_error().decode()}")
+    return y.reshape(*x.shape[:-1], 12)
 
 
 def pack_sdf_geometry(sdf) -> np.ndarray:
@@ -328,7 +371,7 @@ class FusedShader:
 
         L = lambda Wb, order: pack_layer(Wb[0], Wb[1], order)
         d = RenderDesc()
-        d.env_blob = blob([L(env[i], o) for i, o in enumerate(env_orders(_np32(env[0][0]).shape[0]))])
+        d.env_blob = blob([L(env[i], o) for i, o in enumerate(env_orders(*_np32(env[0][0]).shape))])
         d.head_blob = blob([L(dif[0], 0), L(dif[1], 2), L(spc[0], 0), L(spc[1], 1), L(spc[2], 2)])
         d.ide_degree, d.env_hidden = ide_degree, _np32(env[0][0]).shape[0]
         d.diffuse_kappa_inv, d.light_intensity_scale, d.intensity_scale = diffuse_kappa_inv, light_intensity_scale, 1.0
@@ -417,7 +460,7 @@ class FusedRenderer:
         L = lambda Wb, order: pack_layer(Wb[0], Wb[1], order)
         d.sdf_blob = blob([L(sdf[0], 0), L(sdf[1], 1), L(sdf[2], 2),
                            pack_layer(sdf[1][0], None, 1, transpose=True), pack_layer(sdf[0][0], None, 1, transpose=True)])
-        d.env_blob = blob([L(env[i], o) for i, o in enumerate(env_orders(_np32(env[0][0]).shape[0]))]) if env is not None else None
+        d.env_blob = blob([L(env[i], o) for i, o in enumerate(env_orders(*_np32(env[0][0]).shape))]) if env is not None else None
         d.dir_sh_degree = sh_degree
         d.head_blob = blob([L(dif[0], 0), L(dif[1], 2), L(spc[0], 0), L(spc[1], 1), L(spc[2], 2)])
         renv = mlps.get("renv")

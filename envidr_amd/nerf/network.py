@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import fused as _fused
 from ..encoding import get_encoder
 from .renderer import NeRFRenderer
 
@@ -45,7 +46,16 @@ def _mlp(dims, bias=True):
     return nn.ModuleList([nn.Linear(dims[i], dims[i + 1], bias=bias) for i in range(len(dims) - 1)])
 
 
+ENV_MLP_OPERATOR_MIN_ROWS = 4096      # below this the four torch GEMMs are not slower than packing / launching the operator
+
+
 def _run_mlp(net, h):
+    # inference on the GPU, a shape the environment-MLP operator is built for (csrc/fused_render.hip k_env_mlp: the pass the fused
+    # shading kernels run): one launch instead of four GEMMs and three ReLU passes over [M, H] activations.  With autograd
+    # recording (training, or normals that need a graph) the torch layers below run, like the reference's.
+    if (not torch.is_grad_enabled() and h.is_cuda and h.dtype == torch.float32 and h.numel() // max(h.shape[-1], 1) >= ENV_MLP_OPERATOR_MIN_ROWS
+            and _fused.env_mlp_supported(net)):
+        return _fused.env_mlp_forward(net, h)
     for i, lin in enumerate(net):
         h = lin(h)
         if i != len(net) - 1:

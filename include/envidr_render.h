@@ -37,9 +37,10 @@ extern "C" {
  *            2 = tile order for a layer of AT MOST 16 OUTPUTS (envidr_pack_layer only): the layer runs on
  *                16-row MFMA blocks, one 64-float fragment per reduction step (ABI 7; E4, D2, S3, renv R4).
  *            3 = tile order, 4 = lane order, each with the layer's LAST 16 reduction steps laid out tile-major (envidr_pack_layer
- *                only).  ABI 7: when env_hidden / 32 is even (256, 128) the environment pass stages a layer's first input tile
- *                inside the layer before it, and its blob must then be E1 (k_order 4) | E2 (3) | E3 (3) | E4 (2); for the other
- *                widths (160) E1 (0) | E2 (1) | E3 (1) | E4 (2).
+ *                only).  ABI 7: when T = env_hidden / 32 is even and >= 4 (256, 128) and the first layer has at least T + 18 reduction
+ *                steps (IDE degree 5: 36; degree 4 has 19 and does not qualify at hidden 128) the environment pass stages a layer's
+ *                first input tile inside the layer before it, and its blob must then be E1 (k_order 4) | E2 (3) | E3 (3) | E4 (2);
+ *                otherwise (hidden 160; IDE degree 4 with hidden 128) E1 (0) | E2 (1) | E3 (1) | E4 (2).
  *   transpose != 0 packs W^T (the input-gradient layers of the SDF network). */
 uint32_t envidr_packed_weight_floats(int k_order, uint32_t k_in, uint32_t m_out);
 uint32_t envidr_packed_rowvec_floats(uint32_t m_out);
@@ -266,6 +267,15 @@ int envidr_render_rays(const envidr_render_desc* desc, const float* rays_o, cons
 int envidr_shade_samples(const envidr_render_desc* desc, const float* normals, const float* dirs, const float* geo_feat,
                          uint32_t geo_feat_stride, const float* roughness, uint32_t roughness_stride, uint32_t M,
                          float* c_diffuse, float* c_specular, envidr_stream_t stream);
+
+/* The environment MLP alone, for callers that keep the reference's operator loop (IDE encoder, MLPs and compositor as separate
+ * calls): y = W4 relu(W3 relu(W2 relu(W1 x + b1) + b2) + b3) + b4 -- the Linear / ReLU chain of nerf/network.py:533-536 and
+ * 592-595 (env_net, built by get_env_net, network.py:279-297) -- on the fp32 matrix cores, 64 rows per wave round, the pass the shading kernels run.
+ *   env_blob : device, the four layers packed with envidr_pack_layer in the orders envidr_render_desc.env_blob uses
+ *   x        : device [M, in_dim] IDE codes (in_dim = 72 for IDE degree 5, 38 for degree 4);  y : device [M, 12], raw (not normalised)
+ * Built for (in_dim, hidden) = (72,256) (38,160) (72,128) (38,128); anything else is ENVIDR_EINVAL. */
+int envidr_env_mlp_forward(const float* env_blob, uint32_t in_dim, uint32_t hidden, const float* x, uint32_t M, float* y,
+                           envidr_stream_t stream);
 
 /* Two-phase frames (geometry pass -> shading pass): the records of a geometry_only render are shaded where they lie, in the
  * order they were appended (the count is read on the device: the host does not wait for the geometry pass), and

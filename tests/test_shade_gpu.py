@@ -93,3 +93,69 @@ def test_geometry_cache_relights_bit_exactly():
             assert torch.equal(got[k], want[k]), f"rot {rot}: {k}"
     # the cache is environment-independent: swapping the environment changes the cached render like the direct one
     assert not torch.equal(r.render_cached(cache, 0.7)["image"], r.render_cached(cache, 3.9)["image"].clone())
+
+
+BUILT_ENV_SHAPES = [(5, 256), (4, 160), (5, 128), (4, 128)]      # (IDE degree, hidden width) of launch_shade / envidr_env_mlp_forward
+
+
+@pytest.mark.parametrize("ide_deg,hidden", BUILT_ENV_SHAPES)
+def test_every_built_environment_shape_shades_like_the_oracle(ide_deg, hidden):
+    """each (IDE degree, hidden width) instantiation of the shading kernel against the oracle's forward_color chain on seeded weights:
+    the hand-over form of the environment pass (even tile counts) only applies when the first layer is long enough for it --
+    (4, 128) once ran it with 3 step-major steps and never loaded three of the next layer's bias tiles"""
+    import torch
+    from envidr_amd.fused import FusedShader
+    from oracle.py import render_oracle as ro
+    scene = scenes.toaster_scene(hidden_env=hidden, ide_deg=ide_deg, seed=11)
+    mlps = {k: scene.mlps[k] for k in ("env", "diffuse", "specular")}
+    shader = FusedShader(mlps, ide_degree=ide_deg, diffuse_kappa_inv=0.64)
+    rng = np.random.default_rng(5)
+    unit = lambda v: v / np.linalg.norm(v, axis=1, keepdims=True)
+    M = 777
+    n, d, gf = unit(rng.normal(size=(M, 3))), unit(rng.normal(size=(M, 3))), unit(rng.normal(size=(M, 12)))
+    rough = rng.uniform(0.02, 1, M)
+    cuda = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+    for rot in (None, 0.7):
+        want = ro.shade_surface(mlps, n, d, gf, rough.reshape(-1, 1), ro.RenderOptions(ide_mode="exact", ide_deg=ide_deg), rot)
+        got = shader.shade(cuda(n), cuda(d), cuda(gf), cuda(rough), rot)
+        torch.cuda.synchronize()
+        for key in ("c_diffuse", "c_specular"):
+            assert np.abs(got[key].cpu().numpy().astype(np.float64) - want[key]).max() <= 2e-5, (key, rot)
+
+
+@pytest.mark.parametrize("ide_deg,hidden", BUILT_ENV_SHAPES)
+def test_env_mlp_operator_equals_the_torch_layers(ide_deg, hidden):
+    """envidr_env_mlp_forward (the shading kernels' environment pass as an operator) against torch's Linear / ReLU chain, ragged and
+    unaligned sizes, the weight cache following in-place parameter updates, and the dispatch rule of the network mirror"""
+    import torch
+    import torch.nn as nn
+    from envidr_amd import fused
+    from envidr_amd.nerf import network
+    torch.manual_seed(3)
+    k = (2 ** ide_deg - 1 + ide_deg) * 2
+    assert (k, hidden) in fused.ENV_MLP_SHAPES
+    net = nn.ModuleList([nn.Linear(k, hidden), nn.Linear(hidden, hidden), nn.Linear(hidden, hidden), nn.Linear(hidden, 12)]).cuda()
+
+    def chain(x):
+        for i, lin in enumerate(net):
+            x = lin(x)
+            if i != 3:
+                x = torch.relu(x)
+        return x
+    assert fused.env_mlp_supported(net)
+    with torch.no_grad():
+        for M in (1, 63, 64, 65, 4099, 50001):
+            x = torch.randn(M + 1, k, device="cuda")[1:]          # a view that is not 16-byte aligned when k * 4 is not (k = 38)
+            y, want = fused.env_mlp_forward(net, x), chain(x)
+            assert y.shape == (M, 12) and float((y - want).norm() / want.norm()) <= 2e-6
+        x = torch.randn(5000, k, device="cuda")
+        before = fused.env_mlp_forward(net, x)
+        net[1].weight.mul_(0.5)                                    # an in-place update: the cached blob must follow
+        after = fused.env_mlp_forward(net, x)
+        assert not torch.equal(before, after) and float((after - chain(x)).norm() / chain(x).norm()) <= 2e-6
+        assert fused.env_mlp_forward(net, x[:0]).shape == (0, 12)
+        # the mirror's dispatch: operator without autograd on large batches, torch layers otherwise (same values to fp32 rounding)
+        assert torch.equal(network._run_mlp(net, x), after)
+    small = network._run_mlp(net, x[:100].clone().requires_grad_(True))
+    assert small.requires_grad and float((small.detach() - after[:100]).norm() / after[:100].norm()) <= 2e-6
+    assert not fused.env_mlp_supported(nn.ModuleList([nn.Linear(k, 64), nn.Linear(64, 64), nn.Linear(64, 64), nn.Linear(64, 12)]).cuda())
