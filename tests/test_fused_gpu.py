@@ -183,3 +183,33 @@ def test_two_phase_frame_is_bit_identical(scene, renderer):
             assert torch.equal(got[k], want[k]), f"rot {rot}: {k}"
             assert torch.equal(again[k], want[k]), f"rot {rot} (second call): {k}"
         assert again["n_records"] == got["n_records"] > 0
+
+
+@pytest.mark.parametrize("ide_deg,hidden", [(5, 128), (4, 128), (4, 160)])
+def test_every_built_environment_shape_renders_like_the_oracle(ide_deg, hidden):
+    """the (IDE degree, hidden width) instantiations the other frame tests do not reach, through all three frame implementations
+    (persistent kernel, geometry -> records -> shading pipeline, the same with the split-precision environment MLP) against the
+    oracle's frame on seeded weights"""
+    import torch
+    from envidr_amd.fused import FusedOptions, FusedRenderer
+    from oracle.py import render_oracle as ro
+    scene = scenes.toaster_scene(hidden_env=hidden, ide_deg=ide_deg, seed=13)
+    r = FusedRenderer.from_scene(scene, FusedOptions(ide_degree=ide_deg))
+    rays_o, rays_d = scenes.camera_rays(30, 30, theta=40.0, phi=-25.0)
+    want = ro.render_rays(scene, rays_o, rays_d, ro.RenderOptions(ide_mode="exact", ide_deg=ide_deg), 0.4, force_n_step=1)
+    out = _render(r, rays_o, rays_d, 0.4)
+    for key in KEYS:
+        err = rel_l2(out[key], want[key].reshape(out[key].shape))
+        assert err <= 2e-5, f"persistent kernel, {key}: rel-L2 {err:.3e}"
+    o, d = torch.from_numpy(rays_o).cuda(), torch.from_numpy(rays_d).cuda()
+    from envidr_amd._lib import EnvidrError
+    for precision, tol in (("fp32", 2e-5), ("f16x2", 1e-4)):
+        if precision == "f16x2" and (ide_deg, hidden) not in ((5, 256), (4, 160)):
+            with pytest.raises(EnvidrError, match="split precision is built for"):      # refused, not silently rendered in fp32
+                r.render_frame(o, d, 0.4, env_precision=precision)
+            continue
+        res = r.render_frame(o, d, 0.4, env_precision=precision)
+        torch.cuda.synchronize()
+        for key in ("image", "diffuse_image", "specular_image", "depth", "weights_sum"):
+            err = rel_l2(res[key].cpu().numpy().reshape(out[key].shape), want[key].reshape(out[key].shape))
+            assert err <= tol, f"pipeline ({precision}), {key}: rel-L2 {err:.3e}"
