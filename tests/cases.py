@@ -251,6 +251,54 @@ def grid_backward_cases():
     return out
 
 
+def encoder_sweep_cases():
+    """every (D, C) instantiation of the hash and grid encoders the C ABI dispatches to (D 2-3 x C 1/2/4/8 for the hash encoder,
+    D 1-5 x C 1/2/4/8 for the grid encoder), forward with the input Jacobian and the backward passes, at sizes of a few dozen points:
+    tools/kernel_coverage.sh found two thirds of these kernels never launched by the hand-picked cases above"""
+    from oracle import clib
+    rng = np.random.default_rng(23 + SEED_OFFSET)
+    out = []
+    for D in (2, 3):
+        for C in (1, 2, 4, 8):
+            L, log2T, base, desired = 3, 9, 4, 24
+            offsets, pls = scenes.hash_level_offsets(D, L, base, log2T, desired)
+            S = float(np.log2(pls))
+            B = 70
+            x = _points(rng, B, D)
+            table = rng.uniform(-1, 1, size=(int(offsets[-1]), C)).astype(F)
+            dy_dx = np.zeros((B, L * D * C), F)
+            cid = f"hash_D{D}C{C}"
+            out.append((cid + "_fwd_grad", "hash_encode_forward", (x, table, offsets, np.zeros((L, B, C), F), B, D, C, L, S, base, 1, np.zeros_like(dy_dx)), None))
+            clib.oracle().call("hash_encode_forward", x, table, offsets, np.zeros((L, B, C), F), B, D, C, L, S, base, 1, dy_dx)
+            grad = rng.normal(size=(L, B, C)).astype(F)
+            out.append((cid + "_bwd", "hash_encode_backward",
+                        (grad, x, table, offsets, np.zeros_like(table), B, D, C, L, S, base, 1, dy_dx, np.zeros((B, D), F)), 1e-5))
+            if C != 1:
+                out.append((cid + "_bwd2", "hash_encode_second_backward",
+                            (grad, x, table, offsets, B, D, C, L, S, base, 1, dy_dx, rng.normal(size=(B, D)).astype(F),
+                             np.zeros((L, B, C), F), np.zeros_like(table)), 1e-5))
+    for D in (1, 2, 3, 4, 5):
+        for C in (1, 2, 4, 8):
+            L, log2T, base, desired = 2, 9, 2, 6
+            gridtype, align = (D + C) % 2, (D * C) % 2
+            offsets, pls = scenes.grid_level_offsets(D, L, base, log2T, desired, bool(align))
+            S = float(np.log2(pls))
+            B = 70
+            x = _points(rng, B, D)
+            table = rng.uniform(-1, 1, size=(int(offsets[-1]), C)).astype(F)
+            dy_dx = np.zeros((B, L * D * C), F)
+            cid = f"grid_D{D}C{C}g{gridtype}a{align}"
+            out.append((cid + "_fwd_grad", "grid_encode_forward",
+                        (x, table, offsets, np.zeros((L, B, C), F), B, D, C, L, S, base, np.zeros_like(dy_dx), gridtype, align), None))
+            out.append((cid + "_fwd", "grid_encode_forward",
+                        (x, table, offsets, np.zeros((L, B, C), F), B, D, C, L, S, base, None, gridtype, align), None))
+            clib.oracle().call("grid_encode_forward", x, table, offsets, np.zeros((L, B, C), F), B, D, C, L, S, base, dy_dx, gridtype, align)
+            grad = rng.normal(size=(L, B, C)).astype(F)
+            out.append((cid + "_bwd", "grid_encode_backward",
+                        (grad, x, table, offsets, np.zeros_like(table), B, D, C, L, S, base, dy_dx, np.zeros((B, D), F), gridtype, align), 1e-5))
+    return out
+
+
 def _unit_dirs(rng, B):
     d = rng.normal(size=(B, 3)).astype(F)
     d /= np.linalg.norm(d, axis=1, keepdims=True)
@@ -376,7 +424,7 @@ def half_cases():
 ALL_GROUPS = {
     "near_far": near_far_cases, "misc": misc_cases, "march": march_cases, "composite": composite_cases,
     "train": train_cases, "hash": hash_cases, "hash_bwd": hash_backward_cases, "grid": grid_cases,
-    "grid_bwd": grid_backward_cases, "freq_sh": freq_sh_cases, "ide": ide_cases, "half": half_cases,
+    "grid_bwd": grid_backward_cases, "sweep": encoder_sweep_cases, "freq_sh": freq_sh_cases, "ide": ide_cases, "half": half_cases,
 }
 
 

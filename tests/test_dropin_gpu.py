@@ -387,3 +387,26 @@ def test_fused_vs_operator_loop_on_random_scenes(seed):
         assert flipped.sum() <= 3, f"seed {seed} {key}: {int(flipped.sum())} rays differ by more than 1e-4"
         assert rel_l2(x[~flipped], y[~flipped]) <= 3e-5, f"seed {seed} {key}: {rel_l2(x[~flipped], y[~flipped]):.3e}"
         assert rel_l2(x, y) <= 2e-3, f"seed {seed} {key}: {rel_l2(x, y):.3e}"
+
+
+@pytest.mark.parametrize("ide_deg,hidden", [(4, 160), (5, 128), (4, 128)])
+def test_indirect_frames_of_the_other_built_shapes_equal_the_operator_loop(ide_deg, hidden):
+    """the reflected-radiance instantiations of the record-shading kernel for the (IDE degree, hidden width) shapes the reference
+    fixtures do not cover (tools/kernel_coverage.sh listed them as never launched): three-pass frame, fused against the operator
+    loop (torch MLPs, the reference's statements)"""
+    import torch
+    model, opt = build_model(scenes.toaster_scene(shape=scenes.torus(), seed=3, hidden_env=hidden, ide_deg=ide_deg), indir_ref=True,
+                             sh_degree=ide_deg, hidden_dim_env=hidden)
+    assert model.supports_fused()
+    ro, rd = scenes.camera_rays(36, 36, theta=50.0, phi=-30.0)
+    frames = {}
+    for fused in (True, False):
+        res = model.render(torch.from_numpy(ro).cuda()[None], torch.from_numpy(rd).cuda()[None], staged=True, bg_color=1, perturb=False,
+                           get_normal_image=True, env_rot_radian=None, fused=fused, max_steps=opt.max_steps, T_thresh=opt.T_thresh,
+                           dt_gamma=opt.dt_gamma, early_stop_steps=-1)
+        torch.cuda.synchronize()
+        frames[fused] = {k: res[k].detach().cpu().numpy().reshape(36 * 36, -1) for k in KEYS}
+    assert frames[True]["weights_sum"].max() > 0.9          # the frame sees the object (and its reflected rays)
+    for key in KEYS:
+        err = rel_l2(frames[True][key], frames[False][key])
+        assert err <= 1e-4, f"{key}: rel-L2 {err:.3e}"

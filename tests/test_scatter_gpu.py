@@ -93,3 +93,50 @@ def test_lds_scatter_against_the_oracle_on_two_levels():
     assert ref.shape == (rows, C) and np.abs(ref).max() > 0
     got = gt.cpu().numpy()
     assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-4
+
+
+@pytest.mark.parametrize("D,C", [(3, 1), (3, 4), (3, 8), (2, 1), (2, 2), (2, 4), (2, 8)])
+def test_lds_scatter_of_the_other_instantiations(D, C):
+    """the (D, C) instantiations of the range-owned kernels besides the toaster encoder's (3, 2), both gradients, against the
+    per-point atomic kernels on a small encoder (dense and hashed levels, a level with more rows than one range)"""
+    import torch
+    from envidr_amd import _lib, scenes
+    dev = torch.device("cuda:0")
+    L, base, log2T, desired = 5, 8, 16, 1024
+    off_np, pls = scenes.hash_level_offsets(D, L, base, log2T, desired)
+    offsets = torch.from_numpy(np.ascontiguousarray(off_np, np.int32)).to(dev)
+    S = float(np.log2(pls))
+    B = (1 << 19) + 321
+    g = torch.Generator(device="cpu").manual_seed(100 * D + C)
+    x = torch.rand(B, D, generator=g)
+    x[::1013] = 1.0
+    x[5::997, D - 1] = 1.5
+    x[: B // 2] = x[: B // 2] * 0.05 + 0.4
+    x = x.to(dev)
+    rows = int(off_np[L])
+    table = (torch.rand(rows, C, generator=g) * 2 - 1).to(dev)
+    grad = torch.randn(L, B, C, generator=g).to(dev)
+    ggx = torch.randn(B, D, generator=g).to(dev)
+    dy = torch.zeros(B, L * D * C, device=dev)
+    _lib.call("hash_encode_forward", x, table, offsets, torch.empty(L, B, C, device=dev), B, D, C, L, S, base, 1, dy)
+    for second in ((False, True) if C != 1 else (False,)):
+        def run(lo, hi, into):
+            n = hi - lo
+            gr = grad[:, lo:hi].contiguous()
+            if second:
+                _lib.call("hash_encode_second_backward", gr, x[lo:hi].contiguous(), table, offsets, n, D, C, L, S, base, 1, dy[lo:hi].contiguous(),
+                          ggx[lo:hi].contiguous(), torch.zeros(L, n, C, device=dev), into)
+            else:
+                _lib.call("hash_encode_backward", gr, x[lo:hi].contiguous(), table, offsets, into, n, D, C, L, S, base, 0, None, None)
+        big, small = torch.zeros(rows, C, device=dev), torch.zeros(rows, C, device=dev)
+        run(0, B, big)
+        third = B // 3
+        for lo, hi in ((0, third), (third, 2 * third), (2 * third, B)):
+            run(lo, hi, small)
+        torch.cuda.synchronize()
+        a, b = big.cpu().numpy().astype(np.float64), small.cpu().numpy().astype(np.float64)
+        assert np.isfinite(a).all() and np.abs(b).max() > 0
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) < 2e-5, (second, np.linalg.norm(a - b) / np.linalg.norm(b))
+        for l in range(L):
+            s = slice(int(off_np[l]), int(off_np[l + 1]))
+            assert np.abs(a[s] - b[s]).max() / (np.abs(b[s]).max() + 1e-30) < 3e-4, (second, l)
