@@ -296,6 +296,14 @@ def encoder_sweep_cases():
             grad = rng.normal(size=(L, B, C)).astype(F)
             out.append((cid + "_bwd", "grid_encode_backward",
                         (grad, x, table, offsets, np.zeros_like(table), B, D, C, L, S, base, dy_dx, np.zeros((B, D), F), gridtype, align), 1e-5))
+    for deg in range(1, 11):          # the row-tile frequency kernels are instantiated per degree (D = 3)
+        B, D = 130, 3
+        C = D + 2 * D * deg
+        x = rng.uniform(-1, 1, size=(B, D)).astype(F)
+        out.append((f"freq3_deg{deg}", "freq_encode_forward", (x, B, D, deg, C, np.zeros((B, C), F)), 2e-6))
+        o = np.zeros((B, C), F)
+        clib.oracle().call("freq_encode_forward", x, B, D, deg, C, o)
+        out.append((f"freq3_bwd_deg{deg}", "freq_encode_backward", (rng.normal(size=(B, C)).astype(F), o, B, D, deg, C, np.zeros((B, D), F)), 1e-5))
     return out
 
 

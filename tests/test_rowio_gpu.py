@@ -26,7 +26,7 @@ def test_encoders_ragged_and_unaligned(B):
     d = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1).to(dev)
     rough = torch.rand(B, generator=g).to(dev)
     # spherical harmonics (+ dy_dx), frequency (forward / backward), IDE
-    for deg in (1, 3, 4, 8):
+    for deg in range(1, 9):          # every degree: each is its own instantiation, aligned and not
         C2 = deg * deg
         o, dy = torch.zeros(B, C2, device=dev), torch.zeros(B, 3 * C2, device=dev)
         _lib.call("sh_encode_forward", d, o, B, 3, deg, dy)
@@ -42,7 +42,7 @@ def test_encoders_ragged_and_unaligned(B):
         _lib.call("sh_encode_backward", gr, d, B, 3, deg, dy, gi)
         _lib.call("sh_encode_backward", _shifted(gr), d, B, 3, deg, _shifted(dy), gi2)
         assert torch.equal(gi, gi2), ("sh backward", deg)
-    for deg in (1, 4, 10):
+    for deg in range(1, 11):
         C = 3 + 6 * deg
         o = torch.zeros(B, C, device=dev)
         _lib.call("freq_encode_forward", d, B, 3, deg, C, o)
@@ -54,7 +54,7 @@ def test_encoders_ragged_and_unaligned(B):
         _lib.call("freq_encode_backward", gr, o, B, 3, deg, C, gi)
         _lib.call("freq_encode_backward", _shifted(gr), _shifted(o), B, 3, deg, C, gi2)
         assert torch.equal(gi, gi2), ("freq backward", deg)
-    for deg in (1, 4, 5):
+    for deg in (1, 2, 3, 4, 5):
         C = 2 * ((1 << deg) - 1 + deg)
         o, o2 = torch.zeros(B, C, device=dev), _shifted(torch.zeros(B, C, device=dev))
         _lib.call("ide_encode_forward", d, rough, 0.0, B, deg, o)
