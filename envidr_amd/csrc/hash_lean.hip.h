@@ -2,8 +2,8 @@
 // kernel (geometry_pass.hip).  Same function as hashencoder/src/hashencoder.cu:103-254 (kernel_grid, D = 3, C = 2) --
 // same cell, same smoothstep weights, same eight corner rows -- organised for the vector ALU budget of a kernel that
 // shares its SIMDs with the matrix pipe:
-//   * corner rows are gathered through ONE buffer descriptor over the whole table: 32-bit byte offsets in one VGPR
-//     each, the level's first row as the scalar offset; no 64-bit address arithmetic;
+//   * corner rows are gathered through ONE buffer descriptor over the whole table (one 8-byte load per row): 32-bit byte
+//     offsets in one VGPR each, the level's first row as the scalar offset; no 64-bit address arithmetic;
 //   * the only data-dependent control flow is one wave-uniform choice (dense or hashed level) around eight integer
 //     index computations; hashed levels must have a power-of-two size and dense levels must satisfy the
 //     conditional-subtract wrap (HashEncoder's own sizing always does; the host checks and refuses otherwise);
@@ -28,16 +28,14 @@ struct LeanLevel {
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// One level in flight: weights and the raw gathers.  The two x-neighbours of a (y, z) corner pair are fetched by ONE
-// 16-byte load whenever their rows are adjacent -- always on dense levels (rows r, r + 1), and for even cells on hashed
-// levels (the x prime is 1: rows r and r ^ 1) -- because what a gather costs on gfx950 is texture-address cycles per
-// instruction and per distinct cache line, not bytes: 6 line lookups per level on average instead of 8.
+// One level in flight: weights and the raw gathers, one 8-byte load per corner row.  (Round 3 fetched the two x-neighbours of
+// a (y, z) corner pair with ONE 16-byte load whenever their rows were adjacent -- 6 line lookups per level instead of 8 -- and
+// picked the halves apart with ~45 selects and mask operations per level; since the geometry kernel became issue-bound the
+// selects cost more than the two gathers: 2.84 -> 2.61 ms per headline frame without them, tools/geo/build_variants.py history.)
 struct LeanStage {
     float w[3];             // smoothstep weight of the +1 corner per axis
     float sdw[3];           // scale * d(w)/d(frac) per axis
-    u32x4 pair[4];          // rows base_j, base_j + 1 of (y, z) pair j = by | bz << 1
-    u32x2 solo[4];          // row of the x + 1 corner where it is not in `pair` (loaded only by the lanes that need it)
-    uint32_t sel;           // bit j: the x corner is the upper row of pair j; bit 4 + j: the x + 1 corner is; bit 8 + j: it is in solo[j]
+    u32x2 row[8];           // corner rows, index bx | by << 1 | bz << 2
 };
 
 // host: returns an error text when the table geometry is outside what the lean path handles
@@ -81,7 +79,7 @@ __device__ __forceinline__ void lean_prepare(const LeanLevel& lv, __amdgpu_buffe
         st.sdw[d] = (6 * p * (1.0f - p)) * lv.scale;     // smoothstep' * scale
         st.w[d] = p * p * (3.0f - 2.0f * p);             // smoothstep
     }
-    uint32_t r0[4], r1[4], base[4];
+    uint32_t r0[4], r1[4];          // rows of the x and x + 1 corners of (y, z) pair j = by | bz << 1
     if (lv.hashed) {
         const uint32_t hy0 = cell[1] * 2654435761u, hy1 = hy0 + 2654435761u;
         const uint32_t hz0 = cell[2] * 805459861u, hz1 = hz0 + 805459861u;
@@ -91,7 +89,6 @@ __device__ __forceinline__ void lean_prepare(const LeanLevel& lv, __amdgpu_buffe
         for (int j = 0; j < 4; ++j) {
             r0[j] = (x0 ^ yz[j]) & lv.mask;
             r1[j] = (x1 ^ yz[j]) & lv.mask;
-            base[j] = r0[j] & ~1u;
         }
     } else {
         const uint32_t y0 = cell[1] * lv.m1, y1 = y0 + lv.m1;
@@ -102,45 +99,23 @@ __device__ __forceinline__ void lean_prepare(const LeanLevel& lv, __amdgpu_buffe
             const uint32_t i0 = cell[0] + yz[j], i1 = i0 + 1u;
             r0[j] = min(i0, i0 - lv.size);                // idx mod size for idx < 2 size (unsigned wrap makes the minimum pick it)
             r1[j] = min(i1, i1 - lv.size);
-            base[j] = min(r0[j], lv.size - 2u);           // the pair must not run past the level's last row
         }
     }
     if (rows_out) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { rows_out[2 * j] = r0[j]; rows_out[2 * j + 1] = r1[j]; }
     }
-    uint32_t sel = 0;
-    bool need = false;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        st.pair[j] = __builtin_amdgcn_raw_buffer_load_b128(table, base[j] * 8u + (LANE_LEVEL ? lv.row0_bytes : 0u), LANE_LEVEL ? 0u : lv.row0_bytes, AUX);
-        const uint32_t o0 = r0[j] - base[j], o1 = r1[j] - base[j];     // 0 or 1 when inside the pair
-        sel |= (o0 & 1u) << j;
-        sel |= (o1 == 1u ? 1u : 0u) << (4 + j);
-        const bool out = o1 > 1u;
-        sel |= (out ? 1u : 0u) << (8 + j);
-        need |= out;
-    }
-    st.sel = sel;
-    if (need) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            st.solo[j] = __builtin_amdgcn_raw_buffer_load_b64(table, r1[j] * 8u + (LANE_LEVEL ? lv.row0_bytes : 0u), LANE_LEVEL ? 0u : lv.row0_bytes, AUX);
+        st.row[2 * j] = __builtin_amdgcn_raw_buffer_load_b64(table, r0[j] * 8u + (LANE_LEVEL ? lv.row0_bytes : 0u), LANE_LEVEL ? 0u : lv.row0_bytes, AUX);
+        st.row[2 * j + 1] = __builtin_amdgcn_raw_buffer_load_b64(table, r1[j] * 8u + (LANE_LEVEL ? lv.row0_bytes : 0u), LANE_LEVEL ? 0u : lv.row0_bytes, AUX);
     }
 }
 
 // the eight corner rows of a stage, index = bx | by << 1 | bz << 2
 __device__ __forceinline__ void lean_corners(const LeanStage& st, float2 (&c)[8]) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const u32x4 p = st.pair[j];
-        const bool up0 = (st.sel >> j) & 1u, up1 = (st.sel >> (4 + j)) & 1u, out = (st.sel >> (8 + j)) & 1u;
-        c[2 * j].x = __uint_as_float(up0 ? p[2] : p[0]);
-        c[2 * j].y = __uint_as_float(up0 ? p[3] : p[1]);
-        const uint32_t ix = up1 ? p[2] : p[0], iy = up1 ? p[3] : p[1];
-        c[2 * j + 1].x = __uint_as_float(out ? st.solo[j][0] : ix);
-        c[2 * j + 1].y = __uint_as_float(out ? st.solo[j][1] : iy);
-    }
+    for (int i = 0; i < 8; ++i) { c[i].x = __uint_as_float(st.row[i][0]); c[i].y = __uint_as_float(st.row[i][1]); }
 }
 
 // value (2 channels) and d value / d x01 (3 x 2), multiplied by `m` (level mask x inside-the-cube mask).  The two channels of a

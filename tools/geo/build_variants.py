@@ -69,10 +69,8 @@ VARIANTS = {
                                       "            for (int r_ = 0; r_ < 16; ++r_) { h1[0][r_] = in[r_]; h1[1][r_] = in[r_]; h2[0][r_] = in[r_]; h2[1][r_] = in[r_]; o3[r_] = in[r_]; }\n"),
                                      ("geometry_pass.hip", "            pipe_layer_from_tiles<2, 2, kSdfW2t, kSdfN, false, false>(wp, lane, g2, g1);\n", "            g1[0] = g2[1]; g1[1] = g2[0];\n"),
                                      ("geometry_pass.hip", "            pipe_layer_from_tiles<2, 1, kSdfW1t, kSdfN, false, false>(wp, lane, g1, gf);\n            wp.template end_pass<kSdfFrags>();\n", "            gf[0] = g1[0] + g1[1];\n")]),
-    "eval_nogather": ("geometry_pass", [("hash_lean.hip.h", "        st.pair[j] = __builtin_amdgcn_raw_buffer_load_b128(table, base[j] * 8u + (LANE_LEVEL ? lv.row0_bytes : 0u), LANE_LEVEL ? 0u : lv.row0_bytes, AUX);",
-                                         "        st.pair[j] = u32x4{r0[j], r1[j], base[j], lv.row0_bytes};"),
-                                        ("hash_lean.hip.h", "            st.solo[j] = __builtin_amdgcn_raw_buffer_load_b64(table, r1[j] * 8u + (LANE_LEVEL ? lv.row0_bytes : 0u), LANE_LEVEL ? 0u : lv.row0_bytes, AUX);",
-                                         "            st.solo[j] = u32x2{r1[j], base[j]};")]),
+    "eval_nogather": ("geometry_pass", [("hash_lean.hip.h", "        st.row[2 * j] = __builtin_amdgcn_raw_buffer_load_b64(table, r0[j] * 8u + (LANE_LEVEL ? lv.row0_bytes : 0u), LANE_LEVEL ? 0u : lv.row0_bytes, AUX);\n        st.row[2 * j + 1] = __builtin_amdgcn_raw_buffer_load_b64(table, r1[j] * 8u + (LANE_LEVEL ? lv.row0_bytes : 0u), LANE_LEVEL ? 0u : lv.row0_bytes, AUX);\n",
+                                         "        st.row[2 * j] = u32x2{r0[j], lv.row0_bytes};\n        st.row[2 * j + 1] = u32x2{r1[j], lv.row0_bytes};\n")]),
     # ablations of the record-shading kernel (timing only: results are wrong): where does a round's time go besides the MFMAs?
     "shade_noide": ("fused_render", [("fused_render.hip", "        ide_eval<IDE_DEG, true>(vx, vy, vz, kinv, [&](int j, float re, float im) {\n            code[j] = re * c.light_scale;\n            code[TERMS + j] = im * c.light_scale;\n        });\n",
                                       "        for (int j = 0; j < TERMS; ++j) { code[j] = vx * kinv + (float)j; code[TERMS + j] = vy * vz - (float)j; }\n")]),
@@ -183,6 +181,7 @@ VARIANTS = {
     "scatter_noatomic": ("hashencoder", [("hashencoder.hip", "                    for (int c = 0; c < C; ++c) __hip_atomic_fetch_add(&s_acc[c * kRows + at], v[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n",
                                           "                    for (int c = 0; c < C; ++c) if (v[c] == 123.456f) s_acc[c * kRows + at] = v[c];\n")]),
 }
+
 
 
 VARIANTS["scatter_timers_noatomic"] = ("hashencoder", VARIANTS["scatter_timers"][1] + VARIANTS["scatter_noatomic"][1])
