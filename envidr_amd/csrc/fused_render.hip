@@ -998,19 +998,27 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_env_mlp(const float* __res
         float code[IN];
         if (aligned) wave_load_rows<IN, true>(s_io, code, x + (size_t)base * IN, rows, lane);
         else wave_load_rows<IN, false>(s_io, code, x + (size_t)base * IN, rows, lane);
+        // the second group's operands wait in the (now free) row tile instead of in 36 registers beside the first group's pass
+        float in[TERMS];
 #pragma unroll
-        for (int s = 0; s < TERMS; ++s) pack_pair(code[2 * s], code[2 * s + 1]);
+        for (int s = 0; s < TERMS; ++s) {
+            pack_pair(code[2 * s], code[2 * s + 1]);
+            s_io[s * 64 + lane] = code[2 * s + 1];
+            in[s] = code[2 * s];
+        }
         f32x16 outA, outB;
 #pragma unroll 1
         for (int grp = 0; grp < 2; ++grp) {
-            float in[TERMS];
+            if (grp) {
 #pragma unroll
-            for (int s = 0; s < TERMS; ++s) in[s] = grp ? code[2 * s + 1] : code[2 * s];
+                for (int s = 0; s < TERMS; ++s) in[s] = s_io[s * 64 + lane];
+            }
             f32x16 o;
             wp.begin_pass(env_blob, kEnvChunks, env_blob, kEnvChunks);
             env_pass<TERMS, ENV_T, kEnvN, env_handoff(TERMS, ENV_T)>(wp, lane, aux, in, o);
             if (grp == 0) outA = o; else outB = o;
         }
+        __builtin_amdgcn_wave_barrier();
         float e12[12];
         {
             float alo[4], ahi[4], blo[4], bhi[4];
