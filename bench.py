@@ -450,11 +450,11 @@ def run(argv: list[str]) -> None:
                                            "mfma": {"achieved": evaluated * FLOP_PER_SAMPLE_GEOMETRY / (geometry_ms * 1e-3) / 1e12,
                                                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                                     "frac": evaluated * FLOP_PER_SAMPLE_GEOMETRY / (geometry_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}},
-                "geometry_pass_bound_note": ("neither roofline binds this stage: k_geo_eval32 runs at the SUM of its matrix-pipe time (224 fp32 MFMAs "
-                                             "per 32 samples, 58 %) and its vector issue time (2 497 instructions per batch, 40 %) -- on this chip a wave "
-                                             "issuing MFMAs back to back starves its SIMD partner (tools/probe/cross_wave_probe.hip), so two waves per SIMD "
-                                             "do not overlap the two; without any table load the kernel is 8 % faster, halving its L2 misses (tile order) "
-                                             "bought 2 % (DESIGN.md 3.1)"),
+                "geometry_pass_bound_note": ("neither roofline binds this stage: k_geo_eval32 runs at the SUM of its matrix-pipe time (208 fp32 MFMA steps' worth "
+                                             "per 32 samples, about two thirds) and its vector issue time (1 718 instructions per batch, about one third) -- on this "
+                                             "chip a wave issuing MFMAs back to back starves its SIMD partner whatever their priorities (tools/probe/"
+                                             "cross_wave_probe.hip), so two waves per SIMD do not overlap the two; without any table load the kernel was 8 % faster, "
+                                             "halving its L2 misses (tile order) bought 2 %, dropping the selects of the paired gathers 8 % (DESIGN.md 3.1)"),
                 "record_bytes_per_sample": 92}
         if world == 1 and not strong and not args.headline_only and pipeline:
             context_legs(result, renderer, dev, args.steps, N_frame)
