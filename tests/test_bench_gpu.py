@@ -35,8 +35,9 @@ def test_force_dist_single_rank_rccl_path_matches_the_plain_run():
     assert forced["dist"]["gathered_equals_rendered"] is True
     assert forced["config"]["samples_per_frame"] == plain["config"]["samples_per_frame"]
     assert forced["gather_ms"] > 0                                           # the gathers ran, on the side stream, and were timed
-    # the gather overlaps the next frame: within 3 % of the plain run (1 % typical; the bound leaves room for clock noise on a shared box)
-    assert forced["value"] >= 0.97 * plain["value"], (forced["value"], plain["value"])
+    # the gather overlaps the next frame: 0.1 - 1 % off the plain run when measured (profiles/r04*/bench_force_dist.json); the bound here only
+    # catches a serialised gather (it would cost a frame's 7.7 MB copy + sync per step), not clock noise between two processes on a shared box
+    assert forced["value"] >= 0.92 * plain["value"], (forced["value"], plain["value"])
 
 
 def test_strong_scaling_mode_on_one_rank():
