@@ -429,10 +429,76 @@ def half_cases():
     return out
 
 
+def half_sweep_cases():
+    """every (D, C) instantiation of the half-precision hash / grid kernels and every SH degree (tools/kernel_coverage.sh: the
+    hand-picked half cases above reach a third of them), at sizes of a few dozen points"""
+    from oracle import clib
+    rng = np.random.default_rng(29 + SEED_OFFSET)
+    h = lambda a: np.ascontiguousarray(a, dtype=np.float16).view(np.int16)
+    out = []
+    for D in (2, 3):
+        for C in (1, 2, 4, 8):
+            L, log2T, base, desired = 3, 9, 4, 24
+            offsets, pls = scenes.hash_level_offsets(D, L, base, log2T, desired)
+            S = float(np.log2(pls))
+            B = 70
+            x = _points(rng, B, D).astype(np.float16)
+            table = rng.uniform(-1, 1, size=(int(offsets[-1]), C)).astype(np.float16)
+            cid = f"hash16_D{D}C{C}"
+            dy = np.zeros((B, L * D * C), np.int16)
+            out.append((cid + "_fwd_grad", "hash_encode_forward_f16", (h(x), h(table), offsets, np.zeros((L, B, C), np.int16), B, D, C, L, S, base, 1, dy), None))
+            dy = dy.copy()
+            clib.oracle().call("hash_encode_forward_f16", h(x), h(table), offsets, np.zeros((L, B, C), np.int16), B, D, C, L, S, base, 1, dy)
+            grad = h(rng.normal(size=(L, B, C)) * 0.1)
+            out.append((cid + "_bwd_inputs", "hash_encode_backward_f16", (grad, h(x), h(table), offsets, None, B, D, C, L, S, base, 1, dy, np.zeros((B, D), np.int16)), None))
+            out.append((cid + "_bwd_table", "hash_encode_backward_f16", (grad, h(x), h(table), offsets, np.zeros((int(offsets[-1]), C), np.int16), B, D, C, L, S, base, 0, None, None), "f16"))
+            if C > 1:
+                ggx = h(rng.normal(size=(B, D)) * 0.1)
+                out.append((cid + "_bwd2", "hash_encode_second_backward_f16", (grad, h(x), h(table), offsets, B, D, C, L, S, base, 1, dy, ggx,
+                                                                                np.zeros((L, B, C), np.int16), np.zeros((int(offsets[-1]), C), np.int16)), "f16"))
+    for D in (1, 2, 3, 4, 5):
+        for C in (1, 2, 4, 8):
+            L, log2T, base, desired = 2, 9, 2, 6
+            gridtype, align = (D + C) % 2, (D * C) % 2
+            offsets, pls = scenes.grid_level_offsets(D, L, base, log2T, desired, bool(align))
+            S = float(np.log2(pls))
+            B = 70
+            x = _points(rng, B, D)
+            table = rng.uniform(-1, 1, size=(int(offsets[-1]), C)).astype(np.float16)
+            cid = f"grid16_D{D}C{C}g{gridtype}a{align}"
+            dy = np.zeros((B, L * D * C), np.int16)
+            out.append((cid + "_fwd_grad", "grid_encode_forward_f16", (x, h(table), offsets, np.zeros((L, B, C), np.int16), B, D, C, L, S, base, dy, gridtype, align), None))
+            out.append((cid + "_fwd", "grid_encode_forward_f16", (x, h(table), offsets, np.zeros((L, B, C), np.int16), B, D, C, L, S, base, None, gridtype, align), None))
+            dy = dy.copy()
+            clib.oracle().call("grid_encode_forward_f16", x, h(table), offsets, np.zeros((L, B, C), np.int16), B, D, C, L, S, base, dy, gridtype, align)
+            grad = h(rng.normal(size=(L, B, C)) * 0.1)
+            out.append((cid + "_bwd", "grid_encode_backward_f16", (grad, x, h(table), offsets, np.zeros((int(offsets[-1]), C), np.int16), B, D, C, L, S, base, dy,
+                                                                   np.zeros((B, D), np.int16), gridtype, align), "f16"))
+    for degree in (3, 5, 7):          # (1, 2, 4, 6, 8 are in half_cases)
+        B = 100
+        d16 = _unit_dirs(rng, B).astype(np.float16)
+        C2 = degree * degree
+        out.append((f"sh16_deg{degree}", "sh_encode_forward_f16", (h(d16), np.zeros((B, C2), np.int16), B, 3, degree, None), "hulp"))
+        dy = np.zeros((B, 3 * C2), np.int16)
+        out.append((f"sh16_deg{degree}_grad", "sh_encode_forward_f16", (h(d16), np.zeros((B, C2), np.int16), B, 3, degree, dy), "hulp"))
+        dy = dy.copy()
+        clib.oracle().call("sh_encode_forward_f16", h(d16), np.zeros((B, C2), np.int16), B, 3, degree, dy)
+        out.append((f"sh16_deg{degree}_bwd", "sh_encode_backward_f16", (h(rng.normal(size=(B, C2)) * 0.3), h(d16), B, 3, degree, dy, h(rng.normal(size=(B, 3)))), None))
+    return out
+
+
+def reference_adds_nothing(cid: str, op: str) -> bool:
+    """The one place where this build deliberately does NOT do what the reference does: gridencoder's at::Half table gradient with
+    C = 1 goes through `atomicAdd(at::Half*, at::Half)`, which gridencoder.cu:21-26 defines with its body commented out ("never
+    used") -- the reference leaves grad_embeddings untouched there.  The oracle and the HIP kernels form the sums; the pinning
+    test checks that the reference body indeed returns zeros for these cases instead of comparing."""
+    return op == "grid_encode_backward_f16" and "grid16_D" in cid and "C1g" in cid
+
+
 ALL_GROUPS = {
     "near_far": near_far_cases, "misc": misc_cases, "march": march_cases, "composite": composite_cases,
     "train": train_cases, "hash": hash_cases, "hash_bwd": hash_backward_cases, "grid": grid_cases,
-    "grid_bwd": grid_backward_cases, "sweep": encoder_sweep_cases, "freq_sh": freq_sh_cases, "ide": ide_cases, "half": half_cases,
+    "grid_bwd": grid_backward_cases, "sweep": encoder_sweep_cases, "freq_sh": freq_sh_cases, "ide": ide_cases, "half": half_cases, "sweep_half": half_sweep_cases,
 }
 
 

@@ -24,6 +24,10 @@ def test_oracle_matches_reference_bodies(cid, op, args, tol, ref_lib):
     got = run_op("oracle", op, *args)
     want = run_op("ref", op, *args)
     assert len(got) == len(want)
+    if cases.reference_adds_nothing(cid, op):
+        # documented deviation (tests/cases.py reference_adds_nothing): the reference's stub atomic adds nothing to the table gradient
+        assert not want[4].any() and got[4].any()
+        got, want = [g for k, g in enumerate(got) if k != 4], [w for k, w in enumerate(want) if k != 4]
     for k, (g, w) in enumerate(zip(got, want)):
         if g is None:
             continue

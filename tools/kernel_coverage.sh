@@ -13,7 +13,7 @@ root = os.environ["GRAFT_REPO_ROOT"]
 out = root + "/gpurun_out/coverage"
 def norm(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n)
-    n = re.sub(r"^void ", "", n.strip())
+    n = re.sub(r"^void ", "", n.strip()).replace("_Float16", "half").replace("__half", "half")
     depth, cut = 0, len(n)
     for i, ch in enumerate(n):          # cut the argument list: the first '(' outside template brackets
         if ch == "<": depth += 1
@@ -32,7 +32,7 @@ for s in syms:
     if i < 0:
         if s.endswith(".kd") and s[:-3].isidentifier(): names.add(s[:-3])
         continue
-    d = subprocess.run(["c++filt", s[i:-3]], capture_output=True, text=True).stdout
+    d = subprocess.run(["c++filt", s[i:-3].replace("DF16_", "Dh")], capture_output=True, text=True).stdout          # (binutils' c++filt predates _Float16's DF16_)
     names.add(norm(d))
 mine = sorted(n for n in names if n)
 never = [n for n in mine if n not in launched]
