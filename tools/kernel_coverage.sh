@@ -21,9 +21,15 @@ def norm(n):
         elif ch == "(" and depth == 0: cut = i; break
     return n[:cut].replace(" ", "")
 launched = set()
+demangled = {}
 for f in glob.glob("/tmp/cov/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        launched.add(norm(r["Kernel_Name"]))
+        n = r["Kernel_Name"]
+        if n.startswith("_Z"):          # (the tracer's demangler does not know _Float16's DF16_ either)
+            if n not in demangled:
+                demangled[n] = subprocess.run(["c++filt", n.split()[0].replace("DF16_", "Dh")], capture_output=True, text=True).stdout
+            n = demangled[n]
+        launched.add(norm(n))
 syms = subprocess.run("strings -n 8 %s/envidr_amd/libenvidr_amd.so | grep '\\.kd$' | sort -u" % root, shell=True, capture_output=True, text=True).stdout.split("\n")
 names = set()
 for s in syms:
