@@ -33,6 +33,9 @@ def test_encoders_ragged_and_unaligned(B):
         o2, dy2 = _shifted(torch.zeros(B, C2, device=dev)), _shifted(torch.zeros(B, 3 * C2, device=dev))
         _lib.call("sh_encode_forward", d, o2, B, 3, deg, dy2)
         assert torch.equal(o, o2) and torch.equal(dy, dy2), ("sh", deg)
+        o3 = _shifted(torch.zeros(B, C2, device=dev))
+        _lib.call("sh_encode_forward", d, o3, B, 3, deg, None)          # unaligned outputs without the Jacobian: its own instantiation
+        assert torch.equal(o, o3), ("sh without dy_dx", deg)
         # reference values: one point at a time through the same operator (a single-row tile)
         one = torch.zeros(1, C2, device=dev)
         _lib.call("sh_encode_forward", d[B - 1:B].contiguous(), one, 1, 3, deg, None)
