@@ -7,8 +7,10 @@ What it does
   2. drops the `#include` lines and every host-side function (the column-0 `void f(...) {...}`
      definitions, which contain `<<<...>>>` launches / AT_DISPATCH), keeping helpers + kernels;
   3. writes those slices to a TEMPORARY directory (never into the repo, never onto the GPU box);
-  4. compiles oracle/ref/ref_entry.cpp (ours) with g++ against kernel_keywords.h (ours), with
-     `-I <tmp>` so the `#include "<ext>_kernels.inc"` lines resolve; output -> oracle/_ref/.
+  4. compiles oracle/ref/ref_entry.cpp (ours) with g++ against kernel_keywords.h (ours: CUDA keywords only -- at::Half is the
+     REAL c10/util/Half.h of this image's torch wheel, include path from torch.utils.cpp_extension), with
+     `-I <tmp>` so the `#include "<ext>_kernels.inc"` lines resolve; output -> oracle/_ref/;
+  5. compiles the same translation unit a second time with `-ffp-contract=fast -mfma` -> libenvidr_ref_fma.so (contraction sweep).
 
 This is not a build of the reference's CUDA extension (that is unbuildable here: no nvcc, no CUDA
 headers, no CUDA device) -- see kernel_keywords.h for the exact list of deviations.
@@ -25,6 +27,10 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 OUT_DIR = HERE.parent / "_ref"
 OUT_LIB = OUT_DIR / "libenvidr_ref.so"
+# the same slices compiled the way nvcc compiles device code by default: a*b+c contracted into fused multiply-adds
+# (`-ffp-contract=fast -mfma`).  Only tests/test_oracle_pinning.py's contraction sweep loads it: it shows which outputs of the
+# marchers / grid encoders are invariant under the one rounding deviation a real CUDA build certainly has.
+OUT_LIB_FMA = OUT_DIR / "libenvidr_ref_fma.so"
 REFERENCE = Path(os.environ.get("ENVIDR_REFERENCE", "/root/reference"))
 EXTENSIONS = ["raymarching", "hashencoder", "gridencoder", "freqencoder", "shencoder"]
 
@@ -69,6 +75,15 @@ def slice_kernels(text: str) -> str:
     return body + "\n"
 
 
+def torch_include_dirs() -> list[str]:
+    """where c10/util/Half.h lives (header-only; nothing of torch is linked)."""
+    from torch.utils.cpp_extension import include_paths
+    dirs = [d for d in include_paths() if (Path(d) / "c10" / "util" / "Half.h").is_file()]
+    if not dirs:
+        raise RuntimeError("c10/util/Half.h not found under torch's include paths")
+    return dirs
+
+
 def build(verbose: bool = True) -> Path | None:
     if not reference_available():
         if verbose:
@@ -77,19 +92,21 @@ def build(verbose: bool = True) -> Path | None:
         return OUT_LIB if OUT_LIB.exists() else None
     srcs = [REFERENCE / e / "src" / f"{e}.cu" for e in EXTENSIONS]
     deps = srcs + [HERE / "ref_entry.cpp", HERE / "kernel_keywords.h", Path(__file__)]
-    if OUT_LIB.exists() and all(d.stat().st_mtime <= OUT_LIB.stat().st_mtime for d in deps):
+    if all(o.exists() and all(d.stat().st_mtime <= o.stat().st_mtime for d in deps) for o in (OUT_LIB, OUT_LIB_FMA)):
         return OUT_LIB
     OUT_DIR.mkdir(parents=True, exist_ok=True)
     with tempfile.TemporaryDirectory(prefix="envidr_ref_slices_") as tmp:
         for e, src in zip(EXTENSIONS, srcs):
             (Path(tmp) / f"{e}_kernels.inc").write_text(slice_kernels(src.read_text()))
-        cmd = ["g++", "-O2", "-std=c++17", "-w", "-fPIC", "-shared", "-ffp-contract=off", "-fvisibility=hidden",
-               "-I", tmp, "-I", str(HERE), str(HERE / "ref_entry.cpp"), "-o", str(OUT_LIB)]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("reference kernel-body build failed:\n" + r.stderr[-6000:])
-    if verbose:
-        print(f"[oracle/ref] built {OUT_LIB} ({OUT_LIB.stat().st_size >> 10} KiB)")
+        inc = [x for d in torch_include_dirs() for x in ("-isystem", d)]
+        for out, fp in ((OUT_LIB, ["-ffp-contract=off"]), (OUT_LIB_FMA, ["-ffp-contract=fast", "-mfma"])):
+            cmd = ["g++", "-O2", "-std=c++17", "-w", "-fPIC", "-shared", *fp, "-fvisibility=hidden",
+                   "-I", tmp, "-I", str(HERE), *inc, str(HERE / "ref_entry.cpp"), "-o", str(out)]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("reference kernel-body build failed:\n" + r.stderr[-6000:])
+            if verbose:
+                print(f"[oracle/ref] built {out} ({out.stat().st_size >> 10} KiB)")
     return OUT_LIB
 
 

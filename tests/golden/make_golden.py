@@ -483,6 +483,91 @@ def golden_ops():
     print(f"[golden] ops_ref: {len(out)} arrays from {len(keep)} cases")
 
 
+def golden_torch_only():
+    """Fixtures from the reference's TORCH-ONLY code: no kernel body, no keyword header, no oracle/_ref anywhere in the arithmetic.
+
+    * `encoding.FreqEncoder` (encoding.py:6-44, the `frequency_torch` branch of get_encoder: max_freq_log2 = multires - 1,
+      N_freqs = multires) -- forward and, through torch autograd, the input gradient: pins freq_encode_forward / _backward.
+    * the volume-rendering arithmetic of `nerf/render_func/non_cuda_ray.run` (non_cuda_ray.py:108-156: deltas, alphas, the cumprod
+      transmittance, weights, weights_sum, normal image, depth, image + background), executed by calling the reference's own `run`
+      on a model object of ours whose `density` / `color` return prescribed tensors.  The one extension call in that function,
+      `raymarching.near_far_from_aabb`, is answered by the harness with prescribed (near, far): they are inputs of the fixture.
+      Pins the compositing recurrence of composite_rays / composite_rays_train_forward.
+    """
+    import encoding as ref_encoding
+    rng = np.random.default_rng(41)
+    out = {}
+    for D, deg in ((3, 4), (3, 10), (2, 6), (1, 1)):
+        enc = ref_encoding.FreqEncoder(input_dim=D, max_freq_log2=deg - 1, N_freqs=deg, log_sampling=True)
+        x = rng.uniform(-1.0, 1.0, size=(700, D)).astype(F)
+        x[0] = 0
+        x[1] = 1
+        x[2] = -1
+        xt = torch.from_numpy(x).requires_grad_(True)
+        y = enc(xt)
+        g = rng.normal(size=tuple(y.shape)).astype(F)
+        (y * torch.from_numpy(g)).sum().backward()
+        tag = f"freq_D{D}deg{deg}"
+        out.update({f"{tag}|x": x, f"{tag}|y": y.detach().numpy(), f"{tag}|g": g, f"{tag}|gx": xt.grad.numpy()})
+        assert y.shape[1] == D + 2 * D * deg
+    print("[golden] torch_only: FreqEncoder", [k for k in out if k.endswith("|y")])
+
+    from nerf.render_func import non_cuda_ray
+    N, T = 300, 48
+    nears = rng.uniform(0.3, 2.0, size=N).astype(F)
+    fars = (nears + rng.uniform(0.5, 2.5, size=N)).astype(F)
+    sigma = rng.uniform(0, 1, size=(N, T)).astype(F) ** 4 * 300            # mostly thin, some opaque
+    sigma[:20] = 0                                                          # rays through empty space
+    sigma[20:40, 10:] = 1e4                                                 # rays that saturate (T underflows to the 1e-15 floor)
+    rgb = rng.uniform(0, 1, size=(N, T, 3)).astype(F)
+    normal = rng.normal(size=(N, T, 3)).astype(F)
+    bg = np.array([0.25, 0.5, 0.75], F)
+    rays_o = rng.normal(size=(N, 3)).astype(F)
+    rays_d = rng.normal(size=(N, 3)).astype(F)
+    rays_d /= np.linalg.norm(rays_d, axis=1, keepdims=True)
+
+    class _Opt:
+        debug = False
+        backsdf_loss = False
+        eikonal_loss = False
+
+    class _Model:
+        opt = _Opt()
+        use_normal_with_mlp = True
+        use_n_dot_viewdir = True
+        use_reflected_dir = True
+        training = False
+        aabb_train = aabb_infer = torch.tensor([-8.0, -8, -8, 8, 8, 8])
+        min_near = 0.2
+        density_scale = 1
+        bg_radius = -1
+
+        def density(self, xyzs, **kw):
+            return {"sigma": torch.from_numpy(sigma).reshape(-1, 1), "normal": torch.from_numpy(normal).reshape(-1, 3)}
+
+        def color(self, xyzs, dirs, mask=None, **kw):
+            return torch.from_numpy(rgb).reshape(-1, 3)
+
+    class _NearFar:                                     # stands in for the `raymarching` module inside non_cuda_ray only
+        @staticmethod
+        def near_far_from_aabb(rays_o, rays_d, aabb, min_near):
+            return torch.from_numpy(nears.copy()), torch.from_numpy(fars.copy())
+
+    saved = non_cuda_ray.raymarching
+    non_cuda_ray.raymarching = _NearFar
+    try:
+        res = non_cuda_ray.run(_Model(), torch.from_numpy(rays_o), torch.from_numpy(rays_d), num_steps=T, upsample_steps=0,
+                               bg_color=torch.from_numpy(bg), perturb=False, get_normal_image=True)
+    finally:
+        non_cuda_ray.raymarching = saved
+    out.update({"vr|nears": nears, "vr|fars": fars, "vr|sigma": sigma, "vr|rgb": rgb, "vr|normal": normal, "vr|bg": bg,
+                "vr|image": res["image"].detach().numpy(), "vr|depth": res["depth"].detach().numpy(),
+                "vr|weights_sum": res["weights_sum"].detach().numpy(), "vr|normal_image": res["normal_image"].detach().numpy()})
+    np.savez_compressed(OUT / "torch_only.npz", **out)
+    print("[golden] torch_only: volume rendering", tuple(res["image"].shape), "weights_sum",
+          float(res["weights_sum"].min()), "...", float(res["weights_sum"].max()))
+
+
 def train_targets(n):
     """deterministic stand-in for ground-truth pixels of a training batch"""
     i = np.arange(n, dtype=np.float64)
@@ -549,6 +634,9 @@ def main():
     if sys.argv[1:] == ["ide"]:
         golden_ide()
         return
+    if sys.argv[1:] == ["torch_only"]:         # only the fixtures from the reference's torch-only code
+        golden_torch_only()
+        return
     if sys.argv[1:] == ["inorm"]:              # only the instanceNorm feature-activation chain
         golden_instance_norm()
         return
@@ -562,6 +650,7 @@ def main():
     golden_ops()
     golden_rays()
     golden_ide()
+    golden_torch_only()
     scene = scenes.toaster_scene()
     model, opt = build_reference_model(scene)
     print("[golden] reference model built:", type(model).__name__, "visual_items", opt.visual_items, "indir_ref", opt.indir_ref)

@@ -205,3 +205,19 @@ def test_ide_gradient_oracle_vs_reference_autograd():
         assert rel_l2(res[-2], g[f"gdirs{deg}"]) <= tol_d and rel_l2(res[-1], g[f"grough{deg}"].reshape(-1)) <= tol_r, deg
         res = run_op("oracle", "ide_encode_backward", go, d, None, 0.64, B, deg, np.zeros((B, 3), np.float32), None)
         assert rel_l2(res[-2], g[f"gdirs{deg}_k064"]) <= 5e-6, deg
+
+
+# ---- fixtures from the reference's torch-only code (no kernel body, no keyword header in the expected values) ----
+from tests import torch_only  # noqa: E402
+
+
+@pytest.mark.parametrize("D,deg", torch_only.FREQ_CASES)
+def test_freq_oracle_matches_reference_torch_encoder(D, deg):
+    """oracle_freq_encode_{forward,backward} vs encoding.FreqEncoder (encoding.py:6-44) and torch autograd through it"""
+    torch_only.check_freq("oracle", D, deg)
+
+
+def test_compositing_oracle_matches_reference_torch_volume_rendering():
+    """the compositing recurrence of both compositors vs the cumprod formulation of non_cuda_ray.run (non_cuda_ray.py:108-156)"""
+    torch_only.check_composite_train_forward("oracle")
+    torch_only.check_composite_rays("oracle")

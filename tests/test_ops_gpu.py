@@ -249,3 +249,20 @@ def test_hash_encoder_double_backward_in_half():
         grads[name] = table.grad.float()
     rel = float((grads["f16"] - grads["f32"]).norm() / grads["f32"].norm())
     assert float(grads["f32"].norm()) > 0 and rel <= 5e-2, rel
+
+
+# ---- the HIP operators against fixtures from the reference's torch-only code (tests/torch_only.py: no kernel body, no keyword
+# ---- header and no oracle in the expected values) ----
+from tests import torch_only  # noqa: E402
+
+
+@pytest.mark.parametrize("backend", ["hip", "shim"])
+@pytest.mark.parametrize("D,deg", torch_only.FREQ_CASES)
+def test_freq_encode_matches_reference_torch_encoder(backend, D, deg):
+    torch_only.check_freq(backend, D, deg)
+
+
+@pytest.mark.parametrize("backend", ["hip", "shim"])
+def test_compositors_match_reference_torch_volume_rendering(backend):
+    torch_only.check_composite_train_forward(backend)
+    torch_only.check_composite_rays(backend)
