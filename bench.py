@@ -110,12 +110,20 @@ def cpu_baseline(scene, env_rot: float, frames: int, res: int) -> dict:
         times.append(time.perf_counter() - t0)
     dt = float(np.median(times))
     n = res * res
-    return {"value": n / dt, "unit": "rays/s", "cores": threads, "kind": "port",
+    host = host_cpu_info()
+    try:
+        host_cores = int(host["Socket(s)"]) * int(host["Core(s) per socket"])
+    except Exception:       # noqa: BLE001
+        host_cores = None
+    return {"value": n / dt, "unit": "rays/s", "cores": threads, "threads_used": threads, "host_cores": host_cores,
+            "cores_note": "`cores` / `threads_used` = the torch + OpenMP thread count that rendered the probe frame fastest, NOT the size of the "
+                          "host (`host_cores` physical cores, `host.logical_cpus` hardware threads)",
+            "kind": "port",
             "sample": f"{res}x{res} frame of the same scene and camera ({n} rays, {out['n_samples']} samples): oracle/ C+OpenMP ops + torch "
                       f"CPU fp32 GEMMs, reference n_step schedule; median of {len(times)} frames ({dt:.1f} s each) at the fastest of the "
                       f"thread counts tried on a {probe_res}x{probe_res} frame of the same scene",
             "frame_seconds": times, "threads_tried_seconds_on_probe_frame": tried, "probe_frame": f"{probe_res}x{probe_res}",
-            "ide_mode": "torch (the reference's fp32 complex-power formulation, ide_encoder.py:98-130)", "host": host_cpu_info(),
+            "ide_mode": "torch (the reference's fp32 complex-power formulation, ide_encoder.py:98-130)", "host": host,
             "samples_per_s": out["n_samples"] / dt, "image": out["image"]}
 
 
@@ -149,7 +157,9 @@ def parse(argv: list[str]):
                     "(RCCL on the GPU), gather on the side stream, slot events, barrier -- the branch the multi-GPU run takes")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="weak: one full view per rank per step (default); "
                     "strong: ONE view per step, its 8x8-pixel tiles interleaved over the ranks, gathered and assembled on rank 0")
-    ap.add_argument("--cold", action="store_true", help="headline frames without the per-ray hint (profiling the cold frame)")
+    ap.add_argument("--hinted", action="store_true", help="timed frames WITH the previous frame's per-ray sample counts as a hint (the fixed-camera "
+                    "video of BASELINE configs[4]); the default is the cold frame: configs[2] is ONE view, nothing is known about it beforehand")
+    ap.add_argument("--cold", action="store_true", help="(the default since round 5; kept so that older command lines still parse)")
     ap.add_argument("--corrupt-rank", type=int, default=-1, help="test hook: this rank damages one pixel of the LAST step's image before "
                     "sending it; dist.gathered_equals_rendered must then come out false for that rank (tests/test_bench_cpu.py)")
     ap.add_argument("--stub", action="store_true", help="CPU plumbing test: gloo, a stand-in renderer, tiny frames "
@@ -193,6 +203,7 @@ def load_scene(rank: int, world: int, dist_on: bool, dev):
 
 def run(argv: list[str]) -> None:
     args = parse(argv)
+    args.cold = not args.hinted
     from envidr_amd import parallel
     import torch.distributed as dist
 
@@ -381,6 +392,11 @@ def run(argv: list[str]) -> None:
         dist.all_gather(per_rank, t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    ranks_seen = None
+    if dist_on:
+        ones = torch.ones(1, device=dev, dtype=torch.float32)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)          # how many ranks the collective library really joined
+        ranks_seen = int(ones.item())
 
     if rank == 0:
         rays_per_step = N_frame if strong else world * N_frame
@@ -399,9 +415,12 @@ def run(argv: list[str]) -> None:
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             # (the first ~120 characters carry what a truncated record must still show: the scene's samples per ray -- rays/s scales
             #  inversely with it -- and whether the frames had the previous frame's per-ray counts as a hint)
-            "config": {"workload": f"toaster.ini network 800x800, {samples / max(N, 1):.2f} samples/ray (thin synthetic shell), "
-                                   + ("COLD frames (no per-ray hint); " if args.cold else "HINTED frames (fixed camera: exact per-ray counts); ")
-                                   + "BASELINE configs[2]/[4]: hash L16xC2 + SDF 32-64-64-15 + IDE deg5 + env MLP "
+            # (the first ~120 characters carry what a truncated record must still show: COLD or HINTED, the scene's samples per ray --
+            #  rays/s scales inversely with it -- and samples/s; at N = 1 the SURVEY 8(d)-density leg is spliced in behind them below)
+            "config": {"workload": ("COLD" if args.cold else "HINTED (fixed-camera video)") + f" 800x800 toaster.ini frames, {samples / max(N, 1):.2f} samples/ray, "
+                                   f"{(1 if strong else world) * samples * args.steps / dt / 1e6:.0f} M samples/s; "
+                                   + ("no per-ray hint; " if args.cold else "per-ray counts of the previous frame as hint; ")
+                                   + "thin synthetic shell; BASELINE configs[2]/[4]: hash L16xC2 + SDF 32-64-64-15 + IDE deg5 + env MLP "
                                    "72-256-256-256-12 x2 + diffuse/specular heads, one view per "
                                    + ("step sharded by 8x8-pixel tiles" if strong else "GPU per step, env-rotation video frames sharded by view")
                                    + ", normal/diffuse/specular/roughness images on",
@@ -410,18 +429,20 @@ def run(argv: list[str]) -> None:
                        "schedule": ("geometry pipeline (device-driven march rounds + sample-parallel hash grid / SDF network, one record "
                                     "per composited sample) -> shading pass (k_shade_samples) -> per-ray composite; every frame marches, "
                                     "evaluates and shades from scratch.  "
-                                    + ("NO per-ray hint (--cold): 16 samples first, then chunks predicted per ray from its transmittance."
+                                    + ("NO per-ray hint (the default): 16 samples first, then chunks predicted per ray from its transmittance; "
+                                       "video_fixed_camera is the same loop with the previous frame's counts as hint."
                                        if args.cold else
                                        "The camera is fixed (env-rotation video), so the per-ray sample counts kept from the previous frame "
-                                       "are an EXACT hint: one march round, samples_evaluated == samples_composited.  See cold_frame / "
-                                       "moving_camera for frames without that help.")
+                                       "are an EXACT hint: one march round, samples_evaluated == samples_composited (--hinted).")
                                     if pipeline else "one persistent kernel per frame")},
             "samples_per_s": (1 if strong else world) * samples * args.steps / dt,
             "per_rank_ms_per_step": [float(x.item()) / args.steps * 1e3 for x in per_rank],
             "gather_ms": gather_ms,
         }
         if dist_on:
-            result["dist"] = {"backend": dist.get_backend(), "world": world, "force_dist": bool(args.force_dist), "gathered_equals_rendered": delivered_ok,
+            result["dist"] = {"backend": dist.get_backend(), "world": world, "ranks_seen": ranks_seen,
+                              "ranks_seen_note": "all_reduce(SUM) of a one per rank over the benchmark's own process group",
+                              "force_dist": bool(args.force_dist), "gathered_equals_rendered": delivered_ok,
                               "gathered_equals_rendered_per_rank": delivered_per_rank,
                               "gathered_check": "rank 0 re-rendered every rank's last view / the whole last frame and compared the gathered pixels bit for bit",
                               "scene": "none (stub)" if stub else ("generated on rank 0, table + bitfield broadcast" if dist_on else "generated locally")}
@@ -457,7 +478,7 @@ def run(argv: list[str]) -> None:
                                              "halving its L2 misses (tile order) bought 2 %, dropping the selects of the paired gathers 8 % (DESIGN.md 3.1)"),
                 "record_bytes_per_sample": 92}
         if world == 1 and not strong and not args.headline_only and pipeline:
-            context_legs(result, renderer, dev, args.steps, N_frame)
+            context_legs(result, renderer, dev, args.steps, N_frame, headline_cold=args.cold)
         if world == 1 and not strong and not args.headline_only:
             other_configs(result, dev, rays_o, rays_d, N)
         # HBM traffic of the dominant kernel from the PMC summary -- only if it was collected on THESE kernel sources
@@ -526,9 +547,11 @@ def _finish(result, dist_on: bool) -> None:
         print(json.dumps(result), flush=True)
 
 
-def context_legs(result, renderer, dev, steps: int, N: int) -> None:
-    """the headline workload WITHOUT the exact per-ray hint its fixed camera provides: (a) every frame cold, (b) a camera that
-    moves 2 degrees per step, rays generated on the device inside the timed region, hint = the previous pose's counts"""
+def context_legs(result, renderer, dev, steps: int, N: int, headline_cold: bool = True) -> None:
+    """the headline workload in its other regimes: (a) the loop the headline did NOT run -- `video_fixed_camera` (BASELINE configs[4]: the
+    previous frame's per-ray counts are an exact hint) when the headline is cold, `cold_frame` when it was run --hinted; (b) a camera
+    that moves 2 degrees per step, rays generated on the device inside the timed region, hint = the previous pose's counts; (c) the same
+    network on the density SURVEY.md 8(d) specifies (~28 samples per ray), cold like the headline"""
     from envidr_amd import scenes
     from envidr_amd.nerf.utils import get_rays
     steps = max(steps, 4)
@@ -561,8 +584,14 @@ def context_legs(result, renderer, dev, steps: int, N: int) -> None:
                 "evaluated_over_composited": float(stats[:, 0].sum() / max(stats[:, 1].sum(), 1)), "frames": steps}
 
     fixed = tuple(torch.from_numpy(a).to(dev) for a in scenes.camera_rays(H, W))
-    result["cold_frame"] = dict(leg(lambda i: fixed, False, 1),
-                                note="use_cost_hint=False every frame: 16 samples per ray first, then per-ray predicted chunks")
+    if headline_cold:
+        result["video_fixed_camera"] = dict(leg(lambda i: fixed, True, 2),
+                                            note="BASELINE configs[4], one GPU's share: env-rotation video frames of a FIXED camera -- the per-ray sample counts "
+                                                 "kept from the previous frame are an exact hint (one march round, evaluated == composited); every frame "
+                                                 "still marches, evaluates and shades from scratch")
+    else:
+        result["cold_frame"] = dict(leg(lambda i: fixed, False, 1),
+                                    note="use_cost_hint=False every frame: 16 samples per ray first, then per-ray predicted chunks")
     # moving camera: theta advances 2 degrees per step; poses uploaded once, rays by envidr_get_rays INSIDE the timed region
     n_pose = steps + 2
     poses = torch.from_numpy(np.stack([scenes.nerf_matrix_to_ngp(scenes.pose_spherical(30.0 + 2.0 * i, -20.0, 4.0), scale=0.65)
@@ -581,11 +610,17 @@ def context_legs(result, renderer, dev, steps: int, N: int) -> None:
     from envidr_amd.fused import FusedRenderer
     headline_renderer = renderer
     renderer = FusedRenderer.from_scene(scenes.toaster_scene(sdf_bias=0.065), device=dev)
-    thick = leg(lambda i: fixed, True, 2, sizing_hint=40.0)
+    thick = leg(lambda i: fixed, not headline_cold, 2, sizing_hint=40.0)
     renderer = headline_renderer
     result["survey_density_scene"] = dict(thick, samples_per_ray=thick["samples_composited_per_frame"] / N,
                                           samples_per_s=thick["samples_composited_per_frame"] / (thick["ms_per_frame"] * 1e-3),
-                                          note="toaster_scene(sdf_bias=0.065): the density of SURVEY.md 8(d) (~28 samples per ray), hinted frames like the headline")
+                                          note="toaster_scene(sdf_bias=0.065): the density of SURVEY.md 8(d) (~28 samples per ray), "
+                                               + ("cold" if headline_cold else "hinted") + " frames like the headline")
+    # ... and into the first characters of the workload string, next to the headline's own samples/ray and samples/s
+    d = result["survey_density_scene"]
+    head, sep, tail = result["config"]["workload"].partition(" M samples/s; ")
+    result["config"]["workload"] = (head + sep + f"at SURVEY 8d density ({d['samples_per_ray']:.1f} samples/ray): {d['rays_per_s'] / 1e6:.2f} M rays/s, "
+                                    f"{d['samples_per_s'] / 1e6:.0f} M samples/s; " + tail)
 
 
 def _time(fn, reps: int, dev) -> float:

@@ -283,8 +283,10 @@ class NeRFRenderer(nn.Module):
         for k in chunks[0]:
             if chunks[0][k] is None:
                 out[k] = None
-            else:
+            elif torch.is_tensor(chunks[0][k]):
                 out[k] = torch.cat([c[k] for c in chunks], 0 if k in ("diffuse_image", "specular_image", "roughness_image") else 1)
+            # anything else is chunk-local state of the fused path ("_frame": the raw frame whose records a following pass over the SAME
+            # rays could shade again) -- it does not describe the concatenated rays and is dropped
         return out
 
     def _render_indirect_masked(self, rays_o, rays_d, get_normal_image, use_specular_color, env_net_index, env_rot_radian, **kwargs):

@@ -44,12 +44,14 @@ def test_strong_scaling_mode_shards_one_frame_by_tiles():
     for gpus in (2, 3):
         j = _run(["--gpus", str(gpus), "--steps", "3", "--warmup", "2", "--stub", "--scaling", "strong"])
         assert j["n_gpus"] == gpus and j["scaling"] == "strong" and j["dist"]["gathered_equals_rendered"] is True
+        assert j["dist"]["ranks_seen"] == gpus                    # an all_reduce of ones over the benchmark's own process group
         assert j["config"]["rays_per_step_per_gpu"] in (128, 64) and j["value"] > 0
 
 
 def test_force_dist_runs_one_rank_through_the_collective_path():
     j = _run(["--gpus", "1", "--steps", "3", "--warmup", "2", "--stub", "--force-dist"])
     assert j["n_gpus"] == 1 and j["dist"]["world"] == 1 and j["dist"]["force_dist"] is True and j["dist"]["gathered_equals_rendered"] is True
+    assert j["dist"]["ranks_seen"] == 1
     j = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--stub", "--force-dist", "--scaling", "strong"])
     assert j["scaling"] == "strong" and j["dist"]["gathered_equals_rendered"] is True
 

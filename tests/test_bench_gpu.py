@@ -31,7 +31,7 @@ def _run(args):
 def test_force_dist_single_rank_rccl_path_matches_the_plain_run():
     plain = _run(["--gpus", "1", "--steps", "8", "--warmup", "2", "--headline-only"])
     forced = _run(["--gpus", "1", "--steps", "8", "--warmup", "2", "--headline-only", "--force-dist"])
-    assert forced["dist"]["backend"] == "nccl" and forced["dist"]["world"] == 1
+    assert forced["dist"]["backend"] == "nccl" and forced["dist"]["world"] == 1 and forced["dist"]["ranks_seen"] == 1
     assert forced["dist"]["gathered_equals_rendered"] is True
     assert forced["config"]["samples_per_frame"] == plain["config"]["samples_per_frame"]
     assert forced["gather_ms"] > 0                                           # the gathers ran, on the side stream, and were timed

@@ -13,15 +13,15 @@ fi
 timeout 1500 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" >> $OUT/bench.err
 # kernel trace + stats of the same command (CPU leg skipped: it launches no kernels)
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --headline-only > $OUT/trace.log 2>&1 )
-# the same for COLD frames (no per-ray hint): kernel trace + stats
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cold -o trace -- python $GRAFT_REPO_ROOT/bench.py --headline-only --cold > $OUT/trace_cold.log 2>&1 )
+# the same for HINTED frames (the fixed-camera video loop; the default is the cold frame since round 5): kernel trace + stats
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_hinted -o trace -- python $GRAFT_REPO_ROOT/bench.py --headline-only --hinted > $OUT/trace_hinted.log 2>&1 )
 # the multi-GPU code path on this one GPU (RCCL world of one) and the strong-scaling mode
 timeout 600 python bench.py --headline-only --force-dist > $OUT/bench_force_dist.json 2> $OUT/bench_force_dist.err
 timeout 600 python bench.py --headline-only --force-dist --scaling strong > $OUT/bench_strong.json 2> $OUT/bench_strong.err
 # the driver's launch line for N > 1 (torch.distributed.run sets RANK / WORLD_SIZE; bench.py must not spawn again), with one rank
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --headline-only --force-dist > $OUT/bench_torchrun.json 2> $OUT/bench_torchrun.err
 # microbenchmarks the design arguments of DESIGN.md 3.1 / 3.3 rest on
-for pr in mfma_f16_fill_probe mfma_f32_fill_probe mfma_vmem_probe cross_wave_probe lds_atomic_probe; do [ -x tools/probe/$pr ] && timeout 120 tools/probe/$pr > $OUT/$pr.txt 2>&1; done
+for pr in mfma_f16_fill_probe mfma_f32_fill_probe mfma_vmem_probe cross_wave_probe lds_atomic_probe coissue_probe; do [ -x tools/probe/$pr ] && timeout 120 tools/probe/$pr > $OUT/$pr.txt 2>&1; done
 # one rank's share of a strong-scaling frame at N = 1 .. 16 (compute side of the scaling curve, on this one GPU)
 timeout 300 python tools/geo/shard_probe.py 1 2 4 8 16 > $OUT/shard_probe.txt 2>&1
 # the standalone operators at headline-like sizes
@@ -81,9 +81,9 @@ tail -3 $OUT/pytest_gpu.log $OUT/smoke.log 2>/dev/null; cat $OUT/bench.json | cu
 # what gets committed under profiles/<tag>/
 P=$OUT/profile; mkdir -p $P
 cp $OUT/bench.json $OUT/summary.json $P/ 2>/dev/null
-cp $OUT/bench_force_dist.json $OUT/bench_strong.json $OUT/bench_torchrun.json $OUT/gather_probe.txt $OUT/mfma_f16_fill_probe.txt $OUT/mfma_f32_fill_probe.txt $OUT/mfma_vmem_probe.txt $OUT/cross_wave_probe.txt $OUT/lds_atomic_probe.txt $OUT/shard_probe.txt $OUT/fuzz_frames.txt $OUT/fuzz_ops.txt $OUT/ops_bench.txt $OUT/loop_frame_bench.txt $OUT/train_step_bench.txt $P/ 2>/dev/null
+cp $OUT/bench_force_dist.json $OUT/bench_strong.json $OUT/bench_torchrun.json $OUT/gather_probe.txt $OUT/mfma_f16_fill_probe.txt $OUT/mfma_f32_fill_probe.txt $OUT/mfma_vmem_probe.txt $OUT/cross_wave_probe.txt $OUT/lds_atomic_probe.txt $OUT/coissue_probe.txt $OUT/shard_probe.txt $OUT/fuzz_frames.txt $OUT/fuzz_ops.txt $OUT/ops_bench.txt $OUT/loop_frame_bench.txt $OUT/train_step_bench.txt $P/ 2>/dev/null
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $P/kernel_stats.csv \;
-find $OUT/trace_cold -name "*kernel_stats.csv" -exec cp {} $P/kernel_stats_cold.csv \;
+find $OUT/trace_hinted -name "*kernel_stats.csv" -exec cp {} $P/kernel_stats_hinted.csv \;
 for d in $OUT/pmc_*/; do n=$(basename $d); find $d -name "*counter_collection.csv" -exec cp {} $P/$n.csv \; ; done
 tail -5 $OUT/pytest_gpu.log > $P/pytest_gpu_tail.txt; tail -2 $OUT/smoke.log >> $P/pytest_gpu_tail.txt
 
