@@ -146,6 +146,10 @@ def _bind_render(lib):
     lib.envidr_geometry_pass.restype = ctypes.c_int
     lib.envidr_env_mlp_forward.argtypes = [_FP, ctypes.c_uint32, ctypes.c_uint32, _FP, ctypes.c_uint32, _FP, _FP]
     lib.envidr_env_mlp_forward.restype = ctypes.c_int
+    lib.envidr_shell_samples.argtypes = [_FP, _FP, _FP, _FP, _FP, _FP, ctypes.c_float, ctypes.c_uint32, ctypes.c_uint32, _FP, _FP, _FP, _FP]
+    lib.envidr_shell_samples.restype = ctypes.c_int
+    lib.envidr_composite_shell.argtypes = [_FP] * 10 + [ctypes.c_uint32] * 3 + [ctypes.c_float] * 2 + [_FP] * 8
+    lib.envidr_composite_shell.restype = ctypes.c_int
     lib._envidr_render_bound = True
 
 
@@ -548,6 +552,57 @@ class FusedRenderer:
             return _shade(self.lib, self.desc, normals, dirs, geo_feat, roughness, env_rot_radian, out)
         finally:
             self._set_precision("fp32", 0)
+
+    def update_sdf(self, sdf) -> None:
+        """replace the SDF network's weights (same shapes): the env-sphere mode folds the material parameters of a render call into the
+        first layer's bias (nerf/network.py:369-379 concatenates them to the hash features; they are constants of the call)"""
+        if self.opt.geometry_kernel != "32":
+            raise _lib.EnvidrError("update_sdf: only the default geometry kernel keeps its weights in sdf_blob")
+        L = lambda Wb, order: pack_layer(Wb[0], Wb[1], order)
+        flat = np.concatenate([L(sdf[0], 0), L(sdf[1], 1), L(sdf[2], 2),
+                               pack_layer(sdf[1][0], None, 1, transpose=True), pack_layer(sdf[0][0], None, 1, transpose=True)])
+        flat = np.concatenate([flat, np.zeros((-flat.size) % 4096, np.float32)])
+        t = torch.from_numpy(flat).to(self.device)
+        row = torch.from_numpy(pack_rowvec(_np32(sdf[2][0])[0])).to(self.device)
+        # kernels already enqueued may still read the previous weights: the last few sets stay referenced (60 KiB each), and the
+        # oldest is only dropped after the stream has drained
+        live = self.__dict__.setdefault("_sdf_sets", [])
+        live.append((t, row))
+        if len(live) > 4:
+            torch.cuda.current_stream(self.device).synchronize()
+            del live[0]
+        self.desc.sdf_blob, self.desc.sdf_w3_row0 = t.data_ptr(), row.data_ptr()
+
+    # ---- env-sphere mode (sph_ray.py run_sph): analytic hits, S samples per hit ray, torch-formula compositing ----------
+    def shell_samples(self, rays_o, rays_d, hit_rays, nears, z_offsets, step_size: float, noise=None):
+        """envidr_shell_samples: sample-major xyz [S,M,3], dirs [S,M,3], z_vals [S,M] of the hit rays"""
+        M, S, dev = int(hit_rays.shape[0]), int(z_offsets.shape[0]), rays_o.device
+        xyz, dirs, z = torch.empty(S, M, 3, device=dev), torch.empty(S, M, 3, device=dev), torch.empty(S, M, device=dev)
+        rc = self.lib.envidr_shell_samples(rays_o.data_ptr(), rays_d.data_ptr(), hit_rays.data_ptr(), nears.data_ptr(), z_offsets.data_ptr(),
+                                           None if noise is None else noise.contiguous().float().data_ptr(), float(step_size), M, S,
+                                           xyz.data_ptr(), dirs.data_ptr(), z.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        if rc:
+            raise _lib.EnvidrError(f"envidr_shell_samples failed ({rc}): {self.lib.envidr_last_error().decode()}")
+        return xyz, dirs, z
+
+    def composite_shell(self, sigma, z_vals, c_diffuse, c_specular, normals, roughness, hit_slot, nears, far_max, bg, step_size: float,
+                        want=("normal_image", "diffuse_image", "specular_image", "roughness_image")) -> dict:
+        """envidr_composite_shell over all N rays (hit_slot [N] int32: -1 = the ray misses the sphere)"""
+        N, dev = int(hit_slot.shape[0]), hit_slot.device
+        S, M = int(z_vals.shape[0]), int(z_vals.shape[1])
+        shapes = {"image": (3,), "depth": (), "weights_sum": (), "normal_image": (3,), "diffuse_image": (3,), "specular_image": (3,),
+                  "roughness_image": ()}
+        out = {k: torch.empty(N, *shapes[k], device=dev) for k in ("image", "depth", "weights_sum", *want)}
+        ptr = lambda k: out[k].data_ptr() if k in out else None
+        opt = lambda t: None if t is None else t.data_ptr()
+        rc = self.lib.envidr_composite_shell(sigma.data_ptr(), z_vals.data_ptr(), c_diffuse.data_ptr(), c_specular.data_ptr(), opt(normals),
+                                             opt(roughness), hit_slot.data_ptr(), nears.data_ptr(), far_max.data_ptr(), bg.data_ptr(), N, M, S,
+                                             float(step_size), float(self.desc.intensity_scale), ptr("image"), ptr("depth"), ptr("weights_sum"),
+                                             ptr("normal_image"), ptr("diffuse_image"), ptr("specular_image"), ptr("roughness_image"),
+                                             torch.cuda.current_stream(dev).cuda_stream)
+        if rc:
+            raise _lib.EnvidrError(f"envidr_composite_shell failed ({rc}): {self.lib.envidr_last_error().decode()}")
+        return out
 
     # ---- geometry cache: march / hash / SDF once per camera, shading per environment -----------------
     def cache_geometry(self, rays_o: torch.Tensor, rays_d: torch.Tensor, samples_per_ray_hint: float = 16.0) -> GeometryCache:

@@ -80,7 +80,7 @@ class NeRFNetwork(NeRFRenderer):
                  geo_feat_dim=15, num_layers_color=3, hidden_dim_color=64, num_layers_bg=2, hidden_dim_bg=64, bound=1,
                  num_levels=16, roughness_bias=-1, opt=None, env_opt=None, **kwargs):
         super().__init__(bound, opt=opt, env_opt=env_opt, **kwargs)
-        if not opt.use_sdf or opt.use_neus_sdf or opt.geometric_init or opt.skip_layers or opt.env_sph_mode:
+        if not opt.use_sdf or opt.use_neus_sdf or opt.geometric_init or opt.skip_layers:
             raise NotImplementedError("only the SDF + Laplace-density configuration family (toaster.ini / neural_renderer.ini) is implemented")
         self.num_layers, self.hidden_dim, self.geo_feat_dim = num_layers, hidden_dim, geo_feat_dim
         self._encoding_dir = encoding_dir
@@ -91,8 +91,20 @@ class NeRFNetwork(NeRFRenderer):
                                                 base_resolution=opt.base_resolution, num_levels=num_levels,
                                                 log2_hashmap_size=opt.log2_hashmap_size, multires=opt.multires)
         self.sdf_density = LaplaceDensity(opt.init_beta, opt.beta_min, opt.beta_max)
+        # material-conditioned SDF input (reference network.py:165-175): in the env-sphere mode the dataset's varying material parameters
+        # -- roughness, metallic, base colour -- are concatenated to the hash features
+        self.in_roughness = self.in_metallic = self.in_base_color = 0
+        if opt.env_sph_mode:
+            if env_opt is None:
+                raise ValueError("env_sph_mode needs env_opt (vary_roughness / vary_metallic / vary_base_color, env_images_names)")
+            self.in_roughness, self.in_metallic, self.in_base_color = \
+                int(env_opt.vary_roughness), int(env_opt.vary_metallic), 3 * int(env_opt.vary_base_color)
+        elif getattr(opt, "render_env_on_sphere", False):
+            self.in_roughness, self.in_metallic, self.in_base_color = 1, 1, 3
+        self.embed_dim = self.in_roughness + self.in_metallic + self.in_base_color
+        self.w_material = self.embed_dim > 0
         out_dim = 1 + geo_feat_dim + (int(opt.use_roughness) + int(opt.learn_indir_blend) if opt.ensemble_mlp else 0)
-        self.sdf_net = _mlp([self.in_dim] + [hidden_dim] * (num_layers - 1) + [out_dim], bias=opt.mlp_bias)
+        self.sdf_net = _mlp([self.in_dim + self.embed_dim] + [hidden_dim] * (num_layers - 1) + [out_dim], bias=opt.mlp_bias)
         if opt.use_roughness and not opt.ensemble_mlp:
             self.roughness_layer = nn.Linear(geo_feat_dim, 1)
 
@@ -109,12 +121,16 @@ class NeRFNetwork(NeRFRenderer):
             self.in_dim_dir = 0
 
         self.use_env_net = opt.use_env_net
-        self.env_net = self.renv_net = None
+        self.env_net = self.env_nets = self.renv_net = None
         if self.use_env_net:
             assert self.use_reflected_dir, "use_env_net requires use_reflected_dir"
             env_dims = [self.in_refdir_dim] + [opt.hidden_dim_env] * (opt.num_layers_env - 1) + [opt.env_feat_dim]
-            self.env_net = _mlp(env_dims, bias=not opt.env_wo_bias)
-            if opt.split_diffuse_env:
+            if opt.env_sph_mode:
+                # one environment MLP per environment of the dataset, selected by env_net_index (reference network.py:290-295, 530, 590)
+                self.env_nets = nn.ModuleList([_mlp(env_dims, bias=not opt.env_wo_bias) for _ in env_opt.env_images_names])
+            else:
+                self.env_net = _mlp(env_dims, bias=not opt.env_wo_bias)
+            if opt.split_diffuse_env and not opt.env_sph_mode:
                 self.diffuse_env_net = _mlp([self.in_refdir_dim_diffuse] + [opt.hidden_dim_env_diffuse] * (opt.num_layers_env - 1)
                                             + [opt.env_feat_dim], bias=not opt.env_wo_bias)
             self.in_refdir_dim = opt.env_feat_dim
@@ -127,7 +143,7 @@ class NeRFNetwork(NeRFRenderer):
         c_in = self.in_dim_dir + geo_feat_dim + self.in_normal_dim + self.in_refdir_dim + self.n_dot_viewdir_dim
         self.color_net = _mlp([c_in] + [hidden_dim_color] * (num_layers_color - 1) + [3], bias=opt.mlp_bias)
         gain = nn.init.calculate_gain("relu")
-        for net in [self.sdf_net, self.env_net, self.renv_net, getattr(self, "diffuse_net", None), self.color_net]:
+        for net in [self.sdf_net, self.env_net, *(self.env_nets or []), self.renv_net, getattr(self, "diffuse_net", None), self.color_net]:
             if net is not None and opt.net_init == "xavier_uniform":
                 for lin in net:
                     nn.init.xavier_uniform_(lin.weight, gain=gain)
@@ -171,6 +187,24 @@ class NeRFNetwork(NeRFRenderer):
         return m.to(device).eval()
 
     # ---- geometry ---------------------------------------------------------------------------------
+    def material_vector(self, material) -> list:
+        """the material parameters in the order the SDF network's extra inputs take them (reference network.py:369-379):
+        [roughness][metallic][r, g, b]"""
+        v = []
+        if self.in_roughness:
+            v.append(float(material["roughness"]))
+        if self.in_metallic:
+            v.append(float(material["metallic"]))
+        if self.in_base_color:
+            v.extend(float(c) for c in list(material["color"])[:3])
+        return v
+
+    def concate_material_params(self, x, material):
+        if material is None:
+            raise ValueError("this model's SDF network takes material parameters: pass material={'roughness', 'metallic', 'color'}")
+        m = torch.tensor(self.material_vector(material), dtype=x.dtype, device=x.device)
+        return torch.cat([x, m.expand(*x.shape[:-1], m.shape[0])], dim=-1)
+
     def forward_geometry(self, xyz, material=None):
         from ..hashencoder import HashEncoder
         # Only when the caller says that nothing but the input gradient (normals) will be taken -- run_cuda's inference loop,
@@ -183,6 +217,8 @@ class NeRFNetwork(NeRFRenderer):
             mask = torch.zeros(self.opt.num_levels, self.opt.level_dim, device=x.device)
             mask[: self.opt.enabled_levels] += 1
             x = x * mask.reshape(-1)
+        if self.w_material:
+            x = self.concate_material_params(x, material)
         h = _run_mlp(self.sdf_net, x)
         sdf = h[..., 0]
         g = self.geo_feat_dim
@@ -218,7 +254,8 @@ class NeRFNetwork(NeRFRenderer):
         if opt.use_diffuse:
             h = geo_feat
             if opt.diffuse_with_env:
-                e = self._env(self.diffuse_env_net if opt.split_diffuse_env else self.env_net, n_env_enc)
+                env_net = self.env_nets[env_net_index] if opt.env_sph_mode else (self.diffuse_env_net if opt.split_diffuse_env else self.env_net)
+                e = self._env(env_net, n_env_enc)
                 h = {"concat": lambda: torch.cat([h, e], -1), "add": lambda: h + e, "mul": lambda: h * e}[opt.diffuse_env_fusion]()
             self.c_diffuse = torch.sigmoid(_run_mlp(self.diffuse_net, h)) * self.metallic
         else:
@@ -232,7 +269,8 @@ class NeRFNetwork(NeRFRenderer):
             h = torch.cat([h, normal], -1)
         branches, renv_mask, blend = {}, None, 1
         if w_r is not None and not opt.train_renv:
-            branches["env"] = torch.cat([h, self._env(self.env_net, w_r) if self.use_env_net else w_r], -1)
+            env_net = self.env_nets[env_net_index] if (opt.env_sph_mode and self.use_env_net) else self.env_net
+            branches["env"] = torch.cat([h, self._env(env_net, w_r) if self.use_env_net else w_r], -1)
         if r_images is not None and opt.use_renv:
             renv_mask = roughness.squeeze() < opt.indir_roughness_thresh
             if r_images.shape[-1] == 4:
@@ -303,6 +341,69 @@ class NeRFNetwork(NeRFRenderer):
         renv_ok = r_images is None or (shade_ok and o.use_renv and self.renv_net is not None and o.learn_indir_blend
                                        and not o.indir_only and not o.train_renv and r_images.shape[-1] == 4)
         return bool(hash_ok and net_ok and (shade_ok or plain_ok) and renv_ok and not self.training)
+
+    # ---- env-sphere mode on the fused kernels --------------------------------------------------------
+    def supports_fused_sph(self) -> bool:
+        """run_sph as shell samples -> envidr_geometry_eval -> envidr_shade_samples -> envidr_composite_shell: the hash grid and the
+        network shapes the fused kernels are built for (configs/neural_renderer.ini is one of them)"""
+        o = self.opt
+        hash_ok = o.encoding_pos == "hashgrid_diff" and o.level_dim == 2 and o.num_levels == 16
+        net_ok = (o.num_layers == 3 and o.hidden_dim == 64 and o.geo_feat_dim == 12 and o.ensemble_mlp and o.use_roughness and o.mlp_bias
+                  and o.geo_feat_act == "unitNorm" and o.env_feat_act == "unitNorm" and o.enabled_levels <= 0 and not o.bypass_roughness
+                  and o.normal_anneal_ratio >= 1)
+        shade_ok = (o.use_diffuse and not o.diffuse_only and o.diffuse_with_env and o.diffuse_env_fusion == "concat"
+                    and not o.split_diffuse_env and o.use_env_net and self.env_nets is not None and not o.env_wo_bias and o.num_layers_env == 4
+                    and o.env_feat_dim == 12 and (o.sh_degree, o.hidden_dim_env) in [(5, 256), (4, 160), (5, 128), (4, 128)]
+                    and o.wo_viewdir and o.normal_with_mlp and o.multires_normal == 0 and o.use_n_dot_viewdir
+                    and o.use_reflected_dir and o.encoding_ref == "integrated_dir" and o.num_layers_diffuse == 2
+                    and o.hidden_dim_diffuse == 32 and o.num_layers_color == 3 and o.hidden_dim_color == 64 and o.color_act == "sigmoid")
+        return bool(hash_ok and net_ok and shade_ok)
+
+    def _sdf_layers_for_material(self, material):
+        """the SDF network as the geometry kernel takes it (2L -> 64 -> 64 -> 15): the material parameters are constants of a render
+        call, so their columns of the first layer fold into its bias -- W1 [x | m] + b1 = W1[:, :2L] x + (b1 + W1[:, 2L:] m) -- and the
+        input gradient (the normal) does not see them; the last layer is padded with zero rows up to the kernel's 15 outputs"""
+        W1, b1 = self.sdf_net[0].weight.detach().double(), self.sdf_net[0].bias.detach().double()
+        feat = self.in_dim
+        if self.w_material:
+            m = torch.tensor(self.material_vector(material), dtype=torch.float64, device=W1.device)
+            b1 = b1 + W1[:, feat:] @ m
+        W3, b3 = self.sdf_net[2].weight.detach(), self.sdf_net[2].bias.detach()
+        if W3.shape[0] < 15:
+            W3 = torch.cat([W3, W3.new_zeros(15 - W3.shape[0], W3.shape[1])])
+            b3 = torch.cat([b3, b3.new_zeros(15 - b3.shape[0])])
+        return [(W1[:, :feat].float().contiguous(), b1.float()), (self.sdf_net[1].weight.detach(), self.sdf_net[1].bias.detach()), (W3, b3)]
+
+    def fused_sph_renderer(self, env_net_index: int, material):
+        """the fused renderer of the env-sphere mode for one environment MLP, its SDF weights set for `material`"""
+        from ..fused import FusedRenderer
+        key = tuple(self.material_vector(material)) if self.w_material else ()
+        entry = self._fused_sph.get(env_net_index)
+        if entry is None:
+            pairs = lambda net: [(l.weight.detach(), l.bias.detach()) for l in net]
+            mlps = {"sdf": self._sdf_layers_for_material(material), "env": pairs(self.env_nets[env_net_index]),
+                    "diffuse": pairs(self.diffuse_net), "specular": pairs(self.color_net)}
+            dev = self.encoder.embeddings.device
+            # (no occupancy grid in this mode: hits are analytic; the renderer only wants a bitfield of the right size)
+            bitfield = torch.zeros(self.cascade * self.grid_size ** 3 // 8, dtype=torch.uint8, device=dev)
+            fr = FusedRenderer(bitfield, self.encoder.embeddings.detach(), self.encoder.offsets.cpu().numpy(), self.encoder.per_level_scale,
+                               mlps, float(self.sdf_density.beta.detach()), self._fused_options(), device=dev)
+            entry = self._fused_sph[env_net_index] = [fr, key]
+        elif entry[1] != key:
+            entry[0].update_sdf(self._sdf_layers_for_material(material))
+            entry[1] = key
+        return entry[0]
+
+    def _fused_options(self):
+        from ..fused import FusedOptions
+        o = self.opt
+        return FusedOptions(bound=self.bound, grid_size=self.grid_size, min_near=self.min_near, max_steps=o.max_steps,
+                            dt_gamma=o.dt_gamma, T_thresh=o.T_thresh, density_scale=self.density_scale,
+                            base_resolution=o.base_resolution, enabled_levels=o.enabled_levels, beta_min=o.beta_min,
+                            beta_max=o.beta_max, roughness_bias=self.roughness_bias, roughness_act_scale=o.roughness_act_scale,
+                            roughness_scale=o.roughness_scale, ide_degree=o.sh_degree, diffuse_kappa_inv=o.diffuse_kappa_inv,
+                            light_intensity_scale=o.light_intensity_scale, intensity_scale=o.intensity_scale,
+                            dir_sh_degree=0 if self.use_env_net else o.sh_degree, indir_roughness_thresh=o.indir_roughness_thresh)
 
     def _build_fused(self):
         from ..fused import FusedOptions, FusedRenderer

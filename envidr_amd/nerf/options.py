@@ -96,14 +96,42 @@ class RenderOptions:
     indir_early_stop_steps: int = 32
     indir_roughness_thresh: float = 0.1
     grad_rays: bool = False
-    # modes that select other render functions in the reference (not on this path)
+    # env-sphere mode (configs/neural_renderer.ini: the pre-training of the rendering MLPs on an environment-lit sphere; reference
+    # renderer.py:376-377 -> render_func.run_sph).  The reference's parser forces cuda_ray off with it (options.py:325-326).
     env_sph_mode: bool = False
     render_env_on_sphere: bool = False
+    env_sph_radius: float = 0.95
+    backsdf_loss: bool = False
+    # modes that select other render functions in the reference (not on this path)
     unwrap_env_sphere: bool = False
     error_bound_sample: bool = False
     debug: bool = False
     plot_roughness: bool = False
     net_init: str = "xavier_uniform"
+
+
+@dataclass
+class EnvOptions:
+    """what the network reads of the env-sphere dataset's options (reference nerf/sph_loader.py:18-47 `config_parser`, passed to
+    NeRFNetwork as `env_opt`): which material parameters are concatenated to the SDF network's input (network.py:165-175) and how many
+    environments -- one environment MLP each (network.py:290-295) -- the dataset has"""
+    vary_roughness: bool = True
+    vary_metallic: bool = True
+    vary_base_color: bool = True
+    env_images_names: list = field(default_factory=lambda: [f"env_{i}" for i in range(11)])   # configs/ktx_images_list.txt: 11 names
+
+
+def neural_renderer_options(**overrides) -> RenderOptions:
+    """configs/neural_renderer.ini resolved against nerf/options.py defaults: the env-sphere mode the shipped rendering MLPs and
+    environment MLPs were trained in (IDE degree 4, environment MLPs 38-160-160-160-12, SDF network 37-64-64-14: 32 hash features + 5
+    material parameters in, sdf + 12 features + roughness out, no indirect blend)"""
+    opt = RenderOptions(scale=0.8, cuda_ray=False, env_sph_mode=True, roughness_act_scale=1.0, sh_degree=4, sh_degree_diffuse=4,
+                        hidden_dim_env=160, learn_indir_blend=False, use_renv=False, visual_items=["diffuse", "specular"])
+    for k, v in overrides.items():
+        if not hasattr(opt, k):
+            raise AttributeError(f"unknown render option {k!r}")
+        setattr(opt, k, v)
+    return opt
 
 
 def toaster_options(**overrides) -> RenderOptions:

@@ -1,2 +1,2 @@
 from .cuda_ray import fused_eligible, run_cuda  # noqa: F401
-from .sph_ray import get_sphere_intersections, render_surface  # noqa: F401
+from .sph_ray import get_sphere_intersections, render_surface, run_sph  # noqa: F401

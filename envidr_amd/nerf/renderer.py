@@ -34,10 +34,10 @@ class NeRFRenderer(nn.Module):
         super().__init__()
         self.opt, self.env_opt = opt, env_opt
         # options that select code of the reference this package does not carry are refused here, never ignored:
-        # error_bound_sample -> the VolSDF sampler (reference renderer.py:373-375); env_sph_mode / render_env_on_sphere ->
-        # run_sph's volume renderer (:376-377); unwrap_env_sphere -> main_nerf.py's environment-map export; plot_roughness ->
-        # matplotlib debugging inside forward_geometry (network.py:336,402,452)
-        for name in ("error_bound_sample", "env_sph_mode", "render_env_on_sphere", "unwrap_env_sphere", "plot_roughness"):
+        # error_bound_sample -> the VolSDF sampler (reference renderer.py:373-375); unwrap_env_sphere -> main_nerf.py's environment-map
+        # export; plot_roughness -> matplotlib debugging inside forward_geometry (network.py:336,402,452).  (env_sph_mode /
+        # render_env_on_sphere select run_sph, renderer.py:376-377: render_func/sph_ray.py here, since round 5.)
+        for name in ("error_bound_sample", "unwrap_env_sphere", "plot_roughness"):
             if getattr(opt, name, False):
                 raise NotImplementedError(f"opt.{name} selects a part of the reference outside the render hot path (DESIGN.md section 7)")
         self.bound = bound
@@ -79,6 +79,7 @@ class NeRFRenderer(nn.Module):
             self.local_step = 0
         self._fused = None
         self._fused_key = None
+        self._fused_sph = {}          # env-sphere mode: one fused renderer per environment MLP (env_net_index)
 
     # ---- per-sample helpers (reference renderer.py:147-198) -------------------------------------
     def get_color_mlp_extra_params(self, normals, dirs, roughness=0, env_rot_radian=None):
@@ -242,6 +243,7 @@ class NeRFRenderer(nn.Module):
 
     def invalidate_fused(self):
         self._fused = None
+        self._fused_sph = {}
 
     def _build_fused(self):
         raise NotImplementedError
@@ -255,8 +257,11 @@ class NeRFRenderer(nn.Module):
         cuda_ray.py:30-33).  Returns the reference's result dict: image [B,N,3],
         depth [B,N], weights_sum [B,N] and, per configuration, normal_image / diffuse_image /
         specular_image / roughness_image."""
+        if self.opt.env_sph_mode or getattr(self.opt, "render_env_on_sphere", False):
+            return self._render_sph(rays_o, rays_d, staged, max_ray_batch, get_normal_image, use_specular_color, env_net_index, material,
+                                    r_images, env_rot_radian, fused, **kwargs)
         if not self.cuda_ray:
-            raise NotImplementedError("only the cuda_ray render path is implemented (reference non-cuda paths are out of scope)")
+            raise NotImplementedError("only the cuda_ray and env-sphere render paths are implemented (reference run / run_volsdf are out of scope)")
         kwargs["material"] = material
         if self.opt.indir_ref:
             return self._render_indirect(rays_o, rays_d, get_normal_image, use_specular_color, env_net_index, env_rot_radian,
@@ -265,6 +270,36 @@ class NeRFRenderer(nn.Module):
                             env_net_index=env_net_index, r_images=r_images, env_rot_radian=env_rot_radian, fused=fused, **kwargs)
         if "weights_sum" in results and get_normal_image and results.get("normal_image") is not None:
             ws = results["weights_sum"][..., None]
+            results["normal_image"] = results["normal_image"] * ws + (1 - ws)
+        return results
+
+    def _render_sph(self, rays_o, rays_d, staged, max_ray_batch, get_normal_image, use_specular_color, env_net_index, material, r_images,
+                    env_rot_radian, fused, **kwargs):
+        """env-sphere mode: `_run = render_func.run_sph` (reference renderer.py:376-377) under render()'s two chunking forms
+        (:381-423 staged chunks of max_ray_batch rays; :425-436 max_ray_batch_cuda) and its normal-image blend (:539-540)."""
+        kwargs["material"] = material
+        B, N = rays_o.shape[:2]
+        if B != 1:
+            raise ValueError("env-sphere mode renders one view per call (the reference's run_sph assumes B == 1)")
+        batch = max_ray_batch if staged else (self.opt.max_ray_batch_cuda if (self.opt.max_ray_batch_cuda or 0) > 0 else N)
+        call = lambda o, d, r: render_func.run_sph(self, o, d, get_normal_image=get_normal_image, use_specular_color=use_specular_color,
+                                                   env_net_index=env_net_index, r_images=r, env_rot_radian=env_rot_radian, fused=fused, **kwargs)
+        if N <= batch:
+            results = call(rays_o, rays_d, r_images)
+        else:
+            # every chunk is a run_sph call of its own, as in the reference: the depth of a chunk is normalised with the largest
+            # `far` of THAT chunk (sph_ray.py:112)
+            parts = [call(rays_o[:, i:i + batch], rays_d[:, i:i + batch], None if r_images is None else r_images[:, i:i + batch])
+                     for i in range(0, N, batch)]
+            results = {}
+            for k in ("image", "depth", "weights_sum", "normal_image", "diffuse_image", "specular_image", "roughness_image"):
+                vals = [p.get(k) for p in parts]
+                if any(v is not None for v in vals):
+                    results[k] = torch.cat(vals, 0 if k == "weights_sum" else 1)
+        if "weights_sum" in results and get_normal_image and results.get("normal_image") is not None:
+            # the reference multiplies [B,N,3] by weights_sum[..., None] with weights_sum [N,1] here, which broadcasts to [N,N,3] (an
+            # accident of run_sph returning an un-reshaped weights_sum); the per-ray blend it means -- its diagonal -- is what is returned
+            ws = results["weights_sum"].reshape(*results["normal_image"].shape[:-1], 1)
             results["normal_image"] = results["normal_image"] * ws + (1 - ws)
         return results
 

@@ -217,3 +217,18 @@ def lego_scene(table_scale: float = 0.1, shape=None, sdf_bias: float = 0.005, be
     return SceneParams(bitfield=occupancy_bitfield(shape or shell()), offsets=offsets, per_level_scale=pls, table=table,
                        mlps=mlps, beta=beta)
 
+
+
+def sphere_table(xyz_encoding: np.ndarray, noise: float = 0.02, seed: int = 11) -> np.ndarray:
+    """hash table of the env-sphere test scene: every level's rows hold that level's two features of the reference's `demo/
+    xyz_encoding.txt` (the constant position feature its notebook distils the trained sphere's table into) plus seeded
+    U(-noise, noise), level by level (numpy PCG64: platform independent) -- so that the SDF network shipped in demo/ sees the
+    inputs it was trained on, perturbed enough for normals, densities and features to vary from sample to sample"""
+    offsets, _ = hash_level_offsets()
+    rng = np.random.default_rng(seed)
+    table = np.empty((int(offsets[-1]), 2), np.float32)
+    enc = np.asarray(xyz_encoding, np.float32).reshape(-1)
+    for l in range(offsets.shape[0] - 1):
+        n = int(offsets[l + 1] - offsets[l])
+        table[offsets[l]:offsets[l + 1]] = enc[2 * l:2 * l + 2][None, :] + rng.uniform(-noise, noise, size=(n, 2)).astype(np.float32)
+    return table

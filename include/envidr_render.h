@@ -355,6 +355,33 @@ int envidr_composite_shaded(const uint32_t* offsets, const float* w, const float
                             const float* weights_sum, uint32_t N, float intensity_scale, float bg_color, float* image,
                             float* diffuse_image, float* specular_image, envidr_stream_t stream);
 
+/* ---- ABI 8: env-sphere mode (nerf/render_func/sph_ray.py:34-221, `run_sph`; selected by opt.env_sph_mode, renderer.py:376) ----------
+ * The object is a sphere of known radius: a ray's hit is analytic (get_sphere_intersections, sph_ray.py:18-32, stays on the host side
+ * in torch), every hit ray gets S samples spaced step_size around its hit, and the samples are composited with the torch formulation of
+ * volume rendering (alphas + cumulative product), not the marcher's compositing kernel.  The SDF network / shading of the samples are
+ * envidr_geometry_eval and envidr_shade_samples.  Per-sample arrays are SAMPLE-major: [S, M, ...].
+ *
+ * envidr_shell_samples (sph_ray.py:69-79): z = z_offsets[s] + near (+ (noise - 0.5) step_size), xyz = o + d z.
+ *   hit_rays [M] int32: ids of the rays that hit, ascending;  nears [N];  z_offsets [S] = linspace(-r, r, S), r = step_size (S-1) / 2;
+ *   noise [M, S] in [0, 1) or NULL (perturb);  out: xyz [S,M,3], dirs [S,M,3] (the ray direction, repeated), z_vals [S,M]. */
+int envidr_shell_samples(const float* rays_o, const float* rays_d, const int32_t* hit_rays, const float* nears, const float* z_offsets,
+                         const float* noise, float step_size, uint32_t M, uint32_t S, float* xyz, float* dirs, float* z_vals,
+                         envidr_stream_t stream);
+
+/* envidr_composite_shell (sph_ray.py:102-151): deltas = z[s+1] - z[s] (last: step_size), alpha = 1 - exp(-delta sigma),
+ * w = alpha prod_{s' < s} (1 - alpha_s' + 1e-15); per ray n with hit_slot[n] = m >= 0:
+ *   weights_sum = sum w;  depth = sum w clamp((z - near) / (*far_max - near), 0, 1);
+ *   image = sum w (c_diffuse + c_specular) intensity_scale + (1 - weights_sum) bg[n];  diffuse / specular images likewise with their colour;
+ *   normal_image = normalize(sum w normal) (eps 1e-12);  roughness_image = sum w roughness;
+ * rays with hit_slot[n] < 0 get bg (image, diffuse, specular) and zeros (depth, weights_sum, normal, roughness).
+ *   sigma, z_vals, roughness [S,M]; c_diffuse, c_specular, normals [S,M,3]; hit_slot, nears [N]; far_max: device scalar (fars.max() over
+ *   ALL rays, sph_ray.py:112); bg [N,3].  normals / roughness and the four optional images may be NULL. */
+int envidr_composite_shell(const float* sigma, const float* z_vals, const float* c_diffuse, const float* c_specular, const float* normals,
+                           const float* roughness, const int32_t* hit_slot, const float* nears, const float* far_max, const float* bg,
+                           uint32_t N, uint32_t M, uint32_t S, float step_size, float intensity_scale, float* image, float* depth,
+                           float* weights_sum, float* normal_image, float* diffuse_image, float* specular_image, float* roughness_image,
+                           envidr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -166,8 +166,10 @@ def sh_encode(dirs: torch.Tensor, degree: int) -> torch.Tensor:
 
 
 def shade_samples(scene, xyzs: np.ndarray, dirs: np.ndarray, opt: RenderOptions, env_rot_radian: float | None = None,
-                  geometry_only: bool = False) -> dict:
-    """all per-sample quantities the render loop composites; numpy in, dict of numpy out."""
+                  geometry_only: bool = False, material=None) -> dict:
+    """all per-sample quantities the render loop composites; numpy in, dict of numpy out.
+    material: the env-sphere mode's material parameters [roughness, metallic, r, g, b] (any prefix the model was built with),
+    concatenated to the hash features in front of the SDF network (network.py:369-379, 412-413)."""
     ide = ide_torch if opt.ide_mode == "torch" else ide_exact
     xyz = torch.from_numpy(np.ascontiguousarray(xyzs, F32)).requires_grad_(True)
     d = torch.from_numpy(np.ascontiguousarray(dirs, F32))
@@ -177,6 +179,9 @@ def shade_samples(scene, xyzs: np.ndarray, dirs: np.ndarray, opt: RenderOptions,
         mask = torch.zeros(opt.num_levels, opt.level_dim)
         mask[:opt.enabled_levels] += 1
         feat = feat * mask.reshape(-1)
+    if material is not None:
+        m = torch.tensor([float(v) for v in material], dtype=torch.float32)
+        feat = torch.cat([feat, m + torch.zeros_like(feat[..., :1])], dim=-1)
     h = _mlp(scene.mlps["sdf"], feat)
     sdf = h[..., 0]
     geo_feat = Fn.normalize(h[..., 1:13], dim=-1)
@@ -247,6 +252,51 @@ def shade_surface(mlps: dict, normals: np.ndarray, dirs: np.ndarray, geo_feat: n
         c_diffuse = torch.sigmoid(_mlp(mlps["diffuse"], torch.cat([gf, e_n], -1)))
         c_specular = torch.sigmoid(_mlp(mlps["specular"], torch.cat([gf, n, e_r, n_dot], -1)))
     return {"c_diffuse": c_diffuse.numpy(), "c_specular": c_specular.numpy()}
+
+
+# ------------------------------------------------------------------------------------------------
+# env-sphere mode (nerf/render_func/sph_ray.py:18-151)
+# ------------------------------------------------------------------------------------------------
+def render_sph(scene, rays_o: np.ndarray, rays_d: np.ndarray, opt: RenderOptions, material, radius: float, num_step: int = 12,
+               step_size: float = 0.002, get_normal_image: bool = False) -> dict:
+    """run_sph: analytic ray / sphere hits (sph_ray.py:18-32), num_step samples around each (:69-79), the material-conditioned SDF
+    network + shading (shade_samples), the torch formulation of volume rendering (:102-109), depth / images / un-masking (:111-151).
+    scene.mlps: sdf (2L + len(material) -> 64 -> 64 -> 14), env, diffuse, specular.  Returns [N, ...] arrays."""
+    o, d = torch.from_numpy(np.ascontiguousarray(rays_o, F32)), torch.from_numpy(np.ascontiguousarray(rays_d, F32))
+    N = o.shape[0]
+    bg = torch.zeros(N, 3) + opt.bg_color
+    ray_cam_dot = torch.bmm(d.view(-1, 1, 3), o.view(-1, 3, 1)).squeeze(-1)
+    nabla = ray_cam_dot ** 2 - (o.norm(2, 1, keepdim=True) ** 2 - radius ** 2)
+    root = torch.sqrt(nabla.clamp_min(0.0))
+    nears, fars, mask = -ray_cam_dot - root, -ray_cam_dot + root, (nabla >= -1e-4)[..., 0]
+    out = {"mask": mask.numpy(), "image": bg.numpy().copy(), "diffuse_image": bg.numpy().copy(), "specular_image": bg.numpy().copy(),
+           "depth": np.zeros(N, F32), "weights_sum": np.zeros(N, F32), "normal_image": np.zeros((N, 3), F32), "roughness_image": np.zeros(N, F32)}
+    if not mask.any():
+        return out
+    near = nears[mask]
+    zr = step_size * (num_step - 1) / 2
+    z = torch.linspace(-zr, zr, num_step)[None, :] + near                                  # [M,S]
+    dirs = d[mask, None, :]
+    xyz = o[mask, None, :] + dirs * z[:, :, None]                                          # [M,S,3]
+    M = xyz.shape[0]
+    s = shade_samples(scene, xyz.reshape(-1, 3).numpy(), dirs.expand(M, num_step, 3).reshape(-1, 3).numpy(), opt, None, material=material)
+    T = lambda k, *shape: torch.from_numpy(s[k]).reshape(M, num_step, *shape)
+    sigma = T("sigma")
+    deltas = torch.cat([z[..., 1:] - z[..., :-1], step_size * torch.ones(M, 1)], dim=-1)
+    alphas = 1 - torch.exp(-deltas * sigma)
+    weights = alphas * torch.cumprod(torch.cat([torch.ones(M, 1), 1 - alphas + 1e-15], dim=-1), dim=-1)[..., :-1]
+    ws = weights.sum(dim=-1, keepdim=True)
+    depth = torch.sum(weights * ((z - near) / (fars.max() - near)).clamp(0, 1), dim=-1)
+    comp = lambda v: torch.sum(weights[..., None] * v, dim=-2)
+    put3 = lambda v: bg.masked_scatter(mask[..., None], v + (1 - ws) * bg[mask]).numpy()
+    out["image"], out["diffuse_image"], out["specular_image"] = put3(comp(T("rgb", 3))), put3(comp(T("c_diffuse", 3))), put3(comp(T("c_specular", 3)))
+    out["depth"] = torch.zeros(N).masked_scatter_(mask, depth).numpy()
+    out["weights_sum"] = torch.zeros(N).masked_scatter_(mask, ws[:, 0]).numpy()
+    out["roughness_image"] = torch.zeros(N).masked_scatter_(mask, comp(T("roughness", 1))[:, 0]).numpy()
+    if get_normal_image:
+        out["normal_image"] = torch.zeros(N, 3).masked_scatter_(mask[..., None], Fn.normalize(comp(T("normal", 3)), dim=-1)).numpy()
+    out["sigmas"], out["sdfs"] = sigma.numpy(), T("sdf").numpy()
+    return out
 
 
 # ------------------------------------------------------------------------------------------------

@@ -1,0 +1,162 @@
+"""Env-sphere mode (reference nerf/render_func/sph_ray.py run_sph; configs/neural_renderer.ini: how the shipped rendering MLPs were
+trained) on the GPU: `NeRFNetwork.render()` in its two forms -- the four-launch fused form (envidr_shell_samples -> envidr_geometry_eval
+-> envidr_shade_samples -> envidr_composite_shell) and the reference-shaped operator chain -- against frames rendered by the imported
+reference itself (tests/golden/sph_render.npz), and the two new operators against the oracle on other inputs."""
+import numpy as np
+import pytest
+
+from tests import sph_case
+from tests.util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fixture():
+    return sph_case.load()
+
+
+@pytest.fixture(scope="module")
+def model_opt(fixture):
+    return sph_case.build_model(fixture)
+
+
+def _render(model, opt, g, tag, fused, normal=False, staged=False, material=None, **kw):
+    import torch
+    res, ro, rd = sph_case.rays(g, tag)
+    out = model.render(torch.from_numpy(ro).cuda()[None], torch.from_numpy(rd).cuda()[None], staged=staged, bg_color=1, perturb=False,
+                       get_normal_image=normal, env_net_index=int(g["env_net_index"]), material=material or sph_case.material_of(g),
+                       fused=fused, **kw)
+    torch.cuda.synchronize()
+    return res, out
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("tag,normal", [("40", True), ("200", False)])
+def test_env_sphere_render_matches_reference(fixture, model_opt, fused, tag, normal):
+    """1e-4 relative L2 on every image of the reference's run_sph render (measured ~1e-6)"""
+    model, opt = model_opt
+    g = fixture
+    res, out = _render(model, opt, g, tag, fused, normal)
+    N = res * res
+    assert tuple(out["image"].shape) == (1, N, 3) and tuple(out["depth"].shape) == (1, N) and tuple(out["weights_sum"].shape) == (N, 1)
+    ws = out["weights_sum"].cpu().numpy().reshape(N)
+    assert np.array_equal(ws > 0, g[f"{tag}|weights_sum"] > 0)                      # the same rays hit the sphere
+    for k in ("image", "depth", "weights_sum", "diffuse_image", "specular_image"):
+        err = rel_l2(out[k].detach().cpu().numpy().reshape(N, -1), g[f"{tag}|{k}"].reshape(N, -1))
+        assert err <= 1e-4, f"{k} (fused={fused}): rel-L2 {err:.3e}"
+    hit = ws > 0
+    assert rel_l2(out["sigmas"].detach().cpu().numpy(), g[f"{tag}|sigmas"]) <= 1e-4
+    if normal:
+        # ours is [1,N,3]: the per-ray blend n ws + (1 - ws), i.e. the diagonal of what the reference's broadcast produces
+        assert tuple(out["normal_image"].shape) == (1, N, 3)
+        assert rel_l2(out["normal_image"].cpu().numpy().reshape(N, 3), g[f"{tag}|normal_image"]) <= 1e-4
+    else:
+        assert out["normal_image"] is None
+    assert hit.sum() > 500
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_staged_env_sphere_render_matches_reference(fixture, model_opt, fused):
+    """`staged=True`: chunks of max_ray_batch = 4096 rays, each a run_sph call that normalises its depth with ITS largest far"""
+    model, opt = model_opt
+    res, out = _render(model, opt, fixture, "64s", fused, staged=True)
+    N = res * res
+    for k in ("image", "depth", "diffuse_image", "specular_image"):
+        err = rel_l2(out[k].detach().cpu().numpy().reshape(N, -1), fixture[f"64s|{k}"].reshape(N, -1))
+        assert err <= 1e-4, f"{k} (fused={fused}, staged): rel-L2 {err:.3e}"
+
+
+def test_fused_and_operator_forms_agree_for_other_materials_and_views(fixture, model_opt):
+    """the material parameters reach the fused form only through the folded first-layer bias (update_sdf per material): another
+    material, another environment slot's (seeded) MLP and another camera must give the operator chain's frame"""
+    import torch
+    from envidr_amd import scenes
+    model, opt = model_opt
+    g = fixture
+    first = None
+    for mat, theta in (({"roughness": 0.05, "metallic": 0.9, "color": [0.8, 0.3, 0.1, 1.0]}, 20.0),
+                       ({"roughness": 0.7, "metallic": 0.0, "color": [0.1, 0.9, 0.4, 1.0]}, 250.0),
+                       (sph_case.material_of(g), 123.0)):
+        ro, rd = scenes.camera_rays(56, 72, theta=theta, phi=-15.0, radius=4.0, scale=float(g["scale"]))
+        args = dict(staged=False, bg_color=torch.tensor([0.2, 0.4, 0.6], device="cuda"), perturb=False, get_normal_image=True,
+                    env_net_index=int(g["env_net_index"]), material=mat)
+        a = model.render(torch.from_numpy(ro).cuda()[None], torch.from_numpy(rd).cuda()[None], fused=True, **args)
+        b = model.render(torch.from_numpy(ro).cuda()[None], torch.from_numpy(rd).cuda()[None], fused=False, **args)
+        for k in ("image", "depth", "weights_sum", "diffuse_image", "specular_image", "normal_image"):
+            err = rel_l2(a[k].cpu().numpy().reshape(56 * 72, -1), b[k].detach().cpu().numpy().reshape(56 * 72, -1))
+            assert err <= 2e-5, (k, theta, err)
+        first = a["image"] if first is None else first
+    assert not torch.equal(first, a["image"])                                  # the material (and the view) did change the frame
+
+
+def test_rays_that_miss_the_sphere(fixture, model_opt):
+    """no hit at all: the reference's `empty` result (sph_ray.py:58-68) -- background everywhere, zero depth"""
+    import torch
+    model, opt = model_opt
+    o = torch.tensor([[0.0, 0.0, 3.0]], device="cuda").repeat(100, 1)[None]
+    d = torch.tensor([[0.0, 1.0, 0.0]], device="cuda").repeat(100, 1)[None]
+    for fused in (True, False):
+        out = model.render(o, d, bg_color=0.25, get_normal_image=True, env_net_index=int(fixture["env_net_index"]),
+                           material=sph_case.material_of(fixture), fused=fused)
+        assert out.get("empty") is True and torch.all(out["image"] == 0.25) and torch.all(out["depth"] == 0)
+
+
+def test_shell_operators_against_the_oracle(fixture):
+    """envidr_shell_samples / envidr_composite_shell on ragged sizes (1, 63, 64, 65, 1000 hit rays; S = 1, 5, 12), with perturbation noise,
+    per-ray backgrounds and misses: against a numpy restatement of sph_ray.py:69-79,102-151"""
+    import torch
+    from envidr_amd.fused import FusedRenderer
+    sc = sph_case.scene_from(fixture)
+    sc.mlps["sdf"] = [(sc.mlps["sdf"][0][0][:, :32].copy(), sc.mlps["sdf"][0][1]), sc.mlps["sdf"][1],
+                      (np.concatenate([sc.mlps["sdf"][2][0], np.zeros((1, 64), np.float32)]), np.concatenate([sc.mlps["sdf"][2][1], np.zeros(1, np.float32)]))]
+    from envidr_amd.fused import FusedOptions
+    fr = FusedRenderer.from_scene(sc, FusedOptions(ide_degree=4), device="cuda")
+    rng = np.random.default_rng(5)
+    for M, S in ((1, 12), (63, 5), (64, 12), (65, 1), (1000, 12)):
+        N = M + 37
+        hit = np.sort(rng.permutation(N)[:M]).astype(np.int32)
+        ro = rng.normal(size=(N, 3)).astype(np.float32)
+        rd = rng.normal(size=(N, 3)).astype(np.float32)
+        rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+        nears = rng.uniform(0.5, 3.0, N).astype(np.float32)
+        step = 0.002
+        zoff = torch.linspace(-step * (S - 1) / 2, step * (S - 1) / 2, S).numpy()
+        noise = rng.uniform(0, 1, (M, S)).astype(np.float32)
+        T = lambda a: torch.from_numpy(a).cuda()
+        xyz, dirs, z = fr.shell_samples(T(ro), T(rd), T(hit), T(nears), T(zoff), step, T(noise))
+        zw = (zoff[None, :] + nears[hit][:, None]).astype(np.float32)
+        zw = (zw + ((noise - np.float32(0.5)) * np.float32(step)).astype(np.float32)).astype(np.float32)                  # [M,S]
+        xw = (ro[hit][:, None, :] + (rd[hit][:, None, :] * zw[:, :, None]).astype(np.float32)).astype(np.float32)          # [M,S,3]
+        assert np.array_equal(z.cpu().numpy(), zw.T) and np.array_equal(xyz.cpu().numpy(), xw.transpose(1, 0, 2))
+        assert np.array_equal(dirs.cpu().numpy(), np.broadcast_to(rd[hit][None], (S, M, 3)))
+        sigma = (rng.uniform(0, 1, (S, M)).astype(np.float32) ** 3 * 800).astype(np.float32)
+        cd, cs = rng.uniform(0, 1, (S, M, 3)).astype(np.float32), rng.uniform(0, 1, (S, M, 3)).astype(np.float32)
+        nr = rng.normal(size=(S, M, 3)).astype(np.float32)
+        rg = rng.uniform(0, 1, (S, M)).astype(np.float32)
+        bg = rng.uniform(0, 1, (N, 3)).astype(np.float32)
+        slot = np.full(N, -1, np.int32)
+        slot[hit] = np.arange(M, dtype=np.int32)
+        far_max = np.float32(nears.max() + 1.5)
+        out = fr.composite_shell(T(sigma), z, T(cd), T(cs), T(nr), T(rg), T(slot), T(nears), T(np.array([far_max])), T(bg), step)
+        # float64 restatement
+        zz = zw.astype(np.float64)
+        delta = np.concatenate([zz[:, 1:] - zz[:, :-1], np.full((M, 1), step)], axis=1)
+        alpha = 1 - np.exp(-delta * sigma.T)
+        Tr = np.cumprod(np.concatenate([np.ones((M, 1)), 1 - alpha + 1e-15], axis=1), axis=1)[:, :-1]
+        w = alpha * Tr
+        ws = w.sum(1)
+        want = {"weights_sum": np.zeros(N), "depth": np.zeros(N), "image": bg.astype(np.float64).copy(), "diffuse_image": bg.astype(np.float64).copy(),
+                "specular_image": bg.astype(np.float64).copy(), "normal_image": np.zeros((N, 3)), "roughness_image": np.zeros(N)}
+        want["weights_sum"][hit] = ws
+        want["depth"][hit] = (w * np.clip((zz - nears[hit][:, None]) / (far_max - nears[hit][:, None]), 0, 1)).sum(1)
+        comp = lambda v: (w[:, :, None] * v.transpose(1, 0, 2)).sum(1)
+        want["image"][hit] = comp(cd.astype(np.float64) + cs) + (1 - ws)[:, None] * bg[hit]
+        want["diffuse_image"][hit] = comp(cd) + (1 - ws)[:, None] * bg[hit]
+        want["specular_image"][hit] = comp(cs) + (1 - ws)[:, None] * bg[hit]
+        nn = comp(nr)
+        want["normal_image"][hit] = nn / np.maximum(np.linalg.norm(nn, axis=1, keepdims=True), 1e-12)
+        want["roughness_image"][hit] = (w * rg.T).sum(1)
+        for k, v in want.items():
+            got = out[k].cpu().numpy().astype(np.float64)
+            assert np.abs(got - v).max() <= 3e-6 * max(1.0, np.abs(v).max()), (M, S, k, float(np.abs(got - v).max()))
