@@ -711,8 +711,41 @@ def other_configs(result, dev, rays_o, rays_d, N) -> None:
         "rays_per_s": N / tl[True][0], "ms_per_frame": tl[True][0] * 1e3, "samples_per_ray": tl[True][1] / N, "records": tl[True][1],
         "records_shaded": tl[True][2], "ms_per_frame_shading_every_record": tl[False][0] * 1e3,
         "frames_identical": bool(torch.equal(tl[True][3], tl[False][3]))}
-    # BASELINE configs[3]: use_renv + indir_ref, three passes per frame through the NeRFRenderer.render() drop-in surface
+    # BASELINE configs[0]'s lineage as the reference itself renders it: the env-sphere mode (configs/neural_renderer.ini -> run_sph:
+    # 12 samples around every analytic ray / sphere hit, SDF network 37-64-64-14 with the material parameters concatenated, IDE degree 4,
+    # environment MLP 38-160-160-160-12 x2, heads, torch-formula compositing) through NeRFNetwork.render(): the four-launch fused form
+    # and the reference-shaped operator chain.  Seeded xavier weights of the shipped shapes (every hit ray has exactly 12 samples: the
+    # time does not depend on the weights); parity is tests/test_sph_gpu.py against the imported reference's render.
     from envidr_amd.nerf.network import NeRFNetwork
+    from envidr_amd.nerf.options import EnvOptions, neural_renderer_options
+    sopt = neural_renderer_options(env_sph_radius=0.95 * 0.8)
+    torch.manual_seed(0)
+    smodel = NeRFNetwork(encoding="hashgrid", encoding_dir=sopt.encoding_dir, bound=sopt.bound, cuda_ray=False, density_scale=1, min_near=sopt.min_near,
+                         density_thresh=sopt.density_thresh, bg_radius=sopt.bg_radius, use_sdf=True, hidden_dim=sopt.hidden_dim, num_layers=sopt.num_layers,
+                         num_layers_color=sopt.num_layers_color, hidden_dim_color=sopt.hidden_dim_color, num_levels=sopt.num_levels,
+                         geo_feat_dim=sopt.geo_feat_dim, opt=sopt, env_opt=EnvOptions()).to(dev).eval()
+    with torch.no_grad():
+        smodel.encoder.embeddings.uniform_(-0.1, 0.1)
+        smodel.sdf_density.beta.fill_(0.005)
+    smat = {"roughness": 0.3, "metallic": 0.2, "color": [20 / 255, 70 / 255, 160 / 255, 1.0]}
+    sph = {}
+    for res in (400, 800):
+        so, sd = (torch.from_numpy(a).to(dev)[None] for a in scenes.camera_rays(res, res, theta=123.0, phi=10.0, radius=4.0, scale=0.8))
+        skw = dict(bg_color=1, perturb=False, get_normal_image=False, env_net_index=3, material=smat)
+        with torch.no_grad():
+            first = smodel.render(so, sd, fused=True, **skw)
+            hits = int((first["weights_sum"] > 0).sum().item())
+            fdt = _time(lambda: smodel.render(so, sd, fused=True, **skw), 5, dev)
+            odt2 = _time(lambda: smodel.render(so, sd, fused=False, **skw), 2, dev)
+            other = smodel.render(so, sd, fused=False, **skw)
+        sph[f"{res}x{res}"] = {"ms_per_frame": fdt * 1e3, "rays_per_s": res * res / fdt, "hit_rays": hits, "samples": hits * 12,
+                               "samples_per_s": hits * 12 / fdt, "operator_chain_ms_per_frame": odt2 * 1e3,
+                               "rel_l2_fused_vs_operator_chain": float(torch.linalg.norm(first["image"] - other["image"]) / torch.linalg.norm(other["image"]))}
+    oc["configs[0] lineage: env-sphere mode (neural_renderer.ini, run_sph: 12 samples per hit ray, material-conditioned SDF), 1 GPU"] = dict(
+        sph, note="BASELINE.md section 2 timed the reference's 1-sample notebook form of this scene on 8 CPU cores: 0.268 s at 400x400, 1.397 s at 800x800; "
+                  "run_sph evaluates 12 samples per hit ray and the hash grid + SDF network as well")
+    del smodel
+    # BASELINE configs[3]: use_renv + indir_ref, three passes per frame through the NeRFRenderer.render() drop-in surface
     from envidr_amd.nerf.options import toaster_options
     iopt = toaster_options(indir_ref=True)
     imodel = NeRFNetwork.from_scene(scenes.toaster_scene(shape=scenes.torus(), seed=3), iopt, device=dev)

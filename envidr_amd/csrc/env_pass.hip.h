@@ -81,6 +81,8 @@ __device__ __forceinline__ void env_step_lanes(Src& wp, const float (&in)[STEPS]
     if constexpr (S >= 2 && S - 2 < MT) other[S - 2 < MT ? S - 2 : 0] = lds_bias_tile(bias, other_tile0 + S - 2);
     __builtin_amdgcn_sched_barrier(0);
 }
+// (ds_max_f32 follows IEEE maxNum: max(NaN, 0) = 0.  A NaN pre-activation therefore becomes 0 here where torch.relu would propagate it;
+//  finite inputs -- everything the parity tests and the reference's own frames contain -- are unaffected.)
 // Piece J (0 .. 31) of the LDS round trip that stages tile KN's 16 operands: 16 ds_max_f32 (accumulator -> zero slot),
 // then 8 x (read two operands), then 8 x (zero two words).  LDS executes a wave's instructions in order, so the pieces only
 // have to be ISSUED in this order; one piece rides behind each MFMA (clumps of 16 overran the 64-cycle shadow of one MFMA).

@@ -1347,6 +1347,11 @@ int envidr_render_rays(const envidr_render_desc* d, const float* rays_o, const f
     return check_launch("k_render_persistent");
 }
 
+// The counter is zeroed by a memset enqueued in front of the kernel that counts on it.  Two host threads enqueueing on the SAME stream
+// must not interleave those pairs (memset, memset, kernel, kernel: the second kernel would start past M and shade nothing): the pair
+// is enqueued under this lock.  (Enqueue only -- microseconds; different streams have different counters and only share the lock.)
+static std::mutex g_work_counter_enqueue;
+
 // one zero-initialised work counter per (device, stream): launches on different streams never share it
 static uint32_t* shade_work_counter(hipStream_t s) {
     static std::mutex mu;
@@ -1375,6 +1380,7 @@ static int launch_shade(const envidr_render_desc* d, ShadeArgs& a, envidr_stream
     const uint32_t blocks = std::min((uint32_t)device_cu_count() * ((heads_only ? 8 : 4) / waves_per_block), ceil_div(a.M, kBlockThreads));
     const dim3 grid(blocks), block(kBlockThreads);
     a.work = shade_work_counter(s);
+    std::lock_guard<std::mutex> enqueue_lock(g_work_counter_enqueue);
     if (a.work && hipMemsetAsync(a.work, 0, sizeof(uint32_t), s) != hipSuccess) return check_launch("shade work counter");
     // split-precision mode: the environment features come from the fp16-pair kernel (shade_split.hip), the heads stay fp32
     const bool split = d->env_split_blob != nullptr && !d->dir_sh_degree;
@@ -1467,6 +1473,7 @@ int envidr_env_mlp_forward(const float* env_blob, uint32_t in_dim, uint32_t hidd
     hipStream_t s = as_stream(stream);
     uint32_t* work = shade_work_counter(s);
     ENVIDR_REQUIRE(work, "env_mlp_forward: no memory for the work counter");
+    std::lock_guard<std::mutex> enqueue_lock(g_work_counter_enqueue);
     if (hipMemsetAsync(work, 0, sizeof(uint32_t), s) != hipSuccess) return check_launch("env_mlp_forward work counter");
     const uint32_t blocks = std::min((uint32_t)device_cu_count() * 4u, ceil_div(M, 64u));
     const uint32_t aligned = aligned16(x) && aligned16(y) ? 1u : 0u;

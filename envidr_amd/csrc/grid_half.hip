@@ -318,14 +318,16 @@ __global__ void __launch_bounds__(kBlock) k_second_backward_table_h(const h16* _
     }
 }
 
-template <typename Fn>
-int dispatch_dc_h(uint32_t D, uint32_t C, uint32_t d_lo, uint32_t d_hi, const char* who, Fn&& fn) {
+// (the dimension range is a COMPILE-time bound: with a run-time one every caller instantiated its kernels for D = 1 .. 5, 42 of them
+//  unreachable through the C ABI -- the hash encoder's entry points take D = 2, 3 only)
+template <int D_LO, int D_HI, typename Fn>
+int dispatch_dc_h(uint32_t D, uint32_t C, const char* who, Fn&& fn) {
 #define ENVIDR_CASE(DD, CC) if (D == DD && C == CC) return fn(std::integral_constant<int, DD>{}, std::integral_constant<int, CC>{});
-#define ENVIDR_ROW(DD) if (DD >= d_lo && DD <= d_hi) { ENVIDR_CASE(DD, 1) ENVIDR_CASE(DD, 2) ENVIDR_CASE(DD, 4) ENVIDR_CASE(DD, 8) }
+#define ENVIDR_ROW(DD) if constexpr (DD >= D_LO && DD <= D_HI) { ENVIDR_CASE(DD, 1) ENVIDR_CASE(DD, 2) ENVIDR_CASE(DD, 4) ENVIDR_CASE(DD, 8) }
     ENVIDR_ROW(1) ENVIDR_ROW(2) ENVIDR_ROW(3) ENVIDR_ROW(4) ENVIDR_ROW(5)
 #undef ENVIDR_ROW
 #undef ENVIDR_CASE
-    set_error("%s: unsupported (D=%u, C=%u); D must be %u..%u and C one of 1, 2, 4, 8", who, D, C, d_lo, d_hi);
+    set_error("%s: unsupported (D=%u, C=%u); D must be %d..%d and C one of 1, 2, 4, 8", who, D, C, D_LO, D_HI);
     return ENVIDR_EINVAL;
 }
 
@@ -338,7 +340,7 @@ int forward_h(const IN* inputs, const uint16_t* embeddings, const int32_t* offse
     ENVIDR_REQUIRE(inputs && embeddings && offsets && outputs, "%s: null pointer", who);
     const LevelScale ls = make_level_scale(L, S, H_);
     const dim3 grid(ceil_div(B, kBlock), L);
-    return dispatch_dc_h(D, C, SMOOTH ? 2 : 1, SMOOTH ? 3 : 5, who, [&](auto d, auto c) {
+    return dispatch_dc_h<(SMOOTH ? 2 : 1), (SMOOTH ? 3 : 5)>(D, C, who, [&](auto d, auto c) {
         constexpr int DD = decltype(d)::value, CC = decltype(c)::value;
         hipLaunchKernelGGL((k_grid_forward_h<DD, CC, SMOOTH, IN>), grid, dim3(kBlock), 0, as_stream(stream), inputs,
                            reinterpret_cast<const h16*>(embeddings), offsets, reinterpret_cast<h16*>(outputs), B, L, ls,
@@ -357,7 +359,7 @@ int backward_h(const uint16_t* grad, const IN* inputs, const int32_t* offsets, u
     ENVIDR_REQUIRE(grad && inputs && offsets, "%s: null pointer", who);
     ENVIDR_REQUIRE(!dy_dx || grad_inputs, "%s: dy_dx given but grad_inputs is null", who);
     const LevelScale ls = make_level_scale(L, S, H_);
-    return dispatch_dc_h(D, C, SMOOTH ? 2 : 1, SMOOTH ? 3 : 5, who, [&](auto d, auto c) {
+    return dispatch_dc_h<(SMOOTH ? 2 : 1), (SMOOTH ? 3 : 5)>(D, C, who, [&](auto d, auto c) {
         constexpr int DD = decltype(d)::value, CC = decltype(c)::value;
         int rc = ENVIDR_OK;
         if (grad_embeddings) {
@@ -408,7 +410,7 @@ int envidr_hash_encode_second_backward_f16(const uint16_t* grad, const uint16_t*
     ENVIDR_REQUIRE(grad && inputs && offsets && dy_dx && grad_grad_inputs && grad_grad && grad2_embeddings, "%s: null pointer", who);
     ENVIDR_REQUIRE(C != 1, "%s: C=1 is not supported (reference: hashencoder.cu:673-679)", who);
     const LevelScale ls = make_level_scale(L, S, H_);
-    return dispatch_dc_h(D, C, 2, 3, who, [&](auto d, auto c) {
+    return dispatch_dc_h<2, 3>(D, C, who, [&](auto d, auto c) {
         constexpr int DD = decltype(d)::value, CC = decltype(c)::value;
         if constexpr (CC == 1) return (int)ENVIDR_EINVAL;
         else {

@@ -605,23 +605,9 @@ __global__ void __launch_bounds__(kLdsScatterThreads) k_table_scatter_lds(const 
   }
 }
 
-// per-(device, stream) scratch for the range masks: grown on demand and kept
-static uint32_t* range_mask_scratch(hipStream_t s, size_t words) {
-    struct Scratch { void* ptr; size_t bytes; };
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, Scratch> pool;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lock(mu);
-    Scratch& sc = pool[{dev, s}];
-    if (words * 4 > sc.bytes) {
-        if (sc.ptr) (void)hipFree(sc.ptr);
-        sc.bytes = words * 4;
-        if (hipMalloc(&sc.ptr, sc.bytes) != hipSuccess) { sc.ptr = nullptr; sc.bytes = 0; }
-    }
-    return static_cast<uint32_t*>(sc.ptr);
-}
-
+// scratch for the range masks (4 bytes per point and level): stream-ordered allocation from the device's default memory pool, released
+// behind the kernels that read it -- nothing outlives the call, nothing synchronises the device, and the pool hands the bytes back
+// (round 4 kept a per-stream hipMalloc that was never freed: 0.5 GiB at 8 M points x 16 levels, outside torch's allocator)
 // pre-pass + range owners
 template <int D, int C, bool SECOND>
 static int launch_table_scatter_lds(const float* grad, const float* inputs, const int32_t* offsets, const float* ggx, float* grad_table, uint32_t B,
@@ -631,14 +617,21 @@ static int launch_table_scatter_lds(const float* grad, const float* inputs, cons
     uint32_t log2_rows = 0;
     while ((1u << log2_rows) < kRows) ++log2_rows;
     const uint32_t pitch = (B + 3u) / 4u * 4u;
-    uint32_t* masks = range_mask_scratch(s, (size_t)L * pitch + kMaskGrain);
-    if (!masks) { set_error("hash_encode_backward: no memory for %zu bytes of range masks", ((size_t)L * pitch + kMaskGrain) * 4); return ENVIDR_ELAUNCH; }
+    const size_t mask_bytes = ((size_t)L * pitch + kMaskGrain) * 4;
+    uint32_t* masks = nullptr;
+    if (hipMallocAsync(reinterpret_cast<void**>(&masks), mask_bytes, s) != hipSuccess || !masks) {
+        (void)hipGetLastError();
+        set_error("hash_encode_backward: no memory for %zu bytes of range masks", mask_bytes);
+        return ENVIDR_ELAUNCH;
+    }
     hipLaunchKernelGGL((k_table_range_masks<D>), dim3(ceil_div(B, kBlock), L), dim3(kBlock), 0, s, inputs, offsets, masks, B, pitch, log2_rows, ls);
     int rc = check_launch("k_table_range_masks");
-    if (rc) return rc;
+    if (rc) { (void)hipFreeAsync(masks, s); return rc; }
     hipLaunchKernelGGL((k_table_scatter_lds<D, C, SECOND>), dim3(kXcds * kLdsScatterSlots), dim3(kLdsScatterThreads), 0, s, grad, inputs, offsets, ggx,
                        masks, pitch, grad_table, B, L, ls);
-    return check_launch("k_table_scatter_lds");
+    rc = check_launch("k_table_scatter_lds");
+    (void)hipFreeAsync(masks, s);             // stream order: behind the scatter kernel
+    return rc;
 }
 
 constexpr uint32_t kLdsScatterMinPoints = 1u << 19;    // below this the per-point atomics (combined inside the wave) are faster
@@ -729,17 +722,20 @@ int envidr_hash_encode_second_backward(const float* grad, const float* inputs, c
     const uint32_t chunks = ceil_div(B, kBlock);
     return dispatch_dc(D, C, "hash_encode_second_backward", [&](auto d, auto c) {
         constexpr int DD = decltype(d)::value, CC = decltype(c)::value;
-        hipLaunchKernelGGL((k_second_backward_grad<DD, CC>), dim3(chunks, L), dim3(kBlock), 0, as_stream(stream),
-                           grad_grad_inputs, dy_dx, grad_grad, B, L);
-        int rc = check_launch("k_second_backward_grad");
-        if (rc) return rc;
-        if (B >= kLdsScatterMinPoints) {
-            return launch_table_scatter_lds<DD, CC, true>(grad, inputs, offsets, grad_grad_inputs, grad2_embeddings, B, L, ls, as_stream(stream));
+        if constexpr (CC == 1) return (int)ENVIDR_EINVAL;         // refused above: no kernel is instantiated for the case
+        else {
+            hipLaunchKernelGGL((k_second_backward_grad<DD, CC>), dim3(chunks, L), dim3(kBlock), 0, as_stream(stream),
+                               grad_grad_inputs, dy_dx, grad_grad, B, L);
+            int rc = check_launch("k_second_backward_grad");
+            if (rc) return rc;
+            if (B >= kLdsScatterMinPoints) {
+                return launch_table_scatter_lds<DD, CC, true>(grad, inputs, offsets, grad_grad_inputs, grad2_embeddings, B, L, ls, as_stream(stream));
+            }
+            hipLaunchKernelGGL((k_second_backward_table<DD, CC>), dim3(xcd_grid_blocks(L, chunks)), dim3(kBlock), 0,
+                               as_stream(stream), grad, inputs, offsets, grad_grad_inputs, grad2_embeddings, B, L, ls,
+                               chunks);
+            return check_launch("k_second_backward_table");
         }
-        hipLaunchKernelGGL((k_second_backward_table<DD, CC>), dim3(xcd_grid_blocks(L, chunks)), dim3(kBlock), 0,
-                           as_stream(stream), grad, inputs, offsets, grad_grad_inputs, grad2_embeddings, B, L, ls,
-                           chunks);
-        return check_launch("k_second_backward_table");
     });
 }
 

@@ -14,6 +14,26 @@
 namespace envidr {
 namespace {
 
+// get_sphere_intersections (sph_ray.py:18-32): near / far parameters of |x| = r along o + t d (d unit), the discriminant clamped at 0
+// under the root; a ray counts as a hit from a discriminant of -1e-4 (grazing rays).  One lane per ray.  (The reference forms d.o with
+// torch.bmm -- 640 000 one-by-three times three-by-one products cost 8.8 ms per 800 x 800 frame on this GPU; the expressions below
+// are the same in the same order, product by product.)
+__global__ void __launch_bounds__(kBlock) k_sphere_intersections(const float* __restrict__ rays_o, const float* __restrict__ rays_d, uint32_t N,
+                                                                 float radius, float* __restrict__ nears, float* __restrict__ fars,
+                                                                 uint8_t* __restrict__ mask) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+    const float dot = dx * ox + dy * oy + dz * oz;                                   // ray_cam_dot
+    const float len = sqrtf(ox * ox + oy * oy + oz * oz);                            // rays_o.norm(2, 1)
+    const float nabla = dot * dot - (len * len - radius * radius);
+    const float root = sqrtf(fmaxf(nabla, 0.0f));
+    nears[n] = -dot - root;
+    fars[n] = -dot + root;
+    mask[n] = nabla >= -1e-4f ? 1 : 0;
+}
+
 __global__ void __launch_bounds__(kBlock) k_shell_samples(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                           const int32_t* __restrict__ hit_rays, const float* __restrict__ nears,
                                                           const float* __restrict__ z_offsets, const float* __restrict__ noise,
@@ -113,6 +133,14 @@ __global__ void __launch_bounds__(kBlock) k_composite_shell(const ShellComposite
 using namespace envidr;
 
 extern "C" {
+
+int envidr_sphere_intersections(const float* rays_o, const float* rays_d, uint32_t N, float radius, float* nears, float* fars, uint8_t* mask,
+                                envidr_stream_t stream) {
+    if (N == 0) return ENVIDR_OK;
+    ENVIDR_REQUIRE(rays_o && rays_d && nears && fars && mask, "sphere_intersections: null pointer");
+    hipLaunchKernelGGL(k_sphere_intersections, dim3(ceil_div(N, kBlock)), dim3(kBlock), 0, as_stream(stream), rays_o, rays_d, N, radius, nears, fars, mask);
+    return check_launch("k_sphere_intersections");
+}
 
 int envidr_shell_samples(const float* rays_o, const float* rays_d, const int32_t* hit_rays, const float* nears, const float* z_offsets,
                          const float* noise, float step_size, uint32_t M, uint32_t S, float* xyz, float* dirs, float* z_vals,

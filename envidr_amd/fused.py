@@ -146,6 +146,8 @@ def _bind_render(lib):
     lib.envidr_geometry_pass.restype = ctypes.c_int
     lib.envidr_env_mlp_forward.argtypes = [_FP, ctypes.c_uint32, ctypes.c_uint32, _FP, ctypes.c_uint32, _FP, _FP]
     lib.envidr_env_mlp_forward.restype = ctypes.c_int
+    lib.envidr_sphere_intersections.argtypes = [_FP, _FP, ctypes.c_uint32, ctypes.c_float, _FP, _FP, _FP, _FP]
+    lib.envidr_sphere_intersections.restype = ctypes.c_int
     lib.envidr_shell_samples.argtypes = [_FP, _FP, _FP, _FP, _FP, _FP, ctypes.c_float, ctypes.c_uint32, ctypes.c_uint32, _FP, _FP, _FP, _FP]
     lib.envidr_shell_samples.restype = ctypes.c_int
     lib.envidr_composite_shell.argtypes = [_FP] * 10 + [ctypes.c_uint32] * 3 + [ctypes.c_float] * 2 + [_FP] * 8
@@ -574,6 +576,16 @@ class FusedRenderer:
         self.desc.sdf_blob, self.desc.sdf_w3_row0 = t.data_ptr(), row.data_ptr()
 
     # ---- env-sphere mode (sph_ray.py run_sph): analytic hits, S samples per hit ray, torch-formula compositing ----------
+    def sphere_intersections(self, rays_o, rays_d, radius: float):
+        """envidr_sphere_intersections: nears [N], fars [N], mask [N] bool of rays [N,3] against the sphere |x| = radius"""
+        N, dev = int(rays_o.shape[0]), rays_o.device
+        nears, fars, mask = torch.empty(N, device=dev), torch.empty(N, device=dev), torch.empty(N, dtype=torch.uint8, device=dev)
+        rc = self.lib.envidr_sphere_intersections(rays_o.data_ptr(), rays_d.data_ptr(), N, float(radius), nears.data_ptr(), fars.data_ptr(),
+                                                  mask.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        if rc:
+            raise _lib.EnvidrError(f"envidr_sphere_intersections failed ({rc}): {self.lib.envidr_last_error().decode()}")
+        return nears, fars, mask.bool()
+
     def shell_samples(self, rays_o, rays_d, hit_rays, nears, z_offsets, step_size: float, noise=None):
         """envidr_shell_samples: sample-major xyz [S,M,3], dirs [S,M,3], z_vals [S,M] of the hit rays"""
         M, S, dev = int(hit_rays.shape[0]), int(z_offsets.shape[0]), rays_o.device
@@ -723,6 +735,13 @@ class FusedRenderer:
         return res
 
     # ---- two-phase frame on the geometry pipeline: march rounds + per-sample evaluation -> shading -> composite ----------
+    def _march_key(self) -> tuple:
+        """the descriptor fields that decide which samples a frame's records are (run_cuda rewrites max_steps / T_thresh / dt_gamma per
+        call, set_aabb the box): records are only shaded again by a frame that would have marched the same samples"""
+        d = self.desc
+        return (int(d.max_steps), float(d.T_thresh), float(d.dt_gamma), float(d.min_near), int(d.has_aabb), tuple(float(v) for v in d.aabb),
+                float(d.density_scale), float(d.bound))
+
     def geometry_eval(self, xyz: torch.Tensor, dt: torch.Tensor | None = None, want=("sigma", "normal", "geo_feat", "roughness")) -> dict:
         """envidr_geometry_eval: hash grid + SDF network forward / input gradient + per-sample terms for positions [M,3]"""
         xyz = xyz.contiguous().view(-1, 3).float()
@@ -878,7 +897,7 @@ class FusedRenderer:
             return res
         if reuse_geometry is not None:
             st = self.__dict__.get("_frames", {}).get((N, buffers) if buffers else N)
-            if (geometry_only or st is None or st.get("records_of") != (rays_o.data_ptr(), rays_d.data_ptr(), N)
+            if (geometry_only or st is None or st.get("records_of") != (rays_o.data_ptr(), rays_d.data_ptr(), N, self._march_key())
                     or reuse_geometry.get("_records_serial") != st.get("records_serial")):
                 reuse_geometry = None                      # not the frame these buffers hold: render from scratch
         if reuse_geometry is not None:
@@ -963,7 +982,7 @@ class FusedRenderer:
                 self.frame_log[tag] = st["stats"].clone()
             res["ray_cost"] = st["cost"]
             # what these buffers hold now (reuse_geometry asks for exactly this frame's records)
-            st["records_of"] = (rays_o.data_ptr(), rays_d.data_ptr(), N)
+            st["records_of"] = (rays_o.data_ptr(), rays_d.data_ptr(), N, self._march_key())
             st["records_serial"] = res["_records_serial"] = st.get("records_serial", 0) + 1
             st["records_cost"], st["records_ex"] = st["cost"], ex       # (envidr_geometry_pass filled in where the per-sample arrays live)
             if not wait:

@@ -53,6 +53,9 @@ def _run_mlp(net, h):
     # inference on the GPU, a shape the environment-MLP operator is built for (csrc/fused_render.hip k_env_mlp: the pass the fused
     # shading kernels run): one launch instead of four GEMMs and three ReLU passes over [M, H] activations.  With autograd
     # recording (training, or normals that need a graph) the torch layers below run, like the reference's.
+    # One semantic difference, on non-finite activations only: the operator's ReLU is the LDS unit's ds_max_f32 against 0, which returns 0
+    # for a NaN input (IEEE maxNum) where torch.relu propagates it -- a diverged environment MLP shows up as finite colours here, as NaN
+    # in the torch chain.  ENV_MLP_OPERATOR_MIN_ROWS = a huge number keeps the torch chain.
     if (not torch.is_grad_enabled() and h.is_cuda and h.dtype == torch.float32 and h.numel() // max(h.shape[-1], 1) >= ENV_MLP_OPERATOR_MIN_ROWS
             and _fused.env_mlp_supported(net)):
         return _fused.env_mlp_forward(net, h)

@@ -94,10 +94,10 @@ def run_sph(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, num
                 or self.use_reflected_dir)
     radius = opt.env_sph_radius
     bg_color = (torch.zeros(N, 3, device=device) + (1 if bg_color is None else bg_color)).reshape(N, 3)
-    nears, fars, mask = get_sphere_intersections(rays_o, rays_d, radius)
     if fused and _sph_fused_ok(self, r_images):
-        return _run_sph_fused(self, prefix, rays_o, rays_d, nears, fars, mask, bg_color, perturb, num_step, step_size, get_normal_image,
+        return _run_sph_fused(self, prefix, rays_o, rays_d, radius, bg_color, perturb, num_step, step_size, get_normal_image,
                               env_net_index or 0, material)
+    nears, fars, mask = get_sphere_intersections(rays_o, rays_d, radius)
     if not mask.any():
         return _empty_results(self, prefix, bg_color, get_normal_image)
     nears_valid = nears[mask]                                                     # [M,1]
@@ -166,21 +166,22 @@ def _sph_fused_ok(model, r_images) -> bool:
             and getattr(model, "supports_fused_sph", lambda: False)())
 
 
-def _run_sph_fused(model, prefix, rays_o, rays_d, nears, fars, mask, bg_color, perturb, num_step, step_size, get_normal_image, env_net_index,
-                   material):
+def _run_sph_fused(model, prefix, rays_o, rays_d, radius, bg_color, perturb, num_step, step_size, get_normal_image, env_net_index, material):
     opt = model.opt
     N, device = rays_o.shape[0], rays_o.device
+    fr = model.fused_sph_renderer(env_net_index, material)
+    rays_o, rays_d = rays_o.float().contiguous(), rays_d.float().contiguous()
+    nears, fars, mask = fr.sphere_intersections(rays_o, rays_d, radius)
     hit_rays = torch.nonzero(mask).squeeze(-1).to(torch.int32)                    # (the one host round trip: M sizes the sample arrays)
     M = int(hit_rays.shape[0])
     if M == 0:
         return _empty_results(model, prefix, bg_color, get_normal_image)
-    fr = model.fused_sph_renderer(env_net_index, material)
     hit_slot = torch.full((N,), -1, dtype=torch.int32, device=device)
     hit_slot[hit_rays.long()] = torch.arange(M, dtype=torch.int32, device=device)
     z_radius = step_size * (num_step - 1) / 2
     z_offsets = torch.linspace(-z_radius, z_radius, num_step, device=device)
     noise = torch.rand(M, num_step, device=device) if perturb else None
-    near1, rays_o, rays_d = nears.reshape(-1).contiguous(), rays_o.float().contiguous(), rays_d.float().contiguous()
+    near1 = nears
     xyz, dirs, z_vals = fr.shell_samples(rays_o, rays_d, hit_rays, near1, z_offsets, step_size, noise)
     geo = fr.geometry_eval(xyz, want=("sigma", "normal", "geo_feat", "roughness"))
     shaded = fr.shade(geo["normal"], dirs, geo["geo_feat"], geo["roughness"], None)

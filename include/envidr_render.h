@@ -356,14 +356,18 @@ int envidr_composite_shaded(const uint32_t* offsets, const float* w, const float
                             float* diffuse_image, float* specular_image, envidr_stream_t stream);
 
 /* ---- ABI 8: env-sphere mode (nerf/render_func/sph_ray.py:34-221, `run_sph`; selected by opt.env_sph_mode, renderer.py:376) ----------
- * The object is a sphere of known radius: a ray's hit is analytic (get_sphere_intersections, sph_ray.py:18-32, stays on the host side
- * in torch), every hit ray gets S samples spaced step_size around its hit, and the samples are composited with the torch formulation of
+ * The object is a sphere of known radius: a ray's hit is analytic (get_sphere_intersections, sph_ray.py:18-32), every hit ray gets S samples spaced step_size around its hit, and the samples are composited with the torch formulation of
  * volume rendering (alphas + cumulative product), not the marcher's compositing kernel.  The SDF network / shading of the samples are
  * envidr_geometry_eval and envidr_shade_samples.  Per-sample arrays are SAMPLE-major: [S, M, ...].
+ *
+ * envidr_sphere_intersections (sph_ray.py:18-32): near = -d.o - sqrt(max(D, 0)), far = -d.o + sqrt(max(D, 0)), D = (d.o)^2 - (|o|^2 - r^2),
+ *   mask = D >= -1e-4; rays_o, rays_d [N,3] (unit directions); nears, fars [N] float, mask [N] uint8.
  *
  * envidr_shell_samples (sph_ray.py:69-79): z = z_offsets[s] + near (+ (noise - 0.5) step_size), xyz = o + d z.
  *   hit_rays [M] int32: ids of the rays that hit, ascending;  nears [N];  z_offsets [S] = linspace(-r, r, S), r = step_size (S-1) / 2;
  *   noise [M, S] in [0, 1) or NULL (perturb);  out: xyz [S,M,3], dirs [S,M,3] (the ray direction, repeated), z_vals [S,M]. */
+int envidr_sphere_intersections(const float* rays_o, const float* rays_d, uint32_t N, float radius, float* nears, float* fars, uint8_t* mask,
+                                envidr_stream_t stream);
 int envidr_shell_samples(const float* rays_o, const float* rays_d, const int32_t* hit_rays, const float* nears, const float* z_offsets,
                          const float* noise, float step_size, uint32_t M, uint32_t S, float* xyz, float* dirs, float* z_vals,
                          envidr_stream_t stream);
