@@ -146,6 +146,10 @@ def _bind_render(lib):
     lib.envidr_geometry_pass.restype = ctypes.c_int
     lib.envidr_env_mlp_forward.argtypes = [_FP, ctypes.c_uint32, ctypes.c_uint32, _FP, ctypes.c_uint32, _FP, _FP]
     lib.envidr_env_mlp_forward.restype = ctypes.c_int
+    lib.envidr_linear_weight_grad_workspace_bytes.argtypes = [ctypes.c_uint32] * 3
+    lib.envidr_linear_weight_grad_workspace_bytes.restype = ctypes.c_uint64
+    lib.envidr_linear_weight_grad.argtypes = [_FP, _FP, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, _FP, _FP, ctypes.c_int, _FP, ctypes.c_uint64, _FP]
+    lib.envidr_linear_weight_grad.restype = ctypes.c_int
     lib.envidr_sphere_intersections.argtypes = [_FP, _FP, ctypes.c_uint32, ctypes.c_float, _FP, _FP, _FP, _FP]
     lib.envidr_sphere_intersections.restype = ctypes.c_int
     lib.envidr_shell_samples.argtypes = [_FP, _FP, _FP, _FP, _FP, _FP, ctypes.c_float, ctypes.c_uint32, ctypes.c_uint32, _FP, _FP, _FP, _FP]
@@ -237,6 +241,28 @@ def env_mlp_forward(layers, x: torch.Tensor) -> torch.Tensor:
     if rc:
         raise _lib.EnvidrError(f"envidr_env_mlp_forward failed ({rc}): {lib.envidr_last_error().decode()}")
     return y.reshape(*x.shape[:-1], 12)
+
+
+def linear_weight_grad(x: torch.Tensor, gy: torch.Tensor, bias: bool = True):
+    """envidr_linear_weight_grad: dW [N_out, K_in] = gy^T x and db [N_out] = column sums of gy, for x [M, K_in], gy [M, N_out] on the GPU
+    (fp32): the reduction over the M samples split across the chip on the fp32 matrix cores, partial sums added in a fixed order"""
+    lib = _lib.load()
+    _bind_render(lib)
+    x = x.contiguous().float()
+    gy = gy.contiguous().float()
+    M, K = x.shape
+    N = gy.shape[1]
+    if gy.shape[0] != M or not x.is_cuda:
+        raise _lib.EnvidrError("linear_weight_grad: x [M, K_in] and gy [M, N_out] on the GPU")
+    dW = torch.empty(N, K, device=x.device)
+    db = torch.empty(N, device=x.device) if bias else None
+    nbytes = int(lib.envidr_linear_weight_grad_workspace_bytes(M, K, N))
+    ws = torch.empty(max(nbytes // 4, 4), device=x.device)
+    rc = lib.envidr_linear_weight_grad(x.data_ptr(), gy.data_ptr(), M, K, N, dW.data_ptr(), None if db is None else db.data_ptr(), 0,
+                                       ws.data_ptr(), nbytes, torch.cuda.current_stream(x.device).cuda_stream)
+    if rc:
+        raise _lib.EnvidrError(f"envidr_linear_weight_grad failed ({rc}): {lib.envidr_last_error().decode()}")
+    return dW, db
 
 
 def pack_sdf_geometry(sdf) -> np.ndarray:

@@ -5,6 +5,8 @@ hashencoder/hashgrid.py (hash_encode :107, HashEncoder :110-169).  fp32, or -- l
 half or torch autocast is on (`hash_encode_*_f16`, the at::Half instantiations, second backward included)."""
 from __future__ import annotations
 
+import contextlib
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -38,9 +40,32 @@ class _HashEncode(Function):
         grad = grad.to(embeddings.dtype).view(B, L, C).permute(1, 0, 2).contiguous()
         # whether the table gradient is wanted is known HERE (needs_input_grad); inside _HashEncodeBackward.forward grad
         # mode is always off, so asking torch.is_grad_enabled() there would never produce it
+        need_table = bool(ctx.needs_input_grad[1]) and not getattr(_INPUT_GRADIENT_ONLY, "on", False)
         grad_inputs, grad_embeddings = _HashEncodeBackward.apply(grad, inputs, embeddings, offsets, B, D, C, L, S, H,
-                                                                 ctx.calc_grad_inputs, dy_dx, bool(ctx.needs_input_grad[1]))
+                                                                 ctx.calc_grad_inputs, dy_dx, need_table)
         return (grad_inputs if ctx.calc_grad_inputs else None), grad_embeddings, None, None, None, None
+
+
+class _Flag:                       # process-wide on purpose: autograd runs the backward of GPU nodes on its own worker thread,
+    on = False                     # where a thread-local set by the caller would not be seen
+
+
+_INPUT_GRADIENT_ONLY = _Flag()
+
+
+@contextlib.contextmanager
+def input_gradient_only():
+    """Inside this context a backward pass through the hash encoding computes the gradient w.r.t. the POSITIONS only.  For callers that
+    run `torch.autograd.grad(features-derived scalar, positions, create_graph=True)` -- the normals of the training branch
+    (renderer.py:182-185): autograd.grad returns the position gradient and throws the table gradient of that pass away, but the custom
+    Function cannot know (needs_input_grad follows requires_grad), so it would zero-fill and scatter a 48.8 MB table gradient per step for
+    nothing.  The pass stays differentiable: the second backward (hashencoder.cu:375-595) still delivers grad2_embeddings."""
+    prev = getattr(_INPUT_GRADIENT_ONLY, "on", False)
+    _INPUT_GRADIENT_ONLY.on = True
+    try:
+        yield
+    finally:
+        _INPUT_GRADIENT_ONLY.on = prev
 
 
 class _HashEncodeBackward(Function):

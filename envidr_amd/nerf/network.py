@@ -47,9 +47,57 @@ def _mlp(dims, bias=True):
 
 
 ENV_MLP_OPERATOR_MIN_ROWS = 4096      # below this the four torch GEMMs are not slower than packing / launching the operator
+WEIGHT_GRAD_OPERATOR_MIN_ROWS = 16384 # training: from this many rows the weight gradient of a layer goes to envidr_linear_weight_grad
 
 
-def _run_mlp(net, h):
+class _RowsTimesMatrix(torch.autograd.Function):
+    """x [M, K] , W [N, K]  ->  x W^T [M, N] for a batch of 10^4 .. 10^6 rows.  Forward and input gradient are library GEMMs (plenty of
+    row parallelism); the gradient w.r.t. W -- an [N, K] result reduced over all rows, which a library GEMM tiles by its RESULT only
+    (32 workgroups on 256 CUs: 0.4 ms per environment-MLP layer of a 144 k-sample batch) -- is _WeightGrad, i.e.
+    envidr_linear_weight_grad.  The pair is closed under differentiation: each one's backward is made of the two, so the SDF network's
+    twice-differentiated layers (normals with create_graph, then the loss) take the same path as the shading networks'."""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        ctx.save_for_backward(x, W)
+        return x @ W.t()
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, W = ctx.saved_tensors
+        gx = _RowsTimesMatrix.apply(gy, W.t().contiguous()) if ctx.needs_input_grad[0] else None
+        gW = _WeightGrad.apply(x, gy) if ctx.needs_input_grad[1] else None
+        return gx, gW
+
+
+class _WeightGrad(torch.autograd.Function):
+    """x [M, K], gy [M, N]  ->  gy^T x [N, K]: envidr_linear_weight_grad (csrc/linear_grad.hip: the reduction over the rows split across
+    the chip on the fp32 matrix cores, partial sums added in a fixed order)."""
+
+    @staticmethod
+    def forward(ctx, x, gy):
+        ctx.save_for_backward(x, gy)
+        return _fused.linear_weight_grad(x, gy, bias=False)[0]
+
+    @staticmethod
+    def backward(ctx, G):
+        x, gy = ctx.saved_tensors
+        gx = _RowsTimesMatrix.apply(gy, G.t().contiguous()) if ctx.needs_input_grad[0] else None       # gy G      [M, K]
+        ggy = _RowsTimesMatrix.apply(x, G.contiguous()) if ctx.needs_input_grad[1] else None           # x G^T    [M, N]
+        return gx, ggy
+
+
+def _linear(lin, h, first_order_only=False):
+    """nn.Linear; in the training branch (autograd recording, a GPU batch of >= WEIGHT_GRAD_OPERATOR_MIN_ROWS rows) as x W^T + b with the
+    big-batch weight gradient"""
+    if (torch.is_grad_enabled() and h.is_cuda and h.dtype == torch.float32 and lin.weight.dtype == torch.float32
+            and (lin.weight.requires_grad or h.requires_grad) and h.numel() // max(h.shape[-1], 1) >= WEIGHT_GRAD_OPERATOR_MIN_ROWS):
+        y = _RowsTimesMatrix.apply(h.reshape(-1, h.shape[-1]), lin.weight).reshape(*h.shape[:-1], lin.weight.shape[0])
+        return y if lin.bias is None else y + lin.bias
+    return lin(h)
+
+
+def _run_mlp(net, h, first_order_only=False):
     # inference on the GPU, a shape the environment-MLP operator is built for (csrc/fused_render.hip k_env_mlp: the pass the fused
     # shading kernels run): one launch instead of four GEMMs and three ReLU passes over [M, H] activations.  With autograd
     # recording (training, or normals that need a graph) the torch layers below run, like the reference's.
@@ -60,7 +108,7 @@ def _run_mlp(net, h):
             and _fused.env_mlp_supported(net)):
         return _fused.env_mlp_forward(net, h)
     for i, lin in enumerate(net):
-        h = lin(h)
+        h = _linear(lin, h, first_order_only)
         if i != len(net) - 1:
             h = F.relu(h)
     return h
@@ -249,7 +297,7 @@ class NeRFNetwork(NeRFRenderer):
 
     # ---- shading ----------------------------------------------------------------------------------
     def _env(self, net, enc):
-        return _feat_act(_run_mlp(net, enc), self.opt.env_feat_act)
+        return _feat_act(_run_mlp(net, enc, first_order_only=True), self.opt.env_feat_act)
 
     def forward_color(self, geo_feat, d, normal=None, w_r=None, n_dot_w_o=None, use_specular_color=False, env_net_index=0,
                       n_env_enc=None, r_images=None, roughness=None):
@@ -260,7 +308,7 @@ class NeRFNetwork(NeRFRenderer):
                 env_net = self.env_nets[env_net_index] if opt.env_sph_mode else (self.diffuse_env_net if opt.split_diffuse_env else self.env_net)
                 e = self._env(env_net, n_env_enc)
                 h = {"concat": lambda: torch.cat([h, e], -1), "add": lambda: h + e, "mul": lambda: h * e}[opt.diffuse_env_fusion]()
-            self.c_diffuse = torch.sigmoid(_run_mlp(self.diffuse_net, h)) * self.metallic
+            self.c_diffuse = torch.sigmoid(_run_mlp(self.diffuse_net, h, first_order_only=True)) * self.metallic
         else:
             self.c_diffuse = 0
         if opt.diffuse_only:
@@ -283,7 +331,7 @@ class NeRFNetwork(NeRFRenderer):
             rough = roughness[renv_mask] / opt.roughness_scale
             remap = torch.sqrt(rough / 0.75)
             blend = 0.98 * self.blend_weight[renv_mask] if opt.learn_indir_blend else 0.95 * torch.sigmoid(80 * (remap - 0.18))
-            e = _feat_act(_run_mlp(self.renv_net, torch.cat([r_images[renv_mask], remap], -1)), opt.env_feat_act)
+            e = _feat_act(_run_mlp(self.renv_net, torch.cat([r_images[renv_mask], remap], -1), first_order_only=True), opt.env_feat_act)
             branches["renv"] = torch.cat([h[renv_mask], e], -1)
         if not branches:
             branches["env"] = h
@@ -291,7 +339,7 @@ class NeRFNetwork(NeRFRenderer):
         for k, hc in branches.items():
             if n_dot_w_o is not None:
                 hc = torch.cat([hc, n_dot_w_o[renv_mask] if k == "renv" else n_dot_w_o], -1)
-            colors[k] = torch.sigmoid(_run_mlp(self.color_net, hc))
+            colors[k] = torch.sigmoid(_run_mlp(self.color_net, hc, first_order_only=True))
         self.c_specular = colors["env"]
         if "renv" in colors:
             if opt.indir_only:

@@ -106,7 +106,11 @@ class NeRFRenderer(nn.Module):
 
     def compute_normal(self, sdf_or_sigma, xyzs, get_eikonal_sdf_gradient=False):
         """normal = normalize(d sdf / d xyz) through autograd (the fused kernel does this analytically)"""
-        grad = torch.autograd.grad(sdf_or_sigma, xyzs, torch.ones_like(sdf_or_sigma), retain_graph=True, create_graph=True)[0]
+        # (only the position gradient of this pass is returned: the hash encoder skips the table gradient it would otherwise form and
+        #  autograd.grad would throw away -- hashencoder.input_gradient_only; the pass stays twice differentiable)
+        from ..hashencoder.hashgrid import input_gradient_only
+        with input_gradient_only():
+            grad = torch.autograd.grad(sdf_or_sigma, xyzs, torch.ones_like(sdf_or_sigma), retain_graph=True, create_graph=True)[0]
         if not self.use_sdf:
             grad = -grad
         eikonal = grad if get_eikonal_sdf_gradient else None

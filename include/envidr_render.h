@@ -386,6 +386,16 @@ int envidr_composite_shell(const float* sigma, const float* z_vals, const float*
                            float* weights_sum, float* normal_image, float* diffuse_image, float* specular_image, float* roughness_image,
                            envidr_stream_t stream);
 
+/* ---- ABI 8: weight gradient of a dense layer over a large batch (training branch, reference cuda_ray.py:64-237: what torch autograd asks of
+ * nn.Linear there; the reference leaves it to cuBLAS) -------------------------------------------------------------------------------------
+ *   dW[o][i] (+)= sum_m gy[m][o] x[m][i]      db[o] (+)= sum_m gy[m][o]        x [M, K_in], gy [M, N_out] row-major, 16-byte aligned
+ * The reduction over the samples is split across the chip (fp32 MFMA, per-chunk partial results in `workspace`, summed in a fixed order:
+ * deterministic).  db may be NULL; accumulate != 0 adds to dW / db.  workspace: device, 16-byte aligned,
+ * >= envidr_linear_weight_grad_workspace_bytes(M, K_in, N_out). */
+uint64_t envidr_linear_weight_grad_workspace_bytes(uint32_t M, uint32_t K_in, uint32_t N_out);
+int envidr_linear_weight_grad(const float* x, const float* gy, uint32_t M, uint32_t K_in, uint32_t N_out, float* dW, float* db, int accumulate,
+                              void* workspace, uint64_t workspace_bytes, envidr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
