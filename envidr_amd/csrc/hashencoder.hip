@@ -85,6 +85,57 @@ __global__ void __launch_bounds__(kBlock) k_hash_forward(const float* __restrict
     }
 }
 
+// forward + dy_dx, rows assembled in LDS (round 5).  With one level per workgroup (above) a point's 16 x 24-byte pieces of its dy_dx row are
+// written by 16 different workgroups on different XCDs at different times: 3.1 GB of 24-byte stores at a 384-byte stride cost more than the
+// gathers (6.5 ms against 2.5 without dy_dx, on a frame's own samples).  Here a workgroup owns 128 points for ALL levels -- thread (p, h) walks
+// the levels of parity h -- parks the derivatives in LDS (row pitch odd: conflict-free) and writes the 128 rows, which are one contiguous range
+// of dy_dx, as full lines.  Same arithmetic per (point, level) as k_hash_forward: same bits.
+constexpr uint32_t kRowsPoints = 128;
+template <int D, int C>
+__global__ void __launch_bounds__(kBlock) k_hash_forward_rows(const float* __restrict__ inputs, const float* __restrict__ embeddings,
+                                                              const int32_t* __restrict__ offsets, float* __restrict__ outputs, uint32_t B,
+                                                              uint32_t L, LevelScale ls, float* __restrict__ dy_dx) {
+    extern __shared__ float s_rows[];                       // [kRowsPoints][pitch]
+    const uint32_t row_floats = L * D * C, pitch = row_floats | 1u;
+    const uint32_t p = threadIdx.x & (kRowsPoints - 1), par = threadIdx.x >> 7;
+    const uint32_t b0 = blockIdx.x * kRowsPoints, b = b0 + p;
+    if (b < B) {
+        float x[D];
+        const bool inside = load_point<D>(inputs, b, x);
+        for (uint32_t level = par; level < L; level += 2) {
+            const uint32_t row0 = (uint32_t)offsets[level];
+            const uint32_t size = (uint32_t)offsets[level + 1] - row0;
+            const LevelGeom<D> g = make_level_geom<D>(size, ls.resolution[level], /*allow_hash=*/true);
+            float out[C], grad[D][C];
+            if (inside) {
+                eval_level<D, C, /*SMOOTH=*/true, true>(x, embeddings + (size_t)row0 * C, g, ls.scale[level], 0.0f, out, grad);
+            } else {
+#pragma unroll
+                for (int c = 0; c < C; ++c) out[c] = 0;
+#pragma unroll
+                for (int d = 0; d < D; ++d)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) grad[d][c] = 0;
+            }
+            float* o = outputs + ((size_t)level * B + b) * C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) o[c] = out[c];
+            float* r = s_rows + p * pitch + level * (D * C);
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+#pragma unroll
+                for (int c = 0; c < C; ++c) r[d * C + c] = grad[d][c];
+        }
+    }
+    __syncthreads();
+    const uint32_t points = min(kRowsPoints, B - b0);
+    float* dst = dy_dx + (size_t)b0 * row_floats;
+    for (uint32_t e = threadIdx.x; e < points * row_floats; e += kBlock) {
+        const uint32_t q = e / row_floats, col = e - q * row_floats;
+        dst[e] = s_rows[q * pitch + col];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // backward w.r.t. the table: scatter w * grad into the 2^D corner rows (hardware fp32 atomics)
 // ------------------------------------------------------------------------------------------
@@ -666,7 +717,11 @@ int envidr_hash_encode_forward(const float* inputs, const float* embeddings, con
     const dim3 grid(xcd_grid_blocks(L, chunks));
     return dispatch_dc(D, C, "hash_encode_forward", [&](auto d, auto c) {
         constexpr int DD = decltype(d)::value, CC = decltype(c)::value;
-        if (calc_grad_inputs)
+        const uint32_t row_floats = L * DD * CC;
+        if (calc_grad_inputs && row_floats <= 127)            // the rows of 128 points fit the LDS budget (64 KiB): full-line dy_dx stores
+            hipLaunchKernelGGL((k_hash_forward_rows<DD, CC>), dim3(ceil_div(B, kRowsPoints)), dim3(kBlock), kRowsPoints * (row_floats | 1u) * sizeof(float),
+                               as_stream(stream), inputs, embeddings, offsets, outputs, B, L, ls, dy_dx);
+        else if (calc_grad_inputs)
             hipLaunchKernelGGL((k_hash_forward<DD, CC, true>), grid, dim3(kBlock), 0, as_stream(stream), inputs,
                                embeddings, offsets, outputs, B, L, ls, chunks, dy_dx);
         else

@@ -57,6 +57,36 @@ bench("hash_encode_backward (7.7 M, + table scatter)", lambda: _lib.call("hash_e
 ggx = torch.randn(M, 3, device=dev); gg = torch.zeros(16, M, 2, device=dev); g2 = torch.zeros_like(table)
 bench("hash_encode_second_backward (7.7 M)", lambda: _lib.call("hash_encode_second_backward", grad, x01, table, offsets, M, 3, 2, 16, S, 16, 1, dy, ggx, gg, g2),
       M * (128 + 384 + 12 + 12 + 128 + 1024), reps=3)
+# ---- the same grid operators on the points a FRAME really has (round 5): the marched samples of the benchmark's camera, in the two orders a
+# caller feeds them in -- ray-major (march_rays_train: consecutive samples of a ray, the training branch) and sample-major (the operator
+# loop's iterations: sample k of every alive ray, image-space neighbours side by side) -- against uniformly random points above
+from envidr_amd import raymarching as rm
+with torch.no_grad():
+    cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+    n_rays = 230_000                                           # ~7.7 M marched samples (33 per ray: marched to the far plane, no termination)
+    pick = torch.arange(0, N, N / n_rays, device=dev).long()[:n_rays]
+    nr, fr_ = nears[pick].contiguous(), fars[pick].contiguous()
+    xyz_r, _, _, rays_r = rm.march_rays_train(ro[pick].contiguous(), rd[pick].contiguous(), 1.0, bitfield, 1, 128, nr, fr_, cnt, 9_000_000, False, 128, False, 0.0, 1024)
+    Mr = int(rays_r[:, 2].sum().item())
+    xyz_r = xyz_r[:Mr].contiguous()
+    x01_ray = ((xyz_r + 1) / 2).contiguous()
+    ray_of = torch.repeat_interleave(torch.arange(n_rays, device=dev), rays_r[:, 2].long())
+    idx_in_ray = torch.arange(Mr, device=dev) - rays_r[:, 1].long()[ray_of]
+    order = torch.argsort(idx_in_ray * n_rays + ray_of)
+    x01_smp = x01_ray[order].contiguous()
+for label, pts in (("ray-major", x01_ray), ("sample-major", x01_smp)):
+    Mp = pts.shape[0]
+    out_p = torch.empty(16, Mp, 2, device=dev); dy_p = torch.empty(Mp, 96, device=dev)
+    grad_p = torch.randn(16, Mp, 2, device=dev); gin_p = torch.zeros(Mp, 3, device=dev); ggx_p = torch.randn(Mp, 3, device=dev); gg_p = torch.zeros(16, Mp, 2, device=dev)
+    bench(f"hash_encode_forward ({Mp / 1e6:.1f} M frame samples, {label}, no dy_dx)",
+          lambda: _lib.call("hash_encode_forward", pts, table, offsets, out_p, Mp, 3, 2, 16, S, 16, 0, None), Mp * (1024 + 12 + 128))
+    bench(f"hash_encode_forward ({Mp / 1e6:.1f} M frame samples, {label}, + dy_dx)",
+          lambda: _lib.call("hash_encode_forward", pts, table, offsets, out_p, Mp, 3, 2, 16, S, 16, 1, dy_p), Mp * (1024 + 12 + 128 + 384))
+    bench(f"hash_encode_backward ({Mp / 1e6:.1f} M frame samples, {label}, + table scatter)",
+          lambda: _lib.call("hash_encode_backward", grad_p, pts, table, offsets, gtab, Mp, 3, 2, 16, S, 16, 1, dy_p, gin_p), Mp * (128 + 384 + 12 + 12 + 1024), reps=3)
+    bench(f"hash_encode_second_backward ({Mp / 1e6:.1f} M frame samples, {label})",
+          lambda: _lib.call("hash_encode_second_backward", grad_p, pts, table, offsets, Mp, 3, 2, 16, S, 16, 1, dy_p, ggx_p, gg_p, g2), Mp * (128 + 384 + 12 + 12 + 128 + 1024), reps=3)
+    del out_p, dy_p, grad_p, gin_p, ggx_p, gg_p
 d = torch.nn.functional.normalize(torch.randn(M, 3, device=dev), dim=-1)
 o16 = torch.empty(M, 16, device=dev)
 bench("sh_encode_forward (7.7 M, degree 4)", lambda: _lib.call("sh_encode_forward", d, o16, M, 3, 4, None), M * (12 + 64))
