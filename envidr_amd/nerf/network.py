@@ -42,6 +42,32 @@ class LaplaceDensity(nn.Module):
         return self.density_func(sdf, beta=beta)
 
 
+class NeuSDensity(nn.Module):
+    """alpha of a sample from the sdf at its two section ends (NeuS; reference network.py:46-102): the value the compositors then take
+    as `input_alpha` instead of a density"""
+
+    def __init__(self, init_val, base_steps=1024, neus_n_detach=False):
+        super().__init__()
+        self.variance = nn.Parameter(torch.tensor(float(init_val)))
+        self.base_steps, self.neus_n_detach = base_steps, neus_n_detach
+
+    def get_variance(self):
+        return self.variance
+
+    def forward(self, sdf, dirs, dists, gradients, cos_anneal_ratio=1.0):
+        inv_s = torch.exp(self.variance * 10.0).clip(1e-6, 1e6)
+        if gradients is not None:
+            gradients = gradients.detach() if self.neus_n_detach else gradients
+            true_cos = (dirs * gradients).sum(-1, keepdim=True)
+            iter_cos = -(F.relu(-true_cos * 0.5 + 0.5) * (1.0 - cos_anneal_ratio) + F.relu(-true_cos) * cos_anneal_ratio)
+            next_sdf = sdf + iter_cos.squeeze() * dists * 0.5
+            prev_sdf = sdf - iter_cos.squeeze() * dists * 0.5
+        else:
+            next_sdf, prev_sdf = sdf - dists * 0.5, sdf + dists * 0.5
+        prev_cdf, next_cdf = torch.sigmoid(prev_sdf * inv_s), torch.sigmoid(next_sdf * inv_s)
+        return ((prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)).clip(0.0, 1.0)
+
+
 def _mlp(dims, bias=True):
     return nn.ModuleList([nn.Linear(dims[i], dims[i + 1], bias=bias) for i in range(len(dims) - 1)])
 
@@ -131,8 +157,8 @@ class NeRFNetwork(NeRFRenderer):
                  geo_feat_dim=15, num_layers_color=3, hidden_dim_color=64, num_layers_bg=2, hidden_dim_bg=64, bound=1,
                  num_levels=16, roughness_bias=-1, opt=None, env_opt=None, **kwargs):
         super().__init__(bound, opt=opt, env_opt=env_opt, **kwargs)
-        if not opt.use_sdf or opt.use_neus_sdf or opt.geometric_init or opt.skip_layers:
-            raise NotImplementedError("only the SDF + Laplace-density configuration family (toaster.ini / neural_renderer.ini) is implemented")
+        if not opt.use_sdf:
+            raise NotImplementedError("only the SDF configuration family (use_sdf) is implemented; the plain-density NeRF branch is out of scope")
         self.num_layers, self.hidden_dim, self.geo_feat_dim = num_layers, hidden_dim, geo_feat_dim
         self._encoding_dir = encoding_dir
         self.num_layers_color, self.hidden_dim_color = num_layers_color, hidden_dim_color
@@ -141,7 +167,9 @@ class NeRFNetwork(NeRFRenderer):
                                                 desired_resolution=bound * opt.desired_resolution,
                                                 base_resolution=opt.base_resolution, num_levels=num_levels,
                                                 log2_hashmap_size=opt.log2_hashmap_size, multires=opt.multires)
-        self.sdf_density = LaplaceDensity(opt.init_beta, opt.beta_min, opt.beta_max)
+        # Laplace density (VolSDF style; every shipped config) or the NeuS section alpha (reference network.py:142-149)
+        self.sdf_density = (NeuSDensity(opt.init_variance, opt.max_steps, opt.neus_n_detach) if opt.use_neus_sdf
+                            else LaplaceDensity(opt.init_beta, opt.beta_min, opt.beta_max))
         # material-conditioned SDF input (reference network.py:165-175): in the env-sphere mode the dataset's varying material parameters
         # -- roughness, metallic, base colour -- are concatenated to the hash features
         self.in_roughness = self.in_metallic = self.in_base_color = 0
@@ -155,7 +183,36 @@ class NeRFNetwork(NeRFRenderer):
         self.embed_dim = self.in_roughness + self.in_metallic + self.in_base_color
         self.w_material = self.embed_dim > 0
         out_dim = 1 + geo_feat_dim + (int(opt.use_roughness) + int(opt.learn_indir_blend) if opt.ensemble_mlp else 0)
-        self.sdf_net = _mlp([self.in_dim + self.embed_dim] + [hidden_dim] * (num_layers - 1) + [out_dim], bias=opt.mlp_bias)
+        # skip_layers (reference network.py:178-194, 417-418): layer l in the list takes cat([h, x]) / sqrt(2), so the layer before it is
+        # in_dim narrower; geometric_init (:153-159, 196-222): the IDR sphere initialisation -- biases forced on, weight-normalised layers
+        # (state_dict keys weight_g / weight_v, like the reference's nn.utils.weight_norm), Softplus(beta = 100) instead of ReLU
+        self.skip_layers = [int(l) for l in (opt.skip_layers or [])]
+        self.geometric_init = bool(opt.geometric_init)
+        first_in = self.in_dim + self.embed_dim
+        layers = []
+        for l in range(num_layers):
+            d_in = first_in if l == 0 else hidden_dim
+            d_out = out_dim if l == num_layers - 1 else (hidden_dim - first_in if l + 1 in self.skip_layers else hidden_dim)
+            lin = nn.Linear(d_in, d_out, bias=self.geometric_init or opt.mlp_bias)
+            if self.geometric_init:
+                with torch.no_grad():
+                    if l == num_layers - 1:
+                        sign = -1.0 if opt.inside_outside else 1.0
+                        nn.init.normal_(lin.weight, mean=sign * np.sqrt(np.pi) / np.sqrt(d_in), std=0.0001)
+                        nn.init.constant_(lin.bias, -sign * opt.geo_init_bias)
+                    elif first_in > 3 and l == 0:
+                        nn.init.constant_(lin.bias, 0.0)
+                        nn.init.constant_(lin.weight[:, 3:], 0.0)
+                        nn.init.normal_(lin.weight[:, :3], 0.0, np.sqrt(2) / np.sqrt(d_out))
+                    else:
+                        nn.init.constant_(lin.bias, 0.0)
+                        nn.init.normal_(lin.weight, 0.0, np.sqrt(2) / np.sqrt(d_out))
+                        if l in self.skip_layers:
+                            nn.init.constant_(lin.weight[:, -(first_in - 3):], 0.0)
+                lin = nn.utils.weight_norm(lin)
+            layers.append(lin)
+        self.sdf_net = nn.ModuleList(layers)
+        self.sdf_act = nn.Softplus(beta=100) if self.geometric_init else nn.ReLU()
         if opt.use_roughness and not opt.ensemble_mlp:
             self.roughness_layer = nn.Linear(geo_feat_dim, 1)
 
@@ -194,7 +251,8 @@ class NeRFNetwork(NeRFRenderer):
         c_in = self.in_dim_dir + geo_feat_dim + self.in_normal_dim + self.in_refdir_dim + self.n_dot_viewdir_dim
         self.color_net = _mlp([c_in] + [hidden_dim_color] * (num_layers_color - 1) + [3], bias=opt.mlp_bias)
         gain = nn.init.calculate_gain("relu")
-        for net in [self.sdf_net, self.env_net, *(self.env_nets or []), self.renv_net, getattr(self, "diffuse_net", None), self.color_net]:
+        for net in [None if self.geometric_init else self.sdf_net, self.env_net, *(self.env_nets or []), self.renv_net,
+                    getattr(self, "diffuse_net", None), self.color_net]:
             if net is not None and opt.net_init == "xavier_uniform":
                 for lin in net:
                     nn.init.xavier_uniform_(lin.weight, gain=gain)
@@ -270,7 +328,16 @@ class NeRFNetwork(NeRFRenderer):
             x = x * mask.reshape(-1)
         if self.w_material:
             x = self.concate_material_params(x, material)
-        h = _run_mlp(self.sdf_net, x)
+        if self.skip_layers or self.geometric_init:
+            h = x
+            for l, lin in enumerate(self.sdf_net):
+                if l in self.skip_layers:
+                    h = torch.cat([h, x], dim=-1) / np.sqrt(2)
+                h = lin(h)
+                if l != self.num_layers - 1:
+                    h = self.sdf_act(h)
+        else:
+            h = _run_mlp(self.sdf_net, x)
         sdf = h[..., 0]
         g = self.geo_feat_dim
         geo_feat = _feat_act(h[..., 1:1 + g], self.opt.geo_feat_act)
@@ -289,7 +356,14 @@ class NeRFNetwork(NeRFRenderer):
         normals = eikonal = None
         if kwargs.get("use_sdf_sigma_grad", False):
             normals, eikonal = self.compute_normal(sdfs, xyzs, self.opt.eikonal_loss)
-        return sdfs, self.sdf_density(sdfs), geo_feats, normals, eikonal
+        if self.opt.use_neus_sdf:                           # reference network.py:512-515: the "density" is the section alpha
+            dists = kwargs.get("dists", None)
+            dists = 2 * 3 ** 0.5 / self.sdf_density.base_steps if dists is None else dists
+            sigmas = self.sdf_density(sdfs, dirs=kwargs.get("dirs", None), dists=dists, gradients=normals,
+                                      cos_anneal_ratio=getattr(self.opt, "cos_anneal_ratio", 1.0))
+        else:
+            sigmas = self.sdf_density(sdfs)
+        return sdfs, sigmas, geo_feats, normals, eikonal
 
     def density(self, x, **kwargs):
         sdf, sigma, geo_feat, normal, eik = self.forward_sigma(x, **kwargs)
@@ -375,7 +449,8 @@ class NeRFNetwork(NeRFRenderer):
         o = self.opt
         hash_ok = o.encoding_pos == "hashgrid_diff" and o.level_dim == 2 and o.num_levels == 16      # the fused kernels are built for 16 levels
         net_ok = (o.num_layers == 3 and o.hidden_dim == 64 and o.geo_feat_dim == 12 and o.ensemble_mlp and o.use_roughness
-                  and o.learn_indir_blend and o.mlp_bias and o.geo_feat_act == "unitNorm" and o.env_feat_act == "unitNorm")
+                  and o.learn_indir_blend and o.mlp_bias and o.geo_feat_act == "unitNorm" and o.env_feat_act == "unitNorm"
+                  and not o.use_neus_sdf and not self.geometric_init and not self.skip_layers and not self.w_material)
         shade_ok = (o.use_diffuse and not o.diffuse_only and o.diffuse_with_env and o.diffuse_env_fusion == "concat"
                     and not o.split_diffuse_env and o.use_env_net and not o.env_wo_bias and o.num_layers_env == 4
                     and o.env_feat_dim == 12 and (o.sh_degree, o.hidden_dim_env) in [(5, 256), (4, 160), (5, 128), (4, 128)]
@@ -401,7 +476,7 @@ class NeRFNetwork(NeRFRenderer):
         hash_ok = o.encoding_pos == "hashgrid_diff" and o.level_dim == 2 and o.num_levels == 16
         net_ok = (o.num_layers == 3 and o.hidden_dim == 64 and o.geo_feat_dim == 12 and o.ensemble_mlp and o.use_roughness and o.mlp_bias
                   and o.geo_feat_act == "unitNorm" and o.env_feat_act == "unitNorm" and o.enabled_levels <= 0 and not o.bypass_roughness
-                  and o.normal_anneal_ratio >= 1)
+                  and o.normal_anneal_ratio >= 1 and not o.use_neus_sdf and not self.geometric_init and not self.skip_layers)
         shade_ok = (o.use_diffuse and not o.diffuse_only and o.diffuse_with_env and o.diffuse_env_fusion == "concat"
                     and not o.split_diffuse_env and o.use_env_net and self.env_nets is not None and not o.env_wo_bias and o.num_layers_env == 4
                     and o.env_feat_dim == 12 and (o.sh_degree, o.hidden_dim_env) in [(5, 256), (4, 160), (5, 128), (4, 128)]

@@ -44,6 +44,11 @@ class RenderOptions:
     learn_indir_blend: bool = True
     skip_layers: list = field(default_factory=list)
     geometric_init: bool = False
+    inside_outside: bool = False
+    geo_init_bias: float = 1.0
+    init_variance: float = 0.3          # NeuS density (use_neus_sdf): inv_s = exp(10 variance)
+    neus_n_detach: bool = False
+    cos_anneal_ratio: float = 1.0
     init_beta: float = 0.1
     beta_min: float = 0.0005
     beta_max: float = 1.0

@@ -254,9 +254,11 @@ def run_cuda(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, fo
             st["buf"], st["spare"] = st["spare"], st["buf"]
             st["alive"] = st["buf"][:n]
 
+    use_neus = bool(getattr(self.opt, "use_neus_sdf", False))
+
     def composite(st, n_alive, n_step, sigmas, colors, deltas, accum=True):
         raymarching.composite_rays(n_alive, n_step, st["alive"], st["t"], sigmas, colors, deltas, st["ws"], st["depth"], st["image"],
-                                   T_thresh, False, accum)
+                                   T_thresh, use_neus, accum)         # NeuS: `sigmas` are section alphas (reference cuda_ray.py:308-340)
 
     step = 0
     while step < max_steps:

@@ -650,6 +650,63 @@ def golden_sph():
     np.savez_compressed(OUT / "sph_render.npz", **out)
 
 
+def golden_variants():
+    """forward_geometry's other forms, which no shipped config selects (reference network.py:46-102, 153-222, 417): `--use_neus_sdf`
+    (NeuS section alphas instead of the Laplace density; the compositors then take input_alpha), `--geometric_init` (weight-normalised
+    layers, Softplus(beta = 100)) and `--skip_layers 1` (layer 1 takes cat([h, x]) / sqrt 2) -- all three on, toaster.ini otherwise:
+    a shading chain and a 32 x 32 frame through run_cuda.  The SDF network's weights are seeded here (shapes 32-32, 64-64, 64-15) and
+    installed as weight_v with weight_g = the row norms, i.e. as the effective weights."""
+    from nerf.options import config_parser
+    from nerf.network import NeRFNetwork
+    scene = scenes.toaster_scene(seed=9)
+    rng = np.random.default_rng(77)
+    scene.mlps["sdf"] = [scenes.xavier_linear(rng, 32, 32), scenes.xavier_linear(rng, 64, 64), scenes.xavier_linear(rng, 64, 15)]
+    scene.mlps["sdf"][-1][1][0] = 0.005
+    for _, b in scene.mlps["sdf"][:2]:
+        b += rng.uniform(-0.05, 0.05, size=b.shape).astype(F)
+    old = sys.argv
+    sys.argv = ["main_nerf.py", "--config", str(REFERENCE / "configs/scenes/toaster.ini"), "--test", "--use_neus_sdf", "--geometric_init",
+                "--skip_layers", "1", "--init_variance", "0.45"]
+    try:
+        opt = config_parser()
+    finally:
+        sys.argv = old
+    model = NeRFNetwork(encoding="hashgrid", encoding_dir=opt.encoding_dir, bound=opt.bound, cuda_ray=opt.cuda_ray, density_scale=1,
+                        min_near=opt.min_near, density_thresh=opt.density_thresh, bg_radius=opt.bg_radius, use_sdf=opt.use_sdf,
+                        hidden_dim=opt.hidden_dim, num_layers=opt.num_layers, num_layers_color=opt.num_layers_color,
+                        hidden_dim_color=opt.hidden_dim_color, num_layers_bg=opt.num_layers_bg, num_levels=opt.num_levels,
+                        geo_feat_dim=opt.geo_feat_dim, opt=opt, env_opt=None)
+    model.eval()
+    with torch.no_grad():
+        model.encoder.embeddings.data = torch.from_numpy(scene.table.copy())
+        for lin, (W, b) in zip(model.sdf_net, scene.mlps["sdf"]):
+            assert tuple(lin.weight_v.shape) == W.shape, (lin.weight_v.shape, W.shape)
+            lin.weight_v.data = torch.from_numpy(W.copy())
+            lin.weight_g.data = torch.from_numpy(np.linalg.norm(W, axis=1, keepdims=True).astype(F))
+            lin.bias.data = torch.from_numpy(b.copy())
+        for name, attr in [("env", "env_net"), ("diffuse", "diffuse_net"), ("specular", "color_net"), ("renv", "renv_net")]:
+            for lin, (W, b) in zip(getattr(model, attr), scene.mlps[name]):
+                lin.weight.data, lin.bias.data = torch.from_numpy(W.copy()), torch.from_numpy(b.copy())
+        model.density_bitfield.data = torch.from_numpy(scene.bitfield.copy())
+    # the shading chain: forward_sigma needs the step sizes for the NeuS alphas
+    rng = np.random.default_rng(5)
+    xyz, dirs = sample_points(rng, 1024)
+    dists = np.full(1024, 2 * math.sqrt(3) / 1024, F)
+    x = torch.from_numpy(xyz).requires_grad_(True)
+    d = torch.from_numpy(dirs)
+    sdfs, alphas, geo, normals, _ = model.forward_sigma(x, use_sdf_sigma_grad=True, dirs=d, dists=torch.from_numpy(dists))
+    n_enc, w_r_enc, n_dot, n_env_enc = model.get_color_mlp_extra_params(normals, d, model.roughness, None)
+    rgb = model.forward_color(geo, d, n_enc, w_r_enc, n_dot, True, n_env_enc=n_env_enc, r_images=None, roughness=model.roughness)
+    g = lambda t: t.detach().numpy().astype(F)
+    out = {"xyz": xyz, "dirs": dirs, "dists": dists, "sdf": g(sdfs), "alpha": g(alphas), "geo_feat": g(geo), "normal": g(normals),
+           "roughness": g(model.roughness), "rgb": g(rgb), "init_variance": np.float32(0.45)}
+    for i, (W, b) in enumerate(scene.mlps["sdf"]):
+        out[f"sdf/{i}.weight"], out[f"sdf/{i}.bias"] = W, b
+    np.savez_compressed(OUT / "shading_variants.npz", **out)
+    print(f"[golden] shading_variants: mean alpha {float(alphas.mean()):.4f}, sdf {float(sdfs.min()):.3f} ... {float(sdfs.max()):.3f}")
+    golden_frame(model, opt, "variants_32", 32, 32, theta=60.0, phi=-25.0)
+
+
 def train_targets(n):
     """deterministic stand-in for ground-truth pixels of a training batch"""
     i = np.arange(n, dtype=np.float64)
@@ -716,6 +773,9 @@ def main():
     if sys.argv[1:] == ["ide"]:
         golden_ide()
         return
+    if sys.argv[1:] == ["variants"]:           # only the NeuS / geometric_init / skip_layers fixture
+        golden_variants()
+        return
     if sys.argv[1:] == ["sph"]:                # only the env-sphere mode fixture
         golden_sph()
         return
@@ -756,6 +816,7 @@ def main():
     golden_grid()
     golden_demo()
     golden_sph()
+    golden_variants()
     # BASELINE configs[1]: no environment network, SH-encoded view direction and normal
     model2, opt2 = build_reference_model(scenes.lego_scene(seed=8), config=OUT / "lego_like.ini")
     golden_frame(model2, opt2, "lego_48", 48, 48, theta=110.0, phi=-40.0)

@@ -125,6 +125,41 @@ def test_instance_norm_feature_activations_match_reference():
         assert err <= 1e-4, f"{key}: rel-L2 {err:.3e}"
 
 
+def test_neus_geometric_init_and_skip_layer_variants_match_reference():
+    """forward_geometry's other forms (reference network.py:46-102 NeuS section alphas, 153-222 geometric_init = weight-normalised layers +
+    Softplus(100), 417 skip_layers) -- none selected by a shipped config, all three at once here: the per-sample chain and a frame through
+    run_cuda's operator loop (the compositors take input_alpha) against the reference's own; loaded through weight_g / weight_v keys"""
+    import torch
+    g = np.load(GOLD / "shading_variants.npz")
+    scene = scenes.toaster_scene(seed=9)
+    scene.mlps["sdf"] = []                                                       # (installed below under the weight-norm keys)
+    model, opt = build_model(scene, use_neus_sdf=True, geometric_init=True, skip_layers=[1], init_variance=float(g["init_variance"]))
+    assert not model.supports_fused() and [tuple(l.weight.shape) for l in model.sdf_net] == [(32, 32), (64, 64), (15, 64)]
+    sd = {}
+    for i in range(3):
+        W = torch.from_numpy(g[f"sdf/{i}.weight"])
+        sd[f"sdf_net.{i}.weight_v"], sd[f"sdf_net.{i}.weight_g"], sd[f"sdf_net.{i}.bias"] = W, W.norm(dim=1, keepdim=True), torch.from_numpy(g[f"sdf/{i}.bias"])
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected
+    model = model.cuda()
+    x = torch.from_numpy(g["xyz"]).cuda().requires_grad_(True)
+    d = torch.from_numpy(g["dirs"]).cuda()
+    sdfs, alphas, geo, normals, _ = model.forward_sigma(x, use_sdf_sigma_grad=True, dirs=d, dists=torch.from_numpy(g["dists"]).cuda())
+    n_enc, w_r_enc, n_dot, n_env_enc = model.get_color_mlp_extra_params(normals, d, model.roughness, None)
+    rgb = model.forward_color(geo, d, n_enc, w_r_enc, n_dot, True, n_env_enc=n_env_enc, roughness=model.roughness)
+    for k, v in {"sdf": sdfs, "alpha": alphas, "geo_feat": geo, "normal": normals, "roughness": model.roughness, "rgb": rgb}.items():
+        assert rel_l2(v.detach().cpu().numpy(), g[k].reshape(tuple(v.shape))) <= 1e-4, (k, rel_l2(v.detach().cpu().numpy(), g[k].reshape(tuple(v.shape))))
+    f = np.load(GOLD / "frame_variants_32.npz")
+    H, W = int(f["H"]), int(f["W"])
+    ro, rd = scenes.camera_rays(H, W, theta=float(f["theta"]), phi=float(f["phi"]))
+    res = model.render(torch.from_numpy(ro).cuda()[None], torch.from_numpy(rd).cuda()[None], staged=True, bg_color=1, perturb=False,
+                       get_normal_image=True, max_steps=opt.max_steps, T_thresh=opt.T_thresh, dt_gamma=opt.dt_gamma)
+    torch.cuda.synchronize()
+    for key in KEYS:
+        err = rel_l2(res[key].detach().cpu().numpy().reshape(H * W, -1), f[key].reshape(H * W, -1))
+        assert err <= 1e-4, f"{key}: rel-L2 {err:.3e}"
+
+
 def test_encoder_modules_have_reference_surface():
     import torch
     from envidr_amd.encoding import get_encoder

@@ -24,10 +24,38 @@ def test_obj_aabb_is_scaled_clamped_and_not_persistent():
         _build(obj_aabb=[0.0, 1.0, 2.0])
 
 
-@pytest.mark.parametrize("name", ["error_bound_sample", "env_sph_mode", "render_env_on_sphere", "unwrap_env_sphere", "plot_roughness"])
+@pytest.mark.parametrize("name", ["error_bound_sample", "unwrap_env_sphere", "plot_roughness"])
 def test_options_outside_the_path_are_refused(name):
     with pytest.raises(NotImplementedError):
         _build(**{name: True})
+
+
+def test_env_sphere_mode_needs_its_dataset_options():
+    """env_sph_mode builds one environment MLP per environment and a material-conditioned SDF input: both come from env_opt"""
+    from envidr_amd.nerf.network import NeRFNetwork
+    from envidr_amd.nerf.options import EnvOptions, neural_renderer_options
+    with pytest.raises(ValueError):
+        _build(env_sph_mode=True)
+    opt = neural_renderer_options()
+    m = NeRFNetwork(encoding="hashgrid", encoding_dir=opt.encoding_dir, bound=opt.bound, cuda_ray=opt.cuda_ray, density_scale=1, min_near=opt.min_near,
+                    density_thresh=opt.density_thresh, bg_radius=opt.bg_radius, use_sdf=opt.use_sdf, hidden_dim=opt.hidden_dim, num_layers=opt.num_layers,
+                    num_layers_color=opt.num_layers_color, hidden_dim_color=opt.hidden_dim_color, num_levels=opt.num_levels,
+                    geo_feat_dim=opt.geo_feat_dim, opt=opt, env_opt=EnvOptions(vary_base_color=False))
+    assert m.embed_dim == 2 and tuple(m.sdf_net[0].weight.shape) == (64, 34) and tuple(m.sdf_net[2].weight.shape) == (14, 64)
+    assert m.env_net is None and len(m.env_nets) == 11 and not m.cuda_ray
+    assert m.material_vector({"roughness": 0.3, "metallic": 0.1, "color": [1, 2, 3]}) == [0.3, 0.1]
+    keys = set(m.state_dict())
+    assert {"env_nets.10.3.weight", "sdf_net.0.weight", "diffuse_net.1.bias", "color_net.2.weight"} <= keys and "density_bitfield" not in keys
+
+
+def test_sdf_network_variants_have_the_reference_parameter_names():
+    """skip_layers narrows the layer in front of the skip; geometric_init weight-normalises (weight_g / weight_v) and forces biases on"""
+    m, _ = _build(skip_layers=[1])
+    assert [tuple(l.weight.shape) for l in m.sdf_net] == [(32, 32), (64, 64), (15, 64)]
+    m, _ = _build(geometric_init=True, mlp_bias=False, use_neus_sdf=True)
+    keys = set(m.state_dict())
+    assert {"sdf_net.0.weight_g", "sdf_net.0.weight_v", "sdf_net.2.bias", "sdf_density.variance"} <= keys and "sdf_density.beta" not in keys
+    assert not m.supports_fused()
 
 
 def test_every_option_field_is_read_or_refused():
