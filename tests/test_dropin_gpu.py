@@ -29,6 +29,8 @@ def build_model(scene, **opt_overrides):
         for i, (W, b) in enumerate(scene.mlps.get(name, [])):
             sd[f"{attr}.{i}.weight"] = torch.from_numpy(W)
             sd[f"{attr}.{i}.bias"] = torch.from_numpy(b)
+    if opt.use_neus_sdf:
+        del sd["sdf_density.beta"]                 # the NeuS density has `variance` instead (set from init_variance)
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert not unexpected
     return m.cuda().eval(), opt
