@@ -15,11 +15,14 @@ namespace envidr {
 namespace {
 
 // get_sphere_intersections (sph_ray.py:18-32): near / far parameters of |x| = r along o + t d (d unit), the discriminant clamped at 0
-// under the root; a ray counts as a hit from a discriminant of -1e-4 (grazing rays).  One lane per ray.  (The reference forms d.o with
-// torch.bmm -- 640 000 one-by-three times three-by-one products cost 8.8 ms per 800 x 800 frame on this GPU; the expressions below
-// are the same in the same order, product by product.)
+// under the root; a ray counts as a hit from a discriminant of -1e-4 (grazing rays).  One lane per ray.  The reference forms d.o with
+// torch.bmm -- 640 000 one-by-three times three-by-one products cost 8.8 ms per 800 x 800 frame on this GPU.  The expressions below are
+// the reference's, in fp32, in its order, product by product (r^2 arrives as the float the reference's Python scalar r ** 2 becomes): the
+// hit set of the reference's CPU run is reproduced on the fixtures (tests/test_sph_gpu.py), which an fp64 evaluation does NOT do -- the
+// discriminant (d.o)^2 - (|o|^2 - r^2) cancels ~95 % of its terms for a camera 4 radii away, its fp32 rounding (1e-6) decides the -1e-4
+// test for a handful of silhouette rays per frame, and those rays are pixels.  Both forms of run_sph take their hits from this kernel.
 __global__ void __launch_bounds__(kBlock) k_sphere_intersections(const float* __restrict__ rays_o, const float* __restrict__ rays_d, uint32_t N,
-                                                                 float radius, float* __restrict__ nears, float* __restrict__ fars,
+                                                                 float radius2, float* __restrict__ nears, float* __restrict__ fars,
                                                                  uint8_t* __restrict__ mask) {
     const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
     if (n >= N) return;
@@ -27,7 +30,7 @@ __global__ void __launch_bounds__(kBlock) k_sphere_intersections(const float* __
     const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
     const float dot = dx * ox + dy * oy + dz * oz;                                   // ray_cam_dot
     const float len = sqrtf(ox * ox + oy * oy + oz * oz);                            // rays_o.norm(2, 1)
-    const float nabla = dot * dot - (len * len - radius * radius);
+    const float nabla = dot * dot - (len * len - radius2);
     const float root = sqrtf(fmaxf(nabla, 0.0f));
     nears[n] = -dot - root;
     fars[n] = -dot + root;
@@ -138,7 +141,8 @@ int envidr_sphere_intersections(const float* rays_o, const float* rays_d, uint32
                                 envidr_stream_t stream) {
     if (N == 0) return ENVIDR_OK;
     ENVIDR_REQUIRE(rays_o && rays_d && nears && fars && mask, "sphere_intersections: null pointer");
-    hipLaunchKernelGGL(k_sphere_intersections, dim3(ceil_div(N, kBlock)), dim3(kBlock), 0, as_stream(stream), rays_o, rays_d, N, radius, nears, fars, mask);
+    const float radius2 = (float)((double)radius * (double)radius);           // torch: the Python scalar r ** 2 (a double) cast to the tensor's float
+    hipLaunchKernelGGL(k_sphere_intersections, dim3(ceil_div(N, kBlock)), dim3(kBlock), 0, as_stream(stream), rays_o, rays_d, N, radius2, nears, fars, mask);
     return check_launch("k_sphere_intersections");
 }
 

@@ -113,13 +113,53 @@ class _WeightGrad(torch.autograd.Function):
         return gx, ggy
 
 
+class _Affine(torch.autograd.Function):
+    """x W^T + b with the bias gradient taken from the same kernel pass as the weight gradient (envidr_linear_weight_grad sums the columns
+    of gy on the way): no separate reduction over the batch per layer.  Differentiable to any order like the pair above."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        return torch.addmm(b, x, W.t())
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, W = ctx.saved_tensors
+        gx = _RowsTimesMatrix.apply(gy, W.t().contiguous()) if ctx.needs_input_grad[0] else None
+        gW = gb = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            gW, gb = _WeightBiasGrad.apply(x, gy)
+        return gx, gW, gb
+
+
+class _WeightBiasGrad(torch.autograd.Function):
+    """(gy^T x [N, K], column sums of gy [N]) in one envidr_linear_weight_grad call"""
+
+    @staticmethod
+    def forward(ctx, x, gy):
+        ctx.save_for_backward(x, gy)
+        return _fused.linear_weight_grad(x, gy, bias=True)
+
+    @staticmethod
+    def backward(ctx, G, g_b):
+        x, gy = ctx.saved_tensors
+        gx = _RowsTimesMatrix.apply(gy, G.t().contiguous()) if ctx.needs_input_grad[0] else None
+        ggy = None
+        if ctx.needs_input_grad[1]:
+            ggy = _RowsTimesMatrix.apply(x, G.contiguous())
+            if g_b is not None:
+                ggy = ggy + g_b
+        return gx, ggy
+
+
 def _linear(lin, h, first_order_only=False):
     """nn.Linear; in the training branch (autograd recording, a GPU batch of >= WEIGHT_GRAD_OPERATOR_MIN_ROWS rows) as x W^T + b with the
     big-batch weight gradient"""
     if (torch.is_grad_enabled() and h.is_cuda and h.dtype == torch.float32 and lin.weight.dtype == torch.float32
             and (lin.weight.requires_grad or h.requires_grad) and h.numel() // max(h.shape[-1], 1) >= WEIGHT_GRAD_OPERATOR_MIN_ROWS):
-        y = _RowsTimesMatrix.apply(h.reshape(-1, h.shape[-1]), lin.weight).reshape(*h.shape[:-1], lin.weight.shape[0])
-        return y if lin.bias is None else y + lin.bias
+        h2 = h.reshape(-1, h.shape[-1])
+        y = _RowsTimesMatrix.apply(h2, lin.weight) if lin.bias is None else _Affine.apply(h2, lin.weight, lin.bias)
+        return y.reshape(*h.shape[:-1], lin.weight.shape[0])
     return lin(h)
 
 

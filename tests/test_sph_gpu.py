@@ -85,9 +85,7 @@ def test_fused_and_operator_forms_agree_for_other_materials_and_views(fixture, m
         b = model.render(torch.from_numpy(ro).cuda()[None], torch.from_numpy(rd).cuda()[None], fused=False, **args)
         for k in ("image", "depth", "weights_sum", "diffuse_image", "specular_image", "normal_image"):
             err = rel_l2(a[k].cpu().numpy().reshape(56 * 72, -1), b[k].detach().cpu().numpy().reshape(56 * 72, -1))
-            # (the two forms differ by the last bit of `near` -- torch.bmm against the intersection kernel's op-by-op products -- which moves
-            #  all 12 samples of a ray along it: measured 3e-6 ... 3e-5; the bar is the render tolerance)
-            assert err <= 1e-4, (k, theta, err)
+            assert err <= 2e-5, (k, theta, err)                  # (both forms take their hits from envidr_sphere_intersections)
         first = a["image"] if first is None else first
     assert not torch.equal(first, a["image"])                                  # the material (and the view) did change the frame
 
@@ -165,8 +163,9 @@ def test_shell_operators_against_the_oracle(fixture):
 
 
 def test_sphere_intersections_operator_matches_the_reference_formula(fixture, model_opt):
-    """envidr_sphere_intersections vs get_sphere_intersections (the reference's torch expressions, sph_ray.py:18-32, on the CPU): the same
-    hit set away from grazing rays, near / far to a few ulp of |d.o| (torch.bmm may contract its three products; the kernel does not)"""
+    """envidr_sphere_intersections vs get_sphere_intersections on the CPU (the reference's torch expressions, sph_ray.py:18-32): the same
+    hit set away from the threshold (on the fixtures: the same hit set, test_env_sphere_render_matches_reference), near / far within the
+    fp32 rounding of the cancelling discriminant"""
     import torch
     from envidr_amd import scenes
     from envidr_amd.nerf.render_func import get_sphere_intersections
