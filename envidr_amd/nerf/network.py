@@ -155,8 +155,8 @@ class _WeightBiasGrad(torch.autograd.Function):
 def _linear(lin, h, first_order_only=False):
     """nn.Linear; in the training branch (autograd recording, a GPU batch of >= WEIGHT_GRAD_OPERATOR_MIN_ROWS rows) as x W^T + b with the
     big-batch weight gradient"""
-    if (torch.is_grad_enabled() and h.is_cuda and h.dtype == torch.float32 and lin.weight.dtype == torch.float32
-            and (lin.weight.requires_grad or h.requires_grad) and h.numel() // max(h.shape[-1], 1) >= WEIGHT_GRAD_OPERATOR_MIN_ROWS):
+    if (lin.training and torch.is_grad_enabled() and h.is_cuda and h.dtype == torch.float32 and lin.weight.dtype == torch.float32
+            and lin.weight.requires_grad and h.numel() // max(h.shape[-1], 1) >= WEIGHT_GRAD_OPERATOR_MIN_ROWS):
         h2 = h.reshape(-1, h.shape[-1])
         y = _RowsTimesMatrix.apply(h2, lin.weight) if lin.bias is None else _Affine.apply(h2, lin.weight, lin.bias)
         return y.reshape(*h.shape[:-1], lin.weight.shape[0])

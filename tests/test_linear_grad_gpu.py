@@ -31,7 +31,7 @@ def test_big_batch_linear_has_nn_linear_gradients_to_second_order():
     import torch
     from envidr_amd.nerf import network as nw
     torch.manual_seed(0)
-    l1, l2 = torch.nn.Linear(32, 64).cuda(), torch.nn.Linear(64, 15).cuda()
+    l1, l2 = torch.nn.Linear(32, 64).cuda().train(), torch.nn.Linear(64, 15).cuda().train()
     x0 = torch.randn(20000, 32, device="cuda")
     w = torch.randn(20000, 15, device="cuda")
 
@@ -64,3 +64,13 @@ def test_big_batch_linear_has_nn_linear_gradients_to_second_order():
         nw._fused.linear_weight_grad = real
     with torch.no_grad():
         assert nw._linear(l1, x0).grad_fn is None
+    # ... and in eval mode (the inference loop differentiates the SDF network w.r.t. positions only: no weight gradient to speed up)
+    l1.eval()
+    before = len(calls)
+    x = x0.clone().requires_grad_(True)
+    nw._fused.linear_weight_grad = lambda *a, **k: (calls.append(a[0].shape[0]), real(*a, **k))[1]
+    try:
+        nw._linear(l1, x).sum().backward()
+    finally:
+        nw._fused.linear_weight_grad = real
+    assert len(calls) == before
