@@ -718,13 +718,15 @@ int envidr_hash_encode_forward(const float* inputs, const float* embeddings, con
     return dispatch_dc(D, C, "hash_encode_forward", [&](auto d, auto c) {
         constexpr int DD = decltype(d)::value, CC = decltype(c)::value;
         const uint32_t row_floats = L * DD * CC;
-        if (calc_grad_inputs && row_floats <= 127)            // the rows of 128 points fit the LDS budget (64 KiB): full-line dy_dx stores
+        constexpr bool kRowsAlwaysFit = kMaxLevels * DD * CC <= 127;     // (then the level-per-workgroup form with dy_dx is not instantiated at all)
+        if (calc_grad_inputs && (kRowsAlwaysFit || row_floats <= 127)) { // the rows of 128 points fit the LDS budget (64 KiB): full-line dy_dx stores
             hipLaunchKernelGGL((k_hash_forward_rows<DD, CC>), dim3(ceil_div(B, kRowsPoints)), dim3(kBlock), kRowsPoints * (row_floats | 1u) * sizeof(float),
                                as_stream(stream), inputs, embeddings, offsets, outputs, B, L, ls, dy_dx);
-        else if (calc_grad_inputs)
-            hipLaunchKernelGGL((k_hash_forward<DD, CC, true>), grid, dim3(kBlock), 0, as_stream(stream), inputs,
-                               embeddings, offsets, outputs, B, L, ls, chunks, dy_dx);
-        else
+        } else if (calc_grad_inputs) {
+            if constexpr (!kRowsAlwaysFit)
+                hipLaunchKernelGGL((k_hash_forward<DD, CC, true>), grid, dim3(kBlock), 0, as_stream(stream), inputs,
+                                   embeddings, offsets, outputs, B, L, ls, chunks, dy_dx);
+        } else
             hipLaunchKernelGGL((k_hash_forward<DD, CC, false>), grid, dim3(kBlock), 0, as_stream(stream), inputs,
                                embeddings, offsets, outputs, B, L, ls, chunks, dy_dx);
         return check_launch("k_hash_forward");

@@ -186,6 +186,24 @@ def hash_cases():
     return out
 
 
+def hash_wide_row_cases():
+    """dy_dx rows longer than 127 floats (L D C > 127): hash_encode_forward then keeps the level-per-workgroup kernel for the
+    derivative (k_hash_forward<D, C, true>) instead of assembling rows in LDS -- every (D, C) for which such an L exists"""
+    rng = np.random.default_rng(31 + SEED_OFFSET)
+    out = []
+    for D, C, L, log2T, base, desired in [(2, 4, 16, 10, 4, 300), (2, 8, 8, 9, 4, 64), (3, 4, 11, 11, 4, 100), (3, 8, 6, 10, 4, 40),
+                                           (3, 2, 22, 9, 2, 400), (2, 2, 32, 8, 2, 1000)]:
+        offsets, pls = scenes.hash_level_offsets(D, L, base, log2T, desired)
+        S = float(np.log2(pls))
+        B = 200
+        x = _points(rng, B, D)
+        table = rng.uniform(-1, 1, size=(int(offsets[-1]), C)).astype(F)
+        assert L * D * C > 127
+        out.append((f"D{D}C{C}L{L}_fwd_grad", "hash_encode_forward",
+                    (x, table, offsets, np.zeros((L, B, C), F), B, D, C, L, S, base, 1, np.zeros((B, L * D * C), F)), None))
+    return out
+
+
 def hash_backward_cases():
     from oracle import clib
     rng = np.random.default_rng(16 + SEED_OFFSET)
@@ -498,7 +516,7 @@ def reference_adds_nothing(cid: str, op: str) -> bool:
 ALL_GROUPS = {
     "near_far": near_far_cases, "misc": misc_cases, "march": march_cases, "composite": composite_cases,
     "train": train_cases, "hash": hash_cases, "hash_bwd": hash_backward_cases, "grid": grid_cases,
-    "grid_bwd": grid_backward_cases, "sweep": encoder_sweep_cases, "freq_sh": freq_sh_cases, "ide": ide_cases, "half": half_cases, "sweep_half": half_sweep_cases,
+    "hash_wide": hash_wide_row_cases, "grid_bwd": grid_backward_cases, "sweep": encoder_sweep_cases, "freq_sh": freq_sh_cases, "ide": ide_cases, "half": half_cases, "sweep_half": half_sweep_cases,
 }
 
 

@@ -201,3 +201,29 @@ def test_every_operator_takes_an_empty_batch_as_a_no_op():
     assert set(empty) | {"compact_alive"} == set(_lib.SIGNATURES), set(_lib.SIGNATURES) ^ set(empty)
     for name, args in empty.items():
         _lib.call(name, *args, stream=0)          # raises EnvidrError on any non-zero return code
+
+
+def test_round5_entry_points_validate_their_arguments():
+    """the env-sphere operators and the weight gradient reject null pointers / impossible sizes before launching anything (no GPU needed)"""
+    from envidr_amd import _lib, fused
+    lib = _lib.load()
+    fused._bind_render(lib)
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.envidr_sphere_intersections(None, None, 0, 1.0, None, None, None, None) == 0                      # N = 0: no-op
+    assert lib.envidr_sphere_intersections(None, None, 4, 1.0, None, None, None, None) == -1 and b"null pointer" in lib.envidr_last_error()
+    assert lib.envidr_shell_samples(None, None, None, None, None, None, 0.002, 0, 12, None, None, None, None) == 0   # M = 0
+    assert lib.envidr_shell_samples(None, None, None, None, None, None, 0.002, 4, 12, None, None, None, None) == -1
+    args = [None] * 10 + [0, 0, 12, 0.002, 1.0] + [None] * 8
+    assert lib.envidr_composite_shell(*args) == 0                                                                 # N = 0
+    args[10] = 4
+    assert lib.envidr_composite_shell(*args) == -1 and b"null pointer" in lib.envidr_last_error()
+    # S = 0 and images without their per-sample inputs
+    ok = [p, p, p, p, None, None, p, p, p, p, 4, 2, 0, 0.002, 1.0, p, p, p, None, None, None, None, None]
+    assert lib.envidr_composite_shell(*ok) == -1 and b"S must be" in lib.envidr_last_error()
+    ok[12] = 12
+    ok[18] = p                                                                                                    # normal_image without normals
+    assert lib.envidr_composite_shell(*ok) == -1 and b"normal_image" in lib.envidr_last_error()
+    assert lib.envidr_linear_weight_grad_workspace_bytes(0, 8, 8) == 0 and lib.envidr_linear_weight_grad_workspace_bytes(1000, 256, 256) > 0
+    assert lib.envidr_linear_weight_grad(None, None, 10, 0, 4, p, None, 0, None, 0, None) == -1 and b"empty layer" in lib.envidr_last_error()
+    assert lib.envidr_linear_weight_grad(None, None, 10, 4, 4, p, None, 0, None, 0, None) == -1 and b"null pointer" in lib.envidr_last_error()

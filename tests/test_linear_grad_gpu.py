@@ -74,3 +74,31 @@ def test_big_batch_linear_has_nn_linear_gradients_to_second_order():
     finally:
         nw._fused.linear_weight_grad = real
     assert len(calls) == before
+
+
+def test_accumulate_and_empty_batches():
+    """accumulate != 0 adds to dW / db; an empty batch leaves them (accumulate) or zeroes them; the workspace size is what the call checks"""
+    import ctypes
+    import torch
+    from envidr_amd import _lib
+    from envidr_amd.fused import _bind_render
+    lib = _lib.load()
+    _bind_render(lib)
+    M, K, N = 5000, 24, 32
+    x, gy = torch.randn(M, K, device="cuda"), torch.randn(M, N, device="cuda")
+    dW, db = torch.full((N, K), 2.0, device="cuda"), torch.full((N,), -1.0, device="cuda")
+    nbytes = int(lib.envidr_linear_weight_grad_workspace_bytes(M, K, N))
+    ws = torch.empty(nbytes // 4, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    assert lib.envidr_linear_weight_grad(x.data_ptr(), gy.data_ptr(), M, K, N, dW.data_ptr(), db.data_ptr(), 1, ws.data_ptr(), nbytes, s) == 0
+    torch.cuda.synchronize()
+    assert torch.allclose(dW, 2.0 + gy.t() @ x, atol=2e-4) and torch.allclose(db, -1.0 + gy.sum(0), atol=2e-4)
+    before = dW.clone()
+    assert lib.envidr_linear_weight_grad(None, None, 0, K, N, dW.data_ptr(), db.data_ptr(), 1, None, 0, s) == 0          # empty, accumulate: untouched
+    torch.cuda.synchronize()
+    assert torch.equal(dW, before)
+    assert lib.envidr_linear_weight_grad(None, None, 0, K, N, dW.data_ptr(), db.data_ptr(), 0, None, 0, s) == 0          # empty, overwrite: zeros
+    torch.cuda.synchronize()
+    assert not dW.any() and not db.any()
+    assert lib.envidr_linear_weight_grad(x.data_ptr(), gy.data_ptr(), M, K, N, dW.data_ptr(), None, 0, ws.data_ptr(), nbytes - 16, s) == -1
+    assert b"workspace" in lib.envidr_last_error()

@@ -29,6 +29,9 @@ PYTHONUNBUFFERED=1 timeout 300 python tools/ops_bench.py > $OUT/ops_bench.txt 2>
 # the reference-shaped operator loop on the headline frame, and one training step
 timeout 300 python tools/loop_frame_bench.py > $OUT/loop_frame_bench.txt 2>&1
 timeout 300 python tools/train_step_bench.py > $OUT/train_step_bench.txt 2>&1
+# where a training step's time goes (kernel stats of 20 steps) and the env-sphere frame by stage
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -o t -- python $GRAFT_REPO_ROOT/tools/train_step_bench.py 20 > $OUT/trace_train.log 2>&1 )
+timeout 300 python tools/sph_stage_times.py > $OUT/sph_stage_times.txt 2>&1
 # every operator case group re-generated with other seeds, HIP against oracle
 timeout 900 python tools/fuzz_ops.py 1 8 > $OUT/fuzz_ops.txt 2>&1
 # randomised differential run of the two frame implementations
@@ -84,6 +87,8 @@ cp $OUT/bench.json $OUT/summary.json $P/ 2>/dev/null
 cp $OUT/bench_force_dist.json $OUT/bench_strong.json $OUT/bench_torchrun.json $OUT/gather_probe.txt $OUT/mfma_f16_fill_probe.txt $OUT/mfma_f32_fill_probe.txt $OUT/mfma_vmem_probe.txt $OUT/cross_wave_probe.txt $OUT/lds_atomic_probe.txt $OUT/coissue_probe.txt $OUT/shard_probe.txt $OUT/fuzz_frames.txt $OUT/fuzz_ops.txt $OUT/ops_bench.txt $OUT/loop_frame_bench.txt $OUT/train_step_bench.txt $P/ 2>/dev/null
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $P/kernel_stats.csv \;
 find $OUT/trace_hinted -name "*kernel_stats.csv" -exec cp {} $P/kernel_stats_hinted.csv \;
+find $OUT/trace_train -name "*kernel_stats.csv" -exec cp {} $P/kernel_stats_train_step.csv \;
+cp $OUT/sph_stage_times.txt $P/ 2>/dev/null
 for d in $OUT/pmc_*/; do n=$(basename $d); find $d -name "*counter_collection.csv" -exec cp {} $P/$n.csv \; ; done
 tail -5 $OUT/pytest_gpu.log > $P/pytest_gpu_tail.txt; tail -2 $OUT/smoke.log >> $P/pytest_gpu_tail.txt
 
