@@ -1,6 +1,7 @@
 """TEST INFRASTRUCTURE: ctypes access to
     * oracle/_build/libenvidr_oracle.so -- our plain-C restatement (oracle/c/envidr_oracle.c), prefix `oracle_`
     * oracle/_ref/libenvidr_ref.so      -- the reference's own kernel bodies on the CPU (oracle/ref), prefix `ref_`
+    * oracle/_ref/libenvidr_ref_hip.so  -- the same kernel text compiled by hipcc, run on the GPU (device pointers)
 Both expose the C-ABI of include/envidr_amd.h minus the stream argument, on host pointers, so the
 same argument tuples drive the oracle, the reference bodies and (via envidr_amd._lib) the HIP library.
 """
@@ -53,6 +54,8 @@ class HostLib:
             if kind == "p":
                 if a is None:
                     conv.append(None)
+                elif isinstance(a, int):
+                    conv.append(a)                                   # a device address (ref_hip)
                 else:
                     assert isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"], f"{name}: need contiguous ndarray"
                     conv.append(a.ctypes.data)
@@ -74,6 +77,25 @@ def oracle() -> HostLib:
     if _oracle is None:
         _oracle = HostLib(build_oracle(), "oracle_")
     return _oracle
+
+
+REF_HIP_LIB = HERE / "_ref" / "libenvidr_ref_hip.so"
+_ref_hip: HostLib | None = None
+
+
+def ref_hip_available() -> bool:
+    return REF_HIP_LIB.exists()
+
+
+def ref_hip() -> HostLib:
+    """The reference's kernels compiled by hipcc for the GPU (oracle/ref/device_keywords.h).  Same entry points as ref(), but the
+    pointer arguments are DEVICE addresses: call it through tests/util.py run_op("refhip", ...), which stages the arrays."""
+    global _ref_hip
+    if _ref_hip is None:
+        if not REF_HIP_LIB.exists():
+            raise FileNotFoundError(f"{REF_HIP_LIB} not built; run `python oracle/ref/build_ref.py` where /root/reference exists")
+        _ref_hip = HostLib(REF_HIP_LIB, "ref_")
+    return _ref_hip
 
 
 def ref_available() -> bool:

@@ -79,3 +79,4 @@ static inline void emu_launch(uint32_t grid_x, uint32_t grid_y, uint32_t block_x
             }
 }
 static inline uint32_t emu_blocks(uint32_t n, uint32_t block) { return (n + block - 1) / block; }
+#define EMU_LAMBDA [&]          /* (the device build captures by value: device_keywords.h) */

@@ -50,11 +50,14 @@ def _compare(cid, op, got, want, tol):
 
 def _regroup_train(out):
     """march_rays_train writes rays in atomic-arrival order: regroup per ray id for comparison."""
-    xyzs, dirs, deltas, rays, counter = out[6], out[7], out[8], out[9], out[10]
+    # pointer arguments in order: rays_o, rays_d, grid, nears, fars, xyzs, dirs, deltas, rays, counter, noises
+    xyzs, dirs, deltas, rays, counter = out[5], out[6], out[7], out[8], out[9]
+    assert rays.dtype == np.int32 and rays.ndim == 2 and counter.dtype == np.int32 and counter.shape == (2,)
     n_rays = int(counter[1])
     per_ray = {}
     for idx, off, cnt in rays[:n_rays]:
         per_ray[int(idx)] = (xyzs[off:off + cnt].copy(), dirs[off:off + cnt].copy(), deltas[off:off + cnt].copy())
+    assert len(per_ray) > 100, "vacuous comparison: no rays regrouped"
     return per_ray, counter.copy()
 
 

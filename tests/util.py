@@ -21,12 +21,19 @@ def run_op(backend: str, name: str, *args):
         work = [np.ascontiguousarray(a).copy() if (k == "p" and a is not None) else a for k, a in zip(sig, args)]
         lib.call(name, *work)
         return [w for k, w in zip(sig, work) if k == "p"]
-    assert backend in ("hip", "shim")
+    assert backend in ("hip", "shim", "refhip")
     import torch
     from envidr_amd import _lib
     dev = torch.device("cuda:0")
     work = [torch.from_numpy(np.ascontiguousarray(a).copy()).to(dev) if (k == "p" and a is not None) else a
             for k, a in zip(sig, args)]
+    if backend == "refhip":
+        # the reference's own kernels, compiled by hipcc, on the same device arrays (oracle/ref/device_keywords.h)
+        from oracle import clib
+        torch.cuda.synchronize()
+        clib.ref_hip().call(name, *[(w.data_ptr() if isinstance(w, torch.Tensor) else w) for w in work])
+        torch.cuda.synchronize()
+        return [None if w is None else w.cpu().numpy() for k, w in zip(sig, work) if k == "p"]
     if backend == "shim":
         # through the reference-named backend modules (envidr_amd.compat): `<pkg>._ext._<pkg>.<name>(tensors...)`
         from envidr_amd.compat.backends import EXTENSIONS, make_backend
