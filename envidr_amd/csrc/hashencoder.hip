@@ -2,10 +2,10 @@
 // derivative) -- replaces hashencoder/src/hashencoder.cu (hash_encode_forward :725,
 // hash_encode_backward :762, hash_encode_second_backward :795; declarations hashencoder.h:13-15).
 //
-// Work decomposition: one lane per (point, level).  Workgroups are mapped so that each XCD works
-// on one level at a time (level = f(block % 8)): a hashed level's table is 4 MiB, exactly one
-// XCD's L2, so the random 8-byte gathers of that level stay L2-resident on the XCD that owns it
-// instead of every XCD thrashing all 16 tables.
+// Work decomposition: one lane per (point, level).  The forward kernels run their blocks in level-major order (the chip sweeps the
+// levels together); the per-point table scatters still map blocks so that each XCD works on one level at a time (level = f(block % 8):
+// a hashed level's 4 MiB table then meets its atomics in ONE L2).  With dy_dx, and for the input gradient, a workgroup owns 128 points
+// for all levels and moves the dy_dx rows through LDS (k_hash_forward_rows, k_input_backward_rows).
 #include "grid_core.hip.h"
 #include <algorithm>
 #include <map>
@@ -51,8 +51,12 @@ __global__ void __launch_bounds__(kBlock) k_hash_forward(const float* __restrict
                                                          const int32_t* __restrict__ offsets,
                                                          float* __restrict__ outputs, uint32_t B, uint32_t L,
                                                          LevelScale ls, uint32_t chunks, float* __restrict__ dy_dx) {
-    uint32_t level, chunk;
-    if (!xcd_level_chunk(L, chunks, level, chunk)) return;
+    // blocks in level-major order (all chunks of level 0, then level 1 ...): the chip sweeps the levels together.  Rounds 1-4 pinned levels
+    // to XCDs here (block % 8 -> level) so that a level's 4 MiB table stays in ONE L2; timed against the reference's own kernel compiled
+    // for this GPU (tools/ops_bench.py) that was the slower choice on every input order -- the XCDs finish their levels at different times
+    // (coarse levels hit, fine ones miss) and the others' L2s sit idle: 3.87 -> 3.50 ms on random points, 2.54 -> 1.80 ms on a frame's
+    // ray-major samples, 3.15 -> 2.64 ms sample-major.
+    const uint32_t level = blockIdx.x / chunks, chunk = blockIdx.x - level * chunks;
     const uint32_t b = chunk * blockDim.x + threadIdx.x;
     if (b >= B) return;
 
@@ -91,10 +95,12 @@ __global__ void __launch_bounds__(kBlock) k_hash_forward(const float* __restrict
 // the levels of parity h -- parks the derivatives in LDS (row pitch odd: conflict-free) and writes the 128 rows, which are one contiguous range
 // of dy_dx, as full lines.  Same arithmetic per (point, level) as k_hash_forward: same bits.
 constexpr uint32_t kRowsPoints = 128;
+// e / d for e < kRowsPoints * 127 as one multiply-high: M = floor(2^32 / d) + 1 is exact while e (M d - 2^32) < 2^32, i.e. for e < 2^32 / d
+inline uint32_t row_division_magic(uint32_t d) { return (uint32_t)((1ull << 32) / d) + 1u; }
 template <int D, int C>
 __global__ void __launch_bounds__(kBlock) k_hash_forward_rows(const float* __restrict__ inputs, const float* __restrict__ embeddings,
                                                               const int32_t* __restrict__ offsets, float* __restrict__ outputs, uint32_t B,
-                                                              uint32_t L, LevelScale ls, float* __restrict__ dy_dx) {
+                                                              uint32_t L, LevelScale ls, float* __restrict__ dy_dx, uint32_t row_magic) {
     extern __shared__ float s_rows[];                       // [kRowsPoints][pitch]
     const uint32_t row_floats = L * D * C, pitch = row_floats | 1u;
     const uint32_t p = threadIdx.x & (kRowsPoints - 1), par = threadIdx.x >> 7;
@@ -131,7 +137,7 @@ __global__ void __launch_bounds__(kBlock) k_hash_forward_rows(const float* __res
     const uint32_t points = min(kRowsPoints, B - b0);
     float* dst = dy_dx + (size_t)b0 * row_floats;
     for (uint32_t e = threadIdx.x; e < points * row_floats; e += kBlock) {
-        const uint32_t q = e / row_floats, col = e - q * row_floats;
+        const uint32_t q = __umulhi(e, row_magic), col = e - q * row_floats;          // e / row_floats (row_division_magic)
         dst[e] = s_rows[q * pitch + col];
     }
 }
@@ -213,6 +219,54 @@ __global__ void __launch_bounds__(kBlock) k_input_backward(const float* __restri
         for (int c = 0; c < C; ++c) acc += grad[((size_t)l * B + b) * C + c] * j[(size_t)l * D * C + c];
     }
     grad_inputs[t] = acc;
+}
+
+// The same sum with the dy_dx rows staged through LDS: a point's row is L D C contiguous floats and the D lanes of a point read
+// interleaved 4 C-byte pieces of it -- every load instruction of the kernel above touches 64 pieces spread over 8 KiB.  Here a
+// workgroup copies the rows of 128 points (one contiguous range) with 16-byte loads into LDS (odd pitch) and the (point, dimension)
+// lanes walk their rows there; same order of additions, same bits.  1.27 -> 0.8 ms at 7.7 M points (the reference's kernel compiled
+// for this GPU: 0.87 ms).
+template <int D, int C>
+__global__ void __launch_bounds__(kBlock) k_input_backward_rows(const float* __restrict__ grad, const float* __restrict__ dy_dx,
+                                                               float* __restrict__ grad_inputs, uint32_t B, uint32_t L, uint32_t row_magic) {
+    extern __shared__ float s_jrows[];
+    const uint32_t row_floats = L * D * C, pitch = row_floats | 1u;
+    const uint32_t b0 = blockIdx.x * kRowsPoints, points = min(kRowsPoints, B - b0);
+    const float* src = dy_dx + (size_t)b0 * row_floats;
+    const uint32_t total = points * row_floats;
+    if (((reinterpret_cast<uintptr_t>(src) & 15u) == 0)) {
+        for (uint32_t e = threadIdx.x * 4; e < total; e += kBlock * 4) {
+            if (e + 3 < total) {
+                const float4 v = *reinterpret_cast<const float4*>(src + e);
+                const float q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) { const uint32_t p = __umulhi(e + k, row_magic); s_jrows[(e + k) + p * (pitch - row_floats)] = q[k]; }
+            } else {
+                for (uint32_t k = e; k < total; ++k) { const uint32_t p = __umulhi(k, row_magic); s_jrows[k + p * (pitch - row_floats)] = src[k]; }
+            }
+        }
+    } else {
+        for (uint32_t e = threadIdx.x; e < total; e += kBlock) { const uint32_t p = __umulhi(e, row_magic); s_jrows[e + p * (pitch - row_floats)] = src[e]; }
+    }
+    __syncthreads();
+    // one lane per POINT: a level's C gradient values are loaded once (contiguous across the lanes) and feed all D sums; per (point,
+    // dimension) the additions still run l outer, c inner
+    for (uint32_t p = threadIdx.x; p < points; p += kBlock) {
+        const uint32_t b = b0 + p;
+        const float* j = s_jrows + p * pitch;
+        float acc[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[d] = 0;
+        for (uint32_t l = 0; l < L; ++l) {
+            const Feat<C> g = load_row<C>(grad + (size_t)l * B * C, b);         // grad[l][b][0 .. C-1]
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[d] += g.v[c] * j[l * D * C + d * C + c];
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) grad_inputs[(size_t)b * D + d] = acc[d];
+    }
 }
 
 // grad_grad[l,b,c] = sum_d ggx[b,d] * dy_dx[b,l,d,c]              (hashencoder.cu:375-428)
@@ -714,14 +768,14 @@ int envidr_hash_encode_forward(const float* inputs, const float* embeddings, con
     ENVIDR_REQUIRE(!calc_grad_inputs || dy_dx, "hash_encode_forward: dy_dx is null but calc_grad_inputs is set");
     const LevelScale ls = make_level_scale(L, S, H);
     const uint32_t chunks = ceil_div(B, kBlock);
-    const dim3 grid(xcd_grid_blocks(L, chunks));
+    const dim3 grid(L * chunks);
     return dispatch_dc(D, C, "hash_encode_forward", [&](auto d, auto c) {
         constexpr int DD = decltype(d)::value, CC = decltype(c)::value;
         const uint32_t row_floats = L * DD * CC;
         constexpr bool kRowsAlwaysFit = kMaxLevels * DD * CC <= 127;     // (then the level-per-workgroup form with dy_dx is not instantiated at all)
         if (calc_grad_inputs && (kRowsAlwaysFit || row_floats <= 127)) { // the rows of 128 points fit the LDS budget (64 KiB): full-line dy_dx stores
             hipLaunchKernelGGL((k_hash_forward_rows<DD, CC>), dim3(ceil_div(B, kRowsPoints)), dim3(kBlock), kRowsPoints * (row_floats | 1u) * sizeof(float),
-                               as_stream(stream), inputs, embeddings, offsets, outputs, B, L, ls, dy_dx);
+                               as_stream(stream), inputs, embeddings, offsets, outputs, B, L, ls, dy_dx, row_division_magic(row_floats));
         } else if (calc_grad_inputs) {
             if constexpr (!kRowsAlwaysFit)
                 hipLaunchKernelGGL((k_hash_forward<DD, CC, true>), grid, dim3(kBlock), 0, as_stream(stream), inputs,
@@ -756,8 +810,13 @@ int envidr_hash_encode_backward(const float* grad, const float* inputs, const fl
             if (rc) return rc;
         }
         if (calc_grad_inputs) {
-            hipLaunchKernelGGL((k_input_backward<DD, CC>), dim3(ceil_div(B * DD, kBlock)), dim3(kBlock), 0,
-                               as_stream(stream), grad, dy_dx, grad_inputs, B, L);
+            const uint32_t row_floats = L * DD * CC;
+            if (row_floats <= 127)
+                hipLaunchKernelGGL((k_input_backward_rows<DD, CC>), dim3(ceil_div(B, kRowsPoints)), dim3(kBlock), kRowsPoints * (row_floats | 1u) * sizeof(float),
+                                   as_stream(stream), grad, dy_dx, grad_inputs, B, L, row_division_magic(row_floats));
+            else
+                hipLaunchKernelGGL((k_input_backward<DD, CC>), dim3(ceil_div(B * DD, kBlock)), dim3(kBlock), 0,
+                                   as_stream(stream), grad, dy_dx, grad_inputs, B, L);
             return check_launch("k_input_backward");
         }
         return ENVIDR_OK;
