@@ -339,7 +339,8 @@ __global__ void __launch_bounds__(kBlock) k_compact_alive(uint32_t n_alive, cons
 // ---------------------------------------------------------------------------------------------
 // training marcher (reference kernel_march_rays_train, raymarching.cu:340-508)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_march_rays_train(const float* __restrict__ rays_o,
+template <int BLOCK, int kTimeCache>
+__global__ void __launch_bounds__(BLOCK) k_march_rays_train(const float* __restrict__ rays_o,
                                                              const float* __restrict__ rays_d, MarchConsts k,
                                                              uint32_t early_stop_steps, uint32_t N, uint32_t M,
                                                              const float* __restrict__ nears,
@@ -348,13 +349,10 @@ __global__ void __launch_bounds__(kBlock) k_march_rays_train(const float* __rest
                                                              float* __restrict__ deltas, int32_t* __restrict__ rays,
                                                              int32_t* __restrict__ counter,
                                                              const float* __restrict__ noises) {
-    // A training batch is a few thousand rays: sixteen workgroups on 256 CUs, so the kernel's run time is the LATENCY of one ray's
-    // walk (a dependent bitfield load per cell), and the reference's second pass walks it all again.  The ray times of the first
-    // kTimeCache samples found by the counting pass stay in LDS ([sample][thread]: conflict-free); position and step are pure
-    // functions of that time (march_visit), so the write pass replays them -- same statements, same bits -- and only marches on
-    // from where the cache ends.
-    constexpr uint32_t kTimeCache = 48;
-    __shared__ float s_time[kTimeCache][kBlock];
+    // The reference's second pass walks every ray again.  The ray times of the first kTimeCache samples found by the counting pass stay
+    // in LDS ([sample][thread]: conflict-free); position and step are pure functions of that time (march_visit), so the write pass
+    // replays them -- same statements, same bits -- and only marches on from where the cache ends.
+    __shared__ float s_time[kTimeCache][BLOCK];
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const RayGeom r = load_ray(rays_o, rays_d, n);
@@ -392,23 +390,39 @@ __global__ void __launch_bounds__(kBlock) k_march_rays_train(const float* __rest
     float* px = xyzs + (size_t)point_index * 3;
     float* pd = dirs + (size_t)point_index * 3;
     float* pl = deltas + (size_t)point_index * 2;
-    t = t0;
     float last_t = near;
-    for (uint32_t s = 0; s < num_steps; ++s) {
-        if (s < kTimeCache) {
-            const float ts = s_time[s][threadIdx.x];
-            x = clampf(r.ox + ts * r.dx, -k.bound, k.bound);          // the statements of march_visit at the sample's time
-            y = clampf(r.oy + ts * r.dy, -k.bound, k.bound);
-            z = clampf(r.oz + ts * r.dz, -k.bound, k.bound);
-            dt = step_size(k, ts);
-            t = ts + dt;
-        } else if (!march_next(k, r, far, t, x, y, z, dt)) break;
+    auto emit = [&]() {
         px[0] = x; px[1] = y; px[2] = z;
         pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
         pl[0] = dt;
         pl[1] = t - last_t;
         last_t = t;
         px += 3; pd += 3; pl += 2;
+    };
+    const uint32_t cached = min(num_steps, (uint32_t)kTimeCache);
+    t = t0;
+    for (uint32_t s = 0; s < cached; ++s) {
+        const float ts = s_time[s][threadIdx.x];
+        x = clampf(r.ox + ts * r.dx, -k.bound, k.bound);          // the statements of march_visit at the sample's time
+        y = clampf(r.oy + ts * r.dy, -k.bound, k.bound);
+        z = clampf(r.oz + ts * r.dz, -k.bound, k.bound);
+        dt = step_size(k, ts);
+        t = ts + dt;
+        emit();
+    }
+    // past the cache: march on, again one cell visit per iteration
+    uint32_t s = cached;
+    auto rest = [&](auto pow2) {
+        while (t < far && s < num_steps) {
+            if (march_visit<decltype(pow2)::value>(k, r, t, x, y, z, dt)) {
+                t += dt;
+                emit();
+                ++s;
+            }
+        }
+    };
+    if (s < num_steps) {
+        if (k.H_pow2) rest(std::true_type{}); else rest(std::false_type{});
     }
 }
 
@@ -648,8 +662,16 @@ int envidr_march_rays_train(const float* rays_o, const float* rays_d, const uint
                    "march_rays_train: null pointer");
     ENVIDR_REQUIRE(C >= 1 && H >= 1 && max_steps >= 1, "march_rays_train: C, H, max_steps must be >= 1");
     const MarchConsts k = make_march_consts(bound, dt_gamma, max_steps, C, H, grid);
-    LAUNCH_1D(k_march_rays_train, N, stream, rays_o, rays_d, k, early_stop_steps, N, M, nears, fars, xyzs, dirs,
-              deltas, rays, counter, noises);
+    if (N == 0) return ENVIDR_OK;
+    // A training batch is a few thousand rays: the run time is the latency of the longest walk, so one wave per workgroup (every wave on
+    // its own CU) and a cache that holds nearly every ray's samples; a frame-sized call is throughput bound and keeps the LDS footprint
+    // per wave small.  Measured, profiles/r05l/march_train_probe.txt.
+#define MARCH_TRAIN(B, T) hipLaunchKernelGGL((k_march_rays_train<B, T>), dim3(ceil_div(N, (uint32_t)B)), dim3(B), 0, as_stream(stream), \
+                                              rays_o, rays_d, k, early_stop_steps, N, M, nears, fars, xyzs, dirs, deltas, rays, counter, noises)
+    if (N <= 32768u) MARCH_TRAIN(64, 192);
+    else MARCH_TRAIN(256, 48);
+#undef MARCH_TRAIN
+    return check_launch("k_march_rays_train");
 }
 
 int envidr_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas,

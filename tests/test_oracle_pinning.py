@@ -184,8 +184,11 @@ def test_march_integer_trace_survives_fma_contraction(cid, op, args, tol, ref_li
 
 def test_training_marcher_trace_survives_fma_contraction(ref_lib, ref_fma_lib):
     for cid, op, args, tol in cases.train_cases():
-        if op != "march_rays_train":
+        if op != "march_rays_train" or cid == "march_train_frame":     # (frame-sized ray sets: the test below, with its measured fraction)
             continue
+        # (perturb off: the jittered start `near + dt * noise` is one multiply-add, which contraction rounds once instead of twice --
+        #  a different start time is a different, equally valid, sample train, not a change of trace)
+        args = args[:-1] + (np.zeros_like(args[-1]),)
         plain, fused = _run_on(ref_lib, op, args), _run_on(ref_fma_lib, op, args)
         # pointer outputs of march_rays_train: ... nears, fars, xyzs, dirs, deltas, rays [N,3] int32, counter, noises
         rays_a, rays_b = plain[-3], fused[-3]

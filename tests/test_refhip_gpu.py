@@ -54,7 +54,14 @@ def test_operator_matches_the_references_kernel_on_this_gpu(cid, op, args, tol, 
         a, b = _regroup(ours), _regroup(theirs)
         both = [r for r in a if r in b and a[r][2].shape == b[r][2].shape]
         assert len(both) >= 0.9 * max(len(a), len(b)) and len(both) > 100
+        # perturbed starts: `near + dt * noise` is one multiply-add, which the device build contracts (one rounding instead of two), so the
+        # whole sample train of a ray may sit one rounding of t away; without jitter step sizes and sample times are identical bits
+        jitter = bool(np.any(args[-1] != 0))
         for r in both:
+            if jitter:
+                assert bits_equal(a[r][1], b[r][1]) and np.abs(a[r][2] - b[r][2]).max() <= 1e-6, f"{cid}: ray {r}: step sizes / sample times differ"
+                assert np.abs(a[r][0] - b[r][0]).max() <= 1e-6 * float(args[3]), f"{cid}: ray {r}: positions beyond the start time's rounding"
+                continue
             assert bits_equal(a[r][2], b[r][2]) and bits_equal(a[r][1], b[r][1]), f"{cid}: ray {r}: step sizes / sample times differ"
             assert np.abs(a[r][0] - b[r][0]).max() <= 2.4e-7 * float(args[3]), f"{cid}: ray {r}: positions beyond the product's last bit"
         return

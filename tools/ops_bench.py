@@ -28,12 +28,14 @@ except Exception:       # noqa: BLE001
 def ref_ms(name, args, reps=3):
     if REF is None or not REF.has(name):
         return None
-    conv = [a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args]
-    REF.call(name, *conv); torch.cuda.synchronize()
+    # `args` may be a list of argument tuples, one per call (kernels that consume their input, e.g. the compositor's alive list)
+    per_call = args if isinstance(args, list) else [args] * (reps + 1)
+    conv = [[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in one] for one in per_call]
+    REF.call(name, *conv[0]); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        REF.call(name, *conv)
+    for i in range(reps):
+        REF.call(name, *conv[1 + i])
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 def bench(name, fn, bytes_, reps=10, note="", ref=None):
@@ -140,15 +142,19 @@ ws, dp, im = torch.zeros(N, device=dev), torch.zeros(N, device=dev), torch.zeros
 als = [torch.arange(N, dtype=torch.int32, device=dev) for _ in range(12)]      # the compositor tombstones finished rays (-1): a fresh list per call
 it = iter(als)
 bench("composite_rays (640 k rays x 8 samples)", lambda: _lib.call("composite_rays", N, n_step, 1e-4, 1, 0, next(it), rt, sig, rgb, dl, ws, dp, im),
-      N * (n_step * 24 + 8 + 40))
+      N * (n_step * 24 + 8 + 40), ref=("composite_rays", [(N, n_step, 1e-4, 1, 0, torch.arange(N, dtype=torch.int32, device=dev), rt, sig, rgb, dl, ws, dp, im) for _ in range(4)]))
 g27 = torch.randn(M, 27, device=dev); gi3 = torch.zeros(M, 3, device=dev)
-bench("freq_encode_backward (7.7 M, degree 4)", lambda: _lib.call("freq_encode_backward", g27, o27, M, 3, 4, 27, gi3), M * (108 + 108 + 12))
+bench("freq_encode_backward (7.7 M, degree 4)", lambda: _lib.call("freq_encode_backward", g27, o27, M, 3, 4, 27, gi3), M * (108 + 108 + 12),
+      ref=("freq_encode_backward", (g27, o27, M, 3, 4, 27, gi3)))
 dy48 = torch.empty(M, 48, device=dev)
-bench("sh_encode_forward (7.7 M, degree 4, + dy_dx)", lambda: _lib.call("sh_encode_forward", d, o16, M, 3, 4, dy48), M * (12 + 64 + 192))
+bench("sh_encode_forward (7.7 M, degree 4, + dy_dx)", lambda: _lib.call("sh_encode_forward", d, o16, M, 3, 4, dy48), M * (12 + 64 + 192),
+      ref=("sh_encode_forward", (d, o16, M, 3, 4, dy48)))
 g16 = torch.randn(M, 16, device=dev)
-bench("sh_encode_backward (7.7 M, degree 4)", lambda: _lib.call("sh_encode_backward", g16, d, M, 3, 4, dy48, gi3), M * (64 + 192 + 24))
+bench("sh_encode_backward (7.7 M, degree 4)", lambda: _lib.call("sh_encode_backward", g16, d, M, 3, 4, dy48, gi3), M * (64 + 192 + 24),
+      ref=("sh_encode_backward", (g16, d, M, 3, 4, dy48, gi3)))
 grid = torch.rand(128 ** 3, device=dev); bits = torch.zeros(128 ** 3 // 8, dtype=torch.uint8, device=dev)
-bench("packbits (128^3 cells)", lambda: _lib.call("packbits", grid, 128 ** 3 // 8, 0.01, bits), 128 ** 3 * 4 + 128 ** 3 // 8, note="N counts bytes of the bitfield, like the reference")
+bench("packbits (128^3 cells)", lambda: _lib.call("packbits", grid, 128 ** 3 // 8, 0.01, bits), 128 ** 3 * 4 + 128 ** 3 // 8, note="N counts bytes of the bitfield, like the reference",
+      ref=("packbits", (grid, 128 ** 3 // 8, 0.01, bits)))
 print()
 print("| operator | ms | algorithmic MB | GB/s | of 8 TB/s (HBM roofline) | of the 6.3 TB/s a copy reaches | the reference's kernel, compiled by hipcc, on this GPU |")
 print("|---|---|---|---|---|---|---|")
