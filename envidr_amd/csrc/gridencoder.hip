@@ -7,6 +7,7 @@
 // Same XCD-aware level scheduling as hashencoder.hip; the per-point math is grid_core.hip.h's
 // eval_level<SMOOTH=false>.
 #include "grid_core.hip.h"
+#include "input_rows.hip.h"
 
 using namespace envidr;
 
@@ -212,8 +213,11 @@ int envidr_grid_encode_backward(const float* grad, const float* inputs, const fl
         int rc = check_launch("k_grid_backward_table");
         if (rc) return rc;
         if (dy_dx) {
-            hipLaunchKernelGGL((k_grid_input_backward<DD, CC>), dim3(ceil_div(B * DD, kBlock)), dim3(kBlock), 0,
-                               as_stream(stream), grad, dy_dx, grad_inputs, B, L);
+            if (input_rows_fit(L, DD, CC))
+                launch_input_backward_rows<DD, CC>(grad, dy_dx, grad_inputs, B, L, as_stream(stream));
+            else
+                hipLaunchKernelGGL((k_grid_input_backward<DD, CC>), dim3(ceil_div(B * DD, kBlock)), dim3(kBlock), 0,
+                                   as_stream(stream), grad, dy_dx, grad_inputs, B, L);
             rc = check_launch("k_grid_input_backward");
         }
         return rc;

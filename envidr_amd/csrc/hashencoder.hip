@@ -4,9 +4,10 @@
 //
 // Work decomposition: one lane per (point, level).  The forward kernels run their blocks in level-major order (the chip sweeps the
 // levels together); the per-point table scatters still map blocks so that each XCD works on one level at a time (level = f(block % 8):
-// a hashed level's 4 MiB table then meets its atomics in ONE L2).  With dy_dx, and for the input gradient, a workgroup owns 128 points
-// for all levels and moves the dy_dx rows through LDS (k_hash_forward_rows, k_input_backward_rows).
+// a hashed level's 4 MiB table then meets its atomics in ONE L2).  With dy_dx a workgroup owns 128 points for all levels and assembles
+// their dy_dx rows in LDS (k_hash_forward_rows); the input gradient moves the rows of 64 points per wave through LDS (input_rows.hip.h).
 #include "grid_core.hip.h"
+#include "input_rows.hip.h"
 #include <algorithm>
 #include <map>
 #include <mutex>
@@ -95,8 +96,6 @@ __global__ void __launch_bounds__(kBlock) k_hash_forward(const float* __restrict
 // the levels of parity h -- parks the derivatives in LDS (row pitch odd: conflict-free) and writes the 128 rows, which are one contiguous range
 // of dy_dx, as full lines.  Same arithmetic per (point, level) as k_hash_forward: same bits.
 constexpr uint32_t kRowsPoints = 128;
-// e / d for e < kRowsPoints * 127 as one multiply-high: M = floor(2^32 / d) + 1 is exact while e (M d - 2^32) < 2^32, i.e. for e < 2^32 / d
-inline uint32_t row_division_magic(uint32_t d) { return (uint32_t)((1ull << 32) / d) + 1u; }
 template <int D, int C>
 __global__ void __launch_bounds__(kBlock) k_hash_forward_rows(const float* __restrict__ inputs, const float* __restrict__ embeddings,
                                                               const int32_t* __restrict__ offsets, float* __restrict__ outputs, uint32_t B,
@@ -219,54 +218,6 @@ __global__ void __launch_bounds__(kBlock) k_input_backward(const float* __restri
         for (int c = 0; c < C; ++c) acc += grad[((size_t)l * B + b) * C + c] * j[(size_t)l * D * C + c];
     }
     grad_inputs[t] = acc;
-}
-
-// The same sum with the dy_dx rows staged through LDS: a point's row is L D C contiguous floats and the D lanes of a point read
-// interleaved 4 C-byte pieces of it -- every load instruction of the kernel above touches 64 pieces spread over 8 KiB.  Here a
-// workgroup copies the rows of 128 points (one contiguous range) with 16-byte loads into LDS (odd pitch) and the (point, dimension)
-// lanes walk their rows there; same order of additions, same bits.  1.27 -> 0.8 ms at 7.7 M points (the reference's kernel compiled
-// for this GPU: 0.87 ms).
-template <int D, int C>
-__global__ void __launch_bounds__(kBlock) k_input_backward_rows(const float* __restrict__ grad, const float* __restrict__ dy_dx,
-                                                               float* __restrict__ grad_inputs, uint32_t B, uint32_t L, uint32_t row_magic) {
-    extern __shared__ float s_jrows[];
-    const uint32_t row_floats = L * D * C, pitch = row_floats | 1u;
-    const uint32_t b0 = blockIdx.x * kRowsPoints, points = min(kRowsPoints, B - b0);
-    const float* src = dy_dx + (size_t)b0 * row_floats;
-    const uint32_t total = points * row_floats;
-    if (((reinterpret_cast<uintptr_t>(src) & 15u) == 0)) {
-        for (uint32_t e = threadIdx.x * 4; e < total; e += kBlock * 4) {
-            if (e + 3 < total) {
-                const float4 v = *reinterpret_cast<const float4*>(src + e);
-                const float q[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) { const uint32_t p = __umulhi(e + k, row_magic); s_jrows[(e + k) + p * (pitch - row_floats)] = q[k]; }
-            } else {
-                for (uint32_t k = e; k < total; ++k) { const uint32_t p = __umulhi(k, row_magic); s_jrows[k + p * (pitch - row_floats)] = src[k]; }
-            }
-        }
-    } else {
-        for (uint32_t e = threadIdx.x; e < total; e += kBlock) { const uint32_t p = __umulhi(e, row_magic); s_jrows[e + p * (pitch - row_floats)] = src[e]; }
-    }
-    __syncthreads();
-    // one lane per POINT: a level's C gradient values are loaded once (contiguous across the lanes) and feed all D sums; per (point,
-    // dimension) the additions still run l outer, c inner
-    for (uint32_t p = threadIdx.x; p < points; p += kBlock) {
-        const uint32_t b = b0 + p;
-        const float* j = s_jrows + p * pitch;
-        float acc[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) acc[d] = 0;
-        for (uint32_t l = 0; l < L; ++l) {
-            const Feat<C> g = load_row<C>(grad + (size_t)l * B * C, b);         // grad[l][b][0 .. C-1]
-#pragma unroll
-            for (int d = 0; d < D; ++d)
-#pragma unroll
-                for (int c = 0; c < C; ++c) acc[d] += g.v[c] * j[l * D * C + d * C + c];
-        }
-#pragma unroll
-        for (int d = 0; d < D; ++d) grad_inputs[(size_t)b * D + d] = acc[d];
-    }
 }
 
 // grad_grad[l,b,c] = sum_d ggx[b,d] * dy_dx[b,l,d,c]              (hashencoder.cu:375-428)
@@ -810,10 +761,8 @@ int envidr_hash_encode_backward(const float* grad, const float* inputs, const fl
             if (rc) return rc;
         }
         if (calc_grad_inputs) {
-            const uint32_t row_floats = L * DD * CC;
-            if (row_floats <= 127)
-                hipLaunchKernelGGL((k_input_backward_rows<DD, CC>), dim3(ceil_div(B, kRowsPoints)), dim3(kBlock), kRowsPoints * (row_floats | 1u) * sizeof(float),
-                                   as_stream(stream), grad, dy_dx, grad_inputs, B, L, row_division_magic(row_floats));
+            if (input_rows_fit(L, DD, CC))
+                launch_input_backward_rows<DD, CC>(grad, dy_dx, grad_inputs, B, L, as_stream(stream));
             else
                 hipLaunchKernelGGL((k_input_backward<DD, CC>), dim3(ceil_div(B * DD, kBlock)), dim3(kBlock), 0,
                                    as_stream(stream), grad, dy_dx, grad_inputs, B, L);
