@@ -150,6 +150,9 @@ def _bind_render(lib):
     lib.envidr_linear_weight_grad_workspace_bytes.restype = ctypes.c_uint64
     lib.envidr_linear_weight_grad.argtypes = [_FP, _FP, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, _FP, _FP, ctypes.c_int, _FP, ctypes.c_uint64, _FP]
     lib.envidr_linear_weight_grad.restype = ctypes.c_int
+    lib.envidr_linear_rows.argtypes = [_FP, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, _FP, ctypes.c_int64, ctypes.c_int64, ctypes.c_uint32, _FP, _FP,
+                                       ctypes.c_uint32, ctypes.c_int, _FP, ctypes.c_uint32, _FP]
+    lib.envidr_linear_rows.restype = ctypes.c_int
     lib.envidr_sphere_intersections.argtypes = [_FP, _FP, ctypes.c_uint32, ctypes.c_float, _FP, _FP, _FP, _FP]
     lib.envidr_sphere_intersections.restype = ctypes.c_int
     lib.envidr_shell_samples.argtypes = [_FP, _FP, _FP, _FP, _FP, _FP, ctypes.c_float, ctypes.c_uint32, ctypes.c_uint32, _FP, _FP, _FP, _FP]
@@ -263,6 +266,49 @@ def linear_weight_grad(x: torch.Tensor, gy: torch.Tensor, bias: bool = True):
     if rc:
         raise _lib.EnvidrError(f"envidr_linear_weight_grad failed ({rc}): {lib.envidr_last_error().decode()}")
     return dW, db
+
+
+ROWS_PLAIN, ROWS_BIAS, ROWS_BIAS_RELU, ROWS_RELU_MASK = 0, 1, 2, 3
+
+
+def linear_rows_supported(x: torch.Tensor, W: torch.Tensor) -> bool:
+    """shapes / layouts envidr_linear_rows takes: fp32 GPU rows, the reduced width a multiple of 4 (16-byte row operands)"""
+    return (x.is_cuda and x.dtype == torch.float32 and W.dtype == torch.float32 and x.dim() == 2 and W.dim() == 2 and x.shape[1] == W.shape[1]
+            and x.shape[1] >= 4 and x.shape[1] % 4 == 0 and W.stride(0) >= 0 and W.stride(1) >= 0)
+
+
+def linear_rows(x: torch.Tensor, W: torch.Tensor, bias: torch.Tensor | None = None, relu: bool = False, mask_act: torch.Tensor | None = None) -> torch.Tensor:
+    """envidr_linear_rows: y [M, N] = epilogue(x [M, K] @ W[N, K]^T) on the fp32 matrix cores.  W may be any 2-D view (its two strides are
+    passed on: W.t() of a row-major matrix costs no copy).  Epilogue: + bias; + bias then ReLU (`relu`); or * (mask_act > 0) (`mask_act` [M, N]:
+    the ReLU gradient of the activation this product's result flows back through)."""
+    lib = _lib.load()
+    _bind_render(lib)
+    if not linear_rows_supported(x, W):
+        raise _lib.EnvidrError(f"linear_rows: unsupported operands x {tuple(x.shape)} {x.dtype} W {tuple(W.shape)} {W.dtype} strides {W.stride()}")
+    if x.stride(1) != 1 or x.stride(0) % 4 != 0 or x.data_ptr() % 16 != 0:
+        x = x.contiguous()
+    M, K = x.shape
+    N = W.shape[0]
+    if mask_act is not None:
+        if bias is not None or relu or mask_act.shape != (M, N):
+            raise _lib.EnvidrError("linear_rows: mask_act [M, N] excludes bias / relu")
+        if mask_act.stride(1) != 1:
+            mask_act = mask_act.contiguous()
+        epi = ROWS_RELU_MASK
+    elif bias is not None:
+        bias = bias.contiguous()
+        epi = ROWS_BIAS_RELU if relu else ROWS_BIAS
+    else:
+        if relu:
+            raise _lib.EnvidrError("linear_rows: relu without a bias is not an epilogue of the operator")
+        epi = ROWS_PLAIN
+    y = torch.empty(M, N, device=x.device)
+    rc = lib.envidr_linear_rows(x.data_ptr(), x.stride(0), M, K, W.data_ptr(), W.stride(0), W.stride(1), N, None if bias is None else bias.data_ptr(),
+                                None if mask_act is None else mask_act.data_ptr(), 0 if mask_act is None else mask_act.stride(0), epi, y.data_ptr(), N,
+                                torch.cuda.current_stream(x.device).cuda_stream)
+    if rc:
+        raise _lib.EnvidrError(f"envidr_linear_rows failed ({rc}): {lib.envidr_last_error().decode()}")
+    return y
 
 
 def pack_sdf_geometry(sdf) -> np.ndarray:

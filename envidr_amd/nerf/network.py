@@ -76,6 +76,58 @@ ENV_MLP_OPERATOR_MIN_ROWS = 4096      # below this the four torch GEMMs are not 
 WEIGHT_GRAD_OPERATOR_MIN_ROWS = 16384 # training: from this many rows the weight gradient of a layer goes to envidr_linear_weight_grad
 
 
+def _rows_product(x, W, bias=None, relu=False, mask_act=None):
+    """epilogue(x [M, K] @ W [N, K]^T) for a big batch of rows: envidr_linear_rows (csrc/linear_rows.hip, fp32 MFMA, W by its strides so a
+    transposed view costs no copy) wherever it is the faster route -- every layer with a side below 160 (1.1 .. 3x the library GEMM at 146 k
+    rows, tools/probe/linear_rows_probe.py) and every product whose bias / ReLU / ReLU-gradient pass it absorbs; a plain 256 x 256 product
+    stays with the library GEMM (0.19 against 0.21 ms)."""
+    fusing = relu or mask_act is not None
+    if _fused.linear_rows_supported(x, W) and (fusing or min(W.shape) < 160):
+        return _fused.linear_rows(x, W, bias=bias, relu=relu, mask_act=mask_act)
+    y = x @ W.t() if bias is None else torch.addmm(bias, x, W.t())
+    if relu:
+        y = torch.relu_(y)
+    if mask_act is not None:
+        y = y * (mask_act > 0)
+    return y
+
+
+class _ReluMlp(torch.autograd.Function):
+    """A whole ReLU MLP (x, W0, b0, W1, b1, ...) -> y as ONE autograd node, for the shading networks of the training branch (environment, diffuse,
+    colour heads: differentiated once, by loss.backward() -- the twice-differentiated SDF network keeps the per-layer pair below).  Forward: one
+    envidr_linear_rows per layer, bias and ReLU in its epilogue, the activations kept.  Backward: per layer one envidr_linear_weight_grad
+    (dW and db in the same pass) and one envidr_linear_rows that carries the gradient to the layer below with the ReLU mask in its epilogue --
+    instead of torch's addmm, clamp_min, threshold_backward, mm, mm, sum per layer (reference: plain nn.Sequential, network.py:524-698)."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        n = len(params) // 2
+        acts, h = [x], x
+        for i in range(n):
+            h = _rows_product(h, params[2 * i], bias=params[2 * i + 1], relu=i != n - 1)
+            acts.append(h)
+        ctx.n = n
+        ctx.save_for_backward(*params[0::2], *acts[:-1])
+        return h
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        n = ctx.n
+        Ws, acts = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        grads = [None] * (2 * n)
+        g = gy.contiguous()
+        gx = None
+        for i in range(n - 1, -1, -1):
+            if ctx.needs_input_grad[1 + 2 * i] or ctx.needs_input_grad[2 + 2 * i]:
+                grads[2 * i], grads[2 * i + 1] = _fused.linear_weight_grad(acts[i], g, bias=True)
+            if i > 0:
+                g = _rows_product(g, Ws[i].t(), mask_act=acts[i])           # acts[i] = relu(layer i-1): its sign is the ReLU gradient
+            elif ctx.needs_input_grad[0]:
+                gx = _rows_product(g, Ws[0].t())
+        return (gx, *grads)
+
+
 class _RowsTimesMatrix(torch.autograd.Function):
     """x [M, K] , W [N, K]  ->  x W^T [M, N] for a batch of 10^4 .. 10^6 rows.  Forward and input gradient are library GEMMs (plenty of
     row parallelism); the gradient w.r.t. W -- an [N, K] result reduced over all rows, which a library GEMM tiles by its RESULT only
@@ -86,12 +138,12 @@ class _RowsTimesMatrix(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W):
         ctx.save_for_backward(x, W)
-        return x @ W.t()
+        return _rows_product(x, W)
 
     @staticmethod
     def backward(ctx, gy):
         x, W = ctx.saved_tensors
-        gx = _RowsTimesMatrix.apply(gy, W.t().contiguous()) if ctx.needs_input_grad[0] else None
+        gx = _RowsTimesMatrix.apply(gy, W.t()) if ctx.needs_input_grad[0] else None
         gW = _WeightGrad.apply(x, gy) if ctx.needs_input_grad[1] else None
         return gx, gW
 
@@ -108,8 +160,8 @@ class _WeightGrad(torch.autograd.Function):
     @staticmethod
     def backward(ctx, G):
         x, gy = ctx.saved_tensors
-        gx = _RowsTimesMatrix.apply(gy, G.t().contiguous()) if ctx.needs_input_grad[0] else None       # gy G      [M, K]
-        ggy = _RowsTimesMatrix.apply(x, G.contiguous()) if ctx.needs_input_grad[1] else None           # x G^T    [M, N]
+        gx = _RowsTimesMatrix.apply(gy, G.t()) if ctx.needs_input_grad[0] else None                    # gy G      [M, K]
+        ggy = _RowsTimesMatrix.apply(x, G) if ctx.needs_input_grad[1] else None                        # x G^T    [M, N]
         return gx, ggy
 
 
@@ -120,12 +172,12 @@ class _Affine(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, b):
         ctx.save_for_backward(x, W)
-        return torch.addmm(b, x, W.t())
+        return _rows_product(x, W, bias=b)
 
     @staticmethod
     def backward(ctx, gy):
         x, W = ctx.saved_tensors
-        gx = _RowsTimesMatrix.apply(gy, W.t().contiguous()) if ctx.needs_input_grad[0] else None
+        gx = _RowsTimesMatrix.apply(gy, W.t()) if ctx.needs_input_grad[0] else None
         gW = gb = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             gW, gb = _WeightBiasGrad.apply(x, gy)
@@ -143,10 +195,10 @@ class _WeightBiasGrad(torch.autograd.Function):
     @staticmethod
     def backward(ctx, G, g_b):
         x, gy = ctx.saved_tensors
-        gx = _RowsTimesMatrix.apply(gy, G.t().contiguous()) if ctx.needs_input_grad[0] else None
+        gx = _RowsTimesMatrix.apply(gy, G.t()) if ctx.needs_input_grad[0] else None
         ggy = None
         if ctx.needs_input_grad[1]:
-            ggy = _RowsTimesMatrix.apply(x, G.contiguous())
+            ggy = _RowsTimesMatrix.apply(x, G)
             if g_b is not None:
                 ggy = ggy + g_b
         return gx, ggy
@@ -173,6 +225,10 @@ def _run_mlp(net, h, first_order_only=False):
     if (not torch.is_grad_enabled() and h.is_cuda and h.dtype == torch.float32 and h.numel() // max(h.shape[-1], 1) >= ENV_MLP_OPERATOR_MIN_ROWS
             and _fused.env_mlp_supported(net)):
         return _fused.env_mlp_forward(net, h)
+    if (first_order_only and torch.is_grad_enabled() and h.is_cuda and h.dtype == torch.float32 and h.numel() // max(h.shape[-1], 1) >= WEIGHT_GRAD_OPERATOR_MIN_ROWS
+            and all(lin.training and lin.bias is not None and lin.weight.dtype == torch.float32 and lin.weight.requires_grad for lin in net)):
+        params = [p for lin in net for p in (lin.weight, lin.bias)]
+        return _ReluMlp.apply(h.reshape(-1, h.shape[-1]), *params).reshape(*h.shape[:-1], net[-1].weight.shape[0])
     for i, lin in enumerate(net):
         h = _linear(lin, h, first_order_only)
         if i != len(net) - 1:

@@ -396,6 +396,17 @@ uint64_t envidr_linear_weight_grad_workspace_bytes(uint32_t M, uint32_t K_in, ui
 int envidr_linear_weight_grad(const float* x, const float* gy, uint32_t M, uint32_t K_in, uint32_t N_out, float* dW, float* db, int accumulate,
                               void* workspace, uint64_t workspace_bytes, envidr_stream_t stream);
 
+/* ---- ABI 9: a dense layer over a large batch of rows (the forward and input-gradient products of the same training branch; the reference:
+ * cuBLAS plus one elementwise kernel per bias / ReLU / ReLU gradient) -----------------------------------------------------------------------
+ *   y[m][o] = epilogue( sum_i x[m][i] W(o, i) ),   W(o, i) = W[o * w_stride_out + i * w_stride_in]          m < M, i < K, o < N
+ * so W [N][K] row-major (strides K, 1) gives y = x W^T, and the same matrix read with strides (1, N') gives the input gradient gy W without a
+ * transposed copy.  Epilogues:  PLAIN none;  BIAS + bias[o];  BIAS_RELU max(. + bias[o], 0);  RELU_MASK . * (act[m][o] > 0) -- the ReLU
+ * gradient for the activation `act` this gradient flows back through.  fp32 on the matrix cores.  x rows 16-byte aligned (ldx % 4 == 0),
+ * K a multiple of 4; ldx / ldact / ldy are row pitches in floats.  bias / act may be NULL where the epilogue does not read them. */
+enum { ENVIDR_ROWS_PLAIN = 0, ENVIDR_ROWS_BIAS = 1, ENVIDR_ROWS_BIAS_RELU = 2, ENVIDR_ROWS_RELU_MASK = 3 };
+int envidr_linear_rows(const float* x, uint32_t ldx, uint32_t M, uint32_t K, const float* W, int64_t w_stride_out, int64_t w_stride_in, uint32_t N,
+                       const float* bias, const float* act, uint32_t ldact, int epilogue, float* y, uint32_t ldy, envidr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

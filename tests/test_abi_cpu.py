@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     # and the Python binding table covers every operator of envidr_amd.h
     ops = {"envidr_" + n for n in _lib.SIGNATURES}
     assert ops <= declared
-    assert lib.envidr_abi_version() == 8
+    assert lib.envidr_abi_version() == 9
 
 
 def test_signature_table_matches_header_arity():
@@ -227,3 +227,12 @@ def test_round5_entry_points_validate_their_arguments():
     assert lib.envidr_linear_weight_grad_workspace_bytes(0, 8, 8) == 0 and lib.envidr_linear_weight_grad_workspace_bytes(1000, 256, 256) > 0
     assert lib.envidr_linear_weight_grad(None, None, 10, 0, 4, p, None, 0, None, 0, None) == -1 and b"empty layer" in lib.envidr_last_error()
     assert lib.envidr_linear_weight_grad(None, None, 10, 4, 4, p, None, 0, None, 0, None) == -1 and b"null pointer" in lib.envidr_last_error()
+    # ABI 9: envidr_linear_rows(x, ldx, M, K, W, w_stride_out, w_stride_in, N, bias, act, ldact, epilogue, y, ldy, stream)
+    assert lib.envidr_linear_rows(p, 8, 10, 6, p, 6, 1, 4, None, None, 0, 0, p, 4, None) == -1 and b"multiple of 4" in lib.envidr_last_error()
+    assert lib.envidr_linear_rows(p, 8, 10, 8, p, 8, 1, 4, None, None, 0, 7, p, 4, None) == -1 and b"unknown epilogue" in lib.envidr_last_error()
+    assert lib.envidr_linear_rows(p, 8, 0, 8, p, 8, 1, 4, None, None, 0, 0, p, 4, None) == 0                       # an empty batch is not an error
+    assert lib.envidr_linear_rows(None, 8, 10, 8, p, 8, 1, 4, None, None, 0, 0, p, 4, None) == -1 and b"null pointer" in lib.envidr_last_error()
+    assert lib.envidr_linear_rows(p, 6, 10, 8, p, 8, 1, 4, None, None, 0, 0, p, 4, None) == -1 and b"16-byte aligned" in lib.envidr_last_error()
+    assert lib.envidr_linear_rows(p, 8, 10, 8, p, 8, 1, 4, None, None, 0, 2, p, 4, None) == -1 and b"needs a bias" in lib.envidr_last_error()
+    assert lib.envidr_linear_rows(p, 8, 10, 8, p, 8, 1, 4, None, None, 0, 3, p, 4, None) == -1 and b"needs act" in lib.envidr_last_error()
+    assert lib.envidr_linear_rows(p, 8, 10, 8, p, 8, 1, 4, None, None, 0, 0, p, 3, None) == -1 and b"ldy" in lib.envidr_last_error()

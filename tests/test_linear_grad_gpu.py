@@ -102,3 +102,111 @@ def test_accumulate_and_empty_batches():
     assert not dW.any() and not db.any()
     assert lib.envidr_linear_weight_grad(x.data_ptr(), gy.data_ptr(), M, K, N, dW.data_ptr(), None, 0, ws.data_ptr(), nbytes - 16, s) == -1
     assert b"workspace" in lib.envidr_last_error()
+
+
+@pytest.mark.parametrize("M,K,N,view", [(1, 4, 1, False), (130, 72, 256, False), (4097, 256, 256, False), (4097, 256, 256, True), (20000, 256, 12, False),
+                                        (20000, 12, 256, True), (33333, 64, 64, False), (33333, 64, 64, True), (9999, 32, 64, False), (5000, 64, 15, False),
+                                        (5000, 16, 64, True), (3000, 128, 3, False), (3000, 300, 260, False), (777, 160, 160, True), (2048, 100, 37, True)])
+def test_rows_product_matches_float64(M, K, N, view):
+    """envidr_linear_rows (csrc/linear_rows.hip) in its four epilogues against float64: both vector layouts of W (row-major [N, K]; the
+    transposed view of a [K, N] matrix -- the input-gradient product) and the strided fallback, whole and ragged slabs / column blocks / row
+    tiles, the uniform-base fast addressing (K % 16 == 0, N a whole column block) and the clamped general path.  Tolerance: 2e-6 of max |y|
+    (an fp32 dot product of K <= 300 terms; torch's own fp32 GEMM lands at 2e-7 .. 8e-7 on the same inputs)."""
+    import torch
+    from envidr_amd import fused
+    g = torch.Generator(device="cuda").manual_seed(M + 7 * K + 13 * N)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    Wm = torch.randn((K, N) if view else (N, K), device="cuda", generator=g) / K ** 0.5
+    W = Wm.t() if view else Wm
+    if (M, K, N) == (2048, 100, 37):
+        W = torch.randn(N, 2 * K + 1, device="cuda", generator=g)[:, ::2][:, :K]       # neither index contiguous: the element-wise staging
+    b = torch.randn(N, device="cuda", generator=g)
+    act = torch.randn(M, N, device="cuda", generator=g)
+    ref = x.double() @ W.double().t()
+    tol = 2e-6 * float(ref.abs().max() + b.abs().max())
+    assert float((fused.linear_rows(x, W).double() - ref).abs().max()) <= tol
+    assert float((fused.linear_rows(x, W, bias=b).double() - (ref + b.double())).abs().max()) <= tol
+    y = fused.linear_rows(x, W, bias=b, relu=True)
+    assert float((y.double() - torch.relu(ref + b.double())).abs().max()) <= tol and float(y.min()) >= 0.0
+    ym = fused.linear_rows(x, W, mask_act=act)
+    assert float((ym.double() - ref * (act > 0)).abs().max()) <= tol
+    assert torch.equal(ym == 0, (act <= 0) | (ym == 0))                        # masked entries are exact zeros
+    assert torch.equal(fused.linear_rows(x, W), fused.linear_rows(x, W))       # deterministic
+    # rows with a pitch (a column slice of a wider matrix) are read in place
+    wide = torch.randn(M, K + 8, device="cuda", generator=g)
+    assert float((fused.linear_rows(wide[:, 4:4 + K], W).double() - wide[:, 4:4 + K].double() @ W.double().t()).abs().max()) <= tol
+
+
+def test_rows_product_refuses_what_it_cannot_take():
+    import torch
+    from envidr_amd import _lib, fused
+    x = torch.randn(64, 6, device="cuda")
+    assert not fused.linear_rows_supported(x, torch.randn(8, 6, device="cuda"))          # K % 4 != 0: the caller keeps the library GEMM
+    with pytest.raises(_lib.EnvidrError):
+        fused.linear_rows(x, torch.randn(8, 6, device="cuda"))
+    with pytest.raises(_lib.EnvidrError):
+        fused.linear_rows(torch.randn(64, 8, device="cuda"), torch.randn(8, 8, device="cuda"), relu=True)
+    assert fused.linear_rows(torch.randn(0, 8, device="cuda"), torch.randn(8, 8, device="cuda")).shape == (0, 8)
+
+
+def test_relu_mlp_node_has_the_layerwise_gradients():
+    """`_run_mlp(..., first_order_only=True)` in the training branch -- one autograd node for the whole ReLU MLP, bias / ReLU / ReLU gradient in
+    the products' epilogues.  Output against the same layers run by torch; gradients (input, weights, biases) against the chain rule in float64
+    on the node's OWN activations (two fp32 GEMMs disagree on the sign of a handful of pre-activations within 1e-7 of zero, so torch's backward
+    differs from ANY other fp32 forward by ~1e-3 of the gradient norm through those few ReLU masks; torch's gradients are checked to be that
+    close).  Shapes: the environment MLP 72-256-256-256-12 and a colour head ending in 3 outputs (whose input-gradient product torch keeps)."""
+    import torch
+    from envidr_amd import fused
+    from envidr_amd.nerf import network as nw
+    for dims in ((72, 256, 256, 256, 12), (40, 64, 64, 3), (16, 32, 12)):
+        torch.manual_seed(len(dims))
+        net = nw._mlp(list(dims)).cuda().train()
+        x0 = torch.randn(20000, dims[0], device="cuda")
+        w = torch.randn(20000, dims[-1], device="cuda")
+
+        def run(fn):
+            net.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            y = fn(net, x)
+            (y * w).sum().backward()
+            return [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+
+        def plain(net_, h):
+            for i, lin in enumerate(net_):
+                h = lin(h)
+                if i != len(net_) - 1:
+                    h = torch.relu(h)
+            return h
+        calls = []
+        real = nw._fused.linear_rows
+        nw._fused.linear_rows = lambda *a, **k: (calls.append(k), real(*a, **k))[1]
+        try:
+            got = run(lambda n, h: nw._run_mlp(n, h, first_order_only=True))
+        finally:
+            nw._fused.linear_rows = real
+        want = run(plain)
+        assert float((got[0] - want[0]).norm() / want[0].norm()) <= 5e-6
+        for a, b in zip(got[1:], want[1:]):
+            assert float((a - b).norm() / b.norm()) <= 2e-2, (dims, float((a - b).norm() / b.norm()))
+        # the chain rule in float64 on the node's activations
+        with torch.no_grad():
+            acts, h = [x0], x0
+            for i, lin in enumerate(net):
+                h = nw._rows_product(h, lin.weight, bias=lin.bias, relu=i != len(net) - 1)
+                acts.append(h)
+            assert torch.equal(h, got[0])
+            g = w.double()
+            exact = []
+            for i in range(len(net) - 1, -1, -1):
+                exact = [g.t() @ acts[i].double(), g.sum(0)] + exact
+                g = g @ net[i].weight.double()
+                if i > 0:
+                    g = g * (acts[i] > 0)
+            exact = [g] + exact
+        for a, b in zip(got[1:], exact):
+            assert float((a.double() - b).norm() / b.norm()) <= 5e-6, (dims, float((a.double() - b).norm() / b.norm()))
+        assert sum(1 for k in calls if k.get("relu")) == len(dims) - 2                      # every hidden layer: bias + ReLU in the epilogue
+        assert sum(1 for k in calls if k.get("mask_act") is not None) >= len(dims) - 3      # the ReLU gradient rides on the gradient products
+        # without the flag (a network that is differentiated twice) or below the row threshold the per-layer path runs
+        y = nw._run_mlp(net, x0[:100].clone().requires_grad_(True), first_order_only=True)
+        assert "ReluMlp" not in type(y.grad_fn).__name__
