@@ -690,7 +690,10 @@ static int launch_table_scatter_lds(const float* grad, const float* inputs, cons
     return rc;
 }
 
-constexpr uint32_t kLdsScatterMinPoints = 1u << 19;    // below this the per-point atomics (combined inside the wave) are faster
+// Per-point atomics run at ~33 G/s however the levels are spread (the fine levels' random rows: ~21 G/s each, one after the other --
+// tools/probe/scatter_levels_probe.py); the LDS ranges cost ~0.2 ms (masks, one pass over the table) plus a quarter of that per point.  The
+// two meet at ~35 k points (profiles/r05l/scatter_threshold_probe.txt); a training batch (146 k samples) is 0.89 -> 0.53 ms.
+constexpr uint32_t kLdsScatterMinPoints = 1u << 15;
 
 // ------------------------------------------------------------------------------------------
 // dispatch helpers
