@@ -76,6 +76,13 @@ ENV_MLP_OPERATOR_MIN_ROWS = 4096      # below this the four torch GEMMs are not 
 WEIGHT_GRAD_OPERATOR_MIN_ROWS = 16384 # training: from this many rows the weight gradient of a layer goes to envidr_linear_weight_grad
 
 
+def _input_gradient_only():
+    """inside hashencoder.input_gradient_only() (the normals pass: autograd.grad w.r.t. the positions, create_graph) a layer's backward
+    skips the weight / bias gradient that autograd.grad would throw away -- a custom Function cannot see which of its gradients are wanted"""
+    from ..hashencoder import hashgrid
+    return bool(getattr(hashgrid._INPUT_GRADIENT_ONLY, "on", False))
+
+
 def _rows_product(x, W, bias=None, relu=False, mask_act=None):
     """epilogue(x [M, K] @ W [N, K]^T) for a big batch of rows: envidr_linear_rows (csrc/linear_rows.hip, fp32 MFMA, W by its strides so a
     transposed view costs no copy) wherever it is the faster route -- every layer with a side below 160 (1.1 .. 3x the library GEMM at 146 k
@@ -144,7 +151,7 @@ class _RowsTimesMatrix(torch.autograd.Function):
     def backward(ctx, gy):
         x, W = ctx.saved_tensors
         gx = _RowsTimesMatrix.apply(gy, W.t()) if ctx.needs_input_grad[0] else None
-        gW = _WeightGrad.apply(x, gy) if ctx.needs_input_grad[1] else None
+        gW = _WeightGrad.apply(x, gy) if ctx.needs_input_grad[1] and not _input_gradient_only() else None
         return gx, gW
 
 
@@ -179,7 +186,7 @@ class _Affine(torch.autograd.Function):
         x, W = ctx.saved_tensors
         gx = _RowsTimesMatrix.apply(gy, W.t()) if ctx.needs_input_grad[0] else None
         gW = gb = None
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+        if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not _input_gradient_only():
             gW, gb = _WeightBiasGrad.apply(x, gy)
         return gx, gW, gb
 
@@ -205,13 +212,18 @@ class _WeightBiasGrad(torch.autograd.Function):
 
 
 def _linear(lin, h, first_order_only=False):
-    """nn.Linear; in the training branch (autograd recording, a GPU batch of >= WEIGHT_GRAD_OPERATOR_MIN_ROWS rows) as x W^T + b with the
-    big-batch weight gradient"""
-    if (lin.training and torch.is_grad_enabled() and h.is_cuda and h.dtype == torch.float32 and lin.weight.dtype == torch.float32
+    """nn.Linear; with autograd recording on a GPU batch of >= WEIGHT_GRAD_OPERATOR_MIN_ROWS rows (the training branch; the SDF network under
+    the inference loop's autograd normals) as x W^T + b through envidr_linear_rows with the big-batch weight gradient -- which the normals
+    pass, asking for the position gradient only, never forms (_input_gradient_only)"""
+    if (torch.is_grad_enabled() and h.is_cuda and h.dtype == torch.float32 and lin.weight.dtype == torch.float32
             and lin.weight.requires_grad and h.numel() // max(h.shape[-1], 1) >= WEIGHT_GRAD_OPERATOR_MIN_ROWS):
         h2 = h.reshape(-1, h.shape[-1])
         y = _RowsTimesMatrix.apply(h2, lin.weight) if lin.bias is None else _Affine.apply(h2, lin.weight, lin.bias)
         return y.reshape(*h.shape[:-1], lin.weight.shape[0])
+    if (not torch.is_grad_enabled() and h.is_cuda and h.dtype == torch.float32 and lin.weight.dtype == torch.float32
+            and h.numel() // max(h.shape[-1], 1) >= ENV_MLP_OPERATOR_MIN_ROWS):
+        # inference (the operator loop's shading heads): the same product, no graph
+        return _rows_product(h.reshape(-1, h.shape[-1]), lin.weight, bias=lin.bias).reshape(*h.shape[:-1], lin.weight.shape[0])
     return lin(h)
 
 
@@ -229,6 +241,13 @@ def _run_mlp(net, h, first_order_only=False):
             and all(lin.training and lin.bias is not None and lin.weight.dtype == torch.float32 and lin.weight.requires_grad for lin in net)):
         params = [p for lin in net for p in (lin.weight, lin.bias)]
         return _ReluMlp.apply(h.reshape(-1, h.shape[-1]), *params).reshape(*h.shape[:-1], net[-1].weight.shape[0])
+    if (not torch.is_grad_enabled() and h.is_cuda and h.dtype == torch.float32 and h.numel() // max(h.shape[-1], 1) >= ENV_MLP_OPERATOR_MIN_ROWS
+            and all(lin.bias is not None and lin.weight.dtype == torch.float32 for lin in net)):
+        # inference, a shape the environment-MLP operator is not built for: per layer one product with bias and ReLU in its epilogue
+        h2 = h.reshape(-1, h.shape[-1])
+        for i, lin in enumerate(net):
+            h2 = _rows_product(h2, lin.weight, bias=lin.bias, relu=i != len(net) - 1)
+        return h2.reshape(*h.shape[:-1], net[-1].weight.shape[0])
     for i, lin in enumerate(net):
         h = _linear(lin, h, first_order_only)
         if i != len(net) - 1:

@@ -64,16 +64,21 @@ def test_big_batch_linear_has_nn_linear_gradients_to_second_order():
         nw._fused.linear_weight_grad = real
     with torch.no_grad():
         assert nw._linear(l1, x0).grad_fn is None
-    # ... and in eval mode (the inference loop differentiates the SDF network w.r.t. positions only: no weight gradient to speed up)
+    # ... and the normals pass (autograd.grad w.r.t. the positions inside hashencoder.input_gradient_only, renderer.compute_normal -- in eval
+    # mode too: the inference loop's autograd normals) never forms a weight gradient: autograd.grad would throw it away
+    from envidr_amd.hashencoder.hashgrid import input_gradient_only
     l1.eval()
     before = len(calls)
     x = x0.clone().requires_grad_(True)
     nw._fused.linear_weight_grad = lambda *a, **k: (calls.append(a[0].shape[0]), real(*a, **k))[1]
     try:
-        nw._linear(l1, x).sum().backward()
+        y = nw._linear(l1, x)
+        with input_gradient_only():
+            gx, = torch.autograd.grad(y.sum(), x, create_graph=True)
     finally:
         nw._fused.linear_weight_grad = real
     assert len(calls) == before
+    assert float((gx - l1.weight.sum(0)).abs().max()) <= 1e-5
 
 
 def test_accumulate_and_empty_batches():
