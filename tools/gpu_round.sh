@@ -32,6 +32,13 @@ timeout 300 python tools/train_step_bench.py > $OUT/train_step_bench.txt 2>&1
 # where a training step's time goes (kernel stats of 20 steps) and the env-sphere frame by stage
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -o t -- python $GRAFT_REPO_ROOT/tools/train_step_bench.py 20 > $OUT/trace_train.log 2>&1 )
 timeout 300 python tools/sph_stage_times.py > $OUT/sph_stage_times.txt 2>&1
+# round 5: the training-batch operators beside the reference's kernels compiled for this GPU, the dense-layer operator beside the library
+# GEMM, the table scatter either side of its LDS threshold and level by level
+timeout 300 python tools/train_ops_bench.py > $OUT/train_ops_bench.txt 2>&1
+timeout 300 python tools/probe/march_train_probe.py ref > $OUT/march_train_probe.txt 2>&1
+timeout 300 python tools/probe/linear_rows_probe.py > $OUT/linear_rows_probe.txt 2>&1
+timeout 300 python tools/probe/scatter_threshold_probe.py > $OUT/scatter_threshold_probe.txt 2>&1
+timeout 300 python tools/probe/scatter_levels_probe.py > $OUT/scatter_levels_probe.txt 2>&1
 # every operator case group re-generated with other seeds, HIP against oracle
 timeout 900 python tools/fuzz_ops.py 1 8 > $OUT/fuzz_ops.txt 2>&1
 # randomised differential run of the two frame implementations
@@ -88,7 +95,7 @@ cp $OUT/bench_force_dist.json $OUT/bench_strong.json $OUT/bench_torchrun.json $O
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $P/kernel_stats.csv \;
 find $OUT/trace_hinted -name "*kernel_stats.csv" -exec cp {} $P/kernel_stats_hinted.csv \;
 find $OUT/trace_train -name "*kernel_stats.csv" -exec cp {} $P/kernel_stats_train_step.csv \;
-cp $OUT/sph_stage_times.txt $P/ 2>/dev/null
+cp $OUT/sph_stage_times.txt $OUT/train_ops_bench.txt $OUT/march_train_probe.txt $OUT/linear_rows_probe.txt $OUT/scatter_threshold_probe.txt $OUT/scatter_levels_probe.txt $P/ 2>/dev/null
 for d in $OUT/pmc_*/; do n=$(basename $d); find $d -name "*counter_collection.csv" -exec cp {} $P/$n.csv \; ; done
 tail -5 $OUT/pytest_gpu.log > $P/pytest_gpu_tail.txt; tail -2 $OUT/smoke.log >> $P/pytest_gpu_tail.txt
 
