@@ -4,8 +4,8 @@
 // ReLU / ReLU-gradient).  fp32 on the matrix cores (v_mfma_f32_32x32x2_f32), like envidr_linear_weight_grad (linear_grad.hip) and the
 // frame's shading kernels.
 //
-// Work decomposition.  A workgroup of four waves owns 128 rows and up to 256 output columns; every wave keeps its 32 rows x (NT x 32) columns
-// in accumulator registers.  W is walked in slabs of 16 inputs: a slab ([16][NT x 32] floats, <= 16 KiB, zero-filled past the layer's
+// Work decomposition.  A workgroup of four waves owns 128 rows and a block of up to 128 output columns; every wave keeps its 32 rows x (NT x 32)
+// columns in accumulator registers.  W is walked in slabs of 16 inputs: a slab ([16][NT x 32] floats, <= 16 KiB, zero-filled past the layer's
 // widths) is fetched from global memory -- L2: all workgroups read the same <= 256 KiB -- into registers while the previous slab is being
 // multiplied, parked in the other half of a double-buffered LDS array, one barrier per slab.  W is addressed by two strides, so W [N][K]
 // (forward: y = x W^T) and its transpose (input gradient: gx = gy W, no materialised W^T) take the same kernel; the staging loads are 16
@@ -317,7 +317,12 @@ int envidr_linear_rows(const float* x, uint32_t ldx, uint32_t M, uint32_t K, con
     if (N <= 32) return launch_rows_layout<1>(a, layout, epilogue, dim3(row_blocks, 1), s);
     if (N <= 64) return launch_rows_layout<2>(a, layout, epilogue, dim3(row_blocks, 1), s);
     if (N <= 128) return launch_rows_layout<4>(a, layout, epilogue, dim3(row_blocks, 1), s);
-    return launch_rows_layout<8>(a, layout, epilogue, dim3(row_blocks, ceil_div(N, 256u)), s);
+    // wider layers: column blocks of 128 or 64, whichever pads N less (ties: 128).  Blocks of 256 (eight tiles per wave) were slower at every
+    // width measured (146 k rows: 256 x 256 0.22 -> 0.20 ms, 72 -> 256 0.088 -> 0.077, 160 x 160 0.13 -> 0.10 with 64-column blocks): half the work
+    // per workgroup spreads 4.45 workgroups per CU more evenly, and 2 .. 3 workgroups fit a CU instead of 2.
+    const uint32_t pad128 = ceil_div(N, 128u) * 128u, pad64 = ceil_div(N, 64u) * 64u;
+    if (pad64 < pad128) return launch_rows_layout<2>(a, layout, epilogue, dim3(row_blocks, pad64 / 64u), s);
+    return launch_rows_layout<4>(a, layout, epilogue, dim3(row_blocks, pad128 / 128u), s);
 }
 
 }  // extern "C"
