@@ -85,11 +85,10 @@ def _input_gradient_only():
 
 def _rows_product(x, W, bias=None, relu=False, mask_act=None):
     """epilogue(x [M, K] @ W [N, K]^T) for a big batch of rows: envidr_linear_rows (csrc/linear_rows.hip, fp32 MFMA, W by its strides so a
-    transposed view costs no copy) wherever it is the faster route -- every layer with a side below 160 (1.1 .. 3x the library GEMM at 146 k
-    rows, tools/probe/linear_rows_probe.py) and every product whose bias / ReLU / ReLU-gradient pass it absorbs; a plain 256 x 256 product
-    stays with the library GEMM (0.19 against 0.21 ms)."""
-    fusing = relu or mask_act is not None
-    if _fused.linear_rows_supported(x, W) and (fusing or min(W.shape) < 160):
+    transposed view costs no copy, bias / ReLU / ReLU-gradient in the epilogue) wherever its operands qualify -- at 146 k rows it is 1.0 .. 3x
+    the library GEMM plus its elementwise passes on every layer shape of the shipped networks (profiles/r05m/linear_rows_probe.txt); torch
+    otherwise (a reduced width that is not a multiple of 4: the colour heads' 3 outputs on the way back)."""
+    if _fused.linear_rows_supported(x, W):
         return _fused.linear_rows(x, W, bias=bias, relu=relu, mask_act=mask_act)
     y = x @ W.t() if bias is None else torch.addmm(bias, x, W.t())
     if relu:

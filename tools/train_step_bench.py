@@ -24,8 +24,17 @@ def step():
     return res
 for _ in range(3):
     res = step()
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(steps):
-    res = step()
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-print(f"training step: 4096 rays, {int(res['sigmas'].shape[0])} samples: {dt * 1e3:.2f} ms per step ({4096 / dt / 1e6:.2f} M rays/s)")
+# three timed batches: wall time per step (fastest and slowest batch) and the HOST's share -- how long Python + autograd need to enqueue a step
+# (the loop's time before the final synchronize).  ~370 launches a step: where the enqueue time is the wall time the step is host-bound,
+# and a loaded or slower host (the GPU boxes share theirs between four jobs) shows up one to one.
+walls, hosts = [], []
+for _ in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        res = step()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    walls.append((t2 - t0) / steps); hosts.append((t1 - t0) / steps)
+dt = min(walls)
+print(f"training step: 4096 rays, {int(res['sigmas'].shape[0])} samples: {dt * 1e3:.2f} ms per step ({4096 / dt / 1e6:.2f} M rays/s); "
+      f"batches of {steps}: {', '.join(f'{w * 1e3:.2f}' for w in walls)} ms, of which the host needs {', '.join(f'{h * 1e3:.2f}' for h in hosts)} ms to enqueue")
