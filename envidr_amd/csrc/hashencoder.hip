@@ -661,9 +661,24 @@ __global__ void __launch_bounds__(kLdsScatterThreads) k_table_scatter_lds(const 
   }
 }
 
-// scratch for the range masks (4 bytes per point and level): stream-ordered allocation from the device's default memory pool, released
-// behind the kernels that read it -- nothing outlives the call, nothing synchronises the device, and the pool hands the bytes back
-// (round 4 kept a per-stream hipMalloc that was never freed: 0.5 GiB at 8 M points x 16 levels, outside torch's allocator)
+// Scratch for the range masks (4 bytes per point and level).  Batches of up to kSmallMaskBytes of masks (a training step's: 146 k samples x 16
+// levels = 9 MiB) use a buffer kept per (device, stream) -- at most kSmallMaskBytes each, allocated once: `hipMallocAsync` / `hipFreeAsync` per call
+// made the HOST wait about as long as the kernels run (0.5 ms per scatter measured, tools/probe/host_call_cost.py: twice a training step that is
+// itself host-bound).  Larger batches take a stream-ordered allocation from the device's memory pool, released behind the kernels that read it: there
+// the wait is small beside 10 ms of kernels, nothing outlives the call, and the pool hands the bytes back (round 4 kept an unbounded per-stream
+// hipMalloc that was never freed: 0.5 GiB at 8 M points x 16 levels, outside torch's allocator).
+constexpr size_t kSmallMaskBytes = 64u << 20;
+struct SmallMaskScratch { uint32_t* ptr = nullptr; };
+static std::mutex g_small_mask_mutex;
+static std::map<std::pair<int, hipStream_t>, SmallMaskScratch> g_small_masks;
+static uint32_t* small_mask_scratch(hipStream_t s) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    std::lock_guard<std::mutex> lock(g_small_mask_mutex);
+    SmallMaskScratch& e = g_small_masks[{dev, s}];
+    if (!e.ptr && hipMalloc(reinterpret_cast<void**>(&e.ptr), kSmallMaskBytes) != hipSuccess) { (void)hipGetLastError(); e.ptr = nullptr; }
+    return e.ptr;
+}
 // pre-pass + range owners
 template <int D, int C, bool SECOND>
 static int launch_table_scatter_lds(const float* grad, const float* inputs, const int32_t* offsets, const float* ggx, float* grad_table, uint32_t B,
@@ -674,19 +689,20 @@ static int launch_table_scatter_lds(const float* grad, const float* inputs, cons
     while ((1u << log2_rows) < kRows) ++log2_rows;
     const uint32_t pitch = (B + 3u) / 4u * 4u;
     const size_t mask_bytes = ((size_t)L * pitch + kMaskGrain) * 4;
-    uint32_t* masks = nullptr;
-    if (hipMallocAsync(reinterpret_cast<void**>(&masks), mask_bytes, s) != hipSuccess || !masks) {
+    uint32_t* masks = mask_bytes <= kSmallMaskBytes ? small_mask_scratch(s) : nullptr;
+    const bool pooled = masks == nullptr;
+    if (pooled && (hipMallocAsync(reinterpret_cast<void**>(&masks), mask_bytes, s) != hipSuccess || !masks)) {
         (void)hipGetLastError();
         set_error("hash_encode_backward: no memory for %zu bytes of range masks", mask_bytes);
         return ENVIDR_ELAUNCH;
     }
     hipLaunchKernelGGL((k_table_range_masks<D>), dim3(ceil_div(B, kBlock), L), dim3(kBlock), 0, s, inputs, offsets, masks, B, pitch, log2_rows, ls);
     int rc = check_launch("k_table_range_masks");
-    if (rc) { (void)hipFreeAsync(masks, s); return rc; }
+    if (rc) { if (pooled) (void)hipFreeAsync(masks, s); return rc; }
     hipLaunchKernelGGL((k_table_scatter_lds<D, C, SECOND>), dim3(kXcds * kLdsScatterSlots), dim3(kLdsScatterThreads), 0, s, grad, inputs, offsets, ggx,
                        masks, pitch, grad_table, B, L, ls);
     rc = check_launch("k_table_scatter_lds");
-    (void)hipFreeAsync(masks, s);             // stream order: behind the scatter kernel
+    if (pooled) (void)hipFreeAsync(masks, s);             // stream order: behind the scatter kernel
     return rc;
 }
 
