@@ -137,23 +137,6 @@ __global__ void __launch_bounds__(kBlock) k_grid_backward_table(const float* __r
     }
 }
 
-template <int D, int C>
-__global__ void __launch_bounds__(kBlock) k_grid_input_backward(const float* __restrict__ grad,
-                                                                const float* __restrict__ dy_dx,
-                                                                float* __restrict__ grad_inputs, uint32_t B,
-                                                                uint32_t L) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= B * D) return;
-    const uint32_t b = t / D, d = t - b * D;
-    const float* j = dy_dx + (size_t)b * L * D * C + d * C;
-    float acc = 0;
-    for (uint32_t l = 0; l < L; ++l) {
-#pragma unroll
-        for (int c = 0; c < C; ++c) acc += grad[((size_t)l * B + b) * C + c] * j[(size_t)l * D * C + c];
-    }
-    grad_inputs[t] = acc;
-}
-
 template <typename F>
 int dispatch_dc(uint32_t D, uint32_t C, const char* who, F&& f) {
 #define ENVIDR_CASE(DD, CC) \
@@ -213,11 +196,7 @@ int envidr_grid_encode_backward(const float* grad, const float* inputs, const fl
         int rc = check_launch("k_grid_backward_table");
         if (rc) return rc;
         if (dy_dx) {
-            if (input_rows_fit(L, DD, CC))
-                launch_input_backward_rows<DD, CC>(grad, dy_dx, grad_inputs, B, L, as_stream(stream));
-            else
-                hipLaunchKernelGGL((k_grid_input_backward<DD, CC>), dim3(ceil_div(B * DD, kBlock)), dim3(kBlock), 0,
-                                   as_stream(stream), grad, dy_dx, grad_inputs, B, L);
+            launch_input_backward<DD, CC>(grad, dy_dx, grad_inputs, B, L, as_stream(stream));
             rc = check_launch("k_grid_input_backward");
         }
         return rc;

@@ -203,22 +203,7 @@ __global__ void __launch_bounds__(kBlock) k_hash_backward_table(const float* __r
     }
 }
 
-// grad_inputs[b,d] = sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c]      (hashencoder.cu:346-372)
-template <int D, int C>
-__global__ void __launch_bounds__(kBlock) k_input_backward(const float* __restrict__ grad,
-                                                           const float* __restrict__ dy_dx,
-                                                           float* __restrict__ grad_inputs, uint32_t B, uint32_t L) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= B * D) return;
-    const uint32_t b = t / D, d = t - b * D;
-    const float* j = dy_dx + (size_t)b * L * D * C + d * C;
-    float acc = 0;
-    for (uint32_t l = 0; l < L; ++l) {
-#pragma unroll
-        for (int c = 0; c < C; ++c) acc += grad[((size_t)l * B + b) * C + c] * j[(size_t)l * D * C + c];
-    }
-    grad_inputs[t] = acc;
-}
+// grad_inputs[b,d] = sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c]      (hashencoder.cu:346-372): input_rows.hip.h
 
 // grad_grad[l,b,c] = sum_d ggx[b,d] * dy_dx[b,l,d,c]              (hashencoder.cu:375-428)
 template <int D, int C>
@@ -780,11 +765,7 @@ int envidr_hash_encode_backward(const float* grad, const float* inputs, const fl
             if (rc) return rc;
         }
         if (calc_grad_inputs) {
-            if (input_rows_fit(L, DD, CC))
-                launch_input_backward_rows<DD, CC>(grad, dy_dx, grad_inputs, B, L, as_stream(stream));
-            else
-                hipLaunchKernelGGL((k_input_backward<DD, CC>), dim3(ceil_div(B * DD, kBlock)), dim3(kBlock), 0,
-                                   as_stream(stream), grad, dy_dx, grad_inputs, B, L);
+            launch_input_backward<DD, CC>(grad, dy_dx, grad_inputs, B, L, as_stream(stream));
             return check_launch("k_input_backward");
         }
         return ENVIDR_OK;

@@ -9,7 +9,7 @@ namespace envidr {
 inline uint32_t row_division_magic(uint32_t d) { return (uint32_t)((1ull << 32) / d) + 1u; }
 
 // A point's row is L D C contiguous floats.  With one lane per (point, dimension) reading global memory directly (the reference's form, kept
-// as k_input_backward / k_grid_input_backward for rows too long for LDS) the D lanes of a point read interleaved 4 C-byte pieces of it --
+// as k_input_backward_long for rows too long for LDS) the D lanes of a point read interleaved 4 C-byte pieces of it --
 // every load instruction touches 64 pieces spread over 8 KiB.  Here ONE WAVE
 // copies the rows of 64 points (one contiguous range, 16-byte loads, eight in flight per lane before the first LDS store) and their
 // gradient rows (contiguous per level) into LDS, then each lane walks its own point's row there (odd pitch: conflict-free): same order
@@ -89,11 +89,33 @@ __global__ void __launch_bounds__(64) k_input_backward_rows(const float* __restr
 
 inline bool input_rows_fit(uint32_t L, uint32_t D, uint32_t C) { return L * D * C <= 127; }          // <= 64 KiB of LDS, magic division valid
 
+// Rows too long for LDS (L D C > 127 floats: e.g. 24 levels of 3 x 2): one lane per (point, dimension) reading global memory, the reference's
+// form; D and C are run-time values here -- ONE kernel instead of an instantiation per (D, C) of both extensions for a path no shipped
+// configuration takes.  Same order of additions (l outer, c inner): same bits.
+static __global__ void __launch_bounds__(kBlock) k_input_backward_long(const float* __restrict__ grad, const float* __restrict__ dy_dx, float* __restrict__ grad_inputs,
+                                                               uint32_t B, uint32_t L, uint32_t D, uint32_t C) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * D) return;
+    const uint32_t b = t / D, d = t - b * D;
+    const float* j = dy_dx + (size_t)b * L * D * C + d * C;
+    float acc = 0;
+    for (uint32_t l = 0; l < L; ++l)
+        for (uint32_t c = 0; c < C; ++c) acc += grad[((size_t)l * B + b) * C + c] * j[(size_t)l * D * C + c];
+    grad_inputs[t] = acc;
+}
+
 template <int D, int C>
 inline void launch_input_backward_rows(const float* grad, const float* dy_dx, float* grad_inputs, uint32_t B, uint32_t L, hipStream_t stream) {
     const uint32_t row_floats = L * D * C;
     hipLaunchKernelGGL((k_input_backward_rows<D, C>), dim3(ceil_div(B, kWaveRows)), dim3(64), (kWaveRows * ((row_floats | 1u) + L * C) + 1) * sizeof(float),
                        stream, grad, dy_dx, grad_inputs, B, L, row_division_magic(row_floats));
+}
+
+// grad_inputs of a (D, C) grid operator, whichever form the row length allows
+template <int D, int C>
+inline void launch_input_backward(const float* grad, const float* dy_dx, float* grad_inputs, uint32_t B, uint32_t L, hipStream_t stream) {
+    if (input_rows_fit(L, D, C)) launch_input_backward_rows<D, C>(grad, dy_dx, grad_inputs, B, L, stream);
+    else hipLaunchKernelGGL(k_input_backward_long, dim3(ceil_div(B * (uint32_t)D, kBlock)), dim3(kBlock), 0, stream, grad, dy_dx, grad_inputs, B, L, (uint32_t)D, (uint32_t)C);
 }
 
 }  // namespace envidr

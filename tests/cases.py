@@ -214,6 +214,33 @@ def hash_wide_row_cases():
         assert L * D * C > 127
         out.append((f"D{D}C{C}L{L}_fwd_grad", "hash_encode_forward",
                     (x, table, offsets, np.zeros((L, B, C), F), B, D, C, L, S, base, 1, np.zeros((B, L * D * C), F)), None))
+    # ... and the input gradient of such rows (k_input_backward_long, input_rows.hip.h: one run-time (D, C) kernel for both extensions);
+    # a generator of their own: the cases above keep their draws
+    from oracle import clib
+    rng2 = np.random.default_rng(131 + SEED_OFFSET)
+    for D, C, L, log2T, base, desired in [(3, 8, 6, 10, 4, 40), (2, 2, 32, 8, 2, 1000)]:
+        offsets, pls = scenes.hash_level_offsets(D, L, base, log2T, desired)
+        S = float(np.log2(pls))
+        B = 333
+        x = _points(rng2, B, D)
+        table = rng2.uniform(-1, 1, size=(int(offsets[-1]), C)).astype(F)
+        dy_dx = np.zeros((B, L * D * C), F)
+        clib.oracle().call("hash_encode_forward", x, table, offsets, np.zeros((L, B, C), F), B, D, C, L, S, base, 1, dy_dx)
+        grad = rng2.normal(size=(L, B, C)).astype(F)
+        out.append((f"D{D}C{C}L{L}_bwd_inputs_only", "hash_encode_backward",
+                    (grad, x, table, offsets, None, B, D, C, L, S, base, 1, dy_dx, np.zeros((B, D), F)), None))
+    for D, C, L, log2T, base, desired, gridtype, align in [(5, 4, 8, 10, 2, 12, 0, 0), (1, 8, 20, 8, 4, 200, 1, 1)]:
+        offsets, pls = scenes.grid_level_offsets(D, L, base, log2T, desired, bool(align))
+        S = float(np.log2(pls))
+        B = 333
+        x = _points(rng2, B, D)
+        table = rng2.uniform(-1, 1, size=(int(offsets[-1]), C)).astype(F)
+        dy_dx = np.zeros((B, L * D * C), F)
+        assert L * D * C > 127
+        clib.oracle().call("grid_encode_forward", x, table, offsets, np.zeros((L, B, C), F), B, D, C, L, S, base, dy_dx, gridtype, align)
+        grad = rng2.normal(size=(L, B, C)).astype(F)
+        out.append((f"grid_D{D}C{C}L{L}_bwd", "grid_encode_backward",
+                    (grad, x, table, offsets, np.zeros_like(table), B, D, C, L, S, base, dy_dx, np.zeros((B, D), F), gridtype, align), 1e-5))
     return out
 
 

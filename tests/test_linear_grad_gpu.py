@@ -111,7 +111,8 @@ def test_accumulate_and_empty_batches():
 
 @pytest.mark.parametrize("M,K,N,view", [(1, 4, 1, False), (130, 72, 256, False), (4097, 256, 256, False), (4097, 256, 256, True), (20000, 256, 12, False),
                                         (20000, 12, 256, True), (33333, 64, 64, False), (33333, 64, 64, True), (9999, 32, 64, False), (5000, 64, 15, False),
-                                        (5000, 16, 64, True), (3000, 128, 3, False), (3000, 300, 260, False), (777, 160, 160, True), (2048, 100, 37, True)])
+                                        (5000, 16, 64, True), (3000, 128, 3, False), (3000, 300, 260, False), (777, 160, 160, True), (2048, 100, 37, True),
+                                        (1500, 64, 32, False), (1500, 64, 32, True), (1500, 12, 20, True), (2048, 100, 100, True), (2048, 100, 20, True)])
 def test_rows_product_matches_float64(M, K, N, view):
     """envidr_linear_rows (csrc/linear_rows.hip) in its four epilogues against float64: both vector layouts of W (row-major [N, K]; the
     transposed view of a [K, N] matrix -- the input-gradient product) and the strided fallback, whole and ragged slabs / column blocks / row
@@ -123,8 +124,8 @@ def test_rows_product_matches_float64(M, K, N, view):
     x = torch.randn(M, K, device="cuda", generator=g)
     Wm = torch.randn((K, N) if view else (N, K), device="cuda", generator=g) / K ** 0.5
     W = Wm.t() if view else Wm
-    if (M, K, N) == (2048, 100, 37):
-        W = torch.randn(N, 2 * K + 1, device="cuda", generator=g)[:, ::2][:, :K]       # neither index contiguous: the element-wise staging
+    if (M, K) == (2048, 100):
+        W = torch.randn(N, 2 * K + 1, device="cuda", generator=g)[:, ::2][:, :K]       # neither index contiguous: the element-wise staging (N = 37 / 100 / 20: column blocks of 64 / 128 / 32)
     b = torch.randn(N, device="cuda", generator=g)
     act = torch.randn(M, N, device="cuda", generator=g)
     ref = x.double() @ W.double().t()
