@@ -481,6 +481,7 @@ def run(argv: list[str]) -> None:
             context_legs(result, renderer, dev, args.steps, N_frame, headline_cold=args.cold)
         if world == 1 and not strong and not args.headline_only:
             other_configs(result, dev, rays_o, rays_d, N)
+            training_and_loop_legs(result)
         # HBM traffic of the dominant kernel from the PMC summary -- only if it was collected on THESE kernel sources
         prof = os.path.join(ROOT, "profiles", "pmc_latest.json")
         note = "no profiles/pmc_latest.json"
@@ -775,6 +776,37 @@ def other_configs(result, dev, rays_o, rays_d, N) -> None:
                              "frac": isamples * HASH_BYTES_PER_SAMPLE / idt / 1e9 / PEAK_HBM_GBPS},
                      "mfma": {"achieved": iflop / idt / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                               "frac": iflop / idt / 1e12 / PEAK_FP32_MFMA_TFLOPS}}}
+
+
+def training_and_loop_legs(result) -> None:
+    """The widening rows next to the frame pipeline (INTEGRATION.md way 1), as context: one training step of the toaster network
+    (tools/train_step_bench.py) and the reference-shaped operator loop on the headline frame (tools/loop_frame_bench.py).  Each runs in its
+    own process after the timed region (its failure or time-out is recorded, never the bench's); neither is `value`."""
+    import re
+    import subprocess
+    oc = result.setdefault("other_configs", {})
+    for key, script, argv in (("training step (run_cuda's training branch: 4 096 rays, ~144 k samples, eikonal loss, Adam), 1 GPU", "train_step_bench.py", ["20"]),
+                              ("reference-shaped operator loop (fused=False) on the headline frame, 800x800, 1 GPU", "loop_frame_bench.py", ["3"])):
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script), *argv], capture_output=True, text=True, timeout=240, cwd=ROOT)
+            lines = [l for l in r.stdout.splitlines() if " ms per " in l]
+            if r.returncode != 0 or not lines:
+                oc[key] = {"error": (r.stderr or r.stdout)[-300:]}
+                continue
+            entry = {"lines": lines}
+            for l in lines:
+                m = re.search(r"([0-9.]+) ms per (step|800x800 frame)", l)
+                if not m:
+                    continue
+                if l.startswith("steady state"):
+                    entry["ms_per_step_steady_state"] = float(m.group(1))
+                elif l.startswith("training step"):
+                    entry["ms_per_step_first_16_steps_regime"] = float(m.group(1))
+                elif l.startswith("fused=False"):
+                    entry["ms_per_frame"] = float(m.group(1))
+            oc[key] = entry
+        except Exception as e:      # noqa: BLE001
+            oc[key] = {"error": repr(e)[:300]}
 
 
 def main() -> None:
