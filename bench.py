@@ -51,7 +51,11 @@ FLOP_PER_SAMPLE_PLAIN = 41_984     # configs[1]: no env MLP
 FLOP_PER_SAMPLE_RENV = 30_592      # third pass of indirect rendering: renv MLP 4-64-64-64-12 (18 432) + the specular head again (12 160)
 HASH_BYTES_PER_SAMPLE = 1024       # 16 levels x 8 corners x 8 B gathered per sample
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+PEAK_FP16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak
 PEAK_HBM_GBPS = 8000.0
+HEADLINE_SDF_BIAS = 0.065          # the scene density SURVEY.md 8(d) specifies: ~28 samples per ray at a 37 % hit rate (round 6: the headline)
+HEADLINE_SIZING_HINT = 40.0        # samples per ray the headline's sample / record buffers are sized for before the first frame
+PREFLIGHT_TIMEOUT_S = float(os.environ.get("ENVIDR_PREFLIGHT_TIMEOUT_S", "30"))      # (the tests shrink it)
 
 
 def csrc_hash() -> str:
@@ -72,27 +76,40 @@ def host_cpu_info() -> dict:
         for line in out.splitlines():
             k, _, v = line.partition(":")
             k, v = k.strip(), v.strip()
-            if k in ("Model name", "Socket(s)", "Core(s) per socket", "Thread(s) per core"):
+            if k in ("Model name", "Socket(s)", "Core(s) per socket", "Thread(s) per core", "CPU max MHz", "CPU MHz", "Flags"):
                 info[k] = v
     except Exception:
         pass
     return info
 
 
+def host_peak_fp32_gflops(host: dict) -> dict | None:
+    """what the host's cores could do in fp32 on paper: physical cores x 2 FMA pipes x vector lanes x 2 FLOP x clock (lscpu)"""
+    try:
+        cores = int(host["Socket(s)"]) * int(host["Core(s) per socket"])
+        lanes = 16 if "avx512f" in host.get("Flags", "") else 8
+        mhz = float(host.get("CPU max MHz") or host.get("CPU MHz") or 0.0)
+        if mhz <= 0:
+            return None
+        return {"gflops": cores * 2 * lanes * 2 * mhz / 1e3, "formula": f"{cores} cores x 2 FMA pipes x {lanes} fp32 lanes x 2 FLOP x {mhz / 1e3:.2f} GHz"}
+    except Exception:       # noqa: BLE001
+        return None
+
+
 def cpu_baseline(scene, env_rot: float, frames: int, res: int) -> dict:
     """the CPU restatement (oracle: C/OpenMP ops + torch CPU fp32 GEMMs, reference n_step schedule) timed on the host cores
-    on the benchmark's own frame.  Thread count: every candidate in {16, 32, 64} (capped at the hardware threads) renders a 400x400 frame
-    of the SAME scene and camera once (160 000 rays: the first loop iterations are 160 k-row GEMMs, the regime of the full
-    frame -- a 96x96 probe is not), after a small warm-up; the fastest is used.  Then the median of `frames` full frames."""
+    on a BOUNDED sample of the benchmark's workload: a `res` x `res` view (default 400: a quarter of the rays of the 800x800 frame, same scene,
+    same camera, same samples per ray -- about 30 s of CPU work).  Thread count: every candidate in {16, 32, 64} (capped at the hardware
+    threads) renders a 200x200 view of the SAME scene and camera once, after a small warm-up; the fastest is used."""
     from envidr_amd import scenes
     from oracle.py import render_oracle as ro
     opt = ro.RenderOptions(ide_mode="torch")
-    probe_res = min(400, res)
+    probe_res = min(200, res)
     probe_o, probe_d = scenes.camera_rays(probe_res, probe_res)
     best, threads, tried = None, 1, {}
     ncpu = os.cpu_count() or 1
     # (all hardware threads is not a candidate: on the 2 x 64-core, 256-thread host of the GPU box that setting took 413 s for
-    # the probe frame the others render in 9-15 s -- profiles/r03g/bench.json -- and would alone take the run past ten minutes)
+    # a 400x400 frame the others render in 9-15 s -- profiles/r03g/bench.json)
     for th in sorted({min(c, ncpu) for c in (16, 32, 64)}):
         torch.set_num_threads(th)
         ro.render_rays(scene, probe_o[:256], probe_d[:256], opt, env_rot)    # warm-up (library loads, thread pools)
@@ -115,16 +132,24 @@ def cpu_baseline(scene, env_rot: float, frames: int, res: int) -> dict:
         host_cores = int(host["Socket(s)"]) * int(host["Core(s) per socket"])
     except Exception:       # noqa: BLE001
         host_cores = None
+    peak = host_peak_fp32_gflops(host)
+    host.pop("Flags", None)
+    reached = out["n_samples"] * FLOP_PER_SAMPLE / dt / 1e9
     return {"value": n / dt, "unit": "rays/s", "cores": threads, "threads_used": threads, "host_cores": host_cores,
-            "cores_note": "`cores` / `threads_used` = the torch + OpenMP thread count that rendered the probe frame fastest, NOT the size of the "
+            "cores_note": "`cores` / `threads_used` = the torch + OpenMP thread count that rendered the probe view fastest, NOT the size of the "
                           "host (`host_cores` physical cores, `host.logical_cpus` hardware threads)",
             "kind": "port",
-            "sample": f"{res}x{res} frame of the same scene and camera ({n} rays, {out['n_samples']} samples): oracle/ C+OpenMP ops + torch "
-                      f"CPU fp32 GEMMs, reference n_step schedule; median of {len(times)} frames ({dt:.1f} s each) at the fastest of the "
-                      f"thread counts tried on a {probe_res}x{probe_res} frame of the same scene",
+            "sample": f"{res}x{res} view of the same scene and camera ({n} rays, {out['n_samples']} samples, {out['n_samples'] / n:.1f} per ray as in the 800x800 "
+                      f"frame): oracle/ C+OpenMP ops + torch CPU fp32 GEMMs, reference n_step schedule; median of {len(times)} view(s) ({dt:.1f} s each) at the "
+                      f"fastest of the thread counts tried on a {probe_res}x{probe_res} view of the same scene",
             "frame_seconds": times, "threads_tried_seconds_on_probe_frame": tried, "probe_frame": f"{probe_res}x{probe_res}",
             "ide_mode": "torch (the reference's fp32 complex-power formulation, ide_encoder.py:98-130)", "host": host,
-            "samples_per_s": out["n_samples"] / dt, "image": out["image"]}
+            "samples_per_s": out["n_samples"] / dt,
+            "dense_layer_gflops_reached": reached, "host_fp32_peak_estimate": peak,
+            "host_note": ("a reported baseline, not a target: the port keeps the reference's loop structure (per-round torch CPU GEMMs on the live samples, "
+                          "complex-power IDE) and reaches the `dense_layer_gflops_reached` figure; `host_fp32_peak_estimate` is what the host's cores could do "
+                          "on paper -- the ratio of the GPU figure to this baseline says nothing about kernel quality, `roofline.frac` does"),
+            "image": out["image"]}
 
 
 def _free_port() -> int:
@@ -147,8 +172,12 @@ def parse(argv: list[str]):
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (profiling runs)")
-    ap.add_argument("--cpu-frames", type=int, default=3, help="full CPU frames timed for cpu_baseline (median)")
-    ap.add_argument("--cpu-res", type=int, default=800, help="resolution of the CPU frame (the benchmark's own: 800)")
+    ap.add_argument("--cpu-frames", type=int, default=1, help="CPU views timed for cpu_baseline (median)")
+    ap.add_argument("--cpu-res", type=int, default=400, help="resolution of the CPU view: a bounded sample of the 800x800 frame (same scene, camera and "
+                    "samples per ray; 400 = a quarter of its rays, about 30 s of CPU work)")
+    ap.add_argument("--preflight", action="store_true", help="multi-GPU pre-flight only: device count, process group, one 1 MB gather and the ranks_seen "
+                    "all-reduce under a 30 s limit; prints one JSON line (ok or which rank / which call failed) and exits.  Runs automatically before the "
+                    "timed loop of every N > 1 run")
     ap.add_argument("--path", choices=["pipeline", "fused"], default="pipeline",
                     help="pipeline: geometry pipeline + shading pass per frame (default); fused: one persistent kernel per frame")
     ap.add_argument("--headline-only", action="store_true", help="skip the CPU leg and the other_configs renders, so that a "
@@ -189,9 +218,9 @@ def load_scene(rank: int, world: int, dist_on: bool, dev):
     import torch.distributed as dist
     from envidr_amd import scenes
     if not dist_on:
-        return scenes.toaster_scene()
+        return scenes.toaster_scene(sdf_bias=HEADLINE_SDF_BIAS)
     # (a forced world of one goes through the same calls: the broadcasts are then trivial, but the code that runs on N ranks has run)
-    sc = scenes.toaster_scene(arrays=(rank == 0))
+    sc = scenes.toaster_scene(sdf_bias=HEADLINE_SDF_BIAS, arrays=(rank == 0))
     rows = int(sc.offsets[-1])
     table = torch.from_numpy(sc.table).to(dev) if rank == 0 else torch.empty(rows, 2, dtype=torch.float32, device=dev)
     bitfield = torch.from_numpy(sc.bitfield).to(dev) if rank == 0 else torch.empty(sc.cascades * sc.grid_size ** 3 // 8, dtype=torch.uint8, device=dev)
@@ -218,7 +247,17 @@ def run(argv: list[str]) -> None:
     elif int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.force_dist:
         _REAL_STDOUT = os.dup(1)
         os.dup2(2, 1)
-    rank, world, local = parallel.init_from_env(backend="gloo" if stub else None, force=args.force_dist)
+    env_rank, env_world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    will_dist = env_world > 1 or args.force_dist
+    if not stub and will_dist and torch.cuda.device_count() < env_world:
+        _preflight_failed({"ok": False, "stage": "device_count", "rank": env_rank, "world": env_world,
+                           "error": f"torch.cuda.device_count() = {torch.cuda.device_count()} < {env_world} ranks"})
+    try:
+        rank, world, local = parallel.init_from_env(backend="gloo" if stub else None, force=args.force_dist,
+                                                    timeout_s=4 * PREFLIGHT_TIMEOUT_S if will_dist else None)
+    except Exception as e:      # noqa: BLE001
+        _preflight_failed({"ok": False, "stage": "init_process_group", "rank": env_rank, "world": env_world, "error": f"{type(e).__name__}: {e}"[:500],
+                           "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}"})
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist_on = world > 1 or args.force_dist         # the collective code path (a world of one with --force-dist)
@@ -230,6 +269,19 @@ def run(argv: list[str]) -> None:
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
         n_side = H
+    # multi-GPU pre-flight: the collectives the run depends on, small and under a time limit, before anything expensive
+    pre = None
+    if dist_on:
+        if os.environ.get("ENVIDR_PREFLIGHT_ABSENT_RANK") == str(rank):      # test hook: this rank never joins the pre-flight collectives
+            time.sleep(3 * PREFLIGHT_TIMEOUT_S)
+            os._exit(4)
+        pre = parallel.preflight(rank, world, dev, PREFLIGHT_TIMEOUT_S)
+        if not pre["ok"]:
+            _preflight_failed(pre)
+    if args.preflight:
+        _finish({"preflight": pre if pre is not None else {"ok": True, "stage": "done", "note": "one rank, no process group: nothing to check"},
+                 "n_gpus": world, "backend": dist.get_backend() if dist_on else None} if rank == 0 else None, dist_on)
+        return
     N_frame = n_side * n_side
 
     def env_rot(view: int) -> float:
@@ -269,7 +321,7 @@ def run(argv: list[str]) -> None:
             # (weak mode: the rays ARE a row-major 800-wide image -- the layout hint lets the pipeline form its 64-ray blocks from
             #  8x8-pixel tiles; strong mode already lists a rank's rays tile by tile)
             return renderer.render_frame(rays_o, rays_d, env_rot(view) if not stub else float(view), out=outs[slot], events=events, wait=False,
-                                         use_cost_hint=not args.cold, image_width=0 if strong else n_side)
+                                         use_cost_hint=not args.cold, image_width=0 if strong else n_side, samples_per_ray_hint=HEADLINE_SIZING_HINT)
         if events:
             events[0].record()
         res = renderer.render(rays_o, rays_d, env_rot(view), extras=True, stats=True, out=outs[slot], ray_cost=ray_cost)
@@ -353,7 +405,7 @@ def run(argv: list[str]) -> None:
             ro, rd = full_rays
             if pipeline:
                 r2 = renderer.render_frame(ro, rd, env_rot(view) if not stub else float(view), out={}, wait=False,
-                                           use_cost_hint=False, image_width=n_side)
+                                           use_cost_hint=False, image_width=n_side, samples_per_ray_hint=HEADLINE_SIZING_HINT)
             else:
                 r2 = renderer.render(ro, rd, env_rot(view), extras=True, stats=True, out={})
             return r2["image"]
@@ -417,10 +469,10 @@ def run(argv: list[str]) -> None:
             #  inversely with it -- and whether the frames had the previous frame's per-ray counts as a hint)
             # (the first ~120 characters carry what a truncated record must still show: COLD or HINTED, the scene's samples per ray --
             #  rays/s scales inversely with it -- and samples/s; at N = 1 the SURVEY 8(d)-density leg is spliced in behind them below)
-            "config": {"workload": ("COLD" if args.cold else "HINTED (fixed-camera video)") + f" 800x800 toaster.ini frames, {samples / max(N, 1):.2f} samples/ray, "
+            "config": {"workload": ("COLD" if args.cold else "HINTED (fixed-camera video)") + f" 800x800 toaster.ini frames at SURVEY 8d density, {samples / max(N, 1):.2f} samples/ray, "
                                    f"{(1 if strong else world) * samples * args.steps / dt / 1e6:.0f} M samples/s; "
                                    + ("no per-ray hint; " if args.cold else "per-ray counts of the previous frame as hint; ")
-                                   + "thin synthetic shell; BASELINE configs[2]/[4]: hash L16xC2 + SDF 32-64-64-15 + IDE deg5 + env MLP "
+                                   + f"synthetic shell, toaster_scene(sdf_bias={HEADLINE_SDF_BIAS}); BASELINE configs[2]/[4]: hash L16xC2 + SDF 32-64-64-15 + IDE deg5 + env MLP "
                                    "72-256-256-256-12 x2 + diffuse/specular heads, one view per "
                                    + ("step sharded by 8x8-pixel tiles" if strong else "GPU per step, env-rotation video frames sharded by view")
                                    + ", normal/diffuse/specular/roughness images on",
@@ -440,7 +492,7 @@ def run(argv: list[str]) -> None:
             "gather_ms": gather_ms,
         }
         if dist_on:
-            result["dist"] = {"backend": dist.get_backend(), "world": world, "ranks_seen": ranks_seen,
+            result["dist"] = {"backend": dist.get_backend(), "world": world, "ranks_seen": ranks_seen, "preflight": pre,
                               "ranks_seen_note": "all_reduce(SUM) of a one per rank over the benchmark's own process group",
                               "force_dist": bool(args.force_dist), "gathered_equals_rendered": delivered_ok,
                               "gathered_equals_rendered_per_rank": delivered_per_rank,
@@ -502,7 +554,7 @@ def run(argv: list[str]) -> None:
             from envidr_amd import scenes
             cpu = cpu_baseline(scene, env_rot(0), args.cpu_frames, args.cpu_res)
             so, sd = (torch.from_numpy(a).to(dev) for a in scenes.camera_rays(args.cpu_res, args.cpu_res))
-            g = renderer.render_frame(so, sd, env_rot(0))["image"].cpu().numpy()
+            g = renderer.render_frame(so, sd, env_rot(0), samples_per_ray_hint=HEADLINE_SIZING_HINT)["image"].cpu().numpy()
             ref = cpu.pop("image")
             mse = float(np.mean((g.astype(np.float64) - ref) ** 2))
             result["psnr_vs_cpu_reference_db"] = -10 * math.log10(max(mse, 1e-20))
@@ -512,13 +564,25 @@ def run(argv: list[str]) -> None:
                                      "rounding noise (DESIGN.md 4.4) -- most of this figure; with ide_mode='exact' on the CPU the two sides "
                                      "agree to ~1e-7 (tests/test_geometry_gpu.py::test_integer_trace_is_the_oracles)")
             result["cpu_baseline"] = cpu
-            result["speedup_vs_cpu_baseline"] = rays_per_s / cpu["value"]
         _finish(result, dist_on)
         return
     _finish(None, dist_on)
 
 
 _REAL_STDOUT = None          # rank 0 of a distributed run: the saved stdout (see run())
+
+
+def _preflight_failed(info: dict) -> None:
+    """one diagnosable JSON line -- which rank, which call -- on stderr (every rank) and on the real stdout (rank 0), then leave
+    without waiting for a communicator that may never come back"""
+    line = json.dumps({"preflight": info, "error": f"multi-GPU pre-flight failed on rank {info.get('rank')} in {info.get('stage')}: {info.get('error')}"})
+    print(line, file=sys.stderr, flush=True)
+    if int(info.get("rank", 0)) == 0:
+        try:
+            os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (line + "\n").encode())
+        except OSError:
+            pass
+    os._exit(3)
 
 
 def _flush_c_stdio() -> None:
@@ -557,7 +621,7 @@ def context_legs(result, renderer, dev, steps: int, N: int, headline_cold: bool 
     from envidr_amd.nerf.utils import get_rays
     steps = max(steps, 4)
 
-    def leg(make_rays, use_hint: bool, warm: int, sizing_hint: float = 20.0) -> dict:
+    def leg(make_rays, use_hint: bool, warm: int, sizing_hint: float = HEADLINE_SIZING_HINT) -> dict:
         out: dict = {}
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
         log = []
@@ -605,22 +669,21 @@ def context_legs(result, renderer, dev, steps: int, N: int, headline_cold: bool 
     result["moving_camera"] = dict(leg(moving, True, 2),
                                    note="camera orbit advanced 2 degrees per frame; envidr_get_rays inside the timed region; the per-ray hint is "
                                         "the previous pose's sample counts (wrong for rays near silhouettes: extra rounds / zero-filled slots)")
-    # rays/s scales inversely with the scene's samples per ray, and the headline shell is thin (12 per ray).  The same network, camera
-    # and pipeline on the density SURVEY.md 8(d) proposed (mean sdf slightly positive inside the shell: ~28 samples per ray at the
-    # same 37 % hit rate): the portable figure is samples/s, which should not move.
+    # rays/s scales inversely with the scene's samples per ray.  Rounds 1-5 quoted `value` on a thinner shell (sdf_bias = 0.005: ~12 samples
+    # per ray at the same 37 % hit rate); since round 6 the headline is the density SURVEY.md 8(d) specifies and the thin shell is this
+    # context leg: the portable figure is samples/s, which should not move between the two.
     from envidr_amd.fused import FusedRenderer
     headline_renderer = renderer
-    renderer = FusedRenderer.from_scene(scenes.toaster_scene(sdf_bias=0.065), device=dev)
-    thick = leg(lambda i: fixed, not headline_cold, 2, sizing_hint=40.0)
+    renderer = FusedRenderer.from_scene(scenes.toaster_scene(), device=dev)
+    thin = leg(lambda i: fixed, not headline_cold, 2, sizing_hint=20.0)
     renderer = headline_renderer
-    result["survey_density_scene"] = dict(thick, samples_per_ray=thick["samples_composited_per_frame"] / N,
-                                          samples_per_s=thick["samples_composited_per_frame"] / (thick["ms_per_frame"] * 1e-3),
-                                          note="toaster_scene(sdf_bias=0.065): the density of SURVEY.md 8(d) (~28 samples per ray), "
-                                               + ("cold" if headline_cold else "hinted") + " frames like the headline")
-    # ... and into the first characters of the workload string, next to the headline's own samples/ray and samples/s
-    d = result["survey_density_scene"]
+    result["thin_shell_scene"] = dict(thin, samples_per_ray=thin["samples_composited_per_frame"] / N,
+                                      samples_per_s=thin["samples_composited_per_frame"] / (thin["ms_per_frame"] * 1e-3),
+                                      note="toaster_scene(sdf_bias=0.005): the thinner shell rounds 1-5 quoted `value` on (~12 samples per ray), "
+                                           + ("cold" if headline_cold else "hinted") + " frames like the headline")
+    d = result["thin_shell_scene"]
     head, sep, tail = result["config"]["workload"].partition(" M samples/s; ")
-    result["config"]["workload"] = (head + sep + f"at SURVEY 8d density ({d['samples_per_ray']:.1f} samples/ray): {d['rays_per_s'] / 1e6:.2f} M rays/s, "
+    result["config"]["workload"] = (head + sep + f"on the thinner shell of rounds 1-5 ({d['samples_per_ray']:.1f} samples/ray): {d['rays_per_s'] / 1e6:.2f} M rays/s, "
                                     f"{d['samples_per_s'] / 1e6:.0f} M samples/s; " + tail)
 
 
@@ -656,7 +719,7 @@ def other_configs(result, dev, rays_o, rays_d, N) -> None:
         "rays_per_s": N / pdt, "ms_per_frame": pdt * 1e3, "samples_per_s": psamples / pdt, "samples_per_frame": psamples, "samples_per_ray": psamples / N,
         "roofline": _both_rooflines(psamples, pdt, FLOP_PER_SAMPLE_PLAIN)}
     # the headline frames through the single persistent kernel (envidr_render_rays)
-    one = FusedRenderer.from_scene(scenes.toaster_scene(), device=dev)
+    one = FusedRenderer.from_scene(scenes.toaster_scene(sdf_bias=HEADLINE_SDF_BIAS), device=dev)
     oout: dict = {}
     ocost = torch.zeros(N, dtype=torch.int16, device=dev)
     k = [0]
@@ -675,10 +738,11 @@ def other_configs(result, dev, rays_o, rays_d, N) -> None:
     oc["configs[2] relight variant: IDE deg 4 + env MLP 38-160-160-160-12 x2 (shape of the shipped env nets), 800x800, 1 GPU"] = {
         "rays_per_s": N / rdt, "ms_per_frame": rdt * 1e3, "samples_per_frame": rs, "samples_per_ray": rs / N, "roofline": _both_rooflines(rs, rdt, FLOP_PER_SAMPLE_RELIGHT)}
     # BASELINE configs[4] with the geometry cache (NOT the headline): fixed camera, rotating environment
-    headline = FusedRenderer.from_scene(scenes.toaster_scene(), device=dev)
+    headline = FusedRenderer.from_scene(scenes.toaster_scene(sdf_bias=HEADLINE_SDF_BIAS), device=dev)
+    headline.cache_geometry(rays_o, rays_d, samples_per_ray_hint=HEADLINE_SIZING_HINT)          # (first call: buffer sizing)
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
-    cache = headline.cache_geometry(rays_o, rays_d)
+    cache = headline.cache_geometry(rays_o, rays_d, samples_per_ray_hint=HEADLINE_SIZING_HINT)
     torch.cuda.synchronize(dev)
     build_ms = (time.perf_counter() - t1) * 1e3
     cout: dict = {}
@@ -687,16 +751,36 @@ def other_configs(result, dev, rays_o, rays_d, N) -> None:
         "rays_per_s": N / cdt, "ms_per_frame": cdt * 1e3, "cache_build_ms": build_ms, "cached_samples": cache.n_samples,
         "samples_per_ray": cache.n_samples / N}
     # split-precision shading mode (env MLP on the fp16 matrix cores with (hi, lo) operand pairs, heads fp32): reported here
-    # only, NEVER the headline (whose dtype is f32 throughout); error measured against the fp32 frame of the same view
-    ref = {k_: v.clone() for k_, v in headline.render_frame(rays_o, rays_d, 0.1, out={}).items() if k_ in ("image", "specular_image")}
-    sout: dict = {}
-    sdt = _time(lambda: headline.render_frame(rays_o, rays_d, 0.1, out=sout, wait=False, env_precision="f16x2", image_width=W), 5, dev)
-    headline.check_frames()
-    split = headline.render_frame(rays_o, rays_d, 0.1, out=sout, env_precision="f16x2")
-    srel = {k_: float(torch.linalg.norm(split[k_] - ref[k_]) / torch.linalg.norm(ref[k_])) for k_ in ref}
-    oc["headline workload in the optional split-precision shading mode (env MLP: fp16 MFMA on (hi, lo) pairs; NOT f32, not comparable to value), 800x800, 1 GPU"] = {
-        "rays_per_s": N / sdt, "ms_per_frame": sdt * 1e3, "dtype": "f16x2 pairs (env MLP) + f32 (everything else)",
-        "rel_l2_vs_f32_frame": srel, "parity_tests": "tests/test_split_gpu.py: <= 1e-4 rel-L2 vs the reference's chains and frames"}
+    # only, NEVER the headline (whose dtype is f32 throughout); error measured against the fp32 frame of the same view.  Its own
+    # roofline is the fp16 MFMA peak: 3 fp16 MFMA products per fp32 product of the environment network.
+    del cache
+    split_legs = {}
+    for tag, fr, hint in (("headline scene", headline, HEADLINE_SIZING_HINT), ("thinner shell of rounds 1-5", FusedRenderer.from_scene(scenes.toaster_scene(), device=dev), 20.0)):
+        ref = {k_: v.clone() for k_, v in fr.render_frame(rays_o, rays_d, 0.1, out={}, samples_per_ray_hint=hint).items() if k_ in ("image", "specular_image")}
+        sout: dict = {}
+        sev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(5)]
+        k = [0]
+
+        def split_frame():
+            fr.render_frame(rays_o, rays_d, 0.1, out=sout, wait=False, env_precision="f16x2", image_width=W, samples_per_ray_hint=hint,
+                            events=sev[k[0] % 5])
+            k[0] += 1
+        sdt = _time(split_frame, 5, dev)
+        fr.check_frames()
+        shade_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in sev]))
+        geo_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in sev]))
+        split = fr.render_frame(rays_o, rays_d, 0.1, out=sout, env_precision="f16x2", samples_per_ray_hint=hint)
+        ssamples = int(fr._frame["last"][1])
+        srel = {k_: float(torch.linalg.norm(split[k_] - ref[k_]) / torch.linalg.norm(ref[k_])) for k_ in ref}
+        f16_flops = 3 * ssamples * 2 * 305_152 / (shade_ms * 1e-3) / 1e12           # three fp16 products per fp32 product of the env MLP, both evaluations
+        split_legs[tag] = {"rays_per_s": N / sdt, "ms_per_frame": sdt * 1e3, "geometry_ms": geo_ms, "shading_ms": shade_ms, "samples_per_frame": ssamples,
+                           "rel_l2_vs_f32_frame": srel,
+                           "roofline": {"bound": "mfma", "achieved": f16_flops, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": f16_flops / PEAK_FP16_MFMA_TFLOPS,
+                                        "note": "fp16 MFMA FLOPs actually issued by the environment network (3 per fp32 product: hi*hi + hi*lo + lo*hi) over the "
+                                                "HIP-event time of the whole shading stage (environment kernel + fp32 heads), against the dense fp16 MFMA peak"}}
+    oc["headline workload in the optional split-precision shading mode (env MLP: fp16 MFMA on (hi, lo) pairs; NOT f32, not comparable to value), 800x800, 1 GPU"] = dict(
+        split_legs, dtype="f16x2 pairs (env MLP) + f32 (everything else)", parity_tests="tests/test_split_gpu.py: <= 1e-4 rel-L2 vs the reference's chains and frames")
+    del headline
     # A "trained-like" scene (sharp Laplace density, beta = 1e-3; sdf mostly positive in front of the surface): most
     # samples inside the occupancy shell then have alpha = 1 - exp(-sigma dt) == 0 EXACTLY in fp32.  The reference shades them all;
     # the pipeline composites them (they are records) but gathers only the records with a non-zero weight for shading.
@@ -814,6 +898,9 @@ def main() -> None:
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # the driver's command line (`python bench.py --gpus N ...`) works by itself: start the N ranks here
         import torch.multiprocessing as mp
+        if not args.stub and torch.cuda.device_count() < args.gpus:
+            _preflight_failed({"ok": False, "stage": "device_count", "rank": 0, "world": args.gpus,
+                               "error": f"torch.cuda.device_count() = {torch.cuda.device_count()} < --gpus {args.gpus}"})
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         mp.spawn(_spawned, args=(args.gpus, _free_port(), sys.argv[1:]), nprocs=args.gpus, join=True)
         return

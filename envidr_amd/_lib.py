@@ -98,6 +98,15 @@ def load() -> ctypes.CDLL:
     return lib
 
 
+def release_scratch() -> int:
+    """envidr_release_scratch(): hands back the buffers the library keeps between calls outside torch's allocator (the range-mask scratch of
+    the table-gradient scatters); returns the bytes released.  Waits for the device."""
+    lib = load()
+    lib.envidr_release_scratch.restype = ctypes.c_uint64
+    lib.envidr_release_scratch.argtypes = []
+    return int(lib.envidr_release_scratch())
+
+
 def exported_symbols() -> dict[str, bool]:
     lib = load()
     return {name: hasattr(lib, "envidr_" + name) for name in SIGNATURES}

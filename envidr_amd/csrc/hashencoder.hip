@@ -653,16 +653,43 @@ __global__ void __launch_bounds__(kLdsScatterThreads) k_table_scatter_lds(const 
 // the wait is small beside 10 ms of kernels, nothing outlives the call, and the pool hands the bytes back (round 4 kept an unbounded per-stream
 // hipMalloc that was never freed: 0.5 GiB at 8 M points x 16 levels, outside torch's allocator).
 constexpr size_t kSmallMaskBytes = 64u << 20;
-struct SmallMaskScratch { uint32_t* ptr = nullptr; };
+// The kept buffer is as large as the largest request seen on its (device, stream) -- rounded up to a power of two from 1 MiB, at most
+// kSmallMaskBytes -- not a flat 64 MiB: a training run that scatters 9 MiB of masks pins 16 MiB outside torch's allocator.  It grows by
+// hipFree + hipMalloc (hipFree waits for the device: the kernels reading the old buffer are done).  envidr_release_scratch() hands all of it
+// back (entries of streams that no longer exist included).
+struct SmallMaskScratch { uint32_t* ptr = nullptr; size_t bytes = 0; };
 static std::mutex g_small_mask_mutex;
 static std::map<std::pair<int, hipStream_t>, SmallMaskScratch> g_small_masks;
-static uint32_t* small_mask_scratch(hipStream_t s) {
+static uint32_t* small_mask_scratch(hipStream_t s, size_t need) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     std::lock_guard<std::mutex> lock(g_small_mask_mutex);
     SmallMaskScratch& e = g_small_masks[{dev, s}];
-    if (!e.ptr && hipMalloc(reinterpret_cast<void**>(&e.ptr), kSmallMaskBytes) != hipSuccess) { (void)hipGetLastError(); e.ptr = nullptr; }
+    if (e.bytes < need) {
+        size_t want = 1u << 20;
+        while (want < need) want <<= 1;
+        if (e.ptr) (void)hipFree(e.ptr);
+        e.ptr = nullptr;
+        e.bytes = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&e.ptr), want) != hipSuccess) { (void)hipGetLastError(); e.ptr = nullptr; return nullptr; }
+        e.bytes = want;
+    }
     return e.ptr;
+}
+size_t release_small_mask_scratch() {
+    std::lock_guard<std::mutex> lock(g_small_mask_mutex);
+    size_t freed = 0;
+    int keep = 0;
+    (void)hipGetDevice(&keep);
+    for (auto& kv : g_small_masks) {
+        if (!kv.second.ptr) continue;
+        (void)hipSetDevice(kv.first.first);
+        if (hipFree(kv.second.ptr) == hipSuccess) freed += kv.second.bytes;
+        else (void)hipGetLastError();
+    }
+    g_small_masks.clear();
+    (void)hipSetDevice(keep);
+    return freed;
 }
 // pre-pass + range owners
 template <int D, int C, bool SECOND>
@@ -674,7 +701,7 @@ static int launch_table_scatter_lds(const float* grad, const float* inputs, cons
     while ((1u << log2_rows) < kRows) ++log2_rows;
     const uint32_t pitch = (B + 3u) / 4u * 4u;
     const size_t mask_bytes = ((size_t)L * pitch + kMaskGrain) * 4;
-    uint32_t* masks = mask_bytes <= kSmallMaskBytes ? small_mask_scratch(s) : nullptr;
+    uint32_t* masks = mask_bytes <= kSmallMaskBytes ? small_mask_scratch(s, mask_bytes) : nullptr;
     const bool pooled = masks == nullptr;
     if (pooled && (hipMallocAsync(reinterpret_cast<void**>(&masks), mask_bytes, s) != hipSuccess || !masks)) {
         (void)hipGetLastError();
@@ -713,6 +740,11 @@ int dispatch_dc(uint32_t D, uint32_t C, const char* who, F&& f) {
 }  // namespace
 
 extern "C" {
+
+// Hands back what the library keeps between calls outside the caller's allocator (the range-mask scratch of the table-gradient scatters:
+// one buffer per (device, stream), as large as the largest batch seen, at most 64 MiB).  Waits for the device.  Returns the bytes released.
+uint64_t envidr_release_scratch(void) { return (uint64_t)release_small_mask_scratch(); }
+
 
 int envidr_hash_encode_forward(const float* inputs, const float* embeddings, const int32_t* offsets, float* outputs,
                                uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,

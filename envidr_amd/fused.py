@@ -285,14 +285,15 @@ def linear_rows(x: torch.Tensor, W: torch.Tensor, bias: torch.Tensor | None = No
     _bind_render(lib)
     if not linear_rows_supported(x, W):
         raise _lib.EnvidrError(f"linear_rows: unsupported operands x {tuple(x.shape)} {x.dtype} W {tuple(W.shape)} {W.dtype} strides {W.stride()}")
-    if x.stride(1) != 1 or x.stride(0) % 4 != 0 or x.data_ptr() % 16 != 0:
+    # (a row-expanded operand -- stride (0, 1): the gradient of y.sum(0) -- has rows that overlap: the kernel wants ldx >= K)
+    if x.stride(1) != 1 or x.stride(0) % 4 != 0 or x.stride(0) < x.shape[1] or x.data_ptr() % 16 != 0:
         x = x.contiguous()
     M, K = x.shape
     N = W.shape[0]
     if mask_act is not None:
         if bias is not None or relu or mask_act.shape != (M, N):
             raise _lib.EnvidrError("linear_rows: mask_act [M, N] excludes bias / relu")
-        if mask_act.stride(1) != 1:
+        if mask_act.stride(1) != 1 or mask_act.stride(0) < N:
             mask_act = mask_act.contiguous()
         epi = ROWS_RELU_MASK
     elif bias is not None:

@@ -74,6 +74,12 @@ def _mlp(dims, bias=True):
 
 ENV_MLP_OPERATOR_MIN_ROWS = 4096      # below this the four torch GEMMs are not slower than packing / launching the operator
 WEIGHT_GRAD_OPERATOR_MIN_ROWS = 16384 # training: from this many rows the weight gradient of a layer goes to envidr_linear_weight_grad
+# The shading networks of the training branch (environment, diffuse, colour heads) run as ONE autograd node each (_ReluMlp) from that many rows on.
+# That node is once-differentiable: a loss that differentiates the colours with create_graph=True (a gradient penalty through the environment /
+# diffuse / colour networks) raises there, where the reference's nn.Sequential works -- set SHADING_MLP_SINGLE_NODE = False for such a loss (the
+# per-layer nodes below are twice differentiable).  Its ReLU, like the inference operator's, maps a NaN pre-activation to 0 where torch.relu
+# propagates it: a diverged network then trains on finite colours instead of failing loudly.
+SHADING_MLP_SINGLE_NODE = True
 
 
 def _input_gradient_only():
@@ -236,7 +242,7 @@ def _run_mlp(net, h, first_order_only=False):
     if (not torch.is_grad_enabled() and h.is_cuda and h.dtype == torch.float32 and h.numel() // max(h.shape[-1], 1) >= ENV_MLP_OPERATOR_MIN_ROWS
             and _fused.env_mlp_supported(net)):
         return _fused.env_mlp_forward(net, h)
-    if (first_order_only and torch.is_grad_enabled() and h.is_cuda and h.dtype == torch.float32 and h.numel() // max(h.shape[-1], 1) >= WEIGHT_GRAD_OPERATOR_MIN_ROWS
+    if (first_order_only and SHADING_MLP_SINGLE_NODE and torch.is_grad_enabled() and h.is_cuda and h.dtype == torch.float32 and h.numel() // max(h.shape[-1], 1) >= WEIGHT_GRAD_OPERATOR_MIN_ROWS
             and all(lin.training and lin.bias is not None and lin.weight.dtype == torch.float32 and lin.weight.requires_grad for lin in net)):
         params = [p for lin in net for p in (lin.weight, lin.bias)]
         return _ReluMlp.apply(h.reshape(-1, h.shape[-1]), *params).reshape(*h.shape[:-1], net[-1].weight.shape[0])
@@ -618,7 +624,15 @@ class NeRFNetwork(NeRFRenderer):
         """the fused renderer of the env-sphere mode for one environment MLP, its SDF weights set for `material`"""
         from ..fused import FusedRenderer
         key = tuple(self.material_vector(material)) if self.w_material else ()
+        # The renderer copies the packed MLPs and beta at construction (the hash table is used in place).  cuda_ray is off in this mode,
+        # so update_extra_state() -- the only automatic invalidate_fused() -- never runs: the weights' own (address, version) pairs are
+        # part of the cache key, as in fused.env_mlp_forward, so an optimizer step between two evaluations rebuilds the renderer.
+        nets = (self.sdf_net, self.env_nets[env_net_index], self.diffuse_net, self.color_net)
+        stamp = tuple((p.data_ptr(), p._version) for net in nets for p in net.parameters()) + ((self.sdf_density.beta.data_ptr(), self.sdf_density.beta._version),
+                                                                                                 self.encoder.embeddings.data_ptr())
         entry = self._fused_sph.get(env_net_index)
+        if entry is not None and entry[2] != stamp:
+            entry = None
         if entry is None:
             pairs = lambda net: [(l.weight.detach(), l.bias.detach()) for l in net]
             mlps = {"sdf": self._sdf_layers_for_material(material), "env": pairs(self.env_nets[env_net_index]),
@@ -628,7 +642,7 @@ class NeRFNetwork(NeRFRenderer):
             bitfield = torch.zeros(self.cascade * self.grid_size ** 3 // 8, dtype=torch.uint8, device=dev)
             fr = FusedRenderer(bitfield, self.encoder.embeddings.detach(), self.encoder.offsets.cpu().numpy(), self.encoder.per_level_scale,
                                mlps, float(self.sdf_density.beta.detach()), self._fused_options(), device=dev)
-            entry = self._fused_sph[env_net_index] = [fr, key]
+            entry = self._fused_sph[env_net_index] = [fr, key, stamp]
         elif entry[1] != key:
             entry[0].update_sdf(self._sdf_layers_for_material(material))
             entry[1] = key

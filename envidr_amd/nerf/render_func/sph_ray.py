@@ -83,15 +83,22 @@ def render_surface(shader, rays_o: torch.Tensor, rays_d: torch.Tensor, geo_feat:
 
 
 def _empty_results(model, prefix, bg_color, get_normal_image):
-    """no ray reaches the sphere (reference sph_ray.py:58-68; weights_sum added so that chunks can be concatenated)"""
+    """no ray reaches the sphere (reference sph_ray.py:58-68; weights_sum added so that chunks can be concatenated).  The optional
+    images follow the conditions of the non-empty path (normal image in eval mode only, diffuse / specular only with use_diffuse), so
+    that a chunk without a hit has the keys of a chunk with one"""
     N = bg_color.shape[0]
     vis = model.opt.visual_items
-    return {"image": bg_color.reshape(*prefix, 3), "depth": bg_color.new_zeros(*prefix),
-            "normal_image": torch.zeros_like(bg_color).reshape(*prefix, 3) if get_normal_image else None,
-            "diffuse_image": bg_color.reshape(*prefix, 3) if "diffuse" in vis else None,
-            "specular_image": bg_color.reshape(*prefix, 3) if "specular" in vis else None,
-            "roughness_image": torch.zeros_like(bg_color[..., :1]).reshape(*prefix, 1) if "roughness" in vis else None,
-            "weights_sum": bg_color.new_zeros(N, 1), "empty": True}
+    out = {"image": bg_color.reshape(*prefix, 3), "depth": bg_color.new_zeros(*prefix),
+           "normal_image": torch.zeros_like(bg_color).reshape(*prefix, 3) if (get_normal_image and not model.training) else None,
+           "weights_sum": bg_color.new_zeros(N, 1), "empty": True}
+    if model.opt.use_diffuse:
+        if "diffuse" in vis:
+            out["diffuse_image"] = bg_color.reshape(*prefix, 3)
+        if "specular" in vis:
+            out["specular_image"] = bg_color.reshape(*prefix, 3)
+    if "roughness" in vis:
+        out["roughness_image"] = torch.zeros_like(bg_color[..., :1]).reshape(*prefix, 1)
+    return out
 
 
 def run_sph(model, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, num_step=12, step_size=0.002, get_normal_image=False,

@@ -296,10 +296,20 @@ class NeRFRenderer(nn.Module):
             parts = [call(rays_o[:, i:i + batch], rays_d[:, i:i + batch], None if r_images is None else r_images[:, i:i + batch])
                      for i in range(0, N, batch)]
             results = {}
+            hit = [p for p in parts if not p.get("empty")]
             for k in ("image", "depth", "weights_sum", "normal_image", "diffuse_image", "specular_image", "roughness_image"):
-                vals = [p.get(k) for p in parts]
-                if any(v is not None for v in vals):
-                    results[k] = torch.cat(vals, 0 if k == "weights_sum" else 1)
+                # a key is part of the frame if the chunks that hit the sphere carry it (all of them do or none); a chunk without a hit
+                # contributes its background / zeros (its own entry where it has one)
+                if not any(p.get(k) is not None for p in (hit or parts)):
+                    continue
+                vals = []
+                for p in parts:
+                    v = p.get(k)
+                    if v is None:
+                        img = p["image"]
+                        v = img if k in ("diffuse_image", "specular_image") else img.new_zeros(*img.shape[:-1], 1 if k == "roughness_image" else 3)
+                    vals.append(v)
+                results[k] = torch.cat(vals, 0 if k == "weights_sum" else 1)
         if "weights_sum" in results and get_normal_image and results.get("normal_image") is not None:
             # the reference multiplies [B,N,3] by weights_sum[..., None] with weights_sum [N,1] here, which broadcasts to [N,N,3] (an
             # accident of run_sph returning an un-reshaped weights_sum); the per-ray blend it means -- its diagonal -- is what is returned

@@ -22,11 +22,11 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: str | None = None, force: bool = False) -> tuple[int, int, int]:
+def init_from_env(backend: str | None = None, force: bool = False, timeout_s: float | None = None) -> tuple[int, int, int]:
     """(rank, world, local_rank) from the torchrun environment; initialises the process group when
     WORLD_SIZE > 1 -- or, with `force`, also for a world of one (the collectives then run for real on a
     single rank: how the multi-GPU code path is exercised on a one-GPU box).  Rendezvous on 127.0.0.1
-    unless MASTER_ADDR says otherwise."""
+    unless MASTER_ADDR says otherwise.  `timeout_s` bounds the rendezvous (a missing rank then raises instead of hanging)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -47,8 +47,63 @@ def init_from_env(backend: str | None = None, force: bool = False) -> tuple[int,
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if timeout_s is not None:
+            import datetime
+            kw["timeout"] = datetime.timedelta(seconds=timeout_s)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
+
+
+def preflight(rank: int, world: int, dev: torch.device, timeout_s: float = 30.0) -> dict:
+    """The collectives a multi-GPU run depends on, once, small, under a time limit -- so that a node whose ranks cannot talk to each
+    other yields a diagnosable record instead of a hang: one 1 MB `gather` to rank 0 (contents checked there) and the `ranks_seen`
+    all-reduce.  Runs in a worker thread; the caller gets {"ok": bool, "stage": ..., "error": ..., "ms": {...}} and decides what to do
+    (bench.py prints it as one JSON line and exits).  Needs an initialised process group."""
+    import threading
+    import time
+    state = {"ok": False, "stage": "start", "error": None, "ms": {}, "rank": rank, "world": world}
+
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+
+    def work():
+        try:
+            if dev.type == "cuda":
+                torch.cuda.set_device(dev)
+            state["stage"] = "gather_1MB"
+            t0 = time.perf_counter()
+            mine = torch.full((262144,), float(rank), dtype=torch.float32, device=dev)
+            got = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+            dist.gather(mine, gather_list=got, dst=0)
+            sync()
+            if rank == 0:
+                bad = [r for r, g in enumerate(got) if not bool((g == float(r)).all())]
+                if bad:
+                    raise RuntimeError(f"gather delivered wrong contents for rank(s) {bad}")
+            state["ms"]["gather_1MB"] = (time.perf_counter() - t0) * 1e3
+            state["stage"] = "all_reduce_ranks_seen"
+            t0 = time.perf_counter()
+            ones = torch.ones(1, dtype=torch.float32, device=dev)
+            dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+            sync()
+            seen = int(ones.item())
+            state["ranks_seen"] = seen
+            if seen != world:
+                raise RuntimeError(f"all_reduce saw {seen} ranks of {world}")
+            state["ms"]["all_reduce_ranks_seen"] = (time.perf_counter() - t0) * 1e3
+            state["stage"] = "done"
+            state["ok"] = True
+        except Exception as e:      # noqa: BLE001
+            state["error"] = f"{type(e).__name__}: {e}"[:500]
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        state["error"] = f"timed out after {timeout_s:.0f} s in {state['stage']} (a rank did not join the collective)"
+    return dict(state)
 
 
 def views_for_rank(num_views: int, rank: int, world: int) -> list[int]:

@@ -36,6 +36,10 @@ typedef void* envidr_stream_t;     /* hipStream_t */
 const char* envidr_last_error(void);
 /* ABI version of this library: bumped on any signature or struct-layout change and when entry points are added (see csrc/capi.hip for the history). */
 int envidr_abi_version(void);
+/* Releases what the library keeps between calls outside the caller's allocator: the range-mask scratch of the table-gradient scatters
+ * (hash_encode_backward / _second_backward with >= 32 k points: one buffer per (device, stream), sized to the largest batch seen, at most
+ * 64 MiB).  Waits for the device; returns the number of bytes released.  No reference counterpart (torch's caching allocator there). */
+uint64_t envidr_release_scratch(void);
 
 /* ------------------------------------------------------------------------------------------
  * raymarching  (reference: raymarching/src/raymarching.h:7-18, bindings.cpp:5-19)

@@ -98,6 +98,25 @@ def ref_hip() -> HostLib:
     return _ref_hip
 
 
+REF_HIP_EXACT_LIB = HERE / "_ref" / "libenvidr_ref_hip_exact.so"
+_ref_hip_exact: HostLib | None = None
+
+
+def ref_hip_exact_available() -> bool:
+    return REF_HIP_EXACT_LIB.exists()
+
+
+def ref_hip_exact() -> HostLib:
+    """ref_hip() built with `-ffp-contract=off`: the reference's kernel text evaluated operation by operation on the GPU, the way
+    libenvidr_amd.so is built -- the bit-for-bit comparison partner (tests/test_refhip_gpu.py)."""
+    global _ref_hip_exact
+    if _ref_hip_exact is None:
+        if not REF_HIP_EXACT_LIB.exists():
+            raise FileNotFoundError(f"{REF_HIP_EXACT_LIB} not built; run `python oracle/ref/build_ref.py` where /root/reference exists")
+        _ref_hip_exact = HostLib(REF_HIP_EXACT_LIB, "ref_")
+    return _ref_hip_exact
+
+
 def ref_available() -> bool:
     return REF_LIB.exists()
 

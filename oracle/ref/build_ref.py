@@ -11,7 +11,8 @@ What it does
      REAL c10/util/Half.h of this image's torch wheel, include path from torch.utils.cpp_extension), with
      `-I <tmp>` so the `#include "<ext>_kernels.inc"` lines resolve; output -> oracle/_ref/;
   5. compiles the same translation unit a second time with `-ffp-contract=fast -mfma` -> libenvidr_ref_fma.so (contraction sweep);
-  6. compiles it a third time with hipcc for gfx950 against device_keywords.h -> libenvidr_ref_hip.so: the kernels run on the GPU.
+  6. compiles it a third time with hipcc for gfx950 against device_keywords.h -> libenvidr_ref_hip.so: the kernels run on the GPU;
+  7. and a fourth time, the same hipcc command plus `-ffp-contract=off` -> libenvidr_ref_hip_exact.so (bit-for-bit comparisons on the GPU).
 
 This is not a build of the reference's CUDA extension (that is unbuildable here: no nvcc, no CUDA
 headers, no CUDA device) -- see kernel_keywords.h for the exact list of deviations.
@@ -36,6 +37,10 @@ OUT_LIB_FMA = OUT_DIR / "libenvidr_ref_fma.so"
 # the same slices compiled by hipcc FOR THE GPU (device_keywords.h): the reference's kernel text run on the MI355X itself -- device
 # intrinsics, device atomics, the compiler's own FMA contraction.  Entry points take DEVICE pointers.  tests/test_refhip_gpu.py.
 OUT_LIB_HIP = OUT_DIR / "libenvidr_ref_hip.so"
+# ... and once more with `-ffp-contract=off`: the reference's expressions evaluated operation by operation ON THE GPU, which is how the
+# product is built.  Against this one tests/test_refhip_gpu.py asserts BIT EQUALITY (marchers, compositors, grid / hash gathers and input
+# gradients, frequency encoder); what is left to bounds there is what cannot be identical: atomic summation order, device transcendentals.
+OUT_LIB_HIP_EXACT = OUT_DIR / "libenvidr_ref_hip_exact.so"
 REFERENCE = Path(os.environ.get("ENVIDR_REFERENCE", "/root/reference"))
 EXTENSIONS = ["raymarching", "hashencoder", "gridencoder", "freqencoder", "shencoder"]
 
@@ -97,7 +102,7 @@ def build(verbose: bool = True) -> Path | None:
         return OUT_LIB if OUT_LIB.exists() else None
     srcs = [REFERENCE / e / "src" / f"{e}.cu" for e in EXTENSIONS]
     deps = srcs + [HERE / "ref_entry.cpp", HERE / "kernel_keywords.h", HERE / "device_keywords.h", Path(__file__)]
-    if all(o.exists() and all(d.stat().st_mtime <= o.stat().st_mtime for d in deps) for o in (OUT_LIB, OUT_LIB_FMA, OUT_LIB_HIP)):
+    if all(o.exists() and all(d.stat().st_mtime <= o.stat().st_mtime for d in deps) for o in (OUT_LIB, OUT_LIB_FMA, OUT_LIB_HIP, OUT_LIB_HIP_EXACT)):
         return OUT_LIB
     OUT_DIR.mkdir(parents=True, exist_ok=True)
     with tempfile.TemporaryDirectory(prefix="envidr_ref_slices_") as tmp:
@@ -113,13 +118,14 @@ def build(verbose: bool = True) -> Path | None:
             if verbose:
                 print(f"[oracle/ref] built {out} ({out.stat().st_size >> 10} KiB)")
         hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-        cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-w", "-fPIC", "-shared", "-fno-gpu-rdc", "-x", "hip",
-               '-DENVIDR_REF_KEYWORDS="device_keywords.h"', "-I", tmp, "-I", str(HERE), *inc, str(HERE / "ref_entry.cpp"), "-o", str(OUT_LIB_HIP)]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("reference kernel device build failed:\n" + r.stderr[-6000:])
-        if verbose:
-            print(f"[oracle/ref] built {OUT_LIB_HIP} ({OUT_LIB_HIP.stat().st_size >> 10} KiB)")
+        for out, fp in ((OUT_LIB_HIP, []), (OUT_LIB_HIP_EXACT, ["-ffp-contract=off"])):
+            cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-w", "-fPIC", "-shared", "-fno-gpu-rdc", "-x", "hip", *fp,
+                   '-DENVIDR_REF_KEYWORDS="device_keywords.h"', "-I", tmp, "-I", str(HERE), *inc, str(HERE / "ref_entry.cpp"), "-o", str(out)]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("reference kernel device build failed:\n" + r.stderr[-6000:])
+            if verbose:
+                print(f"[oracle/ref] built {out} ({out.stat().st_size >> 10} KiB)")
     return OUT_LIB
 
 

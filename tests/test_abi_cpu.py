@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     # and the Python binding table covers every operator of envidr_amd.h
     ops = {"envidr_" + n for n in _lib.SIGNATURES}
     assert ops <= declared
-    assert lib.envidr_abi_version() == 9
+    assert lib.envidr_abi_version() == 10
 
 
 def test_signature_table_matches_header_arity():

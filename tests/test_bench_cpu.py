@@ -74,3 +74,38 @@ def test_a_damaged_shard_of_any_rank_is_noticed():
             j = _run(["--gpus", "3", "--steps", "3", "--warmup", "1", "--stub", "--scaling", mode, "--corrupt-rank", str(bad)])
             assert j["dist"]["gathered_equals_rendered"] is False
             assert j["dist"]["gathered_equals_rendered_per_rank"] == [r != bad for r in range(3)], (mode, bad, j["dist"])
+
+
+def _run_failing(args, env_extra=None):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
+    return json.loads(lines[0])
+
+
+def test_preflight_reports_ok_and_rides_along_with_every_multi_rank_run():
+    j = _run(["--gpus", "2", "--stub", "--preflight"])
+    assert j["preflight"]["ok"] is True and j["preflight"]["ranks_seen"] == 2 and j["n_gpus"] == 2 and j["backend"] == "gloo"
+    assert set(j["preflight"]["ms"]) == {"gather_1MB", "all_reduce_ranks_seen"}
+    j = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--stub"])
+    assert j["dist"]["preflight"]["ok"] is True and j["dist"]["preflight"]["stage"] == "done"
+
+
+def test_preflight_failures_are_one_diagnosable_json_line_not_a_hang():
+    # fewer devices than ranks (this container has no GPU at all): refused before any rank is started
+    j = _run_failing(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert j["preflight"]["stage"] == "device_count" and j["preflight"]["ok"] is False and "device_count() = 0" in j["error"]
+    # a rank that never reaches the rendezvous: rank 0 of a world of two, started alone
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    j = _run_failing(["--gpus", "2", "--stub", "--preflight"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                                                              "MASTER_PORT": str(port), "ENVIDR_PREFLIGHT_TIMEOUT_S": "2"})
+    assert j["preflight"]["stage"] == "init_process_group" and j["preflight"]["rank"] == 0
+    # a rank that joins the process group but not the collectives: the others name the call they are stuck in
+    j = _run_failing(["--gpus", "2", "--stub", "--preflight"], {"ENVIDR_PREFLIGHT_TIMEOUT_S": "3", "ENVIDR_PREFLIGHT_ABSENT_RANK": "1"})
+    assert j["preflight"]["stage"] == "gather_1MB" and j["preflight"]["rank"] == 0 and "timed out" in j["preflight"]["error"]

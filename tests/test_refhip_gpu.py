@@ -79,3 +79,59 @@ def test_operator_matches_the_references_kernel_on_this_gpu(cid, op, args, tol, 
         r = rel_l2(_f64(x), _f64(y))
         bound = 3e-3 if half else 1e-4
         assert r <= bound, f"{cid}: pointer arg {k}: rel-L2 {r:.2e} against the reference's device run"
+
+
+# ---- the same kernels built WITHOUT contraction: bit for bit ------------------------------------------------------------------------
+# libenvidr_ref_hip_exact.so = the reference's kernel text, hipcc, gfx950, `-ffp-contract=off` -- the way libenvidr_amd.so is built.  With the
+# compiler's freedom to fuse a*b+c gone, "restated slightly differently" and "moved by contraction" can be told apart: every output below
+# must have the reference's BITS.  What stays on bounds, and why:
+#   * table gradients (grad_embeddings, grad2_embeddings): sums formed by atomics -- the order of the additions differs from run to run of
+#     the reference's own kernel;
+#   * outputs marked in NOT_BITWISE: measured with tools/refhip_sweep.py --exact (profiles/r06*/refhip_sweep_exact.txt), reason beside each.
+ATOMIC_SUMS = {"grad_embeddings", "grad2_embeddings"}
+NOT_BITWISE: dict[tuple[str, str], str] = {}
+
+
+@pytest.fixture(scope="module")
+def refexact():
+    from oracle import clib
+    if not clib.ref_hip_exact_available():
+        pytest.skip("oracle/_ref/libenvidr_ref_hip_exact.so not built (needs /root/reference at build time)")
+    return clib.ref_hip_exact()
+
+
+@pytest.fixture(scope="module")
+def pointer_names():
+    import re
+    from pathlib import Path
+    text = (Path(__file__).resolve().parents[1] / "include" / "envidr_amd.h").read_text()
+    return {m.group(1): [re.split(r"[\s\*]+", p.strip())[-1] for p in m.group(2).split(",") if "*" in p]
+            for m in re.finditer(r"int\s+envidr_(\w+)\s*\(([^;]*?)\)\s*;", text, re.S)}
+
+
+@pytest.mark.parametrize("cid,op,args,tol", CASES, ids=[c[0] for c in CASES])
+def test_operator_has_the_bits_of_the_references_kernel_built_without_contraction(cid, op, args, tol, refexact, pointer_names):
+    if not refexact.has(op):
+        pytest.skip(f"no reference kernel for {op}")
+    if cases.reference_adds_nothing(cid, op):
+        pytest.skip("the reference's stub atomic leaves this gradient untouched (tests/cases.py reference_adds_nothing)")
+    ours, theirs = run_op("hip", op, *args), run_op("refhip_exact", op, *args)
+    names = pointer_names[op]
+    half = op.endswith("_f16")
+    if op == "march_rays_train":
+        a, b = _regroup(ours), _regroup(theirs)
+        both = [r for r in a if r in b and a[r][2].shape == b[r][2].shape]
+        assert len(both) >= 0.9 * max(len(a), len(b)) and len(both) > 100
+        for r in both:
+            assert all(bits_equal(x, y) for x, y in zip(a[r], b[r])), f"{cid}: ray {r}: positions / directions / step sizes differ"
+        return
+    for k, (x, y) in enumerate(zip(ours, theirs)):
+        if x is None or bits_equal(x, y):
+            continue
+        name = names[k] if k < len(names) else f"arg{k}"
+        if name in ATOMIC_SUMS or (op, name) in NOT_BITWISE:
+            r = rel_l2(_f64(x), _f64(y))
+            assert r <= (3e-3 if half else 1e-5), f"{cid}: {name}: rel-L2 {r:.2e} against the reference's device run"
+            continue
+        raise AssertionError(f"{cid}: {name} differs from the reference's kernel built with -ffp-contract=off in "
+                             f"{int((x != y).sum())} of {x.size} entries")

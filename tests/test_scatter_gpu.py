@@ -140,3 +140,28 @@ def test_lds_scatter_of_the_other_instantiations(D, C):
         for l in range(L):
             s = slice(int(off_np[l]), int(off_np[l + 1]))
             assert np.abs(a[s] - b[s]).max() / (np.abs(b[s]).max() + 1e-30) < 3e-4, (second, l)
+
+
+def test_mask_scratch_is_sized_to_the_batch_and_can_be_released():
+    """the range-mask scratch the LDS scatter keeps per (device, stream) outside torch's allocator: as large as the largest batch seen (a power
+    of two from 1 MiB, at most 64 MiB), handed back by envidr_release_scratch() -- and rebuilt by the next call (round-5 advisor finding)"""
+    import torch
+    from envidr_amd import _lib
+    from tests.util import run_op
+    _lib.release_scratch()
+    rng = np.random.default_rng(3)
+    from envidr_amd import scenes
+    offsets, pls = scenes.hash_level_offsets()
+    L, B = 16, 40000
+    table = rng.uniform(-0.1, 0.1, size=(int(offsets[-1]), 2)).astype(np.float32)
+    x = rng.uniform(0, 1, size=(B, 3)).astype(np.float32)
+    grad = rng.standard_normal((L, B, 2)).astype(np.float32)
+    S = float(np.log2(pls))
+    args = (grad, x, table, offsets.astype(np.int32), np.zeros_like(table), B, 3, 2, L, S, 16, 0, None, None)
+    first = run_op("hip", "hash_encode_backward", *args)[4]
+    freed = _lib.release_scratch()
+    assert (1 << 20) <= freed <= (4 << 20), freed                  # 16 levels x 40 000 points x 4 B = 2.6 MB of masks -> one 4 MiB buffer, not 64 MiB
+    assert _lib.release_scratch() == 0
+    again = run_op("hip", "hash_encode_backward", *args)[4]
+    assert float(np.abs(first - again).max()) <= 1e-5 * float(np.abs(first).max())
+    assert _lib.release_scratch() == freed

@@ -182,3 +182,57 @@ def test_sphere_intersections_operator_matches_the_reference_formula(fixture, mo
     inside = disc > 1e-3                                                    # (the root amplifies rounding of the discriminant near 0)
     assert np.abs(near.cpu().numpy() - wn.numpy()[:, 0])[inside].max() <= 2e-5 and np.abs(far.cpu().numpy() - wf.numpy()[:, 0])[inside].max() <= 2e-5
     assert near.shape == (60000,) and mask.dtype == torch.bool
+
+
+def test_fused_form_sees_an_optimizer_step_between_two_evaluations(fixture, model_opt):
+    """train / eval / train / eval: the fused renderer of the env-sphere mode copies the packed MLPs and beta at first use, and nothing in
+    this mode calls invalidate_fused() (cuda_ray is off).  The cache key carries the weights' versions: after an in-place update of every
+    network the fused frame must be the operator chain's frame again, not the first evaluation's (round-5 advisor finding)"""
+    import copy
+    import torch
+    model, opt = model_opt
+    model = copy.deepcopy(model)
+    g = fixture
+    res, before = _render(model, opt, g, "40", True)
+    torch.manual_seed(5)
+    with torch.no_grad():
+        for net in (model.sdf_net, model.env_nets[int(g["env_net_index"])], model.diffuse_net, model.color_net):
+            for p in net.parameters():
+                p.add_(0.02 * torch.randn_like(p))              # what optimizer.step() does: an in-place write, version + 1
+        model.sdf_density.beta.mul_(1.5)
+    _, after = _render(model, opt, g, "40", True)
+    _, chain = _render(model, opt, g, "40", False)
+    N = res * res
+    assert rel_l2(after["image"].cpu().numpy().reshape(N, 3), before["image"].cpu().numpy().reshape(N, 3)) > 1e-3      # the step did move the frame
+    for k in ("image", "depth", "weights_sum", "diffuse_image", "specular_image"):
+        err = rel_l2(after[k].detach().cpu().numpy().reshape(N, -1), chain[k].detach().cpu().numpy().reshape(N, -1))
+        assert err <= 2e-5, f"{k}: fused frame after the step differs from the operator chain: {err:.3e}"
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_chunked_frames_with_chunks_that_miss_the_sphere(fixture, model_opt, fused):
+    """a staged frame whose first and last chunks contain no hit: their `empty` results carry background / zeros for exactly the images the
+    hit chunks carry, and the concatenated frame equals the un-chunked one (round-5 advisor finding: torch.cat met a None)"""
+    import torch
+    from envidr_amd import scenes
+    model, opt = model_opt
+    g = fixture
+    ro, rd = scenes.camera_rays(48, 48, theta=123.0, phi=10.0, radius=4.0, scale=float(g["scale"]))
+    ro, rd = torch.from_numpy(ro).cuda(), torch.from_numpy(rd).cuda()
+    away = rd.clone()
+    away[:, :] = torch.tensor([0.0, 1.0, 0.0], device="cuda")
+    far_o = torch.tensor([[0.0, 0.0, 3.0]], device="cuda").repeat(ro.shape[0], 1)
+    o = torch.cat([far_o, ro, far_o])[None]
+    d = torch.cat([away, rd, away])[None]
+    kw = dict(bg_color=0.3, perturb=False, get_normal_image=True, env_net_index=int(g["env_net_index"]), material=sph_case.material_of(g), fused=fused)
+    whole = model.render(o, d, staged=False, **kw)
+    parts = model.render(o, d, staged=True, max_ray_batch=48 * 48, **kw)
+    n = 48 * 48
+    keys = [k for k in ("image", "weights_sum", "diffuse_image", "specular_image", "normal_image", "roughness_image") if whole.get(k) is not None]
+    assert "image" in keys and "normal_image" in keys
+    for k in keys:
+        a = parts[k].detach().reshape(3 * n, -1)
+        b = whole[k].detach().reshape(3 * n, -1)
+        assert a.shape == b.shape, k
+        assert float((a[n:2 * n] - b[n:2 * n]).abs().max()) <= 2e-5, k
+        assert torch.equal(a[:n], b[:n]) and torch.equal(a[2 * n:], b[2 * n:]), k        # the chunks without a hit: background / zeros

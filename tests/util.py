@@ -21,17 +21,17 @@ def run_op(backend: str, name: str, *args):
         work = [np.ascontiguousarray(a).copy() if (k == "p" and a is not None) else a for k, a in zip(sig, args)]
         lib.call(name, *work)
         return [w for k, w in zip(sig, work) if k == "p"]
-    assert backend in ("hip", "shim", "refhip")
+    assert backend in ("hip", "shim", "refhip", "refhip_exact")
     import torch
     from envidr_amd import _lib
     dev = torch.device("cuda:0")
     work = [torch.from_numpy(np.ascontiguousarray(a).copy()).to(dev) if (k == "p" and a is not None) else a
             for k, a in zip(sig, args)]
-    if backend == "refhip":
+    if backend in ("refhip", "refhip_exact"):
         # the reference's own kernels, compiled by hipcc, on the same device arrays (oracle/ref/device_keywords.h)
         from oracle import clib
         torch.cuda.synchronize()
-        clib.ref_hip().call(name, *[(w.data_ptr() if isinstance(w, torch.Tensor) else w) for w in work])
+        (clib.ref_hip() if backend == "refhip" else clib.ref_hip_exact()).call(name, *[(w.data_ptr() if isinstance(w, torch.Tensor) else w) for w in work])
         torch.cuda.synchronize()
         return [None if w is None else w.cpu().numpy() for k, w in zip(sig, work) if k == "p"]
     if backend == "shim":
