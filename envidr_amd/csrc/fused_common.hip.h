@@ -228,5 +228,6 @@ struct ShadeArgs {
 
 int device_cu_count();   // fused_render.hip
 int launch_env_split(const envidr_render_desc* d, const ShadeArgs& a, hipStream_t s, const char* who);   // shade_split.hip
+int launch_env_split2(const envidr_render_desc* d, const ShadeArgs& a, hipStream_t s, const char* who);  // shade_split2.hip
 
 }  // namespace envidr

@@ -1387,7 +1387,7 @@ static int launch_shade(const envidr_render_desc* d, ShadeArgs& a, envidr_stream
     if (split) {
         ENVIDR_REQUIRE(!renv, "%s: split precision does not cover the reflected-radiance branch", who);
         a.env_pre = d->env_features;
-        const int rc = launch_env_split(d, a, s, who);
+        const int rc = d->env_split_form == 1 ? launch_env_split2(d, a, s, who) : launch_env_split(d, a, s, who);
         if (rc) return rc;
     }
 #define ENVIDR_LAUNCH(DEG, HT) do { if (renv) hipLaunchKernelGGL((k_shade_samples<DEG, HT, 0, true>), grid, block, 0, s, a); \
@@ -1451,7 +1451,7 @@ int envidr_shade_records(const envidr_render_desc* d, const envidr_geometry_expo
         a.rough_scale = d->roughness_scale; a.indir_rough_thresh = d->indir_roughness_thresh;
     }
     a.c_diffuse = c_diffuse; a.c_specular = c_specular;
-    if (rec->shade_list && !(d->env_split_blob && !d->dir_sh_degree)) {
+    if (rec->shade_list && !(d->env_split_blob && !d->dir_sh_degree && d->env_split_form != 1)) {
         hipStream_t s = as_stream(stream);
         const uint32_t n_blocks = ceil_div(rec->capacity, kGatherChunk);
         uint32_t* counts = rec->shade_list + 1 + rec->capacity;          // behind the list (envidr_render.h: capacity + 1 + capacity / 1024 + 1 words)

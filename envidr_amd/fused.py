@@ -52,7 +52,7 @@ class RenderDesc(ctypes.Structure):
         ("ray_cost", _FP), ("scratch", _FP), ("scratch_bytes", ctypes.c_uint64),
         ("has_aabb", ctypes.c_int32), ("aabb", ctypes.c_float * 6), ("ray_mask", _FP),
         ("env_split_blob", _FP), ("env_split_bias", _FP), ("env_features", _FP),
-        ("sdf_geo_blob", _FP), ("image_width", ctypes.c_uint32),
+        ("sdf_geo_blob", _FP), ("image_width", ctypes.c_uint32), ("env_split_form", ctypes.c_uint32),
     ]
 
 
@@ -119,6 +119,10 @@ def _bind_render(lib):
     lib.envidr_split_group.restype = ctypes.c_uint32
     lib.envidr_pack_layer_split.argtypes = [_FP, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, _FP]
     lib.envidr_pack_layer_split.restype = ctypes.c_int
+    lib.envidr_env_split2_halves.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+    lib.envidr_env_split2_halves.restype = ctypes.c_uint32
+    lib.envidr_pack_env_split2.argtypes = [_FP] * 4 + [ctypes.c_uint32, ctypes.c_uint32, _FP]
+    lib.envidr_pack_env_split2.restype = ctypes.c_int
     lib.envidr_pack_rowvec.argtypes = [_FP, ctypes.c_uint32, _FP]
     lib.envidr_pack_rowvec.restype = ctypes.c_int
     lib.envidr_render_rays.argtypes = [ctypes.POINTER(RenderDesc), _FP, _FP, ctypes.c_uint32, ctypes.POINTER(RenderOut), _FP, _FP]
@@ -349,6 +353,23 @@ def pack_env_split(env) -> tuple[np.ndarray, np.ndarray]:
     return np.concatenate([flat, np.zeros((-flat.size) % chunk, np.uint16)]), np.concatenate(biases)
 
 
+def pack_env_split2(env, ide_degree: int) -> tuple[np.ndarray, np.ndarray]:
+    """the four environment-MLP layers for the two-group split-precision kernel (csrc/shade_split2.hip): (uint16 blob of (hi, lo) fp16
+    fragments in ITS consumption order -- layers fused in pairs; float32 biases as packed row-vector tiles, as for the round-3 form)"""
+    lib = _lib.load()
+    _bind_render(lib)
+    Ws = [_np32(W) for W, _ in env]
+    hidden = Ws[0].shape[0]
+    n = lib.envidr_env_split2_halves(ide_degree, hidden)
+    if n == 0 or Ws[0].shape[1] != 2 * (2 ** ide_degree - 1 + ide_degree) or [w.shape for w in Ws[1:]] != [(hidden, hidden), (hidden, hidden), (12, hidden)]:
+        raise _lib.EnvidrError(f"split precision is built for (ide_degree, env_hidden) = (5,256) and (4,160), not ({ide_degree},{hidden})")
+    dst = np.empty(n, np.uint16)
+    rc = lib.envidr_pack_env_split2(*[w.ctypes.data for w in Ws], ide_degree, hidden, dst.ctypes.data)
+    if rc:
+        raise _lib.EnvidrError(lib.envidr_last_error().decode())
+    return dst, np.concatenate([pack_rowvec(b) for _, b in env])
+
+
 def pack_rowvec(v) -> np.ndarray:
     lib = _lib.load()
     _bind_render(lib)
@@ -566,26 +587,31 @@ class FusedRenderer:
         self._env_layers = env
         self._split = None            # (blob tensor, bias tensor) of the split-precision mode, packed on first use
         self._env_feat = None
-        if self.opt.env_precision not in ("fp32", "f16x2"):
-            raise _lib.EnvidrError(f"env_precision must be 'fp32' or 'f16x2', not {self.opt.env_precision!r}")
+        if self.opt.env_precision not in ("fp32", "f16x2", "f16x2_v1"):
+            raise _lib.EnvidrError(f"env_precision must be 'fp32', 'f16x2' or 'f16x2_v1', not {self.opt.env_precision!r}")
 
     def _set_precision(self, precision: str | None, records: int) -> None:
-        """point the descriptor at the split-precision weights + a feature scratch of `records` rows, or clear them"""
+        """point the descriptor at the split-precision weights + a feature scratch of `records` rows, or clear them.  "f16x2" = the two-group
+        kernel (csrc/shade_split2.hip); "f16x2_v1" = the round-3 form (csrc/shade_split.hip), kept as its bit-for-bit cross-check"""
         precision = precision or self.opt.env_precision
         d = self.desc
         if precision == "fp32":
             d.env_split_blob = d.env_split_bias = d.env_features = None
             return
-        if precision != "f16x2":
-            raise _lib.EnvidrError(f"env_precision must be 'fp32' or 'f16x2', not {precision!r}")
+        if precision not in ("f16x2", "f16x2_v1"):
+            raise _lib.EnvidrError(f"env_precision must be 'fp32', 'f16x2' or 'f16x2_v1', not {precision!r}")
         if self._env_layers is None:
             raise _lib.EnvidrError("split precision belongs to the environment-MLP family")
+        form = 1 if precision == "f16x2" else 0
         if self._split is None:
-            blob, bias = pack_env_split(self._env_layers)
-            self._split = (torch.from_numpy(blob.view(np.int16)).to(self.device), torch.from_numpy(bias).to(self.device))
+            self._split = {}
+        if form not in self._split:
+            blob, bias = pack_env_split2(self._env_layers, self.opt.ide_degree) if form == 1 else pack_env_split(self._env_layers)
+            self._split[form] = (torch.from_numpy(blob.view(np.int16)).to(self.device), torch.from_numpy(bias).to(self.device))
         if self._env_feat is None or self._env_feat.shape[0] < records:
             self._env_feat = torch.empty(max(records, 1), 24, device=self.device)
-        d.env_split_blob, d.env_split_bias, d.env_features = self._split[0].data_ptr(), self._split[1].data_ptr(), self._env_feat.data_ptr()
+        d.env_split_blob, d.env_split_bias, d.env_features = self._split[form][0].data_ptr(), self._split[form][1].data_ptr(), self._env_feat.data_ptr()
+        d.env_split_form = form
 
     @classmethod
     def from_scene(cls, scene, opt: FusedOptions | None = None, device="cuda"):

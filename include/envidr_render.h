@@ -93,7 +93,7 @@ typedef struct envidr_geometry_export {
      * records whose compositing weight is NOT exactly zero (shade_list[0] = their number, shade_list[1..] = their indices, ascending) and shades
      * only those; envidr_composite_records skips zero-weight records (w * c = 0 whatever c is).  On a trained scene (beta ~ 1e-3)
      * most samples inside the occupancy shell have alpha = 1 - exp(-sigma * dt) == 0 exactly in fp32; the reference shades them
-     * all.  Outputs are unchanged bit for bit.  Ignored by the split-precision mode. */
+     * all.  Outputs are unchanged bit for bit.  Ignored by the round-3 form of the split-precision mode (env_split_form 0). */
     uint32_t* shade_list;
 } envidr_geometry_export;
 
@@ -228,6 +228,13 @@ typedef struct envidr_render_desc {
      * is still indexed by the ray's position in the call's list and has the same bits; 0 (or a size that does not qualify) =
      * list order. */
     uint32_t image_width;
+
+    /* ABI 10: which kernel evaluates the split-precision mode, i.e. what env_split_blob holds.
+     *   0  the round-3 form (csrc/shade_split.hip): a wave's two groups of 32 items one after the other; blob = the four layers packed by
+     *      envidr_pack_layer_split in consumption order
+     *   1  the two-group form (csrc/shade_split2.hip): every weight fragment serves both groups, layers fused in pairs; blob packed by
+     *      envidr_pack_env_split2 (envidr_env_split2_halves() halves).  Same results bit for bit.  Honours geometry_export.shade_list. */
+    uint32_t env_split_form;
 } envidr_render_desc;
 
 /* ---- per-call outputs (device pointers; any optional pointer may be NULL) --------------------- */

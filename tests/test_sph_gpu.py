@@ -188,11 +188,9 @@ def test_fused_form_sees_an_optimizer_step_between_two_evaluations(fixture, mode
     """train / eval / train / eval: the fused renderer of the env-sphere mode copies the packed MLPs and beta at first use, and nothing in
     this mode calls invalidate_fused() (cuda_ray is off).  The cache key carries the weights' versions: after an in-place update of every
     network the fused frame must be the operator chain's frame again, not the first evaluation's (round-5 advisor finding)"""
-    import copy
     import torch
-    model, opt = model_opt
-    model = copy.deepcopy(model)
     g = fixture
+    model, opt = sph_case.build_model(g)                        # a model of its own: its weights are about to change
     res, before = _render(model, opt, g, "40", True)
     torch.manual_seed(5)
     with torch.no_grad():

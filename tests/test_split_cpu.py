@@ -104,3 +104,72 @@ def test_sdf_geometry_packer_layout(lib):
                 q, r = m >> 2, m & 3
                 assert frag[B1 + s * 2 + T, lane] == W1[k, 2 * (4 * (2 * T + (r >> 1)) + q) + (r & 1)]
     assert np.all(frag[217:] == 0)
+
+
+@pytest.mark.parametrize("ide_degree,hidden", [(5, 256), (4, 160)])
+def test_two_group_packer_matches_its_layout(lib, ide_degree, hidden):
+    """envidr_pack_env_split2 (csrc/mlp_split2.hip.h Split2Layout): per layer-1 tile t [its S1 steps | steps 2t, 2t+1 of every layer-2 tile],
+    then per layer-3 tile t [its 2 T steps | steps 2t, 2t+1 of the 12-row last layer] -- in the kernel's consumption order, in which the
+    tile after next is computed before a tile is consumed (A1(0) A1(1) | A2(0) A1(2) | ...; B3(0) | B3(1) B4(0) | ...); layer 1 in lane order,
+    the rest in tile order; (hi, lo) fragments of 512 halves each; padded to whole 8-fragment chunks"""
+    from envidr_amd.fused import pack_env_split2
+    terms = 2 ** ide_degree - 1 + ide_degree
+    K1, T = 2 * terms, hidden // 32
+    S1, SH = (K1 + 15) // 16, 2 * T
+    rng = np.random.default_rng(ide_degree)
+    env = [(rng.normal(size=(hidden, K1)), rng.normal(size=hidden)), (rng.normal(size=(hidden, hidden)), rng.normal(size=hidden)),
+           (rng.normal(size=(hidden, hidden)), rng.normal(size=hidden)), (rng.normal(size=(12, hidden)), rng.normal(size=12))]
+    env = [(W.astype(np.float32) * rng.choice([1e-5, 0.05, 1.0, 20.0], size=W.shape).astype(np.float32), b.astype(np.float32)) for W, b in env]
+    blob, bias = pack_env_split2(env, ide_degree)
+    frags = T * (2 * S1 + 4 * T) + T * (2 * SH + 4)
+    padded = (frags + 7) // 8 * 8
+    assert blob.dtype == np.uint16 and blob.size == padded * 512 == lib.envidr_env_split2_halves(ide_degree, hidden)
+    assert bias.dtype == np.float32 and bias.size == (3 * T + 1) * 32
+    F = blob.reshape(padded, 64, 8)
+    (W1, _), (W2, _), (W3, _), (W4, _) = env
+    hi = lambda W: W.astype(np.float16)
+    lo = lambda W: (W - W.astype(np.float16).astype(np.float32)).astype(np.float16)
+    A1, A2, B3, B4 = 2 * S1, 4 * T, 2 * SH, 4
+    FB = T * (A1 + A2)
+    a2_block = lambda t: min(t + 2, T) * A1 + t * A2
+    a1_block = lambda t: t * A1 if t < 2 else a2_block(t - 2) + A2
+    b4_block = lambda t: FB + min(t + 2, T) * B3 + t * B4
+    b3_block = lambda t: FB if t == 0 else FB + t * B3 + (t - 1) * B4
+    # the blocks tile the pass without gaps or overlaps, in execution order
+    order = [("a1", 0), ("a1", 1)] + [x for t in range(T) for x in ([("a2", t)] + ([("a1", t + 2)] if t + 2 < T else []))]
+    order += [("b3", 0)] + [x for t in range(T) for x in (([("b3", t + 1)] if t + 1 < T else []) + [("b4", t)])]
+    at = 0
+    for kind, t in order:
+        start, size = {"a1": (a1_block, A1), "a2": (a2_block, A2), "b3": (b3_block, B3), "b4": (b4_block, B4)}[kind]
+        assert start(t) == at, (kind, t)
+        at += size
+    assert at == frags
+    rows = np.arange(32)
+
+    def check(frag, W, m_of_lane, k_of):
+        for h in (0, 1):
+            for i in range(8):
+                k = k_of(h, i)
+                m = m_of_lane
+                ok = (m < W.shape[0]) & (k >= 0)
+                want_h = np.where(ok, hi(W)[np.minimum(m, W.shape[0] - 1), max(k, 0)], np.float16(0)).view(np.uint16)
+                want_l = np.where(ok, lo(W)[np.minimum(m, W.shape[0] - 1), max(k, 0)], np.float16(0)).view(np.uint16)
+                assert np.array_equal(F[frag, 32 * h:32 * h + 32, i], want_h), (frag, h, i)
+                assert np.array_equal(F[frag + 1, 32 * h:32 * h + 32, i], want_l), (frag, h, i)
+
+    for t in (0, T // 2, T - 1):
+        for s in range(S1):
+            def k1(h, i):
+                k = _k(0, s, h, i)
+                return -1 if k >= K1 else k
+            check(a1_block(t) + 2 * s, W1, 32 * t + rows, k1)
+        for s in (0, 1):
+            for u in (0, T - 1):
+                check(a2_block(t) + s * 2 * T + 2 * u, W2, 32 * u + rows, lambda h, i: _k(1, 2 * t + s, h, i))
+        for s in (0, 1, SH - 1):
+            check(b3_block(t) + 2 * s, W3, 32 * t + rows, lambda h, i: _k(1, s, h, i))
+        for s in (0, 1):
+            check(b4_block(t) + 2 * s, W4, rows, lambda h, i: _k(1, 2 * t + s, h, i))
+    assert not F[frags:].any()
+    with pytest.raises(_lib.EnvidrError):
+        pack_env_split2([(np.zeros((128, 72), np.float32), np.zeros(128, np.float32))] * 4, 5)

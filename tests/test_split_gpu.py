@@ -70,3 +70,57 @@ def test_split_frames_match_reference_frames(renderer, tag):
         assert err <= 1e-4, f"{key}: rel-L2 {err:.3e}"
     mse = float(np.mean((out["image"].astype(np.float64) - g["image"].reshape(-1, 3)) ** 2))
     assert -10 * np.log10(max(mse, 1e-30)) > 70.0
+
+
+def _random_shading_inputs(M, seed):
+    import torch
+    rng = np.random.default_rng(seed)
+    n = rng.normal(size=(M, 3)).astype(np.float32); n /= np.linalg.norm(n, axis=1, keepdims=True)
+    d = rng.normal(size=(M, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    geo = rng.normal(size=(M, 12)).astype(np.float32); geo /= np.linalg.norm(geo, axis=1, keepdims=True)
+    rough = rng.uniform(0.0, 1.0, size=M).astype(np.float32)
+    return [torch.from_numpy(x).cuda() for x in (n, d, geo)], torch.from_numpy(rough).cuda()
+
+
+@pytest.mark.parametrize("hidden_env,ide_deg", [(256, 5), (160, 4)])
+def test_two_group_kernel_has_the_bits_of_the_one_group_kernel(hidden_env, ide_deg):
+    """"f16x2" (csrc/shade_split2.hip: both item groups share every weight fragment, layers fused in pairs) against "f16x2_v1" (csrc/shade_split.hip:
+    one group at a time): the same (hi, lo) split, the same three products per step in the same order into every accumulator -- the colours must
+    be IDENTICAL, on sample counts that leave waves / workgroups / the last round ragged and on many rounds per workgroup"""
+    import torch
+    from envidr_amd.fused import FusedOptions, FusedRenderer
+    r = FusedRenderer.from_scene(scenes.toaster_scene(hidden_env=hidden_env, ide_deg=ide_deg), FusedOptions(ide_degree=ide_deg))
+    for M, rot in ((1, None), (33, 0.3), (127, None), (129, 1.1), (1000, 0.4), (256 * 128 + 77, 2.0), (700_001, 0.7)):
+        args, rough = _random_shading_inputs(M, M)
+        a = r.shade(*args, rough, rot, env_precision="f16x2")
+        b = r.shade(*args, rough, rot, env_precision="f16x2_v1")
+        c = r.shade(*args, rough, rot, env_precision="fp32")
+        torch.cuda.synchronize()
+        for k in ("c_diffuse", "c_specular"):
+            assert torch.isfinite(a[k]).all()
+            assert torch.equal(a[k], b[k]), (M, k, float((a[k] - b[k]).abs().max()))
+            assert rel_l2(a[k].cpu().numpy(), c[k].cpu().numpy()) <= 2e-6, (M, k)
+
+
+def test_two_group_kernel_is_deterministic_and_frames_agree():
+    """the same frame three times through the two-group kernel (bit-identical: no atomics, no schedule dependence), and equal to the one-group
+    kernel's frame; a frame with zero-weight skipping (the list of records to shade, which only the two-group form honours) equals the frame
+    that shades every record"""
+    import torch
+    from envidr_amd.fused import FusedOptions, FusedRenderer
+    rays_o, rays_d = (torch.from_numpy(x).cuda() for x in scenes.camera_rays(96, 96))
+    r = FusedRenderer.from_scene(scenes.toaster_scene())
+    frames = [r.render_frame(rays_o, rays_d, 0.2, out={}, env_precision="f16x2")["image"].clone() for _ in range(3)]
+    old = r.render_frame(rays_o, rays_d, 0.2, out={}, env_precision="f16x2_v1")["image"].clone()
+    f32 = r.render_frame(rays_o, rays_d, 0.2, out={}, env_precision="fp32")["image"].clone()
+    assert torch.equal(frames[0], frames[1]) and torch.equal(frames[0], frames[2]) and torch.equal(frames[0], old)
+    assert rel_l2(frames[0].cpu().numpy(), f32.cpu().numpy()) <= 1e-6
+    sharp = scenes.toaster_scene(beta=1e-3, sdf_bias=0.065)
+    img = {}
+    for skip in (True, False):
+        fr = FusedRenderer.from_scene(sharp, FusedOptions(skip_zero_weight=skip))
+        img[skip] = fr.render_frame(rays_o, rays_d, 0.2, out={}, env_precision="f16x2")["image"].clone()
+        if skip:
+            listed, records = int(fr._frame["shade_list"][0].item()), int(fr._frame["last"][1])
+            assert 0 < listed < records
+    assert torch.equal(img[True], img[False])

@@ -127,6 +127,19 @@ VARIANTS = {
     "rounds4": ("geometry_pass", [("geometry_pass.hip", "    constexpr uint32_t kRounds = 7;", "    constexpr uint32_t kRounds = 4;")]),
     "first_chunk12": ("geometry_pass", [("geometry_pass.hip", "std::min(16u, d->max_steps)", "std::min(12u, d->max_steps)")]),
     "first_chunk24": ("geometry_pass", [("geometry_pass.hip", "std::min(16u, d->max_steps)", "std::min(24u, d->max_steps)")]),
+    # ---- the fused-pair split kernel (round 6), timing only unless noted ----
+    "s2_base": ("shade_split2", []),
+    # the round's prologue (record loads, IDE, layer-1 operands -> LDS) only in a workgroup's first round
+    "s2_noprologue": ("shade_split2", [("shade_split2.hip", "        ide_eval<IDE_DEG, true>(enc ? wr[0]", "        if (base == blockIdx.x * 128u) ide_eval<IDE_DEG, true>(enc ? wr[0]")]),
+    "s2_nobarrier": ("shade_split2", [("mlp_split2.hip.h", 'asm volatile("s_waitcnt vmcnt(%0)\\n\\ts_barrier" ::"n"(kS2Slots - 3) : "memory");', "")]),       # racy
+    "s2_nodma": ("shade_split2", [("mlp_split2.hip.h", "        dma(fill_lds, fill_off);                          // the piece aimed at the last barrier\n", "")]),
+    "s2_ahead2": ("shade_split2", [("mlp_split2.hip.h", "constexpr int kS2Ahead = 4; ", "constexpr int kS2Ahead = 2; "),
+                                   ("mlp_split2.hip.h", "kS2ChunkFrags == 8 && kS2Ahead == 4 && kS2MeetAt == 4", "kS2ChunkFrags == 8 && kS2MeetAt == 4")]),
+    "s2_floor": ("shade_split2", [("mlp_split2.hip.h", 'asm volatile("s_waitcnt vmcnt(%0)\\n\\ts_barrier" ::"n"(kS2Slots - 3) : "memory");', ""),
+                                  ("mlp_split2.hip.h", "        dma(fill_lds, fill_off);                          // the piece aimed at the last barrier\n", ""),
+                                  ("shade_split2.hip", "        ide_eval<IDE_DEG, true>(enc ? wr[0]", "        if (base == blockIdx.x * 128u) ide_eval<IDE_DEG, true>(enc ? wr[0]")]),
+    "s2_noconvert": ("shade_split2", [("mlp_split.hip.h", "    split_f16(a, hi, lo); h[r % 8] = hi; l[r % 8] = lo;\n    split_f16(b, hi, lo); h[(r + 1) % 8] = hi; l[(r + 1) % 8] = lo;\n",
+                                       "    hi = (_Float16)a; lo = (_Float16)b; h[r % 8] = hi; l[r % 8] = lo; h[(r + 1) % 8] = lo; l[(r + 1) % 8] = hi;\n")]),
     "split_group4": ("shade_split", [("mlp_split.hip.h", "constexpr int kSplitGroup = 2;", "constexpr int kSplitGroup = 4;")]),
     "ring16": ("fused_render", [("fused_render.hip", "constexpr int kRingDepth = 32;", "constexpr int kRingDepth = 16;")]),
     # issue priority by phase (MI355X_MICROARCH.md "Two waves per SIMD": VALU issue is arbitrated by priority, then age): does the SIMD

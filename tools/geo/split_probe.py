@@ -14,14 +14,15 @@ if "--copies" in sys.argv:          # split_copies4 variant: workgroups stream d
         blob, bias = orig(env)
         return np.concatenate([np.concatenate([blob, np.zeros(256, np.uint16)]) for _ in range(n)]), bias
     fused.pack_env_split = tiled
+PREC = "f16x2_v1" if "--v1" in sys.argv else "f16x2"
 dev = torch.device("cuda:0")
 r = FusedRenderer.from_scene(scenes.toaster_scene(), device=dev)
 ro, rd = (torch.from_numpy(a).to(dev) for a in scenes.camera_rays(800, 800))
 out = {}
 for i in range(3):
-    r.render_frame(ro, rd, 0.1, out=out, env_precision="f16x2")
+    r.render_frame(ro, rd, 0.1, out=out, env_precision=PREC)
 ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(5)]
 for i in range(5):
-    r.render_frame(ro, rd, 0.1, out=out, events=ev[i], wait=False, env_precision="f16x2")
+    r.render_frame(ro, rd, 0.1, out=out, events=ev[i], wait=False, env_precision=PREC)
 r.check_frames(); torch.cuda.synchronize()
-print(f"shading (split env + fp32 heads) {sum(e[1].elapsed_time(e[2]) for e in ev)/5:.2f} ms")
+print(f"{PREC}: frame {sum(e[0].elapsed_time(e[3]) for e in ev)/5:.2f} ms, geometry {sum(e[0].elapsed_time(e[1]) for e in ev)/5:.2f} ms; shading (split env + fp32 heads) {sum(e[1].elapsed_time(e[2]) for e in ev)/5:.2f} ms")
