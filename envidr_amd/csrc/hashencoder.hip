@@ -567,11 +567,33 @@ __global__ void __launch_bounds__(kLdsScatterThreads) k_table_scatter_lds(const 
 #pragma unroll
                     for (int c = 0; c < C; ++c) v[c] = w * r.gcur[c];
                 }
-                if (pending) {
+                bool mine = pending != 0;
+                // Dense levels: consecutive points of a frame or a training batch (consecutive samples of a ray, neighbouring rays) sit in the same
+                // cell, so neighbouring lanes add to the SAME row -- whichever corner each of them picked.  Runs of equal rows are summed in the wave
+                // (segmented scan, grid_core.hip.h RunScatter) and the run's last lane issues the one atomic: the LDS atomic unit takes its 1.9
+                // cycles per LANE, and the few ranges of a dense level that hold the scene get most of its points.  Decided per round from the
+                // rows themselves (wave-uniform); on the hashed levels neighbours never share a row and nothing of this runs.
+                if (!g.hashed) {
+                    const RunScatter rs(mine);
+                    uint32_t start; bool tail; unsigned long long heads;
+                    rs.runs(at, mine, start, tail, heads);
+                    if (4 * __popcll(heads) <= 3 * __popcll(rs.active)) {
+#pragma unroll
+                        for (uint32_t off = 1; off < 64; off <<= 1) {
+#pragma unroll
+                            for (int c = 0; c < C; ++c) {
+                                const float up = __shfl_up(v[c], off, 64);
+                                if (mine && lane >= start + off) v[c] += up;
+                            }
+                        }
+                        mine = tail;
+                    }
+                }
+                if (mine) {
 #pragma unroll
                     for (int c = 0; c < C; ++c) __hip_atomic_fetch_add(&s_acc[c * kRows + at], v[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    pending &= pending - 1;
                 }
+                pending &= pending - 1;
             }
         };
 
