@@ -2,7 +2,7 @@
 a race that changes a result shows up as a differing bit, a lost wake-up as a hang (run under `timeout`):
   * k_env_split2 (LDS-DMA ring with a counted vmcnt + bare s_barrier, eight waves in lock step) and k_env_split: the shaded colours, bit for bit;
   * envidr_compact_alive (decoupled look-back scan across workgroups): the compacted list and its count, bit for bit;
-  * the geometry pipeline's device-driven rounds + record shading (work counters claimed a round ahead): a whole 96x96 frame, bit for bit;
+  * the geometry pipeline's device-driven rounds + record shading (work counters claimed a round ahead): a whole 256x256 frame, bit for bit;
   * the LDS-range table scatter (range ownership, LDS atomics): fp32 sums whose order of additions is not fixed -- compared to 1e-5 of the
     largest entry, and the set of touched rows exactly.
     python tools/stress_sync.py [iterations=1000]"""
@@ -19,7 +19,7 @@ ITER = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 dev = torch.device("cuda:0")
 r = FusedRenderer.from_scene(scenes.toaster_scene(), device=dev)
 rng = np.random.default_rng(0)
-M = 40_001
+M = 700_001            # 21 rounds per workgroup: the weight ring wraps, work counters run ahead
 n = rng.normal(size=(M, 3)).astype(np.float32); n /= np.linalg.norm(n, axis=1, keepdims=True)
 d = rng.normal(size=(M, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
 geo = rng.normal(size=(M, 12)).astype(np.float32); geo /= np.linalg.norm(geo, axis=1, keepdims=True)
@@ -59,7 +59,7 @@ for it in range(ITER):
 torch.cuda.synchronize()
 print(f"compact_alive: {ITER} runs on {a.numel()} ids, all identical ({time.time() - t0:.1f} s)")
 
-ro, rd = (torch.from_numpy(x).to(dev) for x in scenes.camera_rays(96, 96))
+ro, rd = (torch.from_numpy(x).to(dev) for x in scenes.camera_rays(256, 256))
 first = None
 t0 = time.time()
 for it in range(max(ITER // 4, 10)):
@@ -70,13 +70,13 @@ for it in range(max(ITER // 4, 10)):
     elif not torch.equal(cur, first):
         bad += 1
         print(f"frame iteration {it}: {int((cur != first).sum())} values differ from the first run")
-print(f"96x96 frame (cold and hinted alternating): {max(ITER // 4, 10)} runs, all identical ({time.time() - t0:.1f} s)")
+print(f"256x256 frame (cold and hinted alternating): {max(ITER // 4, 10)} runs, all identical ({time.time() - t0:.1f} s)")
 
 sc = scenes.toaster_scene()
 table = torch.from_numpy(sc.table).to(dev)
 offsets = torch.from_numpy(np.ascontiguousarray(sc.offsets, np.int32)).to(dev)
 S = float(np.log2(sc.per_level_scale))
-B = 100_000
+B = 1_000_000
 x = torch.from_numpy(rng.uniform(0, 1, (B, 3)).astype(np.float32)).to(dev)
 x[: B // 2] = x[: B // 2] * 0.05 + 0.4
 grad = torch.from_numpy(rng.standard_normal((16, B, 2)).astype(np.float32)).to(dev)
