@@ -496,11 +496,20 @@ class NeRFNetwork(NeRFRenderer):
     def forward_color(self, geo_feat, d, normal=None, w_r=None, n_dot_w_o=None, use_specular_color=False, env_net_index=0,
                       n_env_enc=None, r_images=None, roughness=None):
         opt = self.opt
+        # The diffuse side (encoded normal) and the specular side (encoded reflection) query the SAME environment network unless
+        # split_diffuse_env: one evaluation over both batches -- half the launches (forward and backward), and a big batch's last, partly
+        # filled round of workgroups once instead of twice (reference network.py:533-536 and 592-595 call it twice)
+        e_normal = e_reflect = None
+        if (opt.use_diffuse and opt.diffuse_with_env and not opt.diffuse_only and not opt.split_diffuse_env and self.use_env_net
+                and n_env_enc is not None and w_r is not None and not opt.train_renv and n_env_enc.shape == w_r.shape):
+            net = self.env_nets[env_net_index] if opt.env_sph_mode else self.env_net
+            both = self._env(net, torch.cat([n_env_enc, w_r], 0))
+            e_normal, e_reflect = both[:n_env_enc.shape[0]], both[n_env_enc.shape[0]:]
         if opt.use_diffuse:
             h = geo_feat
             if opt.diffuse_with_env:
                 env_net = self.env_nets[env_net_index] if opt.env_sph_mode else (self.diffuse_env_net if opt.split_diffuse_env else self.env_net)
-                e = self._env(env_net, n_env_enc)
+                e = e_normal if e_normal is not None else self._env(env_net, n_env_enc)
                 h = {"concat": lambda: torch.cat([h, e], -1), "add": lambda: h + e, "mul": lambda: h * e}[opt.diffuse_env_fusion]()
             self.c_diffuse = torch.sigmoid(_run_mlp(self.diffuse_net, h, first_order_only=True)) * self.metallic
         else:
@@ -515,7 +524,7 @@ class NeRFNetwork(NeRFRenderer):
         branches, renv_mask, blend = {}, None, 1
         if w_r is not None and not opt.train_renv:
             env_net = self.env_nets[env_net_index] if (opt.env_sph_mode and self.use_env_net) else self.env_net
-            branches["env"] = torch.cat([h, self._env(env_net, w_r) if self.use_env_net else w_r], -1)
+            branches["env"] = torch.cat([h, (e_reflect if e_reflect is not None else self._env(env_net, w_r)) if self.use_env_net else w_r], -1)
         if r_images is not None and opt.use_renv:
             renv_mask = roughness.squeeze() < opt.indir_roughness_thresh
             if r_images.shape[-1] == 4:

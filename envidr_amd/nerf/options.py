@@ -13,6 +13,8 @@ class RenderOptions:
     bound: float = 1.0
     scale: float = 0.33
     cuda_ray: bool = True
+    num_steps: int = 512                 # cuda_ray = False (render_func.run): uniform samples per ray ...
+    upsample_steps: int = 0              # ... and importance re-samples per ray (reference nerf/options.py defaults)
     dt_gamma: float = 0.0
     max_steps: int = 1024
     T_thresh: float = 1e-4
@@ -132,6 +134,19 @@ def neural_renderer_options(**overrides) -> RenderOptions:
     material parameters in, sdf + 12 features + roughness out, no indirect blend)"""
     opt = RenderOptions(scale=0.8, cuda_ray=False, env_sph_mode=True, roughness_act_scale=1.0, sh_degree=4, sh_degree_diffuse=4,
                         hidden_dim_env=160, learn_indir_blend=False, use_renv=False, visual_items=["diffuse", "specular"])
+    for k, v in overrides.items():
+        if not hasattr(opt, k):
+            raise AttributeError(f"unknown render option {k!r}")
+        setattr(opt, k, v)
+    return opt
+
+
+def plain_options(**overrides) -> RenderOptions:
+    """tests/golden/plain_like.ini resolved against nerf/options.py defaults: the plainest SDF configuration (SH view direction, no normal /
+    n.v / reflection inputs, no environment network) -- what the torch-only render function `run` can drive; cuda_ray off"""
+    opt = RenderOptions(scale=0.8, cuda_ray=False, encoding_dir="sphere_harmonics", sh_degree=4, wo_viewdir=False, normal_with_mlp=False,
+                        use_reflected_dir=False, use_n_dot_viewdir=False, use_env_net=False, diffuse_with_env=False, use_renv=False,
+                        visual_items=["roughness"])
     for k, v in overrides.items():
         if not hasattr(opt, k):
             raise AttributeError(f"unknown render option {k!r}")

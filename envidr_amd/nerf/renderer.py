@@ -264,8 +264,11 @@ class NeRFRenderer(nn.Module):
         if self.opt.env_sph_mode or getattr(self.opt, "render_env_on_sphere", False):
             return self._render_sph(rays_o, rays_d, staged, max_ray_batch, get_normal_image, use_specular_color, env_net_index, material,
                                     r_images, env_rot_radian, fused, **kwargs)
+        if self.opt.error_bound_sample:
+            raise NotImplementedError("the VolSDF sampler (reference run_volsdf) is out of scope")
         if not self.cuda_ray:
-            raise NotImplementedError("only the cuda_ray and env-sphere render paths are implemented (reference run / run_volsdf are out of scope)")
+            return self._render_plain(rays_o, rays_d, staged, max_ray_batch, get_normal_image, use_specular_color, env_net_index, material,
+                                      r_images, env_rot_radian, **kwargs)
         kwargs["material"] = material
         if self.opt.indir_ref:
             return self._render_indirect(rays_o, rays_d, get_normal_image, use_specular_color, env_net_index, env_rot_radian,
@@ -275,6 +278,33 @@ class NeRFRenderer(nn.Module):
         if "weights_sum" in results and get_normal_image and results.get("normal_image") is not None:
             ws = results["weights_sum"][..., None]
             results["normal_image"] = results["normal_image"] * ws + (1 - ws)
+        return results
+
+    def _render_plain(self, rays_o, rays_d, staged, max_ray_batch, get_normal_image, use_specular_color, env_net_index, material, r_images,
+                      env_rot_radian, **kwargs):
+        """cuda_ray = False: `_run = render_func.run` (reference renderer.py:368-371) under render()'s two chunking forms -- staged chunks of
+        max_ray_batch rays written into preallocated frames (:381-423; its normal frame is torch.empty where a chunk returns none) or
+        max_ray_batch_cuda (:425-436) -- and the normal-image blend of :539-540."""
+        kwargs["material"] = material
+        B, N = rays_o.shape[:2]
+        call = lambda o, d, r: render_func.run(self, o, d, get_normal_image=get_normal_image, use_specular_color=use_specular_color,
+                                               env_net_index=env_net_index, r_images=r, env_rot_radian=env_rot_radian, **kwargs)
+        if not staged:
+            # one call (the reference's max_ray_batch_cuda chunks cannot be joined for this function: it concatenates the 1-D weights_sum
+            # along dimension 1); the blend of renderer.py:529-530 on the function's own [N,3] normal image
+            results = call(rays_o, rays_d, r_images)
+            if get_normal_image and results.get("normal_image") is not None:
+                ws = results["weights_sum"][..., None]
+                results["normal_image"] = results["normal_image"] * ws + (1 - ws)
+            return results
+        parts = [[call(rays_o[b:b + 1, i:i + max_ray_batch], rays_d[b:b + 1, i:i + max_ray_batch],
+                       None if r_images is None else r_images[b:b + 1, i:i + max_ray_batch]) for i in range(0, N, max_ray_batch)] for b in range(B)]
+        join = lambda k, shape: torch.cat([torch.cat([p[k].reshape(1, -1, *shape) for p in row], 1) for row in parts], 0)
+        results = {"depth": join("depth", ()), "image": join("image", (3,))}
+        # (the staged frames carry no weights_sum, so the reference does not blend the normal image here; its normal frame is torch.empty
+        #  where no chunk returned one -- zeros here.  The reference itself cannot finish a staged render with this function: it then reads
+        #  results_['roughness_image'] & co for every name in visual_items, which `run` never returns, renderer.py:407-412)
+        results["normal_image"] = join("normal_image", (3,)) if parts[0][0]["normal_image"] is not None else torch.zeros(B, N, 3, device=rays_o.device)
         return results
 
     def _render_sph(self, rays_o, rays_d, staged, max_ray_batch, get_normal_image, use_specular_color, env_net_index, material, r_images,

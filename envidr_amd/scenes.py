@@ -219,6 +219,27 @@ def lego_scene(table_scale: float = 0.1, shape=None, sdf_bias: float = 0.005, be
 
 
 
+def plain_scene(table_scale: float = 0.02, shape=None, sdf_bias: float = 0.005, beta: float = 0.1, sh_degree: int = 4,
+                seed: int = 4) -> SceneParams:
+    """The plainest SDF configuration of the reference's network: hash grid + SDF MLP 32-64-64-15, diffuse MLP 12-32-3 on the geometry
+    feature, specular MLP [SH(view dir), geo_feat] = 28-64-64-3 -- no environment network, no normal / n.v inputs.  What the torch-only
+    render function (nerf/render_func/non_cuda_ray.py) can drive (tests/golden/plain_like.ini).  A smooth field on purpose (small table
+    amplitudes, beta = init_beta = 0.1): the importance samples' positions depend on fp32 cumulative sums, and a density as steep as the other
+    synthetic scenes' (beta = 0.01) would turn their last-bit differences between two torch backends into 1e-4 of the image."""
+    rng = np.random.default_rng(seed)
+    offsets, pls = hash_level_offsets()
+    table = np.random.default_rng(seed + 1).uniform(-table_scale, table_scale, size=(int(offsets[-1]), 2)).astype(np.float32)
+    mlps = {
+        "sdf": make_mlp(rng, [32, 64, 64, 15]),
+        "diffuse": make_mlp(rng, [12, 32, 3]),
+        "specular": make_mlp(rng, [sh_degree ** 2 + 12, 64, 64, 3]),
+    }
+    mlps["sdf"][-1][1][0] = sdf_bias
+    mlps["specular"][-1][1][:] -= math.log(3)
+    return SceneParams(bitfield=occupancy_bitfield(shape or shell()), offsets=offsets, per_level_scale=pls, table=table,
+                       mlps=mlps, beta=beta)
+
+
 def sphere_table(xyz_encoding: np.ndarray, noise: float = 0.02, seed: int = 11) -> np.ndarray:
     """hash table of the env-sphere test scene: every level's rows hold that level's two features of the reference's `demo/
     xyz_encoding.txt` (the constant position feature its notebook distils the trained sphere's table into) plus seeded

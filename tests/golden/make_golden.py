@@ -181,7 +181,8 @@ def build_reference_model(scene: scenes.SceneParams, extra_argv=(), config=None)
                 lin.weight.data = torch.from_numpy(W.copy())
                 lin.bias.data = torch.from_numpy(b.copy())
         model.sdf_density.beta.data = torch.tensor(scene.beta)
-        model.density_bitfield.data = torch.from_numpy(scene.bitfield.copy())
+        if model.cuda_ray:                        # (no occupancy grid without cuda_ray)
+            model.density_bitfield.data = torch.from_numpy(scene.bitfield.copy())
     return model, opt
 
 
@@ -764,6 +765,30 @@ def golden_train(tag, scene, config=None, H=32, W=32, theta=55.0, phi=-30.0):
           f"{out['norm/sdf_net.0.weight']:.4e}, table rows touched {touched.size}, beta grad {float(out['grad/beta']):.4e}")
 
 
+def golden_non_cuda_ray():
+    """The reference's torch-only render function (nerf/render_func/non_cuda_ray.py `run`, cuda_ray = False) on the plainest SDF configuration
+    (tests/golden/plain_like.ini: the function hands the colour network neither a reflected direction nor n.v nor an encoded normal): a
+    16x16 view with uniform samples only, and one with importance re-sampling."""
+    scene = scenes.plain_scene()
+    model, opt = build_reference_model(scene, config=OUT / "plain_like.ini")
+    assert not opt.cuda_ray and not model.cuda_ray
+    H = W = 16
+    ro, rd = scenes.camera_rays(H, W, theta=60.0, phi=-25.0, scale=0.8)
+    kw = {k: v for k, v in vars(opt).items() if k not in ("num_steps", "upsample_steps", "max_ray_batch")}
+    out = {}
+    for tag, steps, up in (("uniform", 96, 0), ("resampled", 64, 32)):
+        res = model.render(torch.from_numpy(ro)[None], torch.from_numpy(rd)[None], staged=False, bg_color=1, perturb=False,
+                           get_normal_image=True, num_steps=steps, upsample_steps=up, **kw)
+        for k in ("image", "depth", "weights_sum", "normal_image"):
+            out[f"{tag}|{k}"] = res[k].detach().numpy().astype(F).reshape(H * W, -1)
+        out[f"{tag}|steps"] = np.array([steps, up], np.int32)
+        print(f"[golden] non_cuda_ray {tag}: {steps}+{up} samples per ray, hit fraction {float((res['weights_sum'] > 0.5).float().mean()):.3f}, "
+              f"mean rgb {res['image'].mean(dim=(0, 1)).tolist()}")
+    # (staged=True cannot be taken with this function: render() then reads results_['roughness_image'] & co for every name in visual_items,
+    #  which `run` never returns, and the option parser does not accept an empty visual_items -- renderer.py:407-412)
+    np.savez_compressed(OUT / "frame_plain_nocuda_16.npz", H=H, W=W, theta=60.0, phi=-25.0, scale=0.8, **out)
+
+
 def main():
     if not REFERENCE.exists():
         raise SystemExit("/root/reference is not present: golden vectors can only be regenerated in the build container")
@@ -787,6 +812,9 @@ def main():
         return
     if sys.argv[1:] == ["indir_aabb"]:         # only the obj_aabb variant of the three-pass frame
         golden_indirect_aabb()
+        return
+    if sys.argv[1:] == ["nocuda"]:             # only the torch-only render function's fixture
+        golden_non_cuda_ray()
         return
     if sys.argv[1:] == ["train"]:              # only the training-branch fixtures
         golden_train("toaster", scenes.toaster_scene())
@@ -823,6 +851,7 @@ def main():
     golden_shading(model2, opt2, "lego", n=1024)
     golden_train("toaster", scenes.toaster_scene())
     golden_train("lego", scenes.lego_scene(seed=8), config=OUT / "lego_like.ini", theta=110.0, phi=-40.0)
+    golden_non_cuda_ray()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,97 @@
+"""`cuda_ray = False`: the reference's torch-only render function (nerf/render_func/non_cuda_ray.py `run`, dispatched at
+nerf/renderer.py:368-371) mirrored by envidr_amd/nerf/render_func/non_cuda_ray.py -- uniform samples between the box entry and exit,
+importance re-sampling from the first pass's weights, cumprod compositing -- with this package's HIP encoders underneath, against frames
+the imported reference rendered itself (tests/golden/frame_plain_nocuda_16.npz, make_golden.py golden_non_cuda_ray) on the plainest SDF
+configuration (tests/golden/plain_like.ini: the function feeds the colour network neither reflection nor n.v nor an encoded normal)."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from envidr_amd import scenes
+from tests.util import rel_l2
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).parent / "golden" / "frame_plain_nocuda_16.npz"
+
+
+def build_plain_model():
+    import torch
+    from envidr_amd.nerf.network import NeRFNetwork
+    from envidr_amd.nerf.options import plain_options
+    opt = plain_options()
+    scene = scenes.plain_scene()
+    m = NeRFNetwork(encoding="hashgrid", encoding_dir=opt.encoding_dir, bound=opt.bound, cuda_ray=opt.cuda_ray, density_scale=1,
+                    min_near=opt.min_near, density_thresh=opt.density_thresh, bg_radius=opt.bg_radius, use_sdf=opt.use_sdf,
+                    hidden_dim=opt.hidden_dim, num_layers=opt.num_layers, num_layers_color=opt.num_layers_color,
+                    hidden_dim_color=opt.hidden_dim_color, num_levels=opt.num_levels, geo_feat_dim=opt.geo_feat_dim, opt=opt)
+    sd = {"encoder.embeddings": torch.from_numpy(scene.table), "sdf_density.beta": torch.tensor(scene.beta)}
+    for name, attr in [("sdf", "sdf_net"), ("diffuse", "diffuse_net"), ("specular", "color_net")]:
+        for i, (W, b) in enumerate(scene.mlps[name]):
+            sd[f"{attr}.{i}.weight"] = torch.from_numpy(W)
+            sd[f"{attr}.{i}.bias"] = torch.from_numpy(b)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    return m.cuda().eval(), opt
+
+
+@pytest.fixture(scope="module")
+def model_opt():
+    return build_plain_model()
+
+
+@pytest.mark.parametrize("tag", ["uniform", "resampled"])
+def test_torch_only_render_function_matches_the_reference(model_opt, tag):
+    import torch
+    model, opt = model_opt
+    g = np.load(GOLD)
+    H, W = int(g["H"]), int(g["W"])
+    steps, up = (int(v) for v in g[f"{tag}|steps"])
+    ro, rd = scenes.camera_rays(H, W, theta=float(g["theta"]), phi=float(g["phi"]), scale=float(g["scale"]))
+    res = model.render(torch.from_numpy(ro).cuda()[None], torch.from_numpy(rd).cuda()[None], staged=False, bg_color=1, perturb=False,
+                       get_normal_image=True, num_steps=steps, upsample_steps=up)
+    torch.cuda.synchronize()
+    N = H * W
+    assert tuple(res["image"].shape) == (1, N, 3) and tuple(res["depth"].shape) == (1, N) and tuple(res["weights_sum"].shape) == (N,)
+    assert tuple(res["normal_image"].shape) == (N, 3)                       # the reference's function returns it un-reshaped
+    for k in ("image", "depth", "weights_sum", "normal_image"):
+        got, want = res[k].detach().cpu().numpy().reshape(N, -1), g[f"{tag}|{k}"]
+        # (a ray that misses the box has near == far: the reference's depth normalisation (z - near) / (far - near) is 0 / 0 there, and so is ours)
+        assert np.array_equal(np.isnan(got), np.isnan(want)), k
+        ok = ~np.isnan(want)
+        err = rel_l2(got[ok], want[ok])
+        # (uniform samples sit at the same depths on both sides; the importance samples' depths come out of fp32 cumulative sums, which two
+        #  torch backends add in different orders -- the scene is smooth so that this stays small, and the bound leaves room for it)
+        assert err <= (1e-4 if tag == "uniform" else 1e-3), f"{tag} {k}: rel-L2 {err:.3e}"
+
+
+def test_inverse_cdf_sampling_against_numpy():
+    """the importance sampler alone: deterministic mode lands at the mid-points of equal probability slices of the piecewise-linear CDF"""
+    import torch
+    from envidr_amd.nerf.render_func.non_cuda_ray import inverse_cdf_samples
+    rng = np.random.default_rng(2)
+    edges = np.sort(rng.uniform(0.5, 3.0, size=(7, 33)).astype(np.float32), axis=1)
+    w = rng.uniform(0, 1, size=(7, 32)).astype(np.float32) ** 4
+    got = inverse_cdf_samples(torch.from_numpy(edges).cuda(), torch.from_numpy(w).cuda(), 24, True).cpu().numpy()
+    m = w.astype(np.float64) + 1e-5
+    m /= m.sum(1, keepdims=True)
+    cdf = np.concatenate([np.zeros((7, 1)), np.cumsum(m, 1)], 1)
+    u = np.linspace(0.5 / 24, 1 - 0.5 / 24, 24)
+    want = np.stack([np.interp(u, cdf[i], edges[i].astype(np.float64)) for i in range(7)])
+    assert np.abs(got - want).max() <= 2e-5
+    assert np.all(np.diff(got, axis=1) >= 0)
+
+
+def test_staged_chunks_render_the_same_frame(model_opt):
+    """staged=True (chunks of max_ray_batch rays; the reference cannot finish this combination itself, renderer.py:407-412): the chunks'
+    images and depths are those of the single call"""
+    import torch
+    model, opt = model_opt
+    ro, rd = scenes.camera_rays(12, 20, theta=100.0, phi=-10.0, scale=0.8)
+    ro, rd = torch.from_numpy(ro).cuda()[None], torch.from_numpy(rd).cuda()[None]
+    kw = dict(bg_color=1, perturb=False, get_normal_image=True, num_steps=48, upsample_steps=16)
+    a = model.render(ro, rd, staged=False, **kw)
+    b = model.render(ro, rd, staged=True, max_ray_batch=77, **kw)
+    assert tuple(b["image"].shape) == (1, 240, 3) and tuple(b["normal_image"].shape) == (1, 240, 3)
+    for k in ("image", "depth"):
+        assert rel_l2(b[k].detach().cpu().numpy().reshape(240, -1), a[k].detach().cpu().numpy().reshape(240, -1)) <= 1e-5, k
