@@ -569,6 +569,72 @@ def golden_torch_only():
           float(res["weights_sum"].min()), "...", float(res["weights_sum"].max()))
 
 
+def resample_stub(torch_mod):
+    """the analytic stand-in model of golden_torch_only_resample / tests/test_plain_cpu.py: density and colour are functions of the sample
+    POSITION (a soft shell of radius 1.2), so that the importance re-sampling and the merge of the two sample sets matter"""
+    torch = torch_mod
+
+    class _Opt:
+        debug = False
+        backsdf_loss = False
+        eikonal_loss = False
+
+    class _Model:
+        opt = _Opt()
+        use_normal_with_mlp = True
+        use_n_dot_viewdir = True
+        use_reflected_dir = True
+        training = False
+        aabb_train = aabb_infer = torch.tensor([-8.0, -8, -8, 8, 8, 8])
+        min_near = 0.2
+        density_scale = 1
+        bg_radius = -1
+
+        def density(self, xyzs, **kw):
+            r = xyzs.norm(dim=-1, keepdim=True)
+            return {"sigma": 60.0 * torch.exp(-((r - 1.2) / 0.12) ** 2), "normal": xyzs / r.clamp_min(1e-6)}
+
+        def color(self, xyzs, dirs, mask=None, **kw):
+            return 0.5 + 0.5 * torch.sin(3.0 * xyzs + dirs)
+
+    return _Model()
+
+
+def golden_torch_only_resample():
+    """The reference's `non_cuda_ray.run` WITH importance re-sampling (utils.py sample_pdf, the sort / gather merge of non_cuda_ray.py:71-106)
+    on the analytic stand-in model above -- torch on the CPU on both sides, no kernel anywhere: pins envidr_amd/nerf/render_func/
+    non_cuda_ray.py (inverse_cdf_samples, the merge, the compositing) in tests/test_plain_cpu.py."""
+    from nerf.render_func import non_cuda_ray
+    rng = np.random.default_rng(43)
+    N = 200
+    rays_o = (rng.normal(size=(N, 3)) * 0.2 + np.array([0.0, 0.0, -3.0])).astype(F)
+    rays_d = (rng.normal(size=(N, 3)) * 0.25 + np.array([0.0, 0.0, 1.0])).astype(F)
+    rays_d /= np.linalg.norm(rays_d, axis=1, keepdims=True)
+    nears = rng.uniform(0.8, 1.4, size=N).astype(F)
+    fars = (nears + rng.uniform(2.5, 3.5, size=N)).astype(F)
+    bg = np.array([0.1, 0.2, 0.3], F)
+
+    class _NearFar:
+        @staticmethod
+        def near_far_from_aabb(rays_o, rays_d, aabb, min_near):
+            return torch.from_numpy(nears.copy()), torch.from_numpy(fars.copy())
+
+    saved = non_cuda_ray.raymarching
+    non_cuda_ray.raymarching = _NearFar
+    out = {"rays_o": rays_o, "rays_d": rays_d, "nears": nears, "fars": fars, "bg": bg}
+    try:
+        for tag, steps, up in (("a", 40, 24), ("b", 24, 40), ("c", 64, 0)):
+            res = non_cuda_ray.run(resample_stub(torch), torch.from_numpy(rays_o), torch.from_numpy(rays_d), num_steps=steps, upsample_steps=up,
+                                   bg_color=torch.from_numpy(bg), perturb=False, get_normal_image=True)
+            out.update({f"{tag}|steps": np.array([steps, up], np.int32), f"{tag}|image": res["image"].detach().numpy(),
+                        f"{tag}|depth": res["depth"].detach().numpy(), f"{tag}|weights_sum": res["weights_sum"].detach().numpy(),
+                        f"{tag}|normal_image": res["normal_image"].detach().numpy()})
+            print(f"[golden] torch_only_resample {tag}: {steps}+{up}, weights_sum {float(res['weights_sum'].min()):.3f} ... {float(res['weights_sum'].max()):.3f}")
+    finally:
+        non_cuda_ray.raymarching = saved
+    np.savez_compressed(OUT / "torch_only_resample.npz", **out)
+
+
 SPH_BETA = 0.005
 SPH_MATERIAL = {"roughness": 0.3, "metallic": 0.2, "color": [20 / 255, 70 / 255, 160 / 255, 1.0]}
 SPH_ENV_INDEX = 3
@@ -813,8 +879,9 @@ def main():
     if sys.argv[1:] == ["indir_aabb"]:         # only the obj_aabb variant of the three-pass frame
         golden_indirect_aabb()
         return
-    if sys.argv[1:] == ["nocuda"]:             # only the torch-only render function's fixture
+    if sys.argv[1:] == ["nocuda"]:             # only the torch-only render function's fixtures
         golden_non_cuda_ray()
+        golden_torch_only_resample()
         return
     if sys.argv[1:] == ["train"]:              # only the training-branch fixtures
         golden_train("toaster", scenes.toaster_scene())
@@ -852,6 +919,7 @@ def main():
     golden_train("toaster", scenes.toaster_scene())
     golden_train("lego", scenes.lego_scene(seed=8), config=OUT / "lego_like.ini", theta=110.0, phi=-40.0)
     golden_non_cuda_ray()
+    golden_torch_only_resample()
 
 
 if __name__ == "__main__":
