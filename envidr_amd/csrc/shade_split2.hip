@@ -266,7 +266,7 @@ int launch_env_split2(const envidr_render_desc* d, const ShadeArgs& a, hipStream
 
 extern "C" {
 
-// halves of the weight blob of the two-group kernel for (ide_degree, env_hidden) = (5, 256) or (4, 160); 0 for any other shape
+// halves of the weight blob of the fused-pair kernel for (ide_degree, env_hidden) = (5, 256) or (4, 160); 0 for any other shape
 uint32_t envidr_env_split2_halves(uint32_t ide_degree, uint32_t env_hidden) {
     if (ide_degree == 5 && env_hidden == 256) return (uint32_t)Split2Layout<ide_terms(5), 8>::Padded * kSplitFragHalves;
     if (ide_degree == 4 && env_hidden == 160) return (uint32_t)Split2Layout<ide_terms(4), 5>::Padded * kSplitFragHalves;

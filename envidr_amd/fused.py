@@ -87,7 +87,8 @@ class FusedOptions:
     light_intensity_scale: float = 1.0
     intensity_scale: float = 1.0
     # arithmetic of the environment MLP: "fp32" (default, what every headline number uses) or "f16x2" -- fp16 matrix cores
-    # with every operand carried as a (hi, lo) fp16 pair, fp32 accumulation (csrc/mlp_split.hip.h); the heads stay fp32
+    # with every operand carried as a (hi, lo) fp16 pair, fp32 accumulation (csrc/mlp_split2.hip.h; "f16x2_v1": the round-3 kernel of
+    # csrc/mlp_split.hip.h, same bits); the heads stay fp32
     env_precision: str = "fp32"
     # records whose compositing weight alpha * T is exactly 0 in fp32 are not shaded (they contribute w * c = 0 whatever c is; the
     # reference shades them all): nothing on the synthetic benchmark scene, most of the samples of a trained scene (beta ~ 1e-3)
@@ -354,7 +355,7 @@ def pack_env_split(env) -> tuple[np.ndarray, np.ndarray]:
 
 
 def pack_env_split2(env, ide_degree: int) -> tuple[np.ndarray, np.ndarray]:
-    """the four environment-MLP layers for the two-group split-precision kernel (csrc/shade_split2.hip): (uint16 blob of (hi, lo) fp16
+    """the four environment-MLP layers for the fused-pair split-precision kernel (csrc/shade_split2.hip): (uint16 blob of (hi, lo) fp16
     fragments in ITS consumption order -- layers fused in pairs; float32 biases as packed row-vector tiles, as for the round-3 form)"""
     lib = _lib.load()
     _bind_render(lib)
@@ -591,7 +592,7 @@ class FusedRenderer:
             raise _lib.EnvidrError(f"env_precision must be 'fp32', 'f16x2' or 'f16x2_v1', not {self.opt.env_precision!r}")
 
     def _set_precision(self, precision: str | None, records: int) -> None:
-        """point the descriptor at the split-precision weights + a feature scratch of `records` rows, or clear them.  "f16x2" = the two-group
+        """point the descriptor at the split-precision weights + a feature scratch of `records` rows, or clear them.  "f16x2" = the fused-pair
         kernel (csrc/shade_split2.hip); "f16x2_v1" = the round-3 form (csrc/shade_split.hip), kept as its bit-for-bit cross-check"""
         precision = precision or self.opt.env_precision
         d = self.desc

@@ -232,7 +232,7 @@ typedef struct envidr_render_desc {
     /* ABI 10: which kernel evaluates the split-precision mode, i.e. what env_split_blob holds.
      *   0  the round-3 form (csrc/shade_split.hip): a wave's two groups of 32 items one after the other; blob = the four layers packed by
      *      envidr_pack_layer_split in consumption order
-     *   1  the two-group form (csrc/shade_split2.hip): every weight fragment serves both groups, layers fused in pairs; blob packed by
+     *   1  the fused-pair form (csrc/shade_split2.hip): layers fused in pairs, eight waves of 256 registers on one weight stream; blob packed by
      *      envidr_pack_env_split2 (envidr_env_split2_halves() halves).  Same results bit for bit.  Honours geometry_export.shade_list. */
     uint32_t env_split_form;
 } envidr_render_desc;

@@ -84,7 +84,7 @@ def _random_shading_inputs(M, seed):
 
 @pytest.mark.parametrize("hidden_env,ide_deg", [(256, 5), (160, 4)])
 def test_two_group_kernel_has_the_bits_of_the_one_group_kernel(hidden_env, ide_deg):
-    """"f16x2" (csrc/shade_split2.hip: both item groups share every weight fragment, layers fused in pairs) against "f16x2_v1" (csrc/shade_split.hip:
+    """"f16x2" (csrc/shade_split2.hip: layers fused in pairs, eight waves of 256 registers on one weight stream) against "f16x2_v1" (csrc/shade_split.hip:
     one group at a time): the same (hi, lo) split, the same three products per step in the same order into every accumulator -- the colours must
     be IDENTICAL, on sample counts that leave waves / workgroups / the last round ragged and on many rounds per workgroup"""
     import torch
@@ -103,8 +103,8 @@ def test_two_group_kernel_has_the_bits_of_the_one_group_kernel(hidden_env, ide_d
 
 
 def test_two_group_kernel_is_deterministic_and_frames_agree():
-    """the same frame three times through the two-group kernel (bit-identical: no atomics, no schedule dependence), and equal to the one-group
-    kernel's frame; a frame with zero-weight skipping (the list of records to shade, which only the two-group form honours) equals the frame
+    """the same frame three times through the fused-pair kernel (bit-identical: no atomics, no schedule dependence), and equal to the one-group
+    kernel's frame; a frame with zero-weight skipping (the list of records to shade, which only the fused-pair form honours) equals the frame
     that shades every record"""
     import torch
     from envidr_amd.fused import FusedOptions, FusedRenderer
