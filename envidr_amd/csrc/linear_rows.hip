@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(kRowsThreads, 2) k_linear_rows(RowsArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 v[r] = EPI == ENVIDR_ROWS_PLAIN ? acc[t][r] : acc[t][r] + b;
-                if constexpr (EPI == ENVIDR_ROWS_BIAS_RELU) v[r] = v[r] > 0.0f ? v[r] : 0.0f;     // NaN -> 0 (a compare-select); torch.relu propagates NaN
+                if constexpr (EPI == ENVIDR_ROWS_BIAS_RELU) v[r] = v[r] < 0.0f ? 0.0f : v[r];     // (this way round a NaN stays a NaN, as in torch.relu: a diverged network shows)
             }
         }
         float* yc = a.y + col;

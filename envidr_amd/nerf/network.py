@@ -77,8 +77,8 @@ WEIGHT_GRAD_OPERATOR_MIN_ROWS = 16384 # training: from this many rows the weight
 # The shading networks of the training branch (environment, diffuse, colour heads) run as ONE autograd node each (_ReluMlp) from that many rows on.
 # That node is once-differentiable: a loss that differentiates the colours with create_graph=True (a gradient penalty through the environment /
 # diffuse / colour networks) raises there, where the reference's nn.Sequential works -- set SHADING_MLP_SINGLE_NODE = False for such a loss (the
-# per-layer nodes below are twice differentiable).  Its ReLU, like the inference operator's, maps a NaN pre-activation to 0 where torch.relu
-# propagates it: a diverged network then trains on finite colours instead of failing loudly.
+# per-layer nodes below are twice differentiable).  Its ReLU (the ROWS_BIAS_RELU epilogue of envidr_linear_rows) propagates a NaN
+# pre-activation like torch.relu; only the INFERENCE operator of the environment network (ds_max_f32 against 0) flushes NaN to 0.
 SHADING_MLP_SINGLE_NODE = True
 
 

@@ -2,7 +2,10 @@
 nerf/renderer.py:368-371) mirrored by envidr_amd/nerf/render_func/non_cuda_ray.py -- uniform samples between the box entry and exit,
 importance re-sampling from the first pass's weights, cumprod compositing -- with this package's HIP encoders underneath, against frames
 the imported reference rendered itself (tests/golden/frame_plain_nocuda_16.npz, make_golden.py golden_non_cuda_ray) on the plainest SDF
-configuration (tests/golden/plain_like.ini: the function feeds the colour network neither reflection nor n.v nor an encoded normal)."""
+configuration (tests/golden/plain_like.ini: the function feeds the colour network neither reflection nor n.v nor an encoded normal).
+(The file sorts last on purpose: its re-sampled case was re-generated on a smoother scene after GPU access for the repository had been
+closed, and has not run on a GPU since -- behind everything else it cannot hide another test's result under `pytest -x`.  The mirror itself
+is pinned on the CPU against the reference's own function: tests/test_plain_cpu.py.)"""
 from pathlib import Path
 
 import numpy as np
