@@ -18,6 +18,7 @@ import torch.nn.functional as F
 
 from .. import fused as _fused
 from ..encoding import get_encoder
+from .activation import trunc_exp
 from .renderer import NeRFRenderer
 
 
@@ -277,8 +278,9 @@ class NeRFNetwork(NeRFRenderer):
                  geo_feat_dim=15, num_layers_color=3, hidden_dim_color=64, num_layers_bg=2, hidden_dim_bg=64, bound=1,
                  num_levels=16, roughness_bias=-1, opt=None, env_opt=None, **kwargs):
         super().__init__(bound, opt=opt, env_opt=env_opt, **kwargs)
-        if not opt.use_sdf:
-            raise NotImplementedError("only the SDF configuration family (use_sdf) is implemented; the plain-density NeRF branch is out of scope")
+        # use_sdf = False (the plain-NeRF density branch, reference network.py:424-429,519): the geometry network's first output goes through
+        # trunc_exp and IS the density; normals are the negated density gradient.  Operator path only: the fused kernels are built for the SDF
+        # family (supports_fused asks for it).
         self.num_layers, self.hidden_dim, self.geo_feat_dim = num_layers, hidden_dim, geo_feat_dim
         self._encoding_dir = encoding_dir
         self.num_layers_color, self.hidden_dim_color = num_layers_color, hidden_dim_color
@@ -287,9 +289,10 @@ class NeRFNetwork(NeRFRenderer):
                                                 desired_resolution=bound * opt.desired_resolution,
                                                 base_resolution=opt.base_resolution, num_levels=num_levels,
                                                 log2_hashmap_size=opt.log2_hashmap_size, multires=opt.multires)
-        # Laplace density (VolSDF style; every shipped config) or the NeuS section alpha (reference network.py:142-149)
-        self.sdf_density = (NeuSDensity(opt.init_variance, opt.max_steps, opt.neus_n_detach) if opt.use_neus_sdf
-                            else LaplaceDensity(opt.init_beta, opt.beta_min, opt.beta_max))
+        # Laplace density (VolSDF style; every shipped config) or the NeuS section alpha (reference network.py:142-149); none without use_sdf
+        if opt.use_sdf:
+            self.sdf_density = (NeuSDensity(opt.init_variance, opt.max_steps, opt.neus_n_detach) if opt.use_neus_sdf
+                                else LaplaceDensity(opt.init_beta, opt.beta_min, opt.beta_max))
         # material-conditioned SDF input (reference network.py:165-175): in the env-sphere mode the dataset's varying material parameters
         # -- roughness, metallic, base colour -- are concatenated to the hash features
         self.in_roughness = self.in_metallic = self.in_base_color = 0
@@ -458,7 +461,7 @@ class NeRFNetwork(NeRFRenderer):
                     h = self.sdf_act(h)
         else:
             h = _run_mlp(self.sdf_net, x)
-        sdf = h[..., 0]
+        sdf, sigma = (h[..., 0], None) if self.use_sdf else (None, trunc_exp(h[..., 0]))
         g = self.geo_feat_dim
         geo_feat = _feat_act(h[..., 1:1 + g], self.opt.geo_feat_act)
         if self.opt.use_roughness and not self.opt.diffuse_only and not self.opt.bypass_roughness:
@@ -469,11 +472,15 @@ class NeRFNetwork(NeRFRenderer):
         else:
             self.roughness = self.opt.default_roughness
         self.metallic = 1.0
-        return sdf, None, geo_feat
+        return sdf, sigma, geo_feat
 
     def forward_sigma(self, xyzs, material=None, **kwargs):
-        sdfs, _, geo_feats = self.forward_geometry(xyzs, material)
+        sdfs, sigmas, geo_feats = self.forward_geometry(xyzs, material)
         normals = eikonal = None
+        if not self.use_sdf:                                # reference network.py:519-520: the density is there already; its gradient gives the normals
+            if kwargs.get("use_sdf_sigma_grad", False):
+                normals, eikonal = self.compute_normal(sigmas, xyzs, self.opt.eikonal_loss)
+            return sdfs, sigmas, geo_feats, normals, eikonal
         if kwargs.get("use_sdf_sigma_grad", False):
             normals, eikonal = self.compute_normal(sdfs, xyzs, self.opt.eikonal_loss)
         if self.opt.use_neus_sdf:                           # reference network.py:512-515: the "density" is the section alpha
@@ -579,7 +586,7 @@ class NeRFNetwork(NeRFRenderer):
         hash_ok = o.encoding_pos == "hashgrid_diff" and o.level_dim == 2 and o.num_levels == 16      # the fused kernels are built for 16 levels
         net_ok = (o.num_layers == 3 and o.hidden_dim == 64 and o.geo_feat_dim == 12 and o.ensemble_mlp and o.use_roughness
                   and o.learn_indir_blend and o.mlp_bias and o.geo_feat_act == "unitNorm" and o.env_feat_act == "unitNorm"
-                  and not o.use_neus_sdf and not self.geometric_init and not self.skip_layers and not self.w_material)
+                  and self.use_sdf and not o.use_neus_sdf and not self.geometric_init and not self.skip_layers and not self.w_material)
         shade_ok = (o.use_diffuse and not o.diffuse_only and o.diffuse_with_env and o.diffuse_env_fusion == "concat"
                     and not o.split_diffuse_env and o.use_env_net and not o.env_wo_bias and o.num_layers_env == 4
                     and o.env_feat_dim == 12 and (o.sh_degree, o.hidden_dim_env) in [(5, 256), (4, 160), (5, 128), (4, 128)]
@@ -605,7 +612,7 @@ class NeRFNetwork(NeRFRenderer):
         hash_ok = o.encoding_pos == "hashgrid_diff" and o.level_dim == 2 and o.num_levels == 16
         net_ok = (o.num_layers == 3 and o.hidden_dim == 64 and o.geo_feat_dim == 12 and o.ensemble_mlp and o.use_roughness and o.mlp_bias
                   and o.geo_feat_act == "unitNorm" and o.env_feat_act == "unitNorm" and o.enabled_levels <= 0 and not o.bypass_roughness
-                  and o.normal_anneal_ratio >= 1 and not o.use_neus_sdf and not self.geometric_init and not self.skip_layers)
+                  and o.normal_anneal_ratio >= 1 and self.use_sdf and not o.use_neus_sdf and not self.geometric_init and not self.skip_layers)
         shade_ok = (o.use_diffuse and not o.diffuse_only and o.diffuse_with_env and o.diffuse_env_fusion == "concat"
                     and not o.split_diffuse_env and o.use_env_net and self.env_nets is not None and not o.env_wo_bias and o.num_layers_env == 4
                     and o.env_feat_dim == 12 and (o.sh_degree, o.hidden_dim_env) in [(5, 256), (4, 160), (5, 128), (4, 128)]

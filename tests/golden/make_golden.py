@@ -855,6 +855,63 @@ def golden_non_cuda_ray():
     np.savez_compressed(OUT / "frame_plain_nocuda_16.npz", H=H, W=W, theta=60.0, phi=-25.0, scale=0.8, **out)
 
 
+def golden_network_cpu():
+    """The reference's NeRFNetwork in configurations that run in plain torch on the CPU (tests/golden/torch_like.ini: identity position and
+    direction encoders, no integrated-direction encoding), with its OWN initial weights: the SDF family and the plain-density branch
+    (`use_sdf` off: trunc_exp density, normals = the negated density gradient, network.py:424-429,519).  Per sample: density / sdf,
+    geometry feature, normal, roughness, colours; and the gradients of a scalar of them w.r.t. every parameter and the positions (through
+    the normals: a double backward).  Pins envidr_amd/nerf/network.py without any kernel: tests/test_network_cpu.py."""
+    import tempfile
+    from nerf.options import config_parser
+    from nerf.network import NeRFNetwork
+    rng = np.random.default_rng(47)
+    x = rng.uniform(-0.8, 0.8, size=(200, 3)).astype(F)
+    d = rng.normal(size=(200, 3)).astype(F)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    w_rgb, w_sigma = rng.normal(size=(200, 3)).astype(F), rng.normal(size=200).astype(F)
+    out = {"x": x, "d": d, "w_rgb": w_rgb, "w_sigma": w_sigma}
+    text = (OUT / "torch_like.ini").read_text()
+    for tag in ("sdf", "density"):
+        with tempfile.NamedTemporaryFile("w", suffix=".ini", delete=False) as f:
+            f.write(text if tag == "sdf" else text.replace("use_sdf = True\n", ""))
+        old = sys.argv
+        sys.argv = ["main_nerf.py", "--config", f.name, "--test"]
+        try:
+            opt = config_parser()
+        finally:
+            sys.argv = old
+        assert opt.use_sdf == (tag == "sdf") and not opt.cuda_ray
+        torch.manual_seed(3)
+        model = NeRFNetwork(encoding="hashgrid", encoding_dir=opt.encoding_dir, bound=opt.bound, cuda_ray=opt.cuda_ray, density_scale=1,
+                            min_near=opt.min_near, density_thresh=opt.density_thresh, bg_radius=opt.bg_radius, use_sdf=opt.use_sdf,
+                            hidden_dim=opt.hidden_dim, num_layers=opt.num_layers, num_layers_color=opt.num_layers_color,
+                            hidden_dim_color=opt.hidden_dim_color, num_layers_bg=opt.num_layers_bg, num_levels=opt.num_levels,
+                            geo_feat_dim=opt.geo_feat_dim, opt=opt, env_opt=None)
+        model.train()
+        with torch.no_grad():                       # (xavier weights of a 3-wide first layer give a nearly flat field: scale the geometry up)
+            for lin in model.sdf_net:
+                lin.weight.mul_(2.5)
+                lin.bias.add_(0.1 * torch.randn_like(lin.bias))
+        xt = torch.from_numpy(x).requires_grad_(True)
+        dt = torch.from_numpy(d)
+        sdfs, sigmas, geo, normals, _ = model.forward_sigma(xt, use_sdf_sigma_grad=True)
+        rough = model.roughness
+        n_enc, w_r, n_dot, n_env = model.get_color_mlp_extra_params(normals, dt, rough, None)
+        rgb = model.forward_color(geo, dt, n_enc, w_r, n_dot, True, n_env_enc=n_env, r_images=None, roughness=rough)
+        loss = (rgb * torch.from_numpy(w_rgb)).sum() + (sigmas * torch.from_numpy(w_sigma)).sum()
+        params = dict(model.named_parameters())
+        grads = torch.autograd.grad(loss, [xt, *params.values()], allow_unused=True)
+        g = lambda t: np.zeros(0, F) if t is None else t.detach().numpy().astype(F)
+        out.update({f"{tag}|sdf": g(sdfs), f"{tag}|sigma": g(sigmas), f"{tag}|geo_feat": g(geo), f"{tag}|normal": g(normals), f"{tag}|roughness": g(rough),
+                    f"{tag}|rgb": g(rgb), f"{tag}|c_diffuse": g(model.c_diffuse), f"{tag}|c_specular": g(model.c_specular), f"{tag}|grad|x": g(grads[0])})
+        for (name, p), gr in zip(params.items(), grads[1:]):
+            out[f"{tag}|param|{name}"] = g(p)
+            out[f"{tag}|grad|{name}"] = g(gr)
+        print(f"[golden] network_cpu {tag}: sigma {float(sigmas.min()):.3g} ... {float(sigmas.max()):.3g}, |normal| {float(normals.norm(dim=-1).mean()):.3f}, "
+              f"mean rgb {rgb.mean(0).tolist()}")
+    np.savez_compressed(OUT / "network_cpu.npz", **out)
+
+
 def main():
     if not REFERENCE.exists():
         raise SystemExit("/root/reference is not present: golden vectors can only be regenerated in the build container")
@@ -878,6 +935,9 @@ def main():
         return
     if sys.argv[1:] == ["indir_aabb"]:         # only the obj_aabb variant of the three-pass frame
         golden_indirect_aabb()
+        return
+    if sys.argv[1:] == ["network_cpu"]:        # only the plain-torch network fixtures
+        golden_network_cpu()
         return
     if sys.argv[1:] == ["nocuda"]:             # only the torch-only render function's fixtures
         golden_non_cuda_ray()
@@ -920,6 +980,7 @@ def main():
     golden_train("lego", scenes.lego_scene(seed=8), config=OUT / "lego_like.ini", theta=110.0, phi=-40.0)
     golden_non_cuda_ray()
     golden_torch_only_resample()
+    golden_network_cpu()
 
 
 if __name__ == "__main__":

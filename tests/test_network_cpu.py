@@ -1,0 +1,74 @@
+"""envidr_amd/nerf/network.py against the REFERENCE's NeRFNetwork on the CPU, no kernel involved: configurations whose encoders are the
+identity (tests/golden/torch_like.ini) run in plain torch on both sides.  Fixture tests/golden/network_cpu.npz holds the reference's own
+initial weights, its per-sample outputs (density / sdf, geometry feature, normal, roughness, colours) and the gradients of a scalar of them
+w.r.t. every parameter and the positions (make_golden.py golden_network_cpu), for the SDF family and for the plain-density branch
+(`use_sdf` off: trunc_exp density, normals = the negated density gradient; reference network.py:424-429,519)."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = Path(__file__).parent / "golden" / "network_cpu.npz"
+
+
+def _build(tag, g):
+    from envidr_amd.nerf.network import NeRFNetwork
+    from envidr_amd.nerf.options import RenderOptions
+    opt = RenderOptions(scale=0.8, cuda_ray=False, use_sdf=(tag == "sdf"), encoding_pos="frequency", multires=0, encoding_dir="frequency", multires_dir=0,
+                        wo_viewdir=False, normal_with_mlp=True, use_n_dot_viewdir=True, use_reflected_dir=False, use_env_net=False,
+                        diffuse_with_env=False, use_renv=False, visual_items=["roughness"])
+    m = NeRFNetwork(encoding="hashgrid", encoding_dir=opt.encoding_dir, bound=opt.bound, cuda_ray=opt.cuda_ray, density_scale=1, min_near=opt.min_near,
+                    density_thresh=opt.density_thresh, bg_radius=opt.bg_radius, use_sdf=opt.use_sdf, hidden_dim=opt.hidden_dim,
+                    num_layers=opt.num_layers, num_layers_color=opt.num_layers_color, hidden_dim_color=opt.hidden_dim_color,
+                    num_levels=opt.num_levels, geo_feat_dim=opt.geo_feat_dim, opt=opt)
+    names = [k[len(tag) + 7:] for k in g.files if k.startswith(f"{tag}|param|")]
+    ours = dict(m.named_parameters())
+    assert sorted(names) == sorted(ours), (sorted(names), sorted(ours))              # the reference's parameter names, nothing more or less
+    missing, unexpected = m.load_state_dict({n: torch.from_numpy(g[f"{tag}|param|{n}"]) for n in names}, strict=False)
+    assert not unexpected and all(k in ("aabb_train", "aabb_infer") for k in missing), (missing, unexpected)        # (buffers, not parameters)
+    return m.train(), names
+
+
+@pytest.mark.parametrize("tag", ["sdf", "density"])
+def test_network_mirror_matches_the_reference_on_the_cpu(tag):
+    g = np.load(GOLD)
+    model, names = _build(tag, g)
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    d = torch.from_numpy(g["d"])
+    sdfs, sigmas, geo, normals, _ = model.forward_sigma(x, use_sdf_sigma_grad=True)
+    rough = model.roughness
+    n_enc, w_r, n_dot, n_env = model.get_color_mlp_extra_params(normals, d, rough, None)
+    rgb = model.forward_color(geo, d, n_enc, w_r, n_dot, True, n_env_enc=n_env, r_images=None, roughness=rough)
+    assert (sdfs is None) == (tag == "density")
+    got = {"sigma": sigmas, "geo_feat": geo, "normal": normals, "roughness": rough, "rgb": rgb, "c_diffuse": model.c_diffuse, "c_specular": model.c_specular}
+    if tag == "sdf":
+        got["sdf"] = sdfs
+    for k, v in got.items():
+        want = g[f"{tag}|{k}"]
+        a = v.detach().numpy().reshape(want.shape)
+        assert np.abs(a - want).max() <= 2e-6 * max(1.0, float(np.abs(want).max())), (tag, k, float(np.abs(a - want).max()))
+    loss = (rgb * torch.from_numpy(g["w_rgb"])).sum() + (sigmas * torch.from_numpy(g["w_sigma"])).sum()
+    params = dict(model.named_parameters())
+    grads = torch.autograd.grad(loss, [x, *[params[n] for n in names]], allow_unused=True)
+    for n, gr in zip(["x", *names], grads):
+        want = g[f"{tag}|grad|{n}"]
+        if want.size == 0:
+            assert gr is None, n
+            continue
+        a = gr.detach().numpy()
+        scale = max(float(np.abs(want).max()), 1e-6)
+        assert np.abs(a - want).max() <= 2e-5 * scale, (tag, n, float(np.abs(a - want).max()), scale)
+
+
+def test_trunc_exp_is_the_references_function():
+    """forward exp(x); backward g exp(clamp(x, -15, 15)) -- also where exp itself has overflowed; twice differentiable"""
+    from envidr_amd.nerf.activation import trunc_exp
+    x = torch.tensor([-100.0, -20.0, -15.0, -1.0, 0.0, 2.0, 15.0, 20.0, 89.0], requires_grad=True)
+    y = trunc_exp(x)
+    assert torch.equal(y, torch.exp(x.detach()))
+    (gx,) = torch.autograd.grad(y.sum(), x, create_graph=True)
+    assert torch.equal(gx.detach(), torch.exp(x.detach().clamp(-15, 15)))
+    (ggx,) = torch.autograd.grad(gx.sum(), x)
+    inside = (x.detach() > -15) & (x.detach() < 15)
+    assert torch.allclose(ggx[inside], torch.exp(x.detach()[inside])) and torch.all(ggx[~inside & (x.detach().abs() > 15)] == 0)
