@@ -855,12 +855,27 @@ def golden_non_cuda_ray():
     np.savez_compressed(OUT / "frame_plain_nocuda_16.npz", H=H, W=W, theta=60.0, phi=-25.0, scale=0.8, **out)
 
 
+# tag -> (lines removed from torch_like.ini, lines added): the variants of tests/test_network_cpu.py (its NETWORK_VARIANTS holds the same
+# settings as RenderOptions overrides)
+NETWORK_CPU_VARIANTS = {
+    "sdf": ([], []),
+    "density": (["use_sdf = True"], []),
+    "neus": ([], ["use_neus_sdf = True"]),
+    "skip": (["num_layers = 3"], ["num_layers = 4", "skip_layers = [2]"]),
+    "geoinit": ([], ["geometric_init = True"]),
+    "tanh_separate_roughness": (["geo_feat_act = unitNorm", "ensemble_mlp = True", "learn_indir_blend = True"], ["geo_feat_act = tanh"]),
+    "instance_norm_detached_annealed": (["geo_feat_act = unitNorm"], ["geo_feat_act = instanceNorm", "detach_normal = True", "normal_anneal_ratio = 0.5"]),
+    "diffuse_only": ([], ["diffuse_only = True"]),
+}
+
+
 def golden_network_cpu():
     """The reference's NeRFNetwork in configurations that run in plain torch on the CPU (tests/golden/torch_like.ini: identity position and
-    direction encoders, no integrated-direction encoding), with its OWN initial weights: the SDF family and the plain-density branch
-    (`use_sdf` off: trunc_exp density, normals = the negated density gradient, network.py:424-429,519).  Per sample: density / sdf,
-    geometry feature, normal, roughness, colours; and the gradients of a scalar of them w.r.t. every parameter and the positions (through
-    the normals: a double backward).  Pins envidr_amd/nerf/network.py without any kernel: tests/test_network_cpu.py."""
+    direction encoders, no integrated-direction encoding), with its OWN initial weights: the SDF family, the plain-density branch
+    (`use_sdf` off: trunc_exp density, normals = the negated density gradient, network.py:424-429,519), the NeuS section alpha, the geometric
+    initialisation with a skip layer, the other feature activations, a separate roughness layer, detached / annealed normals, diffuse only.
+    Per sample: density / sdf, geometry feature, normal, roughness, colours; and the gradients of a scalar of them w.r.t. every parameter and
+    the positions (through the normals: a double backward).  Pins envidr_amd/nerf/network.py without any kernel: tests/test_network_cpu.py."""
     import tempfile
     from nerf.options import config_parser
     from nerf.network import NeRFNetwork
@@ -868,19 +883,25 @@ def golden_network_cpu():
     x = rng.uniform(-0.8, 0.8, size=(200, 3)).astype(F)
     d = rng.normal(size=(200, 3)).astype(F)
     d /= np.linalg.norm(d, axis=1, keepdims=True)
+    dists = rng.uniform(0.005, 0.02, size=200).astype(F)
     w_rgb, w_sigma = rng.normal(size=(200, 3)).astype(F), rng.normal(size=200).astype(F)
-    out = {"x": x, "d": d, "w_rgb": w_rgb, "w_sigma": w_sigma}
-    text = (OUT / "torch_like.ini").read_text()
-    for tag in ("sdf", "density"):
+    out = {"x": x, "d": d, "dists": dists, "w_rgb": w_rgb, "w_sigma": w_sigma}
+    base = (OUT / "torch_like.ini").read_text()
+    for tag, (drop, add) in NETWORK_CPU_VARIANTS.items():
+        text = base
+        for line in drop:
+            assert line + "\n" in text, line
+            text = text.replace(line + "\n", "")
+        text += "".join(line + "\n" for line in add)
         with tempfile.NamedTemporaryFile("w", suffix=".ini", delete=False) as f:
-            f.write(text if tag == "sdf" else text.replace("use_sdf = True\n", ""))
+            f.write(text)
         old = sys.argv
         sys.argv = ["main_nerf.py", "--config", f.name, "--test"]
         try:
             opt = config_parser()
         finally:
             sys.argv = old
-        assert opt.use_sdf == (tag == "sdf") and not opt.cuda_ray
+        assert not opt.cuda_ray
         torch.manual_seed(3)
         model = NeRFNetwork(encoding="hashgrid", encoding_dir=opt.encoding_dir, bound=opt.bound, cuda_ray=opt.cuda_ray, density_scale=1,
                             min_near=opt.min_near, density_thresh=opt.density_thresh, bg_radius=opt.bg_radius, use_sdf=opt.use_sdf,
@@ -888,27 +909,28 @@ def golden_network_cpu():
                             hidden_dim_color=opt.hidden_dim_color, num_layers_bg=opt.num_layers_bg, num_levels=opt.num_levels,
                             geo_feat_dim=opt.geo_feat_dim, opt=opt, env_opt=None)
         model.train()
-        with torch.no_grad():                       # (xavier weights of a 3-wide first layer give a nearly flat field: scale the geometry up)
-            for lin in model.sdf_net:
-                lin.weight.mul_(2.5)
-                lin.bias.add_(0.1 * torch.randn_like(lin.bias))
+        if not opt.geometric_init:
+            with torch.no_grad():                   # (xavier weights of a 3-wide first layer give a nearly flat field: scale the geometry up)
+                for lin in model.sdf_net:
+                    lin.weight.mul_(2.5)
+                    lin.bias.add_(0.1 * torch.randn_like(lin.bias))
         xt = torch.from_numpy(x).requires_grad_(True)
         dt = torch.from_numpy(d)
-        sdfs, sigmas, geo, normals, _ = model.forward_sigma(xt, use_sdf_sigma_grad=True)
+        sdfs, sigmas, geo, normals, _ = model.forward_sigma(xt, use_sdf_sigma_grad=True, dirs=dt, dists=torch.from_numpy(dists))
         rough = model.roughness
         n_enc, w_r, n_dot, n_env = model.get_color_mlp_extra_params(normals, dt, rough, None)
         rgb = model.forward_color(geo, dt, n_enc, w_r, n_dot, True, n_env_enc=n_env, r_images=None, roughness=rough)
-        loss = (rgb * torch.from_numpy(w_rgb)).sum() + (sigmas * torch.from_numpy(w_sigma)).sum()
+        loss = (rgb * torch.from_numpy(w_rgb)).sum() + (sigmas.reshape(-1) * torch.from_numpy(w_sigma)).sum()
         params = dict(model.named_parameters())
         grads = torch.autograd.grad(loss, [xt, *params.values()], allow_unused=True)
-        g = lambda t: np.zeros(0, F) if t is None else t.detach().numpy().astype(F)
+        g = lambda t: np.zeros(0, F) if (t is None or not torch.is_tensor(t)) else t.detach().numpy().astype(F)
         out.update({f"{tag}|sdf": g(sdfs), f"{tag}|sigma": g(sigmas), f"{tag}|geo_feat": g(geo), f"{tag}|normal": g(normals), f"{tag}|roughness": g(rough),
                     f"{tag}|rgb": g(rgb), f"{tag}|c_diffuse": g(model.c_diffuse), f"{tag}|c_specular": g(model.c_specular), f"{tag}|grad|x": g(grads[0])})
         for (name, p), gr in zip(params.items(), grads[1:]):
             out[f"{tag}|param|{name}"] = g(p)
             out[f"{tag}|grad|{name}"] = g(gr)
-        print(f"[golden] network_cpu {tag}: sigma {float(sigmas.min()):.3g} ... {float(sigmas.max()):.3g}, |normal| {float(normals.norm(dim=-1).mean()):.3f}, "
-              f"mean rgb {rgb.mean(0).tolist()}")
+        print(f"[golden] network_cpu {tag}: {len(params)} parameters, sigma {float(sigmas.min()):.3g} ... {float(sigmas.max()):.3g}, "
+              f"|normal| {float(normals.norm(dim=-1).mean()):.3f}, mean rgb {[round(v, 4) for v in rgb.mean(0).tolist()]}")
     np.savez_compressed(OUT / "network_cpu.npz", **out)
 
 
