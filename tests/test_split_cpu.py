@@ -173,3 +173,88 @@ def test_two_group_packer_matches_its_layout(lib, ide_degree, hidden):
     assert not F[frags:].any()
     with pytest.raises(_lib.EnvidrError):
         pack_env_split2([(np.zeros((128, 72), np.float32), np.zeros(128, np.float32))] * 4, 5)
+
+
+@pytest.mark.parametrize("ide_degree,hidden", [(5, 256), (4, 160)])
+def test_fused_pair_blob_reproduces_the_mlp_under_the_kernels_dataflow(lib, ide_degree, hidden):
+    """A numpy model of k_env_split2's dataflow eats the packed blob fragment by fragment, in stream order, with the matrix instruction's
+    contract -- D[m][n] += sum over (half h, slot i) of A[lane (m, h)][i] * B[lane (n, h)][i] -- and the kernel's operand conventions (layer 1:
+    slot (s, h, i) = input 16 s + 8 h + i; later layers: the producing tile's accumulator register 8 (s & 1) + i of lane half h, i.e. row
+    tile_row(8 (s & 1) + i, h) of tile s >> 1): phase A = layer-1 tile t, then its two steps of every layer-2 tile; in-place (hi, lo) split;
+    phase B = layer-3 tile t, then its two steps of the last layer.  The result must be the MLP evaluated with (hi, lo) operands."""
+    from envidr_amd.fused import pack_env_split2
+    terms = 2 ** ide_degree - 1 + ide_degree
+    K1, T = 2 * terms, hidden // 32
+    S1, SH = (K1 + 15) // 16, 2 * T
+    rng = np.random.default_rng(7 + ide_degree)
+    dims = [K1, hidden, hidden, hidden, 12]
+    env = [((rng.normal(size=(dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32), (0.1 * rng.normal(size=dims[i + 1])).astype(np.float32))
+           for i in range(4)]
+    blob, _ = pack_env_split2(env, ide_degree)
+    F = blob.view(np.float16).astype(np.float64).reshape(-1, 64, 8)                     # [fragment][lane][slot]
+    A1, A2, B3, B4 = 2 * S1, 4 * T, 2 * SH, 4
+    FB = T * (A1 + A2)
+    a2_block = lambda t: min(t + 2, T) * A1 + t * A2
+    a1_block = lambda t: t * A1 if t < 2 else a2_block(t - 2) + A2
+    b4_block = lambda t: FB + min(t + 2, T) * B3 + t * B4
+    b3_block = lambda t: FB if t == 0 else FB + t * B3 + (t - 1) * B4
+    split = lambda v: ((hi := v.astype(np.float16).astype(np.float64)), (v - hi).astype(np.float16).astype(np.float64))
+    lanes_m, lanes_h = np.arange(64) & 31, np.arange(64) >> 5
+
+    def mfma(acc, frag, Bh, Bl):
+        """acc [32 rows][32 items] += the three products of one (hi, lo) fragment pair with the B operand pair ([64 lanes][8 slots] each)"""
+        Ah, Al = F[frag], F[frag + 1]
+        for A, B in ((Ah, Bh), (Ah, Bl), (Al, Bh)):
+            for h in (0, 1):
+                acc += A[lanes_h == h] @ B[lanes_h == h].T                               # [32 m][8] x [8][32 n]
+
+    def operand_from_rows(rows_hi, rows_lo, s):
+        """B operand pair of step s from a finished tile's rows [32 rows][32 items]: slot (h, i) = row tile_row(8 (s & 1) + i, h)"""
+        Bh, Bl = np.zeros((64, 8)), np.zeros((64, 8))
+        for h in (0, 1):
+            for i in range(8):
+                row = _tile_row(8 * (s & 1) + i, h)
+                Bh[32 * h:32 * h + 32, i], Bl[32 * h:32 * h + 32, i] = rows_hi[row], rows_lo[row]
+        return Bh, Bl
+
+    x = rng.normal(size=(32, K1)).astype(np.float32)                                     # 32 items
+    xh, xl = split(x.astype(np.float64))
+    bias = [b.astype(np.float64) for _, b in env]
+    relu_split = lambda acc: split(np.clip(acc, 0.0, 60000.0))
+    # phase A
+    acc2 = [np.tile(bias[1][32 * u:32 * u + 32, None], (1, 32)) for u in range(T)]
+    for t in range(T):
+        acc1 = np.tile(bias[0][32 * t:32 * t + 32, None], (1, 32))
+        for s in range(S1):
+            Bh, Bl = np.zeros((64, 8)), np.zeros((64, 8))
+            for h in (0, 1):
+                for i in range(8):
+                    k = 16 * s + 8 * h + i
+                    if k < K1:
+                        Bh[32 * h:32 * h + 32, i], Bl[32 * h:32 * h + 32, i] = xh[:, k], xl[:, k]
+            mfma(acc1, a1_block(t) + 2 * s, Bh, Bl)
+        yh, yl = relu_split(acc1)
+        for s in (0, 1):
+            Bh, Bl = operand_from_rows(yh, yl, s)
+            for u in range(T):
+                mfma(acc2[u], a2_block(t) + s * 2 * T + 2 * u, Bh, Bl)
+    x2 = [relu_split(a) for a in acc2]
+    # phase B
+    acc4 = np.tile(np.concatenate([bias[3], np.zeros(20)])[:, None], (1, 32))
+    for t in range(T):
+        acc3 = np.tile(bias[2][32 * t:32 * t + 32, None], (1, 32))
+        for s in range(SH):
+            Bh, Bl = operand_from_rows(*x2[s >> 1], s)
+            mfma(acc3, b3_block(t) + 2 * s, Bh, Bl)
+        zh, zl = relu_split(acc3)
+        for s in (0, 1):
+            Bh, Bl = operand_from_rows(zh, zl, s)
+            mfma(acc4, b4_block(t) + 2 * s, Bh, Bl)
+    got = acc4[:12].T                                                                     # [item][12]
+    h = x.astype(np.float64)
+    for i, (W, b) in enumerate(env):
+        h = h @ W.astype(np.float64).T + b.astype(np.float64)
+        if i < 3:
+            h = np.maximum(h, 0.0)
+    assert np.abs(got - h).max() <= 2e-6 * max(1.0, float(np.abs(h).max())), float(np.abs(got - h).max())
+    assert not acc4[12:].any()                                                            # the padded rows of the 12-row layer stay zero
