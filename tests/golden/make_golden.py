@@ -866,7 +866,22 @@ NETWORK_CPU_VARIANTS = {
     "tanh_separate_roughness": (["geo_feat_act = unitNorm", "ensemble_mlp = True", "learn_indir_blend = True"], ["geo_feat_act = tanh"]),
     "instance_norm_detached_annealed": (["geo_feat_act = unitNorm"], ["geo_feat_act = instanceNorm", "detach_normal = True", "normal_anneal_ratio = 0.5"]),
     "diffuse_only": ([], ["diffuse_only = True"]),
+    # the toaster.ini structure with the identity in place of the integrated-direction encoding (encoding_ref = frequency, zero frequencies):
+    # reflected direction -> environment network -> colour network, diffuse side through the same network; env rotation; intensity scales
+    "env": ([], ["use_reflected_dir = True", "use_env_net = True", "diffuse_with_env = True", "wo_viewdir = True", "hidden_dim_env = 48",
+                 "light_intensity_scale = 1.3", "intensity_scale = 0.9"]),
+    "env_add": ([], ["use_reflected_dir = True", "use_env_net = True", "diffuse_with_env = True", "diffuse_env_fusion = add", "env_feat_dim = 12",
+                     "hidden_dim_env = 48", "env_feat_act = tanh"]),
+    "env_mul_split": ([], ["use_reflected_dir = True", "use_env_net = True", "diffuse_with_env = True", "diffuse_env_fusion = mul", "env_feat_dim = 12",
+                           "split_diffuse_env = True", "hidden_dim_env = 48", "hidden_dim_env_diffuse = 40", "env_wo_bias = True"]),
+    "env_no_diffuse_env": ([], ["use_reflected_dir = True", "use_env_net = True", "hidden_dim_env = 48", "env_feat_act = instanceNorm"]),
+    "renv": ([], ["use_reflected_dir = True", "use_env_net = True", "diffuse_with_env = True", "wo_viewdir = True", "hidden_dim_env = 48", "use_renv = True",
+                  "indir_roughness_thresh = 0.12"]),
+    "renv_fixed_blend": (["learn_indir_blend = True"], ["use_reflected_dir = True", "use_env_net = True", "diffuse_with_env = True", "hidden_dim_env = 48",
+                                                        "use_renv = True", "indir_roughness_thresh = 0.12"]),
 }
+# how forward_color is driven per variant (tests/test_network_cpu.py NETWORK_CALLS holds the same): env rotation, reflected radiance
+NETWORK_CPU_CALLS = {"env": {"env_rot": 0.7}, "env_mul_split": {"env_rot": -1.9}, "renv": {"r_images": 4, "env_rot": 0.4}, "renv_fixed_blend": {"r_images": 3}}
 
 
 def golden_network_cpu():
@@ -885,7 +900,9 @@ def golden_network_cpu():
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     dists = rng.uniform(0.005, 0.02, size=200).astype(F)
     w_rgb, w_sigma = rng.normal(size=(200, 3)).astype(F), rng.normal(size=200).astype(F)
-    out = {"x": x, "d": d, "dists": dists, "w_rgb": w_rgb, "w_sigma": w_sigma}
+    r_images = rng.uniform(0, 1, size=(200, 4)).astype(F)
+    r_images[:, 3] = (rng.uniform(size=200) < 0.7).astype(F)                   # visibility: 0 or 1
+    out = {"x": x, "d": d, "dists": dists, "w_rgb": w_rgb, "w_sigma": w_sigma, "r_images": r_images}
     base = (OUT / "torch_like.ini").read_text()
     for tag, (drop, add) in NETWORK_CPU_VARIANTS.items():
         text = base
@@ -918,8 +935,10 @@ def golden_network_cpu():
         dt = torch.from_numpy(d)
         sdfs, sigmas, geo, normals, _ = model.forward_sigma(xt, use_sdf_sigma_grad=True, dirs=dt, dists=torch.from_numpy(dists))
         rough = model.roughness
-        n_enc, w_r, n_dot, n_env = model.get_color_mlp_extra_params(normals, dt, rough, None)
-        rgb = model.forward_color(geo, dt, n_enc, w_r, n_dot, True, n_env_enc=n_env, r_images=None, roughness=rough)
+        call = NETWORK_CPU_CALLS.get(tag, {})
+        n_enc, w_r, n_dot, n_env = model.get_color_mlp_extra_params(normals, dt, rough, call.get("env_rot"))
+        ri = torch.from_numpy(r_images[:, :call["r_images"]].copy()) if "r_images" in call else None
+        rgb = model.forward_color(geo, dt, n_enc, w_r, n_dot, True, n_env_enc=n_env, r_images=ri, roughness=rough)
         loss = (rgb * torch.from_numpy(w_rgb)).sum() + (sigmas.reshape(-1) * torch.from_numpy(w_sigma)).sum()
         params = dict(model.named_parameters())
         grads = torch.autograd.grad(loss, [xt, *params.values()], allow_unused=True)
