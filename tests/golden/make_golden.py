@@ -868,16 +868,16 @@ NETWORK_CPU_VARIANTS = {
     "diffuse_only": ([], ["diffuse_only = True"]),
     # the toaster.ini structure with the identity in place of the integrated-direction encoding (encoding_ref = frequency, zero frequencies):
     # reflected direction -> environment network -> colour network, diffuse side through the same network; env rotation; intensity scales
-    "env": ([], ["use_reflected_dir = True", "use_env_net = True", "diffuse_with_env = True", "wo_viewdir = True", "hidden_dim_env = 48",
+    "env": ([], ["use_reflected_dir = True", "use_env_net = True", "diffuse_with_env = True", "wo_viewdir = True", "hidden_dim_env = 24",
                  "light_intensity_scale = 1.3", "intensity_scale = 0.9"]),
     "env_add": ([], ["use_reflected_dir = True", "use_env_net = True", "diffuse_with_env = True", "diffuse_env_fusion = add", "env_feat_dim = 12",
-                     "hidden_dim_env = 48", "env_feat_act = tanh"]),
+                     "hidden_dim_env = 24", "env_feat_act = tanh"]),
     "env_mul_split": ([], ["use_reflected_dir = True", "use_env_net = True", "diffuse_with_env = True", "diffuse_env_fusion = mul", "env_feat_dim = 12",
-                           "split_diffuse_env = True", "hidden_dim_env = 48", "hidden_dim_env_diffuse = 40", "env_wo_bias = True"]),
-    "env_no_diffuse_env": ([], ["use_reflected_dir = True", "use_env_net = True", "hidden_dim_env = 48", "env_feat_act = instanceNorm"]),
-    "renv": ([], ["use_reflected_dir = True", "use_env_net = True", "diffuse_with_env = True", "wo_viewdir = True", "hidden_dim_env = 48", "use_renv = True",
+                           "split_diffuse_env = True", "hidden_dim_env = 24", "hidden_dim_env_diffuse = 20", "env_wo_bias = True"]),
+    "env_no_diffuse_env": ([], ["use_reflected_dir = True", "use_env_net = True", "hidden_dim_env = 24", "env_feat_act = instanceNorm"]),
+    "renv": ([], ["use_reflected_dir = True", "use_env_net = True", "diffuse_with_env = True", "wo_viewdir = True", "hidden_dim_env = 24", "use_renv = True",
                   "indir_roughness_thresh = 0.12"]),
-    "renv_fixed_blend": (["learn_indir_blend = True"], ["use_reflected_dir = True", "use_env_net = True", "diffuse_with_env = True", "hidden_dim_env = 48",
+    "renv_fixed_blend": (["learn_indir_blend = True"], ["use_reflected_dir = True", "use_env_net = True", "diffuse_with_env = True", "hidden_dim_env = 24",
                                                         "use_renv = True", "indir_roughness_thresh = 0.12"]),
 }
 # how forward_color is driven per variant (tests/test_network_cpu.py NETWORK_CALLS holds the same): env rotation, reflected radiance

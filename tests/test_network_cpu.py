@@ -25,16 +25,16 @@ NETWORK_VARIANTS = {
     "instance_norm_detached_annealed": {"geo_feat_act": "instanceNorm", "detach_normal": True, "normal_anneal_ratio": 0.5},
     "diffuse_only": {"diffuse_only": True},
     # the toaster.ini structure with the identity in place of the integrated-direction encoding (encoding_ref = frequency, zero frequencies)
-    "env": {"use_reflected_dir": True, "use_env_net": True, "diffuse_with_env": True, "wo_viewdir": True, "hidden_dim_env": 48,
+    "env": {"use_reflected_dir": True, "use_env_net": True, "diffuse_with_env": True, "wo_viewdir": True, "hidden_dim_env": 24,
             "light_intensity_scale": 1.3, "intensity_scale": 0.9},
     "env_add": {"use_reflected_dir": True, "use_env_net": True, "diffuse_with_env": True, "diffuse_env_fusion": "add", "env_feat_dim": 12,
-                "hidden_dim_env": 48, "env_feat_act": "tanh"},
+                "hidden_dim_env": 24, "env_feat_act": "tanh"},
     "env_mul_split": {"use_reflected_dir": True, "use_env_net": True, "diffuse_with_env": True, "diffuse_env_fusion": "mul", "env_feat_dim": 12,
-                      "split_diffuse_env": True, "hidden_dim_env": 48, "hidden_dim_env_diffuse": 40, "env_wo_bias": True},
-    "env_no_diffuse_env": {"use_reflected_dir": True, "use_env_net": True, "hidden_dim_env": 48, "env_feat_act": "instanceNorm"},
-    "renv": {"use_reflected_dir": True, "use_env_net": True, "diffuse_with_env": True, "wo_viewdir": True, "hidden_dim_env": 48, "use_renv": True,
+                      "split_diffuse_env": True, "hidden_dim_env": 24, "hidden_dim_env_diffuse": 20, "env_wo_bias": True},
+    "env_no_diffuse_env": {"use_reflected_dir": True, "use_env_net": True, "hidden_dim_env": 24, "env_feat_act": "instanceNorm"},
+    "renv": {"use_reflected_dir": True, "use_env_net": True, "diffuse_with_env": True, "wo_viewdir": True, "hidden_dim_env": 24, "use_renv": True,
              "indir_roughness_thresh": 0.12},
-    "renv_fixed_blend": {"learn_indir_blend": False, "use_reflected_dir": True, "use_env_net": True, "diffuse_with_env": True, "hidden_dim_env": 48,
+    "renv_fixed_blend": {"learn_indir_blend": False, "use_reflected_dir": True, "use_env_net": True, "diffuse_with_env": True, "hidden_dim_env": 24,
                          "use_renv": True, "indir_roughness_thresh": 0.12},
 }
 # how forward_color is driven per variant (make_golden.NETWORK_CPU_CALLS): env rotation, reflected radiance [N, 3 or 4]
@@ -44,7 +44,7 @@ NETWORK_CALLS = {"env": {"env_rot": 0.7}, "env_mul_split": {"env_rot": -1.9}, "r
 def _build(tag, g):
     from envidr_amd.nerf.network import NeRFNetwork
     from envidr_amd.nerf.options import RenderOptions
-    base = dict(scale=0.8, cuda_ray=False, encoding_pos="frequency", multires=0, encoding_dir="frequency", multires_dir=0, wo_viewdir=False,
+    base = dict(scale=0.8, cuda_ray=False, hidden_dim=32, hidden_dim_color=32, hidden_dim_diffuse=16, encoding_pos="frequency", multires=0, encoding_dir="frequency", multires_dir=0, wo_viewdir=False,
                 normal_with_mlp=True, use_n_dot_viewdir=True, use_reflected_dir=False, use_env_net=False, diffuse_with_env=False, use_renv=False,
                 encoding_ref="frequency", multires_refdir=0, hidden_dim_env=128, env_feat_dim=16, env_feat_act="", visual_items=["roughness"])
     opt = RenderOptions(**{**base, **NETWORK_VARIANTS[tag]})
