@@ -8,11 +8,46 @@ import os
 
 import numpy as np
 
-_hip = ctypes.CDLL(os.environ.get("ENVIDR_ASAN_HIP", "/opt/rocm/lib/libamdhip64.so"), mode=ctypes.RTLD_GLOBAL)
-_hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
-_hip.hipFree.argtypes = [ctypes.c_void_p]
-_hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
-_hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+DRY = os.environ.get("ENVIDR_ASAN_SHIM_DRY") == "1"      # no GPU: "device" blocks are host memory, so the stand-in itself can be exercised
+
+
+class _HostHip:
+    """ENVIDR_ASAN_SHIM_DRY=1: the four runtime calls on host memory (the library's launches then fail with 'no device', which the driver
+    counts apart from failures of this stand-in)"""
+    _libc = ctypes.CDLL(None)
+    _libc.aligned_alloc.restype = ctypes.c_void_p
+    _libc.aligned_alloc.argtypes = [ctypes.c_size_t, ctypes.c_size_t]
+    _libc.free.argtypes = [ctypes.c_void_p]
+
+    def hipMalloc(self, pp, n):
+        pp._obj.value = self._libc.aligned_alloc(256, (n + 255) // 256 * 256)      # (hipMalloc blocks are at least so aligned)
+        return 0
+
+    def hipFree(self, p):
+        self._libc.free(p)
+        return 0
+
+    def hipMemcpy(self, dst, src, n, kind):
+        ctypes.memmove(dst, src, n)
+        return 0
+
+    def hipMemset(self, p, v, n):
+        ctypes.memset(p, v, n)
+        return 0
+
+    def hipDeviceSynchronize(self):
+        return 0
+
+
+if DRY:
+    _hip = _HostHip()
+else:
+    _hip = ctypes.CDLL(os.environ.get("ENVIDR_ASAN_HIP", "/opt/rocm/lib/libamdhip64.so"), mode=ctypes.RTLD_GLOBAL)
+if not DRY:
+    _hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    _hip.hipFree.argtypes = [ctypes.c_void_p]
+    _hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    _hip.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
 
 
 def _check(rc, what):
@@ -160,6 +195,54 @@ class Tensor:
     def __len__(self):
         return self.shape[0]
 
+    def __int__(self):
+        return int(self.item())
+
+    def __iter__(self):
+        return (self[i] for i in range(self.shape[0]))
+
+    def _arith(self, other, fn):
+        """elementwise arithmetic the slow way (through the host): only the few host-side expressions of fused.py use it"""
+        b = other.cpu().numpy() if isinstance(other, Tensor) else other
+        return from_numpy(np.asarray(fn(self.cpu().numpy(), b)).astype(self.dtype.np)).to(self.device)
+
+    __add__ = __radd__ = lambda self, o: self._arith(o, lambda a, b: a + b)
+    __mul__ = __rmul__ = lambda self, o: self._arith(o, lambda a, b: a * b)
+    __sub__ = lambda self, o: self._arith(o, lambda a, b: a - b)
+    __rsub__ = lambda self, o: self._arith(o, lambda a, b: b - a)
+
+    def expand(self, *shape):
+        return from_numpy(np.broadcast_to(self.cpu().numpy(), shape).copy()).to(self.device)
+
+    def __getitem__(self, key):
+        """rows of the first dimension: an index or a unit-stride slice (a view of the same memory); [:, None]: a view with one more axis"""
+        if isinstance(key, tuple):
+            assert key == (slice(None), None), key
+            return self._view((self.shape[0], 1) + self.shape[1:])
+        n = self.shape[0]
+        if isinstance(key, int):
+            start, stop, shape = key % n, key % n + 1, self.shape[1:]
+        else:
+            start, stop, step = key.indices(n)
+            assert step == 1, key
+            shape = (max(stop - start, 0),) + self.shape[1:]
+        row = (int(np.prod(self.shape[1:])) if len(self.shape) > 1 else 1) * self.element_size()
+        if self._host is not None:
+            return Tensor(shape, self.dtype, host=self._host[key] if not isinstance(key, int) else self._host[key:key + 1].reshape(shape), owner=self)
+        return Tensor(shape, self.dtype, ptr=self._ptr + start * row, owner=self)
+
+    def copy_(self, src, non_blocking=False):
+        a = np.ascontiguousarray(src.cpu().numpy().astype(self.dtype.np, copy=False)).reshape(self.shape)
+        if self.is_cuda:
+            if a.nbytes:
+                _check(_hip.hipMemcpy(self._ptr, a.ctypes.data, a.nbytes, 1), "hipMemcpy H2D")
+        else:
+            self._host[...] = a
+        return self
+
+    def pin_memory(self):
+        return self
+
 
 class _Block:
     def __init__(self, ptr):
@@ -207,6 +290,20 @@ def empty_like(t):
     return empty(*t.shape, dtype=t.dtype, device=t.device)
 
 
+def cumsum(x, dim, dtype=None, out=None):
+    r = np.cumsum(x.cpu().numpy(), axis=dim, dtype=None if dtype is None else dtype.np)
+    return out.copy_(from_numpy(r)) if out is not None else from_numpy(r).to(x.device)
+
+
+def maximum(a, b, out=None):
+    r = np.maximum(a.cpu().numpy(), b.cpu().numpy())
+    return out.copy_(from_numpy(r)) if out is not None else from_numpy(r).to(a.device)
+
+
+class OutOfMemoryError(RuntimeError):
+    pass
+
+
 def is_tensor(x):
     return isinstance(x, Tensor)
 
@@ -234,6 +331,22 @@ class cuda:
     @staticmethod
     def is_available():
         return True
+
+    class Event:
+        """the stand-in synchronises the device wherever an event is waited for or queried"""
+
+        def __init__(self, enable_timing=False):
+            pass
+
+        def record(self, stream=None):
+            pass
+
+        def query(self):
+            _check(_hip.hipDeviceSynchronize(), "hipDeviceSynchronize")
+            return True
+
+        def synchronize(self):
+            _check(_hip.hipDeviceSynchronize(), "hipDeviceSynchronize")
 
 
 device = _Device
