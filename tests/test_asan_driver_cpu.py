@@ -11,7 +11,7 @@ ROOT = Path(__file__).resolve().parents[1]
 
 
 def test_sanitizer_driver_rehearsal_reaches_every_launch():
-    env = dict(os.environ, ENVIDR_ASAN_SHIM_DRY="1", ENVIDR_AMD_LIB=str(ROOT / "envidr_amd" / "libenvidr_amd.so"))
+    env = dict(os.environ, ENVIDR_ASAN_SHIM_DRY="1", ENVIDR_AMD_LIB=os.environ.get("ENVIDR_AMD_LIB", str(ROOT / "envidr_amd" / "libenvidr_amd.so")))         # (tools/host_sanitize.sh points it at the host-sanitized build)
     r = subprocess.run([sys.executable, str(ROOT / "tools" / "asan_driver.py")], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "ASAN DRIVER DONE: no failure" in r.stdout, r.stdout[-3000:]
