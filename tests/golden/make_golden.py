@@ -953,6 +953,111 @@ def golden_network_cpu():
     np.savez_compressed(OUT / "network_cpu.npz", **out)
 
 
+SPH_CPU_LINES = ["env_sph_mode = True", "use_reflected_dir = True", "use_env_net = True", "diffuse_with_env = True", "wo_viewdir = True", "hidden_dim_env = 24",
+                 "roughness_act_scale = 1.0"]
+SPH_CPU_MATERIAL = {"roughness": 0.35, "metallic": 0.6, "color": [0.8, 0.5, 0.3]}
+SPH_CPU_RADIUS = 0.76
+
+
+def sph_cpu_weights(model):
+    """weights for the env-sphere pin: the SDF network answers |x| - radius up to a small learnt wobble (layer 1 = +-x, +-y, +-z scaled, the
+    rest seeded noise), so that the shell samples straddle a real surface; everything else stays the reference's own initialisation"""
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        for lin in model.sdf_net:
+            lin.weight.mul_(2.0)
+            lin.bias.add_(0.05 * torch.randn(lin.bias.shape, generator=g))
+        model.sdf_net[-1].bias[0] = -0.2
+        model.sdf_density.beta.fill_(0.02)
+
+
+def golden_sph_cpu():
+    """The reference's `run_sph` (nerf/render_func/sph_ray.py:34-221) in plain torch on the CPU: tests/golden/torch_like.ini + env_sph_mode (the
+    material parameters concatenated to the SDF input, one environment MLP per environment, identity encoders), 90 rays of which a third
+    miss the sphere, 12 shell samples per hit.  Evaluation mode with the normal image; training mode with the perturbation off and every
+    training extra on (backsdf_loss, eikonal_loss, sdf_loss_weight: relsdf / sdf_weights / sdf_dist / sdf_gradients / surf_sdfs), plus the
+    gradients of a scalar of image, depth and the extras w.r.t. every parameter; and a call in which no ray hits.  Pins
+    envidr_amd/nerf/render_func/sph_ray.py's operator form without any kernel: tests/test_sph_cpu.py."""
+    import tempfile
+    from nerf.options import config_parser
+    from nerf.network import NeRFNetwork
+    from nerf import render_func
+    text = (OUT / "torch_like.ini").read_text().replace("visual_items = [roughness]", "visual_items = [roughness, diffuse, specular]")
+    assert "diffuse, specular" in text
+    text += "".join(l + "\n" for l in SPH_CPU_LINES)
+    with tempfile.NamedTemporaryFile("w", suffix=".ini", delete=False) as f:
+        f.write(text)
+    old = sys.argv
+    sys.argv = ["main_nerf.py", "--config", f.name, "--test"]
+    try:
+        opt = config_parser()
+    finally:
+        sys.argv = old
+    assert opt.env_sph_mode and not opt.cuda_ray
+    opt.env_sph_radius = SPH_CPU_RADIUS
+    env_opt = types.SimpleNamespace(vary_roughness=True, vary_metallic=True, vary_base_color=True, env_images_names=["a", "b", "c"])
+    torch.manual_seed(5)
+    model = NeRFNetwork(encoding="hashgrid", encoding_dir=opt.encoding_dir, bound=opt.bound, cuda_ray=opt.cuda_ray, density_scale=1,
+                        min_near=opt.min_near, density_thresh=opt.density_thresh, bg_radius=opt.bg_radius, use_sdf=opt.use_sdf,
+                        hidden_dim=opt.hidden_dim, num_layers=opt.num_layers, num_layers_color=opt.num_layers_color,
+                        hidden_dim_color=opt.hidden_dim_color, num_layers_bg=opt.num_layers_bg, num_levels=opt.num_levels,
+                        geo_feat_dim=opt.geo_feat_dim, opt=opt, env_opt=env_opt)
+    sph_cpu_weights(model)
+    rng = np.random.default_rng(61)
+    n = 90
+    ro = rng.normal(size=(n, 3)).astype(F)
+    ro *= (2.5 / np.linalg.norm(ro, axis=1, keepdims=True)).astype(F)
+    aim = rng.normal(size=(n, 3)).astype(F) * 0.35                      # two thirds aim into the sphere ...
+    aim[::3] = aim[::3] / np.linalg.norm(aim[::3], axis=1, keepdims=True) * 1.6          # ... a third past it
+    rd = aim - ro
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    w_img, w_depth = rng.normal(size=(n, 3)).astype(F), rng.normal(size=n).astype(F)
+    out = {"rays_o": ro, "rays_d": rd, "w_img": w_img, "w_depth": w_depth, "radius": np.float32(SPH_CPU_RADIUS),
+           "material": np.array([SPH_CPU_MATERIAL["roughness"], SPH_CPU_MATERIAL["metallic"], *SPH_CPU_MATERIAL["color"]], F)}
+    for name, prm in model.named_parameters():
+        out[f"param|{name}"] = prm.detach().numpy().copy()
+    g = lambda v: np.zeros(0, F) if (v is None or not torch.is_tensor(v)) else v.detach().numpy().astype(F)
+    o, d = torch.from_numpy(ro)[None], torch.from_numpy(rd)[None]
+
+    # evaluation mode, normal image, second environment
+    model.eval()
+    opt.backsdf_loss = opt.eikonal_loss = False
+    r = render_func.run_sph(model, o, d, bg_color=1, perturb=False, get_normal_image=True, env_net_index=1, material=dict(SPH_CPU_MATERIAL))
+    for k, v in r.items():
+        out[f"eval|{k}"] = g(v)
+    hit = int((r["weights_sum"].reshape(-1) > 0).sum())
+    print(f"[golden] sph_cpu eval: {hit} of {n} rays composite something, weights_sum up to {float(r['weights_sum'].max()):.3f}, keys {sorted(r)}")
+
+    # training mode with every extra
+    model.train()
+    opt.backsdf_loss = opt.eikonal_loss = True
+    opt.sdf_loss_weight = 0.1
+    r = render_func.run_sph(model, o, d, bg_color=1, perturb=False, env_net_index=2, material=dict(SPH_CPU_MATERIAL))
+    for k, v in r.items():
+        out[f"train|{k}"] = g(v)
+    loss = ((r["image"][0] * torch.from_numpy(w_img)).sum() + (r["depth"][0] * torch.from_numpy(w_depth)).sum() + 0.3 * r["surf_sdfs"].abs().mean()
+            + 0.2 * (r["relsdf"] * r["sdf_weights"] * r["sdf_dist"]).sum() + 0.1 * ((r["sdf_gradients"].norm(dim=-1) - 1) ** 2).mean())
+    params = dict(model.named_parameters())
+    grads = torch.autograd.grad(loss, list(params.values()), allow_unused=True)
+    for (name, _), gr in zip(params.items(), grads):
+        out[f"train|grad|{name}"] = g(gr)
+    out["train|loss"] = np.float32(loss.item())
+    print(f"[golden] sph_cpu train: loss {loss.item():.5f}, keys {sorted(r)}, parameters without gradient: {[k for (k, _), gr in zip(params.items(), grads) if gr is None]}")
+
+    # no ray hits
+    model.eval()
+    opt.backsdf_loss = opt.eikonal_loss = False
+    far_o = torch.from_numpy(ro[:5] * 4)[None]
+    side = np.cross(ro[:5], np.array([0.3, -0.2, 0.9], F)).astype(F)
+    side /= np.linalg.norm(side, axis=1, keepdims=True)
+    r = render_func.run_sph(model, far_o, torch.from_numpy(side)[None], bg_color=1, perturb=False, get_normal_image=True, env_net_index=0, material=dict(SPH_CPU_MATERIAL))
+    out["miss|rays_d"] = side
+    for k, v in r.items():
+        out[f"miss|{k}"] = g(v)
+    print(f"[golden] sph_cpu miss: keys {sorted(r)}")
+    np.savez_compressed(OUT / "sph_cpu.npz", **out)
+
+
 def main():
     if not REFERENCE.exists():
         raise SystemExit("/root/reference is not present: golden vectors can only be regenerated in the build container")
@@ -979,6 +1084,9 @@ def main():
         return
     if sys.argv[1:] == ["network_cpu"]:        # only the plain-torch network fixtures
         golden_network_cpu()
+        return
+    if sys.argv[1:] == ["sph_cpu"]:            # only the env-sphere render function in plain torch
+        golden_sph_cpu()
         return
     if sys.argv[1:] == ["nocuda"]:             # only the torch-only render function's fixtures
         golden_non_cuda_ray()
@@ -1022,6 +1130,7 @@ def main():
     golden_non_cuda_ray()
     golden_torch_only_resample()
     golden_network_cpu()
+    golden_sph_cpu()
 
 
 if __name__ == "__main__":
