@@ -12,7 +12,7 @@ cp $G/$TAG/profile/* profiles/$TAG/
 tail -5 $G/$TAG/pytest_gpu_all.log > profiles/$TAG/pytest_gpu_all_tail.txt 2>/dev/null
 for f in asan_driver.txt asan_summary.txt stress_sync.txt asan_build.log; do [ -f $G/${TAG}_asan/$f ] && cp $G/${TAG}_asan/$f profiles/$TAG/; done
 for f in $G/${TAG}_asan/asan_report*; do [ -f "$f" ] && head -200 "$f" > profiles/$TAG/$(basename $f).txt; done
-for f in split_time.txt split_counters.txt pytest_split.log; do [ -f $G/${TAG}_split/$f ] && cp $G/${TAG}_split/$f profiles/$TAG/split2_$f; done
+for f in split_time.txt summary.txt pytest_split.log; do [ -f $G/${TAG}_split/$f ] && cp $G/${TAG}_split/$f profiles/$TAG/split2_$f; done
 ls profiles/$TAG | wc -l
 git add profiles/$TAG profiles/pmc_latest.json
 git commit -qm "profiles/$TAG: the round's final tree on the GPU (tests, smoke, bench, kernel stats, PMC passes -> pmc_latest.json, sanitizer driver, split-precision counters)" && echo committed
