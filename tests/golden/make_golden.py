@@ -1006,7 +1006,7 @@ def golden_sph_cpu():
     rng = np.random.default_rng(61)
     n = 90
     ro = rng.normal(size=(n, 3)).astype(F)
-    ro *= (2.5 / np.linalg.norm(ro, axis=1, keepdims=True)).astype(F)
+    ro *= (rng.uniform(1.8, 3.5, size=(n, 1)) / np.linalg.norm(ro, axis=1, keepdims=True)).astype(F)         # (origins at different distances: chunks then differ in their largest far)
     aim = rng.normal(size=(n, 3)).astype(F) * 0.35                      # two thirds aim into the sphere ...
     aim[::3] = aim[::3] / np.linalg.norm(aim[::3], axis=1, keepdims=True) * 1.6          # ... a third past it
     rd = aim - ro
@@ -1027,6 +1027,21 @@ def golden_sph_cpu():
         out[f"eval|{k}"] = g(v)
     hit = int((r["weights_sum"].reshape(-1) > 0).sum())
     print(f"[golden] sph_cpu eval: {hit} of {n} rays composite something, weights_sum up to {float(r['weights_sum'].max()):.3f}, keys {sorted(r)}")
+
+    # the same through render(): one call with the normal image blended by weights_sum (renderer.py:539-540 broadcasts weights_sum [N,1]
+    # against [1,N,3]: its diagonal is the per-ray blend), and staged in chunks of 32 rays (each normalises its depth by its own largest far)
+    kw = {k: v for k, v in vars(opt).items() if k not in ("bg_color", "perturb", "material", "env_net_index", "max_ray_batch")}
+    r = model.render(o, d, staged=False, bg_color=1, perturb=False, get_normal_image=True, env_net_index=1, material=dict(SPH_CPU_MATERIAL), **kw)
+    ni = r["normal_image"].detach()
+    assert tuple(ni.shape) == (n, n, 3)
+    out["render|normal_image"] = ni[torch.arange(n), torch.arange(n)].numpy()
+    out["render|image"], out["render|depth"] = g(r["image"]), g(r["depth"])
+    r = model.render(o, d, staged=True, max_ray_batch=32, bg_color=1, perturb=False, get_normal_image=False, env_net_index=1,
+                     material=dict(SPH_CPU_MATERIAL), **kw)
+    for k, v in r.items():
+        out[f"staged|{k}"] = g(v)
+    print(f"[golden] sph_cpu render(): staged keys {sorted(r)}, depth differs from the one-call depth by up to "
+          f"{float((r['depth'].reshape(-1) - torch.from_numpy(out['render|depth']).reshape(-1)).abs().max()):.3g}")
 
     # training mode with every extra
     model.train()

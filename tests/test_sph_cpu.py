@@ -33,6 +33,16 @@ def _model(g):
     return m, opt, names
 
 
+class _Files:
+    """an npz file without one of its entries"""
+
+    def __init__(self, g, drop):
+        self.g, self.files = g, [k for k in g.files if k != drop]
+
+    def __getitem__(self, k):
+        return self.g[k]
+
+
 def _compare(got: dict, g, prefix: str, tol: float = 3e-6):
     keys = [k[len(prefix):] for k in g.files if k.startswith(prefix) and "|grad|" not in k and not k.endswith("|loss")]
     assert keys
@@ -59,7 +69,25 @@ def test_env_sphere_render_function_matches_the_reference_in_evaluation_mode():
     r = run_sph(model, o, d, bg_color=1, perturb=False, get_normal_image=True, env_net_index=1, material=dict(MATERIAL))
     keys = _compare(r, g, "eval|")
     assert {"image", "depth", "normal_image", "roughness_image", "diffuse_image", "specular_image", "weights_sum", "sigmas", "sdfs"} <= set(keys)
-    assert int((g["eval|weights_sum"].reshape(-1) > 0).sum()) == 58                  # 58 of the 90 rays composite something
+    assert int((g["eval|weights_sum"].reshape(-1) > 0).sum()) == 61                  # 61 of the 90 rays composite something
+
+
+def test_render_drives_the_env_sphere_function_like_the_reference_in_one_call_and_staged():
+    """render() (reference renderer.py:376-436, 539-540): one call with the normal image blended by weights_sum -- the reference's product
+    there broadcasts to [N,N,3]; its diagonal, the per-ray blend it means, is what the fixture holds -- and staged chunks of 32 rays, each
+    normalising its depth by its own largest far (so the staged depth is NOT the one-call depth)"""
+    g = np.load(GOLD)
+    model, opt, _ = _model(g)
+    model.eval()
+    o, d = torch.from_numpy(g["rays_o"])[None], torch.from_numpy(g["rays_d"])[None]
+    kw = dict(bg_color=1, perturb=False, env_net_index=1, material=dict(MATERIAL))
+    r = model.render(o, d, staged=False, get_normal_image=True, **kw)
+    _compare(r, g, "render|")
+    s = model.render(o, d, staged=True, max_ray_batch=32, get_normal_image=False, **kw)
+    got = {k: v for k, v in s.items() if k != "normal_image"}           # (the reference's staged normal frame is torch.empty when no chunk returns one)
+    assert {"image", "depth", "diffuse_image", "specular_image", "roughness_image"} <= set(got)
+    keys = _compare(got, _Files(g, "staged|normal_image"), "staged|")
+    assert "depth" in keys and float(np.abs(g["staged|depth"].reshape(-1) - g["render|depth"].reshape(-1)).max()) > 1e-4
 
 
 def test_env_sphere_render_function_matches_the_reference_in_training_mode_with_every_extra():
