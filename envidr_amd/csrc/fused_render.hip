@@ -908,7 +908,7 @@ __global__ void __launch_bounds__(kBlockThreads, 1) k_shade_samples(const ShadeA
     // a frame whose records did not fit (count beyond the capacity) is not shaded at all: the host redoes it
     uint32_t M = a.M;
     if (a.m_dev) { const uint32_t md = __builtin_amdgcn_readfirstlane(*a.m_dev); M = md > a.M ? 0u : md; }
-    const uint32_t* list = (a.list && __builtin_amdgcn_readfirstlane(*a.m_all) != M) ? a.list : nullptr;
+    const uint32_t* list = (a.list && (uint32_t)__builtin_amdgcn_readfirstlane(*a.m_all) != M) ? a.list : nullptr;
     // Rounds are CLAIMED, not assigned: a wave takes the next 64 records off a device counter when it starts a round (the claim for
     // the round after is issued at once, so its latency hides behind 280 us of work).  With a static grid stride every wave does
     // 117 or 118 rounds of the headline frame and the kernel lasts as long as its slowest wave -- the waves of the odd XCDs are

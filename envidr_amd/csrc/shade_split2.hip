@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(kSplit2Threads, 1) k_env_split2(const ShadeArg
     };
     uint32_t M = a.M;
     if (a.m_dev) { const uint32_t md = __builtin_amdgcn_readfirstlane(*a.m_dev); M = md > a.M ? 0u : md; }
-    const uint32_t* list = (a.list && __builtin_amdgcn_readfirstlane(*a.m_all) != M) ? a.list : nullptr;
+    const uint32_t* list = (a.list && (uint32_t)__builtin_amdgcn_readfirstlane(*a.m_all) != M) ? a.list : nullptr;
     const uint32_t enc = wave >> 2, quarter = wave & 3u;
     // Both lane halves evaluate the features of item n = lane & 31 (the matrix instruction wants them in lane n AND lane n + 32: slots
     // 8 h .. 8 h + 7 of a step live in half h); each writes the 16-bit slot of feature k at fragment (step k / 16, hi | lo), lane n + 32 h(k):
