@@ -9,7 +9,7 @@ G=gpurun_out
 mkdir -p profiles/$TAG
 cp $G/$TAG/profile/* profiles/$TAG/
 [ -f $G/$TAG/summary.json ] && cp $G/$TAG/summary.json profiles/pmc_latest.json
-tail -5 $G/$TAG/pytest_gpu_all.log > profiles/$TAG/pytest_gpu_all_tail.txt 2>/dev/null
+[ -f $G/$TAG/pytest_gpu_all.log ] && tail -15 $G/$TAG/pytest_gpu_all.log > profiles/$TAG/pytest_gpu_all_tail.txt
 for f in asan_driver.txt asan_summary.txt stress_sync.txt asan_build.log; do [ -f $G/${TAG}_asan/$f ] && cp $G/${TAG}_asan/$f profiles/$TAG/; done
 for f in $G/${TAG}_asan/asan_report*; do [ -f "$f" ] && head -200 "$f" > profiles/$TAG/$(basename $f).txt; done
 for f in split_time.txt summary.txt pytest_split.log; do [ -f $G/${TAG}_split/$f ] && cp $G/${TAG}_split/$f profiles/$TAG/split2_$f; done

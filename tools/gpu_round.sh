@@ -1,12 +1,16 @@
 #!/bin/bash
 # Round-end style GPU pass (run through gpurun): tests, smoke, bench, rocprof summaries.
-#   tools/gpu_round.sh <tag> [quick]
+#   tools/gpu_round.sh <tag> [quick] [all|core|extras]     core = tests, smoke, bench, kernel stats, PMC passes, summary.json (what the
+#   judged numbers come from); extras = the probes, operator / training benches and randomised runs; all (default) = both, extras in between
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 TAG=${1:-r01}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
-if [ "$2" != "quick" ]; then
+PART=${3:-all}
+QUICK=$2
+core_a() {
+if [ "$QUICK" != "quick" ]; then
   timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/smoke.log
 fi
@@ -15,6 +19,8 @@ timeout 1500 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --headline-only > $OUT/trace.log 2>&1 )
 # the same for HINTED frames (the fixed-camera video loop; the default is the cold frame since round 5): kernel trace + stats
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_hinted -o trace -- python $GRAFT_REPO_ROOT/bench.py --headline-only --hinted > $OUT/trace_hinted.log 2>&1 )
+}
+extras() {
 # the multi-GPU code path on this one GPU (RCCL world of one) and the strong-scaling mode
 timeout 600 python bench.py --headline-only --force-dist > $OUT/bench_force_dist.json 2> $OUT/bench_force_dist.err
 timeout 600 python bench.py --headline-only --force-dist --scaling strong > $OUT/bench_strong.json 2> $OUT/bench_strong.err
@@ -45,6 +51,8 @@ timeout 900 python tools/fuzz_ops.py 1 8 > $OUT/fuzz_ops.txt 2>&1
 timeout 600 python tools/geo/fuzz_frames.py 1500 2 > $OUT/fuzz_frames.txt 2>&1
 # random-line gather ceiling of the chip (the bound the geometry evaluation is measured against)
 [ -x tools/probe/gather_probe ] && timeout 300 tools/probe/gather_probe > $OUT/gather_probe.txt 2>&1
+}
+core_b() {
 # PMC passes, each on its own (no trace domains mixed in)
 for SET in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
   N=$(echo $SET | tr ' ' '_' | cut -c1-30)
@@ -88,6 +96,8 @@ json.dump(summary, open(out + "/summary.json", "w"), indent=1)
 print(json.dumps(summary, indent=1)[:3000])
 PY
 tail -3 $OUT/pytest_gpu.log $OUT/smoke.log 2>/dev/null; cat $OUT/bench.json | cut -c1-1500; tail -2 $OUT/bench.err
+}
+collect() {
 # what gets committed under profiles/<tag>/
 P=$OUT/profile; mkdir -p $P
 cp $OUT/bench.json $OUT/summary.json $P/ 2>/dev/null
@@ -99,3 +109,9 @@ cp $OUT/sph_stage_times.txt $OUT/train_ops_bench.txt $OUT/march_train_probe.txt 
 for d in $OUT/pmc_*/; do n=$(basename $d); find $d -name "*counter_collection.csv" -exec cp {} $P/$n.csv \; ; done
 tail -5 $OUT/pytest_gpu.log > $P/pytest_gpu_tail.txt; tail -2 $OUT/smoke.log >> $P/pytest_gpu_tail.txt
 
+}
+case $PART in
+  core) core_a; core_b; collect ;;
+  extras) extras; collect ;;
+  *) core_a; extras; core_b; collect ;;
+esac
