@@ -1,0 +1,103 @@
+"""The HOST LOGIC of the reference-shaped operator path, checked without a GPU -- NOT a parity test of the kernels.
+
+`NeRFNetwork.render()` with `fused=False` is Python on top of the C-ABI operators: the march / compact / composite loop of run_cuda, the
+three passes of indirect rendering, the background sphere, the env-sphere mode's operator chain, the training branch with its autograd
+wrappers (first and second backward of the hash encoder, the compositor's backward), the occupancy-grid maintenance, the checkpoint reader.
+On a GPU box the `-m gpu` tests run all of it on the HIP operators against fixtures the imported reference produced.  Here the SAME test
+bodies (imported from the GPU test modules, same fixtures, same tolerances) run on CPU tensors with `envidr_amd._lib.call` -- the one
+function through which this layer reaches the library -- pointed at the oracle's C restatement of each operator (which tests/test_golden_cpu.py
+and tests/test_oracle_pinning.py pin against the reference's own kernel bodies).  What a pass says: the Python layer of this tree drives the
+operators the way the reference's does (argument order, buffer sizes, loop control, gradient plumbing).  What it does not say: anything
+about the HIP kernels -- that is `-m gpu`.  The product itself has no CPU path: the fused renderers refuse a CPU device, and `_lib.call`
+refuses CPU tensors (tests/test_abi_cpu.py); the substitution below exists only inside this file's fixture."""
+import numpy as np
+import pytest
+import torch
+
+from envidr_amd import scenes
+
+
+@pytest.fixture
+def oracle_operators(monkeypatch):
+    from envidr_amd import _lib
+    from envidr_amd.raymarching import raymarching as rm
+    from oracle import clib
+
+    def call(name, *args, stream=None):
+        work = []
+        for a in args:
+            if isinstance(a, torch.Tensor):
+                assert not a.is_cuda and a.is_contiguous(), name
+                work.append(a.detach().numpy())          # (shares the tensor's memory: outputs land in place, as on the device)
+            else:
+                work.append(a)
+        clib.oracle().call(name, *work)
+
+    monkeypatch.setattr(_lib, "call", call)
+    monkeypatch.setattr(rm, "_gpu", lambda t: t)
+    # the GPU test bodies move their inputs with .cuda() and wait with torch.cuda.synchronize(): both are the identity here
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    monkeypatch.setattr(torch.nn.Module, "cuda", lambda self, *a, **k: self)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+
+
+def test_the_product_refuses_cpu_tensors_without_the_substitution():
+    from envidr_amd import _lib
+    o, d, near, far = torch.zeros(4, 3), torch.ones(4, 3), torch.zeros(4), torch.zeros(4)
+    with pytest.raises(_lib.EnvidrError, match="must live on the GPU"):
+        _lib.call("near_far_from_aabb", o, d, torch.tensor([-1.0, -1, -1, 1, 1, 1]), 4, 0.2, near, far)
+
+
+@pytest.mark.parametrize("tag", ["toaster_48", "toaster_rot_40"])
+def test_operator_loop_renders_the_references_frames(oracle_operators, tag):
+    import tests.test_dropin_gpu as D
+    D.test_render_matches_reference_frames(D.build_model(scenes.toaster_scene()), tag, False)
+
+
+def test_per_sample_chain(oracle_operators):
+    import tests.test_dropin_gpu as D
+    D.test_per_sample_chain_matches_reference(D.build_model(scenes.toaster_scene()))
+
+
+@pytest.mark.parametrize("body", ["test_instance_norm_feature_activations_match_reference", "test_neus_geometric_init_and_skip_layer_variants_match_reference"])
+def test_other_network_forms(oracle_operators, body):
+    import tests.test_dropin_gpu as D
+    getattr(D, body)()
+
+
+@pytest.mark.parametrize("body", ["test_background_sphere_branch_matches_reference", "test_indirect_three_pass_matches_reference",
+                                  "test_chunked_indirect_render_matches_reference", "test_indirect_with_an_object_box_matches_reference",
+                                  "test_relight_with_shipped_checkpoints", "test_config1_no_env_network"])
+def test_render_variants_through_the_operator_loop(oracle_operators, body):
+    """background sphere; the three passes of indirect rendering (whole, chunked, with an object box); relighting through the checkpoint
+    reader with the reference's shipped MLPs; BASELINE configs[1] (no environment network, SH-encoded directions)"""
+    import tests.test_dropin_gpu as D
+    getattr(D, body)(False)
+
+
+@pytest.mark.parametrize("tag", ["toaster", "lego"])
+def test_training_branch_forward_and_gradients(oracle_operators, tag):
+    """march_rays_train -> autograd normals (create_graph) -> colours -> composite_rays_train, then the loss backward: every network's
+    gradient, beta's, and the hash table's rows against the reference's own autograd (tests/golden/train_*.npz)"""
+    import tests.test_train_gpu as T
+    T.test_training_branch_forward_and_gradients_match_the_reference(tag)
+
+
+def test_occupancy_grid_maintenance(oracle_operators):
+    import tests.test_grid_gpu as G
+    G.test_grid_maintenance_matches_reference()
+
+
+@pytest.mark.parametrize("tag,normal", [("40", True), ("200", False)])
+def test_env_sphere_operator_chain(oracle_operators, tag, normal):
+    import tests.test_sph_gpu as S
+    from tests import sph_case
+    g = sph_case.load()
+    S.test_env_sphere_render_matches_reference(g, sph_case.build_model(g, device="cpu"), False, tag, normal)
+
+
+def test_env_sphere_operator_chain_staged(oracle_operators):
+    import tests.test_sph_gpu as S
+    from tests import sph_case
+    g = sph_case.load()
+    S.test_staged_env_sphere_render_matches_reference(g, sph_case.build_model(g, device="cpu"), False)
