@@ -101,3 +101,17 @@ def test_env_sphere_operator_chain_staged(oracle_operators):
     from tests import sph_case
     g = sph_case.load()
     S.test_staged_env_sphere_render_matches_reference(g, sph_case.build_model(g, device="cpu"), False)
+
+
+@pytest.mark.parametrize("tag", ["uniform", "resampled"])
+def test_torch_only_render_function(oracle_operators, tag):
+    """cuda_ray = False (tests/test_zz_plain_gpu.py, which has not met a GPU since its re-sampled fixture was re-generated): the same body,
+    fixture and bounds with the oracle's encoders underneath"""
+    import tests.test_zz_plain_gpu as P
+    P.test_torch_only_render_function_matches_the_reference(P.build_plain_model(), tag)
+
+
+def test_torch_only_render_function_staged_and_its_sampler(oracle_operators):
+    import tests.test_zz_plain_gpu as P
+    P.test_inverse_cdf_sampling_against_numpy()
+    P.test_staged_chunks_render_the_same_frame(P.build_plain_model())
