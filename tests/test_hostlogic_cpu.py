@@ -115,3 +115,37 @@ def test_torch_only_render_function_staged_and_its_sampler(oracle_operators):
     import tests.test_zz_plain_gpu as P
     P.test_inverse_cdf_sampling_against_numpy()
     P.test_staged_chunks_render_the_same_frame(P.build_plain_model())
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_operator_loop_on_random_options_equals_the_oracles_frame_loop(oracle_operators, seed):
+    """The fixtures pin the loop at the shipped options.  Here the loop's own knobs are drawn at random -- step-size growth, step limit,
+    early-termination threshold, near plane, roughness / intensity scales, environment rotation, scene shape and weights -- and the frame
+    is compared with oracle/py/render_oracle.py's restatement of the reference's loop (pinned to the reference's frames and integer
+    schedules by tests/test_golden_cpu.py) on the same operators: what differs is only who drives them."""
+    import tests.test_dropin_gpu as D
+    from oracle.py import render_oracle as ro
+    rng = np.random.default_rng(100 + seed)
+    dt_gamma = float(rng.choice([0.0, 1 / 256, 1 / 128, 1 / 64]))
+    max_steps = int(rng.choice([48, 128, 512, 1024]))
+    T_thresh = float(rng.choice([1e-4, 1e-3, 2e-2]))
+    min_near = float(rng.choice([0.05, 0.2, 0.5]))
+    rough_scale, intensity, light = float(rng.uniform(0.5, 1.2)), float(rng.uniform(0.6, 1.3)), float(rng.uniform(0.7, 1.4))
+    env_rot = None if seed % 2 else float(rng.uniform(-3, 3))
+    shape = scenes.torus() if seed % 3 == 0 else None
+    scene = scenes.toaster_scene(shape=shape, seed=20 + seed, sdf_bias=float(rng.choice([0.005, 0.03])), beta=float(rng.choice([0.01, 0.03])))
+    model, opt = D.build_model(scene, dt_gamma=dt_gamma, max_steps=max_steps, T_thresh=T_thresh, min_near=min_near, roughness_scale=rough_scale,
+                               intensity_scale=intensity, light_intensity_scale=light)
+    H = W = 24
+    rays_o, rays_d = scenes.camera_rays(H, W, theta=float(rng.uniform(0, 360)), phi=float(rng.uniform(-60, -10)))
+    res = model.render(torch.from_numpy(rays_o)[None], torch.from_numpy(rays_d)[None], staged=True, bg_color=1, perturb=False, get_normal_image=True,
+                       env_rot_radian=env_rot, fused=False, max_steps=max_steps, T_thresh=T_thresh, dt_gamma=dt_gamma)
+    want = ro.render_rays(scene, rays_o, rays_d, ro.RenderOptions(ide_mode="exact", dt_gamma=dt_gamma, max_steps=max_steps, T_thresh=T_thresh, min_near=min_near,
+                                                                   roughness_scale=rough_scale, intensity_scale=intensity, light_intensity_scale=light), env_rot)
+    assert want["n_samples"] > 500
+    from tests.util import rel_l2
+    for key in D.KEYS:
+        got = res[key].detach().numpy().reshape(H * W, -1)
+        err = rel_l2(got, want[key].reshape(H * W, -1))
+        assert err <= 2e-5, f"seed {seed} {key}: rel-L2 {err:.3e}"
+    assert np.array_equal(res["depth"].numpy().reshape(-1), want["depth"])          # the integer side: same samples, same order of additions
